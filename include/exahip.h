@@ -1,0 +1,123 @@
+/* exahip.h — C ABI of libexahip.so: the MI355X-native evaluator behind ExaModels' NLPModels surface.
+ *
+ * Drop-in boundary.  The entry points mirror, name for name, the cnlp ABI v0.1 that the reference
+ * itself exports for this surface (ExaModelsCompiler/src/ExaModelsCompiler.jl:1560-1732, prefix P = "exa"),
+ * and each one replaces one NLPModels callback of ext/ExaModelsKernelAbstractions.jl:
+ *
+ *   exa_obj             <- obj            (KA ext :253-271,  CPU src/nlp.jl:1827-1839)
+ *   exa_cons            <- cons_nln!      (KA ext :273-308,  CPU src/nlp.jl:1841-1854)
+ *   exa_grad            <- grad!          (KA ext :310-336,  CPU src/nlp.jl:1858-1868)
+ *   exa_jac_structure   <- jac_structure! (KA ext :212-231,  CPU src/nlp.jl:1798-1807)
+ *   exa_jac             <- jac_coord!     (KA ext :338-351,  CPU src/nlp.jl:1870-1880)
+ *   exa_hess_structure  <- hess_structure!(KA ext :232-250,  CPU src/nlp.jl:1809-1825)
+ *   exa_hess            <- hess_coord!    (KA ext :515-547,  CPU src/nlp.jl:1906-1940)
+ *   exa_set_value       <- set_value!     (src/nlp.jl:1279-1287)
+ *   exa_new_from_table  <- build_extension (KA ext :33-191) + the pattern records of src/simdfunction.jl:78-100
+ *
+ * Conventions (same as cnlp): every function returns an int status — 0 ok, 1 bad id / bad argument,
+ * 2 internal error (HIP failure, kernel compile failure; exa_last_error() has the text) — and never
+ * throws or aborts across the boundary.  Counts return >= 0, or -1 on a bad id.  Indices are 1-based,
+ * the Hessian is the lower triangle (row >= col), outputs are FULLY OVERWRITTEN (callers may pass
+ * uninitialised memory, cf. benchmark/runbenchmark.jl:88-92).  Evaluation never errors on the values
+ * of x (NaN/Inf propagate).
+ *
+ * Pointers: the unsuffixed callbacks take DEVICE pointers (what Julia passes as pointer(::ROCArray))
+ * and are asynchronous on the model's stream (exa_set_stream; default the null stream), except exa_obj
+ * whose `out` is a HOST double and therefore synchronises.  The *_host variants take host pointers,
+ * stage through device scratch owned by the model, and synchronise (the role of WrapperNLPModel,
+ * src/utils.jl:159-208).  One call in flight per model id (reference callbacks share scratch too,
+ * KA ext :21-31); distinct ids are independent.
+ *
+ * There is NO CPU fallback: if no HIP device or the kernel module cannot be built, exa_new_from_table
+ * fails with status 2.
+ */
+#ifndef EXAHIP_H
+#define EXAHIP_H
+#include <stdint.h>
+#include "exahip_ir.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXAHIP_ABI_VERSION 1
+
+int         exa_abi_version(void);
+const char *exa_last_error(void);                       /* thread-local text of the last status-2 failure */
+
+/* ---- build / destroy -------------------------------------------------------------------------- */
+/* Plans the COO layout (slot maps comp1/comp2, o1step/o2step, running offsets in insertion order),
+ * generates + compiles one HIP module for the model (cached on disk by source hash), uploads the SoA
+ * iterator columns.  Returns id > 0 in *id_out. */
+int exa_new_from_table(const exa_model_desc_t *desc, int *id_out);
+/* Same, but only plan + generate source (no device needed): used by the CPU-side build check and tests. */
+int exa_plan_only(const exa_model_desc_t *desc, int *id_out);
+int exa_free(int id);
+
+/* ---- sizes (cnlp: P_nvar/P_ncon/P_nnzj/P_nnzh, Compiler :1564-1582) ---------------------------- */
+int     exa_nvar(int id);
+int     exa_ncon(int id);
+int     exa_nnzj(int id);
+int     exa_nnzh(int id);
+int64_t exa_nvar64(int id);
+int64_t exa_ncon64(int id);
+int64_t exa_nnzj64(int id);
+int64_t exa_nnzh64(int id);
+int64_t exa_nnzg64(int id);     /* number of sparse objective-gradient slots (ExaCore.nnzg) */
+int     exa_npatterns(int id);
+/* Per-pattern layout record, for tests and for hosts that consume the COO in place:
+ * out[0]=kind out[1]=n out[2]=o0 out[3]=o1 out[4]=o2 out[5]=o1step out[6]=o2step out[7]=#leaf visits(1st) out[8]=#visits(2nd) */
+int     exa_pattern_info(int id, int p, int64_t out[9]);
+/* Slot maps: comp1 (length info[7]) / comp2 (length info[8]), 1-based like Compressor (simdfunction.jl:11-14). */
+int     exa_pattern_comp(int id, int p, int order, int32_t *out);
+/* x0,lvar,uvar [nvar]; lcon,ucon [ncon] — HOST pointers (cnlp P_meta, Compiler :1584-1608). */
+int     exa_meta(int id, double *x0, double *lvar, double *uvar, double *lcon, double *ucon);
+/* Generated HIP source of the model's module (NUL-terminated, owned by the library). */
+const char *exa_kernel_source(int id);
+
+/* ---- execution context ------------------------------------------------------------------------- */
+int exa_set_stream(int id, void *hip_stream);
+/* Shard every pattern's iterator: this process evaluates data points [floor(n*rank/world), floor(n*(rank+1)/world))
+ * of every pattern.  COO outputs (jac/hess/structures) are written at their GLOBAL slot
+ * positions, so ranks fill disjoint slices of one global vector; obj/grad/cons hold this rank's partial
+ * sums (base constraint rows outside the shard are written as 0) and are completed by an allreduce(sum)
+ * in the host layer.  rank=0, world=1 restores the unsharded model. */
+int exa_set_shard(int id, int rank, int world);
+/* theta update without rebuild (set_value!, nlp.jl:1279-1287; cnlp :1529-1535) */
+int exa_set_value(int id, int64_t offset, const double *vals, int64_t len);   /* theta[offset .. offset+len) <- vals (HOST) */
+
+/* ---- callbacks, DEVICE pointers ------------------------------------------------------------------ */
+int exa_obj (int id, const double *x, double *out_host);
+int exa_obj_async(int id, const double *x, double *out_dev);                  /* result left on device, no sync */
+int exa_grad(int id, const double *x, double *g);
+int exa_cons(int id, const double *x, double *c);
+int exa_jac (int id, const double *x, double *vals);
+int exa_hess(int id, const double *x, const double *y, double obj_weight, double *vals);
+int exa_jac_structure  (int id, int32_t *rows, int32_t *cols);
+int exa_hess_structure (int id, int32_t *rows, int32_t *cols);
+int exa_jac_structure64 (int id, int64_t *rows, int64_t *cols);               /* Julia Vector{Int} */
+int exa_hess_structure64(int id, int64_t *rows, int64_t *cols);
+
+/* ---- callbacks, HOST pointers (synchronous) ------------------------------------------------------ */
+int exa_obj_host (int id, const double *x, double *out);
+int exa_grad_host(int id, const double *x, double *g);
+int exa_cons_host(int id, const double *x, double *c);
+int exa_jac_host (int id, const double *x, double *vals);
+int exa_hess_host(int id, const double *x, const double *y, double obj_weight, double *vals);
+int exa_jac_structure_host  (int id, int32_t *rows, int32_t *cols);
+int exa_hess_structure_host (int id, int32_t *rows, int32_t *cols);
+int exa_jac_structure64_host (int id, int64_t *rows, int64_t *cols);
+int exa_hess_structure64_host(int id, int64_t *rows, int64_t *cols);
+
+/* ---- measurement hooks --------------------------------------------------------------------------- */
+/* Runs the named callback `reps` times on the model's stream bracketed by hipEvents recorded on THAT
+ * stream and returns the average milliseconds per call in *ms_out.  which: 0 obj,1 grad,2 cons,3 jac,4 hess.
+ * Device pointers as in the callbacks (unused ones may be NULL). */
+int exa_time_callback(int id, int which, int reps, const double *x, const double *y, double obj_weight,
+                      double *out, float *ms_out);
+int exa_sync(int id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EXAHIP_H */
