@@ -1,0 +1,848 @@
+// exa_codegen.cpp — emits one HIP module per model: straight-line, register-resident AD code per pattern.
+//
+// What it replaces: the KernelAbstractions kernels kerf/kerf2/kerg/kerj/kerh/kerh2 of
+// ext/ExaModelsKernelAbstractions.jl:608-684 together with Julia's type-specialisation of the whole
+// expression tree into each of them.  Design differences (MI355X-first, not a translation):
+//   * one FUSED launch per callback for the whole model: blockIdx -> (pattern, data-point tile) through a
+//     cumulative block table, so a 15-pattern ACOPF Hessian is 1 launch instead of 1 memset + 9 kernels;
+//   * every COO slot is accumulated in a VGPR in the reference's contribution order and stored ONCE
+//     (no zero-fill, no read-modify-write on HBM: KA ext :521,:533 + hessian.jl:580-592 do fill! and `+=`);
+//   * the iterator is struct-of-arrays, lane I reads column[I] (coalesced); UnitRange iterators cost no load;
+//   * forward sweep, partials and reverse sweep are symbolic here: constants fold, x*1 / x+0 vanish, common
+//     sub-expressions (one sincos per argument, exp reused for f=f'=f'') are shared by construction.
+// Derivative formulas follow src/functionlist.jl:6-81 (algebraically identical, a few rewritten through the
+// already-computed primal to save FP64 divides; parity bar 1e-10 relative).
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+
+#include "exa_internal.hpp"
+#include "exa_traverse.hpp"
+
+namespace exa {
+namespace {
+
+[[noreturn]] void fail(const std::string &m) { throw std::runtime_error(m); }
+
+// ---------------------------------------------------------------------------------------------------
+// symbolic values
+// ---------------------------------------------------------------------------------------------------
+struct Val {
+    enum K { LF, LI, SF, SI } k = LF;   // literal float / literal int / SSA float / SSA int
+    double f = 0.0;
+    int64_t i = 0;
+    int id = -1;
+    bool is_lit() const { return k == LF || k == LI; }
+    bool is_int() const { return k == LI || k == SI; }
+    double litv() const { return k == LI ? (double)i : f; }
+    bool lit_eq(double v) const { return is_lit() && litv() == v; }
+};
+
+std::string fmt_double(double v) {
+    if (std::isnan(v)) return "__builtin_nan(\"\")";
+    if (std::isinf(v)) return v > 0 ? "__builtin_inf()" : "(-__builtin_inf())";
+    char buf[64];
+    if (v == std::floor(v) && std::fabs(v) < 1e15) snprintf(buf, sizeof buf, "%.1f", v);
+    else snprintf(buf, sizeof buf, "%.17g", v);
+    std::string s = buf;
+    if (s.find_first_of(".en") == std::string::npos) s += ".0";
+    if (v < 0 || (v == 0 && std::signbit(v))) s = "(" + s + ")";
+    return s;
+}
+
+struct Emitter {
+    std::vector<std::string> lines;
+    std::map<std::string, Val> memo;
+    int next = 0;
+
+    static Val litf(double v) { Val r; r.k = Val::LF; r.f = v; return r; }
+    static Val liti(int64_t v) { Val r; r.k = Val::LI; r.i = v; r.f = (double)v; return r; }
+
+    std::string s(const Val &v) const {
+        switch (v.k) {
+        case Val::LF: return fmt_double(v.f);
+        case Val::LI: { char b[40]; snprintf(b, sizeof b, v.i < 0 ? "(%" PRId64 "L)" : "%" PRId64 "L", v.i); return b; }
+        case Val::SF: return "t" + std::to_string(v.id);
+        case Val::SI: return "k" + std::to_string(v.id);
+        }
+        return "?";
+    }
+    // text of v in a floating-point context
+    std::string sd(const Val &v) const {
+        if (v.k == Val::LI) return fmt_double((double)v.i);
+        if (v.k == Val::SI) return "(double)" + s(v);
+        return s(v);
+    }
+    Val tod(const Val &v) {
+        if (v.k == Val::LI) return litf((double)v.i);
+        if (v.k == Val::SI) return raw("(double)" + s(v), false);
+        return v;
+    }
+    // memoised SSA definition of an expression text
+    Val raw(const std::string &expr, bool is_int) {
+        auto it = memo.find(expr);
+        if (it != memo.end()) return it->second;
+        Val r;
+        r.k = is_int ? Val::SI : Val::SF;
+        r.id = next++;
+        lines.push_back(std::string(is_int ? "const long k" : "const double t") + std::to_string(r.id) + " = " + expr + ";");
+        memo[expr] = r;
+        return r;
+    }
+    Val neg(const Val &a) {
+        if (a.k == Val::LF) return litf(-a.f);
+        if (a.k == Val::LI) return liti(-a.i);
+        return raw("-" + s(a), a.is_int());
+    }
+    Val bin(char op, Val a, Val b) {
+        const bool ii = a.is_int() && b.is_int() && op != '/';
+        if (a.is_lit() && b.is_lit()) {
+            if (ii) {
+                switch (op) { case '+': return liti(a.i + b.i); case '-': return liti(a.i - b.i); case '*': return liti(a.i * b.i); }
+            }
+            const double x = a.litv(), y = b.litv();
+            switch (op) { case '+': return litf(x + y); case '-': return litf(x - y); case '*': return litf(x * y); case '/': return litf(x / y); }
+        }
+        // identities on exact literals.  (0*z -> 0 and z+0 -> z differ from IEEE only when z is Inf/NaN.)
+        switch (op) {
+        case '+': if (a.lit_eq(0)) return ii ? b : tod(b); if (b.lit_eq(0)) return ii ? a : tod(a); break;
+        case '-': if (b.lit_eq(0)) return ii ? a : tod(a); if (a.lit_eq(0)) return neg(ii ? b : tod(b)); break;
+        case '*':
+            if (a.lit_eq(0) || b.lit_eq(0)) return ii ? liti(0) : litf(0.0);
+            if (a.lit_eq(1)) return ii ? b : tod(b);
+            if (b.lit_eq(1)) return ii ? a : tod(a);
+            if (a.lit_eq(-1)) return neg(ii ? b : tod(b));
+            if (b.lit_eq(-1)) return neg(ii ? a : tod(a));
+            break;
+        case '/':
+            if (b.lit_eq(1)) return tod(a);
+            if (a.lit_eq(0)) return litf(0.0);
+            break;
+        }
+        if (ii) return raw(s(a) + " " + op + " " + s(b), true);
+        return raw(sd(a) + " " + op + " " + sd(b), false);
+    }
+    Val add(Val a, Val b) { return bin('+', a, b); }
+    Val sub(Val a, Val b) { return bin('-', a, b); }
+    Val mul(Val a, Val b) { return bin('*', a, b); }
+    Val div(Val a, Val b) { return bin('/', a, b); }
+    Val sq(Val a) { return mul(a, a); }
+    // template call: $1 $2 $3 replaced by operand texts (floating context)
+    Val call(const std::string &tmpl, std::initializer_list<Val> args) {
+        std::string out;
+        std::vector<Val> av(args);
+        for (size_t i = 0; i < tmpl.size(); i++) {
+            if (tmpl[i] == '$' && i + 1 < tmpl.size() && tmpl[i + 1] >= '1' && tmpl[i + 1] <= '9') {
+                size_t k = (size_t)(tmpl[i + 1] - '1');
+                if (k >= av.size()) fail("bad template " + tmpl);
+                out += sd(av[k]);
+                i++;
+            } else out += tmpl[i];
+        }
+        return raw(out, false);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// function rules: (x, y, h) of a univariate; $1 = argument, $2 = primal f, $3 = first derivative
+// ---------------------------------------------------------------------------------------------------
+struct UnSpec { const char *f, *df, *ddf; };
+// A leading '=' marks an exact literal (lets the reverse sweep fold it).
+const double kLog2 = 0.69314718055994530942, kLog10 = 2.30258509299404568402, kPi = 3.14159265358979323846;
+const double kD2R = kPi / 180.0, kR2D = 180.0 / kPi;
+
+const UnSpec *un_spec(int fn) {
+    static UnSpec T[EXA_U_COUNT];
+    static bool init = false;
+    if (!init) {
+        init = true;
+        T[EXA_U_PLUS] = {"$1", "=1", "=0"};
+        T[EXA_U_MINUS] = {"-$1", "=-1", "=0"};
+        T[EXA_U_INV] = {"1.0 / $1", "-($2 * $2)", "2.0 * $2 * $2 * $2"};
+        T[EXA_U_SQRT] = {"sqrt($1)", "0.5 / $2", "-0.25 / ($2 * $2 * $2)"};
+        T[EXA_U_CBRT] = {"cbrt($1)", "1.0 / (3.0 * $2 * $2)", "-2.0 / (9.0 * $2 * $2 * $2 * $2 * $2)"};
+        T[EXA_U_ABS] = {"fabs($1)", "(__builtin_signbit($1) ? -1.0 : 1.0)", "=0"};
+        T[EXA_U_ABS2] = {"$1 * $1", "2.0 * $1", "=2"};
+        T[EXA_U_SIGN] = {"exa_sign($1)", "=0", "=0"};
+        T[EXA_U_EXP] = {"exp($1)", "$2", "$2"};
+        T[EXA_U_EXP2] = {"exp2($1)", "EXA_LOG2 * $2", "EXA_LOG2 * EXA_LOG2 * $2"};
+        T[EXA_U_EXP10] = {"exp10($1)", "EXA_LOG10 * $2", "EXA_LOG10 * EXA_LOG10 * $2"};
+        T[EXA_U_EXPM1] = {"expm1($1)", "exp($1)", "$3"};
+        T[EXA_U_LOG] = {"log($1)", "1.0 / $1", "-($3 * $3)"};
+        T[EXA_U_LOG2] = {"log2($1)", "1.0 / (EXA_LOG2 * $1)", "-$3 / $1"};
+        T[EXA_U_LOG1P] = {"log1p($1)", "1.0 / (1.0 + $1)", "-($3 * $3)"};
+        T[EXA_U_LOG10] = {"log10($1)", "1.0 / (EXA_LOG10 * $1)", "-$3 / $1"};
+        T[EXA_U_SIN] = {nullptr, nullptr, nullptr};   // handled through sincos
+        T[EXA_U_COS] = {nullptr, nullptr, nullptr};
+        T[EXA_U_TAN] = {"tan($1)", "1.0 + $2 * $2", "2.0 * $3 * $2"};
+        T[EXA_U_ASIN] = {"asin($1)", "1.0 / sqrt(1.0 - $1 * $1)", "$1 * $3 / (1.0 - $1 * $1)"};
+        T[EXA_U_ACOS] = {"acos($1)", "-1.0 / sqrt(1.0 - $1 * $1)", "$1 * $3 / (1.0 - $1 * $1)"};
+        T[EXA_U_ATAN] = {"atan($1)", "1.0 / (1.0 + $1 * $1)", "-2.0 * $1 * $3 * $3"};
+        T[EXA_U_ACOT] = {"atan(1.0 / $1)", "-1.0 / (1.0 + $1 * $1)", "2.0 * $1 * $3 * $3"};
+        T[EXA_U_CSC] = {"1.0 / sin($1)", "-$2 / tan($1)", "(1.0 + 2.0 * exa_sq(1.0 / tan($1))) * $2"};
+        T[EXA_U_SEC] = {"1.0 / cos($1)", "$2 * tan($1)", "$2 * $2 * $2 + $2 * exa_sq(tan($1))"};
+        T[EXA_U_COT] = {"1.0 / tan($1)", "-1.0 - $2 * $2", "-2.0 * $2 * $3"};
+        T[EXA_U_SINH] = {"sinh($1)", "cosh($1)", "$2"};
+        T[EXA_U_COSH] = {"cosh($1)", "sinh($1)", "$2"};
+        T[EXA_U_TANH] = {"tanh($1)", "1.0 - $2 * $2", "-2.0 * $2 * $3"};
+        T[EXA_U_ASINH] = {"asinh($1)", "1.0 / sqrt(1.0 + $1 * $1)", "-$1 * $3 / (1.0 + $1 * $1)"};
+        T[EXA_U_ACOSH] = {"acosh($1)", "1.0 / sqrt($1 * $1 - 1.0)", "-$1 * $3 / ($1 * $1 - 1.0)"};
+        T[EXA_U_CSCH] = {"1.0 / sinh($1)", "-$2 / tanh($1)", "$2 * $2 * $2 + $2 * exa_sq(1.0 / tanh($1))"};
+        T[EXA_U_SECH] = {"1.0 / cosh($1)", "-tanh($1) * $2", "(2.0 * exa_sq(tanh($1)) - 1.0) * $2"};
+        T[EXA_U_COTH] = {"1.0 / tanh($1)", "-exa_sq(1.0 / sinh($1))", "-2.0 * $3 * $2"};
+        T[EXA_U_SIND] = {"exa_sind($1)", "EXA_D2R * exa_cosd($1)", "-(EXA_D2R * EXA_D2R) * $2"};
+        T[EXA_U_COSD] = {"exa_cosd($1)", "-EXA_D2R * exa_sind($1)", "-(EXA_D2R * EXA_D2R) * $2"};
+        T[EXA_U_TAND] = {"exa_tand($1)", "EXA_D2R * (1.0 + $2 * $2)", "2.0 * EXA_D2R * $2 * $3"};
+        T[EXA_U_CSCD] = {"1.0 / exa_sind($1)", "-EXA_D2R * $2 / exa_tand($1)", "(EXA_D2R * EXA_D2R) * $2 * (1.0 + 2.0 * exa_sq(1.0 / exa_tand($1)))"};
+        T[EXA_U_SECD] = {"1.0 / exa_cosd($1)", "EXA_D2R * exa_tand($1) * $2", "(EXA_D2R * EXA_D2R) * $2 * (1.0 + 2.0 * exa_sq(exa_tand($1)))"};
+        T[EXA_U_COTD] = {"1.0 / exa_tand($1)", "-EXA_D2R * (1.0 + $2 * $2)", "-2.0 * EXA_D2R * $2 * $3"};
+        T[EXA_U_ATAND] = {"EXA_R2D * atan($1)", "1.0 / (EXA_D2R * (1.0 + $1 * $1))", "-2.0 * EXA_D2R * $1 * $3 * $3"};
+        T[EXA_U_ACOTD] = {"EXA_R2D * atan(1.0 / $1)", "-1.0 / (EXA_D2R * (1.0 + $1 * $1))", "2.0 * EXA_D2R * $1 * $3 * $3"};
+        T[EXA_U_SINPI] = {"sinpi($1)", "EXA_PI * cospi($1)", "-(EXA_PI * EXA_PI) * $2"};
+        T[EXA_U_COSPI] = {"cospi($1)", "-EXA_PI * sinpi($1)", "-(EXA_PI * EXA_PI) * $2"};
+        T[EXA_U_SINC] = {"exa_sinc($1)",
+                         "(-sinpi($1) + EXA_PI * $1 * cospi($1)) / (EXA_PI * ($1 * $1))",
+                         "((2.0 * EXA_PI * EXA_PI) * sinpi($1) - (2.0 * EXA_PI * EXA_PI * EXA_PI) * $1 * cospi($1) - "
+                         "(EXA_PI * EXA_PI * EXA_PI * EXA_PI) * ($1 * $1) * sinpi($1)) / ((EXA_PI * EXA_PI * EXA_PI) * ($1 * $1 * $1))"};
+        T[EXA_U_DEG2RAD] = {"EXA_D2R * $1", "=D2R", "=0"};
+        T[EXA_U_RAD2DEG] = {"EXA_R2D * $1", "=R2D", "=0"};
+        T[EXA_U_SIGNBIT] = {"(__builtin_signbit($1) ? 1.0 : 0.0)", "=0", "=0"};
+        T[EXA_U_FLOOR] = {"floor($1)", "=0", "=0"};
+        T[EXA_U_CEIL] = {"ceil($1)", "=0", "=0"};
+        T[EXA_U_ATANH] = {"atanh($1)", "(fabs($1) > 1.0 ? __builtin_nan(\"\") : 1.0 / (1.0 - $1 * $1))",
+                          "(fabs($1) > 1.0 ? __builtin_nan(\"\") : 2.0 * $1 * exa_sq(1.0 / (1.0 - $1 * $1)))"};
+        T[EXA_U_ACOTH] = {"atanh(1.0 / $1)", "(fabs($1) < 1.0 ? __builtin_nan(\"\") : 1.0 / (1.0 - $1 * $1))",
+                          "(fabs($1) < 1.0 ? __builtin_nan(\"\") : 2.0 * $1 * exa_sq(1.0 / (1.0 - $1 * $1)))"};
+    }
+    return &T[fn];
+}
+
+double host_un(int fn, double x) {   // folding of literal arguments, primal only
+    switch (fn) {
+    case EXA_U_PLUS: return x; case EXA_U_MINUS: return -x; case EXA_U_ABS2: return x * x; case EXA_U_ABS: return std::fabs(x);
+    case EXA_U_INV: return 1.0 / x; case EXA_U_SQRT: return std::sqrt(x);
+    default: return NAN;
+    }
+}
+bool host_un_ok(int fn) {
+    return fn == EXA_U_PLUS || fn == EXA_U_MINUS || fn == EXA_U_ABS2 || fn == EXA_U_ABS || fn == EXA_U_INV || fn == EXA_U_SQRT;
+}
+
+struct Triple { Val x, y, h; };
+
+Val lit_or_tmpl(Emitter &e, const char *spec, Val u, Val f, Val d) {
+    if (spec[0] == '=') {
+        std::string v = spec + 1;
+        if (v == "D2R") return Emitter::litf(kD2R);
+        if (v == "R2D") return Emitter::litf(kR2D);
+        return Emitter::litf(atof(v.c_str()));
+    }
+    return e.call(spec, {u, f, d});
+}
+
+Triple un_rule(Emitter &e, int fn, Val u, int order) {
+    Triple r;
+    u = e.tod(u);
+    if (u.is_lit() && host_un_ok(fn) && order == 0) { r.x = Emitter::litf(host_un(fn, u.f)); return r; }
+    if (fn == EXA_U_SIN || fn == EXA_U_COS) {
+        if (order == 0) { r.x = e.call(fn == EXA_U_SIN ? "sin($1)" : "cos($1)", {u}); return r; }
+        // one sincos per argument serves value and both derivatives (functionlist.jl:22-23)
+        const std::string key = "sincos|" + e.s(u);
+        Val sv, cv;
+        auto it = e.memo.find(key);
+        if (it == e.memo.end()) {
+            sv.k = Val::SF; sv.id = e.next++;
+            cv.k = Val::SF; cv.id = e.next++;
+            e.lines.push_back("double t" + std::to_string(sv.id) + ", t" + std::to_string(cv.id) + "; sincos(" + e.s(u) + ", &t" +
+                              std::to_string(sv.id) + ", &t" + std::to_string(cv.id) + ");");
+            e.memo[key] = sv;
+            e.memo[key + "|c"] = cv;
+        } else { sv = it->second; cv = e.memo[key + "|c"]; }
+        if (fn == EXA_U_SIN) { r.x = sv; r.y = cv; r.h = e.neg(sv); }
+        else { r.x = cv; r.y = e.neg(sv); r.h = e.neg(cv); }
+        return r;
+    }
+    if (fn == EXA_U_MINUS) { r.x = e.neg(u); r.y = Emitter::litf(-1); r.h = Emitter::litf(0); return r; }
+    if (fn == EXA_U_PLUS) { r.x = u; r.y = Emitter::litf(1); r.h = Emitter::litf(0); return r; }
+    if (fn == EXA_U_ABS2) { r.x = e.mul(u, u); r.y = e.mul(Emitter::litf(2), u); r.h = Emitter::litf(2); return r; }
+    const UnSpec *sp = un_spec(fn);
+    if (!sp->f) fail("univariate function without rule");
+    r.x = e.call(sp->f, {u});
+    if (order >= 1) r.y = lit_or_tmpl(e, sp->df, u, r.x, r.x);
+    if (order >= 2) r.h = lit_or_tmpl(e, sp->ddf, u, r.x, r.y);
+    return r;
+}
+
+// x^n for a literal integer n by repeated multiplication (Base.^(::Float64, ::Integer); n==3 -> x*x*x)
+Val powi_lit(Emitter &e, Val x, int64_t n) {
+    x = e.tod(x);
+    if (n == 0) return Emitter::litf(1.0);
+    if (x.is_lit()) return Emitter::litf(std::pow(x.f, (double)n));
+    if (n < 0) { Val r = e.div(Emitter::litf(1.0), x); return powi_lit(e, r, -n); }
+    if (n == 1) return x;
+    if (n == 2) return e.mul(x, x);
+    if (n == 3) return e.mul(e.mul(x, x), x);
+    Val y; bool has = false;
+    Val b = x;
+    while (n > 1) {
+        if (n & 1) { y = has ? e.mul(y, b) : b; has = true; }
+        b = e.mul(b, b);
+        n >>= 1;
+    }
+    return has ? e.mul(b, y) : b;
+}
+
+// x1 ^ x2 where the exponent is a typed value
+Val pow_any(Emitter &e, Val x1, Val x2) {
+    if (x2.k == Val::LI) return powi_lit(e, x1, x2.i);
+    if (x2.k == Val::SI) return e.raw("exa_powi(" + e.sd(x1) + ", " + e.s(x2) + ")", false);
+    x1 = e.tod(x1);
+    if (x1.is_lit() && x2.is_lit()) return Emitter::litf(std::pow(x1.f, x2.f));
+    return e.call("pow($1, $2)", {x1, x2});
+}
+Val add_i(Emitter &e, Val v, int64_t k) { return e.add(v, v.is_int() ? Emitter::liti(k) : Emitter::litf((double)k)); }
+
+struct Six { Val x, y1, y2, h11, h12, h22; };
+
+// full bivariate rule (both operands differentiable), functionlist.jl:71-81
+Six bin_rule(Emitter &e, int fn, Val x1, Val x2, int order) {
+    Six r;
+    const Val Z = Emitter::litf(0), O = Emitter::litf(1);
+    r.h11 = r.h12 = r.h22 = Z;
+    switch (fn) {
+    case EXA_B_ADD: r.x = e.add(x1, x2); r.y1 = O; r.y2 = O; return r;
+    case EXA_B_SUB: r.x = e.sub(x1, x2); r.y1 = O; r.y2 = Emitter::litf(-1); return r;
+    case EXA_B_MUL: r.x = e.mul(x1, x2); r.y1 = e.tod(x2); r.y2 = e.tod(x1); r.h12 = O; return r;
+    case EXA_B_DIV: {
+        r.x = e.div(x1, x2);
+        if (order >= 1) {
+            Val inv = e.div(O, x2);
+            r.y1 = inv;
+            r.y2 = e.neg(e.mul(r.x, inv));                       // -x1/x2^2
+            if (order >= 2) {
+                r.h12 = e.neg(e.mul(inv, inv));                  // -1/x2^2
+                r.h22 = e.mul(Emitter::litf(-2), e.mul(r.y2, inv));   // 2 x1 / x2^3
+            }
+        }
+        return r;
+    }
+    case EXA_B_POW: {
+        r.x = pow_any(e, x1, x2);
+        if (order >= 1) {
+            Val pm1 = pow_any(e, x1, add_i(e, x2, -1));
+            Val lg = e.call("log($1)", {x1});
+            r.y1 = e.mul(x2, pm1);
+            r.y2 = e.mul(lg, r.x);
+            if (order >= 2) {
+                r.h11 = e.mul(e.mul(add_i(e, x2, -1), x2), pow_any(e, x1, add_i(e, x2, -2)));
+                r.h12 = e.add(pm1, e.mul(e.mul(x2, pm1), lg));
+                r.h22 = e.mul(e.mul(lg, lg), r.x);
+            }
+        }
+        return r;
+    }
+    case EXA_B_ATAN2: {
+        r.x = e.call("atan2($1, $2)", {x1, x2});
+        if (order >= 1) {
+            Val d = e.add(e.sq(x1), e.sq(x2));
+            r.y1 = e.div(x2, d);
+            r.y2 = e.div(e.neg(x1), d);
+            if (order >= 2) {
+                Val d2 = e.sq(d);
+                r.h11 = e.div(e.mul(e.mul(Emitter::litf(-2), x1), x2), d2);
+                r.h12 = e.div(e.sub(e.sq(x1), e.sq(x2)), d2);     // x1^4 + 2x1^2x2^2 + x2^4 == (x1^2+x2^2)^2
+                r.h22 = e.div(e.mul(e.mul(Emitter::litf(2), x1), x2), d2);
+            }
+        }
+        return r;
+    }
+    case EXA_B_HYPOT: {
+        r.x = e.call("hypot($1, $2)", {x1, x2});
+        if (order >= 1) {
+            r.y1 = e.div(x1, r.x);
+            r.y2 = e.div(x2, r.x);
+            if (order >= 2) {
+                Val h3 = e.mul(e.sq(r.x), r.x);
+                r.h11 = e.div(e.sub(e.sq(r.x), e.sq(x1)), h3);
+                r.h12 = e.div(e.neg(e.mul(x1, x2)), h3);
+                r.h22 = e.div(e.sub(e.sq(r.x), e.sq(x2)), h3);
+            }
+        }
+        return r;
+    }
+    case EXA_B_MAX:
+        r.x = e.call("(($1 > $2 || $1 != $1) ? $1 : $2)", {x1, x2});
+        r.y1 = e.call("($1 > $2 ? 1.0 : 0.0)", {x1, x2});
+        r.y2 = e.call("($1 > $2 ? 0.0 : 1.0)", {x1, x2});
+        return r;
+    case EXA_B_MIN:
+        r.x = e.call("(($1 < $2 || $1 != $1) ? $1 : $2)", {x1, x2});
+        r.y1 = e.call("($1 < $2 ? 1.0 : 0.0)", {x1, x2});
+        r.y2 = e.call("($1 < $2 ? 0.0 : 1.0)", {x1, x2});
+        return r;
+    }
+    fail("unknown bivariate function");
+}
+
+// one operand constant: SecondFixed (constant is 2nd: uses d1, d11) / FirstFixed (constant is 1st: d2, d22)
+Triple fixed_rule(Emitter &e, int fn, int fixed, Val v, Val c, int order) {
+    Triple r;
+    const Val Z = Emitter::litf(0), O = Emitter::litf(1);
+    const bool second = fixed == FX_SECOND;   // v OP c
+    switch (fn) {
+    case EXA_B_ADD: r.x = second ? e.add(v, c) : e.add(c, v); r.y = O; r.h = Z; return r;
+    case EXA_B_SUB:
+        r.x = second ? e.sub(v, c) : e.sub(c, v);
+        r.y = second ? O : Emitter::litf(-1); r.h = Z; return r;
+    case EXA_B_MUL: r.x = second ? e.mul(v, c) : e.mul(c, v); r.y = e.tod(c); r.h = Z; return r;
+    case EXA_B_DIV:
+        if (second) {     // v / c
+            r.x = e.div(v, c);
+            r.y = e.div(O, c); r.h = Z;
+        } else {          // c / v : d2 = -c/v^2, d22 = 2c/v^3
+            r.x = e.div(c, v);
+            if (order >= 1) {
+                Val inv = e.div(O, v);
+                r.y = e.neg(e.mul(r.x, inv));
+                if (order >= 2) r.h = e.mul(Emitter::litf(-2), e.mul(r.y, inv));
+            }
+        }
+        return r;
+    case EXA_B_POW:
+        if (second) {     // v ^ c
+            r.x = pow_any(e, v, c);
+            if (order >= 1) r.y = e.mul(c, pow_any(e, v, add_i(e, c, -1)));
+            if (order >= 2) r.h = e.mul(e.mul(add_i(e, c, -1), c), pow_any(e, v, add_i(e, c, -2)));
+        } else {          // c ^ v
+            r.x = pow_any(e, c, e.tod(v));
+            if (order >= 1) { Val lg = e.call("log($1)", {c}); r.y = e.mul(lg, r.x); if (order >= 2) r.h = e.mul(e.mul(lg, lg), r.x); }
+        }
+        return r;
+    default: {
+        Six s = second ? bin_rule(e, fn, v, e.tod(c), order) : bin_rule(e, fn, e.tod(c), v, order);
+        r.x = s.x;
+        r.y = second ? s.y1 : s.y2;
+        r.h = second ? s.h11 : s.h22;
+        return r;
+    }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-pattern body generator
+// ---------------------------------------------------------------------------------------------------
+struct FV { Val x, y1, y2, h11, h12, h22, vidx; };
+
+struct Body {
+    const Model &m;
+    const Pattern &p;
+    int pi;
+    const ParamLayout &L;
+    Emitter e;
+    std::vector<FV> fv;
+    std::map<int, Val> cmemo;   // IR node -> value of constant subtree
+
+    Body(const Model &mm, int pidx, const ParamLayout &ll) : m(mm), p(mm.pats[pidx]), pi(pidx), L(ll) { fv.resize(p.ad.size()); }
+
+    std::string P(int w) const { return "P[" + std::to_string(w) + "]"; }
+
+    Val column(int c) {
+        const Column &col = p.cols[c];
+        const int w = L.pat[pi].col[c];
+        if (col.type == EXA_COL_RANGE) {
+            if (col.step == 1) return e.raw(P(w) + " + I", true);
+            return e.raw(P(w) + " + " + std::to_string(col.step) + "L * I", true);
+        }
+        if (col.type == EXA_COL_I64) return e.raw("((const long*)" + P(w) + ")[I]", true);
+        return e.raw("((const double*)" + P(w) + ")[I]", false);
+    }
+
+    // value of a Real (non-differentiable) subtree: primal evaluation, Int kept apart from Float64
+    Val cval(int k) {
+        auto it = cmemo.find(k);
+        if (it != cmemo.end()) return it->second;
+        const exa_node_t &nd = p.nodes[k];
+        Val r;
+        switch (nd.op) {
+        case EXA_OP_CONST_F: r = Emitter::litf(nd.fval); break;
+        case EXA_OP_CONST_I: r = Emitter::liti(nd.ival); break;
+        case EXA_OP_NULLV: r = Emitter::litf(nd.fval); break;
+        case EXA_OP_DATA: r = column(nd.a); break;
+        case EXA_OP_PAR: {
+            Val i = cval(nd.a);
+            if (!i.is_int()) fail("parameter index expression is not integer-typed");
+            r = e.raw("th[" + e.s(e.sub(i, Emitter::liti(1))) + "]", false);
+            break;
+        }
+        case EXA_OP_VAR: r = var_load(cval(nd.a)); break;   // primal-only contexts (obj/cons)
+        case EXA_OP_UN: {
+            Val a = cval(nd.a);
+            if (a.is_int() && (nd.fn == EXA_U_PLUS || nd.fn == EXA_U_MINUS || nd.fn == EXA_U_ABS || nd.fn == EXA_U_ABS2)) {
+                if (nd.fn == EXA_U_PLUS) r = a;
+                else if (nd.fn == EXA_U_MINUS) r = e.neg(a);
+                else if (nd.fn == EXA_U_ABS2) r = e.mul(a, a);
+                else r = a.is_lit() ? Emitter::liti(a.i < 0 ? -a.i : a.i) : e.raw("(" + e.s(a) + " < 0 ? -" + e.s(a) + " : " + e.s(a) + ")", true);
+            } else r = un_rule(e, nd.fn, a, 0).x;
+            break;
+        }
+        case EXA_OP_BIN: {
+            Val a = cval(nd.a), b = cval(nd.b);
+            if (a.is_int() && b.is_int() && (nd.fn == EXA_B_ADD || nd.fn == EXA_B_SUB || nd.fn == EXA_B_MUL)) {
+                r = e.bin(nd.fn == EXA_B_ADD ? '+' : nd.fn == EXA_B_SUB ? '-' : '*', a, b);
+            } else if (a.is_int() && b.is_int() && (nd.fn == EXA_B_MAX || nd.fn == EXA_B_MIN)) {
+                const char *op = nd.fn == EXA_B_MAX ? ">" : "<";
+                r = e.raw("(" + e.s(a) + " " + op + " " + e.s(b) + " ? " + e.s(a) + " : " + e.s(b) + ")", true);
+            } else if (nd.fn == EXA_B_POW) {
+                r = pow_any(e, a, b);
+            } else {
+                r = bin_rule(e, nd.fn, e.tod(a), e.tod(b), 0).x;
+            }
+            break;
+        }
+        default: fail("bad opcode");
+        }
+        cmemo[k] = r;
+        return r;
+    }
+
+    Val var_load(Val idx) {
+        if (!idx.is_int()) fail("variable index expression is not integer-typed");
+        return e.raw("x[" + e.s(e.sub(idx, Emitter::liti(1))) + "]", false);
+    }
+
+    // forward sweep over the AD tree (register.jl:65-68, 209-266); `structure` => indices only
+    void forward(int n, int order, bool structure) {
+        const ADNode &t = p.ad[n];
+        FV &v = fv[n];
+        switch (t.kind) {
+        case AD_NULL: v.x = Emitter::litf(p.nodes[t.ir].fval); return;
+        case AD_CONST: if (!structure) v.x = cval(t.ir); return;
+        case AD_VAR:
+            v.vidx = cval(t.ir);
+            if (!structure) v.x = var_load(v.vidx);
+            return;
+        case AD_UN: {
+            forward(t.l, order, structure);
+            if (structure) return;
+            Triple r = (t.fixed == FX_NONE) ? un_rule(e, t.fn, fv[t.l].x, order) : fixed_rule(e, t.fn, t.fixed, fv[t.l].x, cval(t.cir), order);
+            v.x = r.x; v.y1 = r.y; v.h11 = r.h;
+            return;
+        }
+        case AD_BIN: {
+            forward(t.l, order, structure);
+            forward(t.r, order, structure);
+            if (structure) return;
+            Six r = bin_rule(e, t.fn, fv[t.l].x, fv[t.r].x, order);
+            v.x = r.x; v.y1 = r.y1; v.y2 = r.y2; v.h11 = r.h11; v.h12 = r.h12; v.h22 = r.h22;
+            return;
+        }
+        }
+    }
+
+    // 0-based row of this data point: offset0 (nlp.jl:1980-2001)
+    std::string row0() {
+        const int w = L.pat[pi].o0;
+        if (p.kind == EXA_PAT_CONAUG) {
+            Val t = cval(p.target);
+            return P(w) + " + " + e.s(e.sub(t, Emitter::liti(1)));
+        }
+        return P(w) + " + I";
+    }
+};
+
+// symbolic algebra for the reverse sweeps
+struct GenAlg {
+    using T = Val;
+    Body &b;
+    const std::vector<int> &comp;
+    int cnt = 0;
+    std::vector<Val> acc;
+    std::vector<char> has;
+    GenAlg(Body &bb, const std::vector<int> &c, int nslots) : b(bb), comp(c), acc(nslots), has(nslots, 0) {}
+    T y1(int n) { return b.fv[n].y1; }
+    T y2(int n) { return b.fv[n].y2; }
+    T h11(int n) { return b.fv[n].h11; }
+    T h12(int n) { return b.fv[n].h12; }
+    T h22(int n) { return b.fv[n].h22; }
+    T mul(T x, T y) { return b.e.mul(x, y); }
+    T add(T x, T y) { return b.e.add(x, y); }
+    T neg(T x) { return b.e.neg(x); }
+    void put(T v) {
+        const int s = comp[cnt++] - 1;
+        v = b.e.tod(v);
+        if (!has[s]) { acc[s] = v; has[s] = 1; }
+        else acc[s] = b.e.add(acc[s], v);
+    }
+    void leaf1(int, T adj) { put(adj); }
+    void leaf2(int n1, int n2, T val, bool cross) {
+        if (cross) {
+            // hessian.jl:251-268: i == j ? 2adj : adj, compared on run-time indices
+            if (b.p.ad[n1].key == b.p.ad[n2].key) val = b.e.mul(Emitter::litf(2), val);
+            else if (!val.lit_eq(0)) {
+                Val i = b.fv[n1].vidx, j = b.fv[n2].vidx;
+                if (i.is_lit() && j.is_lit()) { if (i.i == j.i) val = b.e.mul(Emitter::litf(2), val); }
+                else val = b.e.raw("(" + b.e.s(i) + " == " + b.e.s(j) + " ? 2.0 * " + b.e.sd(val) + " : " + b.e.sd(val) + ")", false);
+            }
+        }
+        put(val);
+    }
+};
+
+void emit_lines(std::ostringstream &os, const Emitter &e, const char *indent = "    ") {
+    for (const auto &l : e.lines) os << indent << l << "\n";
+}
+
+const char *kPrelude = R"HIP(// Generated by libexahip (examodels.jl_amd/csrc/exa_codegen.cpp) for gfx950.  Do not edit.
+#include <hip/hip_runtime.h>
+#define EXA_LOG2 0.69314718055994530942
+#define EXA_LOG10 2.30258509299404568402
+#define EXA_PI 3.14159265358979323846
+#define EXA_D2R (EXA_PI / 180.0)
+#define EXA_R2D (180.0 / EXA_PI)
+#define EXA_BLOCK 256
+static __device__ __forceinline__ double exa_sq(double x) { return x * x; }
+static __device__ __forceinline__ double exa_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : x); }
+static __device__ __forceinline__ double exa_sind(double x) { return sin(EXA_D2R * fmod(x, 360.0)); }
+static __device__ __forceinline__ double exa_cosd(double x) { return cos(EXA_D2R * fmod(x, 360.0)); }
+static __device__ __forceinline__ double exa_tand(double x) { return tan(EXA_D2R * fmod(x, 180.0)); }
+static __device__ __forceinline__ double exa_sinc(double x) { return x == 0.0 ? 1.0 : sinpi(x) / (EXA_PI * x); }
+// x^n, run-time integer n (Base.^(::Float64, ::Integer)): by squaring; n < 0 through the reciprocal
+static __device__ double exa_powi(double x, long n) {
+    if (n == 0) return 1.0;
+    if (n < 0) { x = 1.0 / x; n = -n; }
+    double y = 1.0;
+    while (n > 1) { if (n & 1) y *= x; x *= x; n >>= 1; }
+    return x * y;
+}
+// sum over the 256-thread workgroup: 64-lane wavefront butterflies, then 4 partials through LDS
+static __device__ __forceinline__ double exa_block_sum(double v) {
+    __shared__ double red[EXA_BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (threadIdx.x == 0) { for (int w = 0; w < EXA_BLOCK / 64; w++) s += red[w]; }
+    return s;
+}
+// second stage of obj: one workgroup folds the per-workgroup partial sums in a fixed order (deterministic)
+extern "C" __global__ void __launch_bounds__(1024) exa_reduce_partials(const double* __restrict__ part, long n, double* __restrict__ out) {
+    __shared__ double red[16];
+    double v = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) v += part[i];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { double s = 0.0; for (int w = 0; w < 16; w++) s += red[w]; out[0] = s; }
+}
+)HIP";
+
+std::string fn_name(int pi, const char *cb) { return "p" + std::to_string(pi) + "_" + cb; }
+
+// ---- per-pattern device functions -----------------------------------------------------------------
+void gen_value_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
+    Body b(m, pi, L);
+    Val v = b.e.tod(b.cval(b.p.root));
+    os << "static __device__ __forceinline__ double " << fn_name(pi, "val")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, long I) {\n";
+    emit_lines(os, b.e);
+    os << "    return " << b.e.s(v) << ";\n}\n";
+}
+
+void gen_cons_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
+    Body b(m, pi, L);
+    const std::string row = b.row0();
+    os << "static __device__ __forceinline__ void " << fn_name(pi, "cons")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ c, long tid) {\n"
+       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n"
+       << "    const double v = " << fn_name(pi, "val") << "(P, x, th, I);\n";
+    emit_lines(os, b.e);
+    if (b.p.kind == EXA_PAT_CONAUG) os << "    unsafeAtomicAdd(&c[" << row << "], v);\n";
+    else os << "    c[" << row << "] = v;\n";
+    os << "}\n";
+}
+
+void gen_first_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L, bool grad) {
+    Body b(m, pi, L);
+    const Pattern &p = b.p;
+    b.forward(p.ad_root, 1, false);
+    GenAlg a(b, p.comp1, p.o1step);
+    grpass(p, p.ad_root, a, Emitter::litf(1.0));
+    os << "static __device__ __forceinline__ void " << fn_name(pi, grad ? "grad" : "jac")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ out, long tid) {\n"
+       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
+    // stores are emitted after the body; index texts are computed first so that they land in e.lines
+    std::vector<std::string> stores;
+    for (int s = 0; s < p.o1step; s++) {
+        if (grad) {
+            if (a.acc[s].lit_eq(0)) continue;
+            Val vi = b.fv[p.slotvar1[s]].vidx;
+            stores.push_back("unsafeAtomicAdd(&out[" + b.e.s(b.e.sub(vi, Emitter::liti(1))) + "], " + b.e.sd(a.acc[s]) + ");");
+        } else {
+            stores.push_back("out[o + " + std::to_string(s) + "] = " + b.e.sd(a.acc[s]) + ";");
+        }
+    }
+    emit_lines(os, b.e);
+    if (!grad) os << "    const long o = " << b.P(L.pat[pi].o1) << " + " << p.o1step << "L * I;\n";
+    for (auto &s : stores) os << "    " << s << "\n";
+    os << "}\n";
+}
+
+void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
+    Body b(m, pi, L);
+    const Pattern &p = b.p;
+    b.forward(p.ad_root, 2, false);
+    Val adj;
+    if (p.kind == EXA_PAT_OBJ) adj = b.e.raw("sigma", false);
+    else adj = b.e.raw("y[" + b.row0() + "]", false);
+    GenAlg a(b, p.comp2, p.o2step);
+    hrpass0(p, p.ad_root, a, adj, Emitter::litf(0.0));
+    os << "static __device__ __forceinline__ void " << fn_name(pi, "hess")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
+          "double* __restrict__ out, double sigma, long tid) {\n"
+       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
+    emit_lines(os, b.e);
+    os << "    const long o = " << b.P(L.pat[pi].o2) << " + " << p.o2step << "L * I;\n";
+    for (int s = 0; s < p.o2step; s++) os << "    out[o + " << s << "] = " << b.e.sd(a.acc[s]) << ";\n";
+    os << "}\n";
+}
+
+void gen_struct_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L, bool hess) {
+    Body b(m, pi, L);
+    const Pattern &p = b.p;
+    b.forward(p.ad_root, 0, true);
+    std::vector<std::string> stores;
+    if (hess) {
+        for (int s = 0; s < p.o2step; s++) {
+            Val i = b.fv[p.slotvar2[s].first].vidx, j = b.fv[p.slotvar2[s].second].vidx;
+            const std::string si = b.e.s(i), sj = b.e.s(j);
+            // lower triangle: (max, min) (hessian.jl:622-642)
+            stores.push_back("rows[o + " + std::to_string(s) + "] = (IT)(" + si + " >= " + sj + " ? " + si + " : " + sj + "); cols[o + " +
+                             std::to_string(s) + "] = (IT)(" + si + " >= " + sj + " ? " + sj + " : " + si + ");");
+        }
+    } else {
+        const std::string row = b.row0();
+        for (int s = 0; s < p.o1step; s++) {
+            Val i = b.fv[p.slotvar1[s]].vidx;
+            stores.push_back("rows[o + " + std::to_string(s) + "] = (IT)(" + row + " + 1); cols[o + " + std::to_string(s) + "] = (IT)(" + b.e.s(i) + ");");
+        }
+    }
+    os << "template <typename IT> static __device__ __forceinline__ void " << fn_name(pi, hess ? "hst" : "jst")
+       << "(const long* __restrict__ P, IT* __restrict__ rows, IT* __restrict__ cols, long tid) {\n"
+       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
+    emit_lines(os, b.e);
+    os << "    const long o = " << b.P(hess ? L.pat[pi].o2 : L.pat[pi].o1) << " + " << (hess ? p.o2step : p.o1step) << "L * I;\n";
+    for (auto &s : stores) os << "    " << s << "\n";
+    os << "}\n";
+}
+
+// ---- fused kernels: blockIdx -> (pattern, tile) ------------------------------------------------------
+void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const std::string &call_prefix, const std::string &call_args) {
+    const auto &act = L.active[cb];
+    os << "    const long b = blockIdx.x;\n";
+    for (size_t k = 0; k < act.size(); k++) {
+        const std::string end = "P[" + std::to_string(L.blk[cb] + (int)k) + "]";
+        const std::string beg = k == 0 ? "0L" : "P[" + std::to_string(L.blk[cb] + (int)k - 1) + "]";
+        os << "    " << (k ? "else " : "") << "if (b < " << end << ") { const long tid = (b - " << beg << ") * EXA_BLOCK + threadIdx.x; "
+           << "p" << act[k] << "_" << call_prefix << "(" << call_args << ", tid); }\n";
+    }
+}
+
+}  // namespace
+
+Generated generate_module(const Model &m) {
+    Generated g;
+    ParamLayout &L = g.layout;
+    const int np = (int)m.pats.size();
+    int w = 0;
+    L.pat.resize(np);
+    for (int k = 0; k < np; k++) {
+        auto &pp = L.pat[k];
+        pp.lo = w++; pp.hi = w++; pp.o0 = w++; pp.o1 = w++; pp.o2 = w++;
+        for (size_t c = 0; c < m.pats[k].cols.size(); c++) pp.col.push_back(w++);
+    }
+    for (int k = 0; k < np; k++) {
+        const Pattern &p = m.pats[k];
+        if (p.n == 0) continue;
+        if (p.kind == EXA_PAT_OBJ) {
+            L.active[CB_OBJ].push_back(k);
+            if (p.o1step > 0) L.active[CB_GRAD].push_back(k);
+        } else {
+            if (p.kind == EXA_PAT_CON) L.active[CB_CONS].push_back(k);
+            else L.active[CB_CONSAUG].push_back(k);
+            if (p.o1step > 0) { L.active[CB_JAC].push_back(k); L.active[CB_JSTRUCT].push_back(k); }
+        }
+        if (p.o2step > 0) { L.active[CB_HESS].push_back(k); L.active[CB_HSTRUCT].push_back(k); }
+    }
+    for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w; w += (int)L.active[cb].size(); }
+    L.nwords = w;
+
+    std::ostringstream os;
+    os << kPrelude;
+    os << "// patterns=" << np << " (sizes, offsets and column pointers are run-time parameters in P[])\n";
+    for (int k = 0; k < np; k++) {
+        const Pattern &p = m.pats[k];
+        if (p.n == 0) continue;
+        os << "// ---- pattern " << k << ": kind=" << p.kind << " o1step=" << p.o1step << " o2step=" << p.o2step << " ----\n";
+        gen_value_fn(os, m, k, L);
+        if (p.kind == EXA_PAT_OBJ) { if (p.o1step > 0) gen_first_fn(os, m, k, L, true); }
+        else {
+            gen_cons_fn(os, m, k, L);
+            if (p.o1step > 0) { gen_first_fn(os, m, k, L, false); gen_struct_fn(os, m, k, L, false); }
+        }
+        if (p.o2step > 0) { gen_hess_fn(os, m, k, L); gen_struct_fn(os, m, k, L, true); }
+    }
+    // obj: per-workgroup partial sums
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_obj(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ th, double* __restrict__ part) {\n    const long b = blockIdx.x;\n    double v = 0.0;\n";
+    {
+        const auto &act = L.active[CB_OBJ];
+        for (size_t k = 0; k < act.size(); k++) {
+            const std::string end = "P[" + std::to_string(L.blk[CB_OBJ] + (int)k) + "]";
+            const std::string beg = k == 0 ? "0L" : "P[" + std::to_string(L.blk[CB_OBJ] + (int)k - 1) + "]";
+            const auto &pp = L.pat[act[k]];
+            os << "    " << (k ? "else " : "") << "if (b < " << end << ") { const long I = P[" << pp.lo << "] + (b - " << beg
+               << ") * EXA_BLOCK + threadIdx.x; if (I < P[" << pp.hi << "]) v = p" << act[k] << "_val(P, x, th, I); }\n";
+        }
+    }
+    os << "    const double s = exa_block_sum(v);\n    if (threadIdx.x == 0) part[b] = s;\n}\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_grad(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ th, double* __restrict__ out) {\n";
+    gen_dispatch(os, L, CB_GRAD, "grad", "P, x, th, out");
+    os << "}\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_cons(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ th, double* __restrict__ out) {\n";
+    gen_dispatch(os, L, CB_CONS, "cons", "P, x, th, out");
+    os << "}\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_consaug(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ th, double* __restrict__ out) {\n";
+    gen_dispatch(os, L, CB_CONSAUG, "cons", "P, x, th, out");
+    os << "}\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jac(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ th, double* __restrict__ out) {\n";
+    gen_dispatch(os, L, CB_JAC, "jac", "P, x, th, out");
+    os << "}\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hess(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma) {\n";
+    gen_dispatch(os, L, CB_HESS, "hess", "P, x, y, th, out, sigma");
+    os << "}\n";
+    for (int wide = 0; wide < 2; wide++) {
+        const char *it = wide ? "long" : "int";
+        const char *sfx = wide ? "64" : "32";
+        os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jstruct" << sfx << "(const long* __restrict__ P, " << it
+           << "* __restrict__ rows, " << it << "* __restrict__ cols) {\n";
+        gen_dispatch(os, L, CB_JSTRUCT, std::string("jst<") + it + ">", "P, rows, cols");
+        os << "}\n";
+        os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hstruct" << sfx << "(const long* __restrict__ P, " << it
+           << "* __restrict__ rows, " << it << "* __restrict__ cols) {\n";
+        gen_dispatch(os, L, CB_HSTRUCT, std::string("hst<") + it + ">", "P, rows, cols");
+        os << "}\n";
+    }
+    g.source = os.str();
+    return g;
+}
+
+}  // namespace exa

@@ -1,0 +1,93 @@
+// exa_internal.hpp — shared declarations of libexahip.so (planner, HIP code generator, runtime).
+#pragma once
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/exahip.h"
+
+namespace exa {
+
+// ---------------------------------------------------------------------------------------------------
+// Deep copy of the wire model (include/exahip_ir.h)
+// ---------------------------------------------------------------------------------------------------
+struct Column {
+    int type = EXA_COL_RANGE;
+    std::vector<int64_t> idata;
+    std::vector<double> fdata;
+    int64_t start = 0, step = 0;
+};
+
+// One node of the per-pattern AD tree: what the reference builds with its adjoint node types
+// (src/graph.jl:337-494) when the pattern's tree is called on an AdjointNodeSource.
+enum ADKind { AD_CONST = 0, AD_VAR = 1, AD_UN = 2, AD_BIN = 3, AD_NULL = 4 };
+enum Fixed { FX_NONE = 0, FX_FIRST = 1, FX_SECOND = 2 };   // FirstFixed / SecondFixed (register.jl:231-266)
+
+struct ADNode {
+    int kind = AD_CONST;
+    int fn = 0;
+    int fixed = FX_NONE;
+    int ir = -1;     // AD_CONST: IR root of the Real subtree; AD_VAR: IR root of the index expression; else own IR id
+    int cir = -1;    // fixed binary: IR root of the constant operand
+    int key = -1;    // AD_VAR: id of the structural key of its index expression
+    int l = -1, r = -1;
+};
+
+struct Pattern {
+    int kind = EXA_PAT_OBJ;
+    std::vector<exa_node_t> nodes;
+    int root = -1, target = -1, base = -1;
+    std::vector<Column> cols;
+    int64_t n = 0;
+    // ---- plan ----
+    std::vector<char> isconst;      // per IR node
+    std::vector<char> isint;        // per IR node: statically Int-typed
+    std::vector<ADNode> ad;         // AD tree, ad_root is its root
+    int ad_root = -1;
+    std::vector<std::string> keys;  // structural keys of VAR index expressions
+    std::vector<int> comp1, comp2;  // 1-based slot maps (Compressor, simdfunction.jl:11-14)
+    std::vector<int> slotvar1;                      // per 1st-order slot: AD leaf (any visit) that defines its variable
+    std::vector<std::pair<int, int>> slotvar2;      // per 2nd-order slot: ordered pair of AD leaves
+    int o1step = 0, o2step = 0;
+    int64_t o0 = 0, o1 = 0, o2 = 0;
+};
+
+struct Model {
+    int64_t nvar = 0, npar = 0, ncon = 0, nnzj = 0, nnzh = 0, nnzg = 0, nobj = 0, nconaug = 0;
+    int minimize = 1;
+    std::vector<Pattern> pats;
+    std::vector<double> x0, lvar, uvar, theta, y0, lcon, ucon;
+};
+
+// Planner (exa_plan.cpp): copies the description, builds AD trees, slot maps and running offsets.
+std::unique_ptr<Model> plan_model(const exa_model_desc_t *desc);   // throws std::runtime_error
+
+// ---------------------------------------------------------------------------------------------------
+// Code generator (exa_codegen.cpp)
+// ---------------------------------------------------------------------------------------------------
+enum Callback { CB_OBJ = 0, CB_GRAD, CB_CONS, CB_CONSAUG, CB_JAC, CB_HESS, CB_JSTRUCT, CB_HSTRUCT, CB_COUNT };
+
+struct ParamLayout {
+    // word indices into the int64 parameter table P that every kernel receives
+    struct Pat {
+        int lo = -1, hi = -1, o0 = -1, o1 = -1, o2 = -1;
+        std::vector<int> col;   // per column: device pointer (I64/F64) or range start (RANGE)
+    };
+    std::vector<Pat> pat;
+    std::vector<int> active[CB_COUNT];   // patterns handled by each callback, in dispatch order
+    int blk[CB_COUNT];                   // first word of the cumulative block-end list of each callback
+    int nwords = 0;
+};
+
+struct Generated {
+    std::string source;
+    ParamLayout layout;
+};
+
+constexpr int kBlock = 256;   // threads per workgroup = 4 wavefronts of 64
+
+Generated generate_module(const Model &m);
+
+}  // namespace exa

@@ -1,0 +1,242 @@
+// exa_plan.cpp — layout planner: from the pattern table to AD trees, slot maps and running offsets.
+//
+// Replaces the build-time half of src/simdfunction.jl:78-100 (sparsity probe with NaN inputs -> raw1/raw2 ->
+// identity-dedup -> Compressor tuples, o1step/o2step) and the counter bookkeeping of src/nlp.jl:1474-1482
+// (_add_obj), :1597-1611 (_add_con), :1730-1738 (_add_con!).  Instead of probing with NaNs it classifies every
+// IR subtree statically (constant for AD <=> contains no VAR) and replays the traversal order symbolically.
+#include <cmath>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+
+#include "exa_internal.hpp"
+#include "exa_traverse.hpp"
+
+namespace exa {
+
+namespace {
+
+[[noreturn]] void fail(const std::string &msg) { throw std::runtime_error(msg); }
+
+void check_pattern(const Pattern &p, int pi) {
+    const int n = (int)p.nodes.size();
+    auto bad = [&](const char *what, int k) {
+        std::ostringstream os;
+        os << "pattern " << pi << ": " << what << " at node " << k;
+        fail(os.str());
+    };
+    if (p.root < 0 || p.root >= n) bad("root out of range", p.root);
+    for (int k = 0; k < n; k++) {
+        const exa_node_t &nd = p.nodes[k];
+        switch (nd.op) {
+        case EXA_OP_CONST_F: case EXA_OP_CONST_I: case EXA_OP_NULLV: break;
+        case EXA_OP_DATA:
+            if (nd.a < 0 || nd.a >= (int)p.cols.size()) bad("column id out of range", k);
+            break;
+        case EXA_OP_PAR: case EXA_OP_VAR: case EXA_OP_UN:
+            if (nd.a < 0 || nd.a >= k) bad("child must precede parent", k);
+            if (nd.op == EXA_OP_UN && (nd.fn < 0 || nd.fn >= EXA_U_COUNT)) bad("unknown univariate function", k);
+            break;
+        case EXA_OP_BIN:
+            if (nd.a < 0 || nd.a >= k || nd.b < 0 || nd.b >= k) bad("child must precede parent", k);
+            if (nd.fn < 0 || nd.fn >= EXA_B_COUNT) bad("unknown bivariate function", k);
+            break;
+        default: bad("unknown opcode", k);
+        }
+    }
+}
+
+// static classification: constant-for-AD, and Int-typed (Julia keeps Int and Float64 apart until promotion)
+void classify(Pattern &p) {
+    const int n = (int)p.nodes.size();
+    p.isconst.assign(n, 1);
+    p.isint.assign(n, 0);
+    for (int k = 0; k < n; k++) {
+        const exa_node_t &nd = p.nodes[k];
+        switch (nd.op) {
+        case EXA_OP_CONST_I: p.isint[k] = 1; break;
+        case EXA_OP_DATA: p.isint[k] = p.cols[nd.a].type != EXA_COL_F64; break;
+        case EXA_OP_VAR: p.isconst[k] = 0; break;
+        case EXA_OP_UN:
+            p.isconst[k] = p.isconst[nd.a];
+            p.isint[k] = p.isint[nd.a] && (nd.fn == EXA_U_PLUS || nd.fn == EXA_U_MINUS || nd.fn == EXA_U_ABS || nd.fn == EXA_U_ABS2);
+            break;
+        case EXA_OP_BIN:
+            p.isconst[k] = p.isconst[nd.a] && p.isconst[nd.b];
+            p.isint[k] = p.isint[nd.a] && p.isint[nd.b] &&
+                         (nd.fn == EXA_B_ADD || nd.fn == EXA_B_SUB || nd.fn == EXA_B_MUL || nd.fn == EXA_B_MAX || nd.fn == EXA_B_MIN);
+            break;
+        default: break;
+        }
+    }
+}
+
+// canonical text of an index expression: two VAR leaves are the same Jacobian/Hessian key iff their index
+// trees are structurally identical (`===` on immutable node structs, simdfunction.jl:63-76)
+void key_text(const Pattern &p, int k, std::ostringstream &os) {
+    const exa_node_t &nd = p.nodes[k];
+    switch (nd.op) {
+    case EXA_OP_CONST_I: os << 'i' << nd.ival; return;
+    case EXA_OP_CONST_F: { uint64_t b; std::memcpy(&b, &nd.fval, 8); os << 'f' << std::hex << b << std::dec; return; }
+    case EXA_OP_DATA: os << 'd' << nd.a; return;
+    default: break;
+    }
+    os << '(' << nd.op << '.' << nd.fn << ' ';
+    key_text(p, nd.a, os);
+    if (nd.op == EXA_OP_BIN) { os << ' '; key_text(p, nd.b, os); }
+    os << ')';
+}
+
+int key_id(Pattern &p, int k) {
+    std::ostringstream os;
+    key_text(p, k, os);
+    const std::string s = os.str();
+    for (size_t i = 0; i < p.keys.size(); i++)
+        if (p.keys[i] == s) return (int)i;
+    p.keys.push_back(s);
+    return (int)p.keys.size() - 1;
+}
+
+int build_ad(Pattern &p, int k) {
+    const exa_node_t nd = p.nodes[k];
+    ADNode a;
+    a.ir = k;
+    if (nd.op == EXA_OP_NULLV) {
+        a.kind = AD_NULL;
+    } else if (p.isconst[k]) {
+        a.kind = AD_CONST;
+    } else if (nd.op == EXA_OP_VAR) {
+        if (!p.isint[nd.a]) fail("variable index expression is not integer-typed");
+        a.kind = AD_VAR; a.ir = nd.a; a.key = key_id(p, nd.a);
+    } else if (nd.op == EXA_OP_UN) {
+        a.kind = AD_UN; a.fn = nd.fn; a.l = build_ad(p, nd.a);
+    } else {   // BIN with at least one differentiable operand
+        a.fn = nd.fn;
+        const bool ca = p.isconst[nd.a] && p.nodes[nd.a].op != EXA_OP_NULLV;
+        const bool cb = p.isconst[nd.b] && p.nodes[nd.b].op != EXA_OP_NULLV;
+        if (cb) { a.kind = AD_UN; a.fixed = FX_SECOND; a.cir = nd.b; a.l = build_ad(p, nd.a); }        // register.jl:231-248
+        else if (ca) { a.kind = AD_UN; a.fixed = FX_FIRST; a.cir = nd.a; a.l = build_ad(p, nd.b); }   // register.jl:249-266
+        else { a.kind = AD_BIN; a.l = build_ad(p, nd.a); a.r = build_ad(p, nd.b); }                    // register.jl:209-230
+    }
+    p.ad.push_back(a);
+    return (int)p.ad.size() - 1;
+}
+
+// dummy algebra: only the visit order matters
+struct ListAlg {
+    using T = char;
+    const Pattern &p;
+    std::vector<int> raw1;
+    std::vector<std::pair<int, int>> raw2;       // ordered key pairs
+    std::vector<int> leaf1s;
+    std::vector<std::pair<int, int>> leaf2s;     // ordered AD-leaf pairs
+    explicit ListAlg(const Pattern &pp) : p(pp) {}
+    T y1(int) { return 0; } T y2(int) { return 0; } T h11(int) { return 0; } T h12(int) { return 0; } T h22(int) { return 0; }
+    T mul(T, T) { return 0; } T add(T, T) { return 0; } T neg(T) { return 0; }
+    void leaf1(int n, T) { raw1.push_back(p.ad[n].key); leaf1s.push_back(n); }
+    void leaf2(int n1, int n2, T, bool) { raw2.push_back({p.ad[n1].key, p.ad[n2].key}); leaf2s.push_back({n1, n2}); }
+};
+
+template <class K>
+int dedup(const std::vector<K> &raw, std::vector<int> &comp, std::vector<int> &first_visit) {
+    std::vector<K> uniq;
+    comp.clear();
+    first_visit.clear();
+    for (size_t i = 0; i < raw.size(); i++) {
+        int f = -1;
+        for (size_t j = 0; j < uniq.size(); j++)
+            if (uniq[j] == raw[i]) { f = (int)j; break; }
+        if (f < 0) { uniq.push_back(raw[i]); first_visit.push_back((int)i); f = (int)uniq.size() - 1; }
+        comp.push_back(f + 1);
+    }
+    return (int)uniq.size();
+}
+
+void plan_pattern(Pattern &p, int pi) {
+    check_pattern(p, pi);
+    classify(p);
+    if (p.kind == EXA_PAT_CONAUG) {
+        if (p.target < 0 || p.target >= (int)p.nodes.size() || !p.isint[p.target] || !p.isconst[p.target])
+            fail("augmentation target must be an integer expression of the data point");
+    }
+    p.ad.clear();
+    p.keys.clear();
+    p.ad_root = build_ad(p, p.root);
+    ListAlg a1(p);
+    grpass(p, p.ad_root, a1, 0);
+    std::vector<int> fv;
+    p.o1step = dedup(a1.raw1, p.comp1, fv);
+    p.slotvar1.clear();
+    for (int v : fv) p.slotvar1.push_back(a1.leaf1s[v]);
+    ListAlg a2(p);
+    hrpass0(p, p.ad_root, a2, 0, 0);
+    p.o2step = dedup(a2.raw2, p.comp2, fv);
+    p.slotvar2.clear();
+    for (int v : fv) p.slotvar2.push_back(a2.leaf2s[v]);
+}
+
+template <class T>
+std::vector<T> copy_or(const T *src, int64_t n, T fill) {
+    std::vector<T> v((size_t)n, fill);
+    if (src) std::memcpy(v.data(), src, sizeof(T) * (size_t)n);
+    return v;
+}
+
+}  // namespace
+
+std::unique_ptr<Model> plan_model(const exa_model_desc_t *d) {
+    if (!d) fail("null model description");
+    if (d->nvar < 0 || d->npar < 0 || d->n_patterns < 0) fail("negative size in model description");
+    auto m = std::make_unique<Model>();
+    m->nvar = d->nvar; m->npar = d->npar; m->minimize = d->minimize;
+    m->x0 = copy_or<double>(d->x0, d->nvar, 0.0);
+    m->lvar = copy_or<double>(d->lvar, d->nvar, -INFINITY);
+    m->uvar = copy_or<double>(d->uvar, d->nvar, INFINITY);
+    m->theta = copy_or<double>(d->theta0, d->npar, 0.0);
+    m->pats.resize(d->n_patterns);
+    for (int k = 0; k < d->n_patterns; k++) {
+        const exa_pattern_t &s = d->patterns[k];
+        Pattern &p = m->pats[k];
+        if (s.n < 0 || s.n_nodes <= 0 || !s.nodes) fail("pattern without nodes");
+        p.kind = s.kind; p.root = s.root; p.target = s.target; p.base = s.base; p.n = s.n;
+        p.nodes.assign(s.nodes, s.nodes + s.n_nodes);
+        p.cols.resize(s.n_cols);
+        for (int c = 0; c < s.n_cols; c++) {
+            const exa_column_t &sc = s.cols[c];
+            Column &col = p.cols[c];
+            col.type = sc.type; col.start = sc.start; col.step = sc.step;
+            if (sc.type == EXA_COL_I64) {
+                if (!sc.data && s.n) fail("I64 column without data");
+                col.idata.assign((const int64_t *)sc.data, (const int64_t *)sc.data + s.n);
+            } else if (sc.type == EXA_COL_F64) {
+                if (!sc.data && s.n) fail("F64 column without data");
+                col.fdata.assign((const double *)sc.data, (const double *)sc.data + s.n);
+            } else if (sc.type != EXA_COL_RANGE) {
+                fail("unknown column type");
+            }
+        }
+        if (p.kind != EXA_PAT_OBJ && p.kind != EXA_PAT_CON && p.kind != EXA_PAT_CONAUG) fail("unknown pattern kind");
+        if (p.kind == EXA_PAT_CONAUG) {
+            if (p.base < 0 || p.base >= k || m->pats[p.base].kind != EXA_PAT_CON) fail("augmentation base must be an earlier CON pattern");
+        }
+        plan_pattern(p, k);
+        // running counters, insertion order (nlp.jl:1474-1482, 1597-1611, 1730-1738)
+        if (p.kind == EXA_PAT_OBJ) {
+            p.o0 = m->nobj; p.o1 = m->nnzg; p.o2 = m->nnzh;
+            m->nobj += p.n; m->nnzg += p.n * p.o1step; m->nnzh += p.n * p.o2step;
+        } else if (p.kind == EXA_PAT_CON) {
+            p.o0 = m->ncon; p.o1 = m->nnzj; p.o2 = m->nnzh;
+            m->ncon += p.n; m->nnzj += p.n * p.o1step; m->nnzh += p.n * p.o2step;
+        } else {
+            p.o0 = m->pats[p.base].o0;   // offset0(c1, 0) (nlp.jl:1683)
+            p.o1 = m->nnzj; p.o2 = m->nnzh;
+            m->nconaug += p.n; m->nnzj += p.n * p.o1step; m->nnzh += p.n * p.o2step;
+        }
+    }
+    m->y0 = copy_or<double>(d->y0, m->ncon, 0.0);
+    m->lcon = copy_or<double>(d->lcon, m->ncon, 0.0);
+    m->ucon = copy_or<double>(d->ucon, m->ncon, 0.0);
+    return m;
+}
+
+}  // namespace exa

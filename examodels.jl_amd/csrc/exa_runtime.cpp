@@ -1,0 +1,552 @@
+// exa_runtime.cpp — libexahip.so runtime + C ABI (include/exahip.h).
+//
+// Owns: model registry, kernel-module build (hipcc --genco for gfx950, cached on disk by source hash), device
+// copies of the SoA iterator columns / theta / parameter table, launches on the model's HIP stream.
+// Replaces the host drivers of ext/ExaModelsKernelAbstractions.jl:253-351, 515-547 (one launch per pattern per
+// callback + fill!) with ONE fused launch per callback and no fill! for the COO outputs.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <mutex>
+#include <sstream>
+#include <stdexcept>
+
+#include "exa_internal.hpp"
+
+using namespace exa;
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_mu;
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    void ensure(size_t n) {
+        if (n <= bytes) return;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        HIPCHK(hipMalloc(&p, n ? n : 8));
+        bytes = n;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct Handle {
+    std::unique_ptr<Model> m;
+    Generated gen;
+    std::string hsaco_path;
+    bool on_device = false;
+    int rank = 0, world = 1;
+    hipStream_t stream = nullptr;
+    hipModule_t module = nullptr;
+    hipFunction_t f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_consaug = nullptr, f_jac = nullptr,
+                  f_hess = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
+    std::vector<int64_t> P;                 // host copy of the parameter table
+    std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
+    DevBuf dP, dtheta, dpart, dobj;
+    std::vector<DevBuf> dcols;              // flattened over patterns
+    std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
+    DevBuf sx, sy, sout, srows, scols;      // scratch of the *_host variants
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    ~Handle() {
+        if (on_device) {
+            dP.release(); dtheta.release(); dpart.release(); dobj.release();
+            for (auto &b : dcols) b.release();
+            sx.release(); sy.release(); sout.release(); srows.release(); scols.release();
+            if (ev0) (void)hipEventDestroy(ev0);
+            if (ev1) (void)hipEventDestroy(ev1);
+            if (module) (void)hipModuleUnload(module);
+        }
+    }
+};
+
+std::vector<std::unique_ptr<Handle>> g_models;   // id = index + 1
+
+Handle *get(int id) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (id < 1 || id > (int)g_models.size()) return nullptr;
+    return g_models[id - 1].get();
+}
+
+int put(std::unique_ptr<Handle> h) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (size_t i = 0; i < g_models.size(); i++)
+        if (!g_models[i]) { g_models[i] = std::move(h); return (int)i + 1; }
+    g_models.push_back(std::move(h));
+    return (int)g_models.size();
+}
+
+// ---- kernel module build ------------------------------------------------------------------------------
+uint64_t fnv1a(const std::string &s) {
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    return h;
+}
+
+std::string lib_dir() {
+    Dl_info info;
+    if (dladdr((void *)&fnv1a, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        auto k = p.find_last_of('/');
+        if (k != std::string::npos) return p.substr(0, k);
+    }
+    return ".";
+}
+
+std::string cache_dir() {
+    const char *env = getenv("EXAHIP_CACHE_DIR");
+    std::string d = env && *env ? std::string(env) : lib_dir() + "/../kernel_cache";
+    mkdir(d.c_str(), 0755);
+    return d;
+}
+
+const char *kArch = "gfx950";
+std::string compile_flags() {
+    const char *extra = getenv("EXAHIP_HIPCC_FLAGS");
+    std::string f = std::string("--genco --offload-arch=") + kArch + " -O3 -std=c++17 -munsafe-fp-atomics -Wno-unused-parameter -Wno-unused-variable";
+    if (extra && *extra) { f += " "; f += extra; }
+    return f;
+}
+
+bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && st.st_size > 0; }
+
+// Compiles `source` for gfx950 into the on-disk cache; returns the path of the code object.
+std::string build_code_object(const std::string &source) {
+    const std::string flags = compile_flags();
+    char name[64];
+    snprintf(name, sizeof name, "exa_%016llx", (unsigned long long)fnv1a(source + "|" + flags));
+    const std::string dir = cache_dir();
+    const std::string src = dir + "/" + name + ".hip", obj = dir + "/" + name + ".hsaco";
+    if (file_exists(obj)) return obj;
+    const std::string tag = "." + std::to_string((long)getpid());
+    {
+        std::ofstream o(src + tag);
+        if (!o) throw std::runtime_error("cannot write kernel source to " + src);
+        o << source;
+    }
+    rename((src + tag).c_str(), src.c_str());
+    const char *cc = getenv("EXAHIP_HIPCC");
+    std::string hipcc = cc && *cc ? cc : "/opt/rocm/bin/hipcc";
+    const std::string log = obj + tag + ".log";
+    const std::string cmd = hipcc + " " + flags + " -o " + obj + tag + " " + src + " > " + log + " 2>&1";
+    const int rc = std::system(cmd.c_str());
+    if (rc != 0 || !file_exists(obj + tag)) {
+        std::ifstream l(log);
+        std::stringstream ss;
+        ss << l.rdbuf();
+        std::string msg = ss.str();
+        if (msg.size() > 4000) msg.resize(4000);
+        throw std::runtime_error("hipcc failed (" + cmd + "):\n" + msg);
+    }
+    unlink(log.c_str());
+    rename((obj + tag).c_str(), obj.c_str());
+    return obj;
+}
+
+std::vector<char> read_file(const std::string &p) {
+    std::ifstream f(p, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot read " + p);
+    return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+// ---- parameter table -------------------------------------------------------------------------------------
+void fill_params(Handle &h) {
+    const Model &m = *h.m;
+    const ParamLayout &L = h.gen.layout;
+    h.P.assign((size_t)L.nwords, 0);
+    for (size_t k = 0; k < m.pats.size(); k++) {
+        const Pattern &p = m.pats[k];
+        const auto &pp = L.pat[k];
+        const int64_t lo = (int64_t)((__int128)p.n * h.rank / h.world), hi = (int64_t)((__int128)p.n * (h.rank + 1) / h.world);
+        h.P[pp.lo] = lo; h.P[pp.hi] = hi; h.P[pp.o0] = p.o0; h.P[pp.o1] = p.o1; h.P[pp.o2] = p.o2;
+        for (size_t c = 0; c < p.cols.size(); c++) {
+            if (p.cols[c].type == EXA_COL_RANGE) h.P[pp.col[c]] = p.cols[c].start;
+            else h.P[pp.col[c]] = h.on_device ? (int64_t)(uintptr_t)h.dcols[h.colslot[k][c]].p : 0;
+        }
+    }
+    for (int cb = 0; cb < CB_COUNT; cb++) {
+        int64_t cum = 0;
+        for (size_t j = 0; j < L.active[cb].size(); j++) {
+            const auto &pp = L.pat[L.active[cb][j]];
+            const int64_t cnt = h.P[pp.hi] - h.P[pp.lo];
+            cum += (cnt + kBlock - 1) / kBlock;
+            h.P[L.blk[cb] + (int)j] = cum;
+        }
+        h.grid[cb] = cum;
+    }
+    if (h.on_device) {
+        h.dP.ensure(sizeof(int64_t) * h.P.size());
+        HIPCHK(hipMemcpy(h.dP.p, h.P.data(), sizeof(int64_t) * h.P.size(), hipMemcpyHostToDevice));
+        h.dpart.ensure(sizeof(double) * (size_t)(h.grid[CB_OBJ] + 1));
+    }
+}
+
+void to_device(Handle &h) {
+    Model &m = *h.m;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        throw HipError("no HIP device available (libexahip has no CPU fallback): " + std::string(hipGetErrorString(e)));
+    h.hsaco_path = build_code_object(h.gen.source);
+    std::vector<char> image = read_file(h.hsaco_path);
+    HIPCHK(hipModuleLoadData(&h.module, image.data()));
+    auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
+    h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
+    h.f_consaug = fn("exa_consaug"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
+    h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
+    h.on_device = true;
+    h.colslot.resize(m.pats.size());
+    for (size_t k = 0; k < m.pats.size(); k++) {
+        Pattern &p = m.pats[k];
+        h.colslot[k].assign(p.cols.size(), -1);
+        for (size_t c = 0; c < p.cols.size(); c++) {
+            Column &col = p.cols[c];
+            if (col.type == EXA_COL_RANGE) continue;
+            DevBuf b;
+            b.ensure(8 * (size_t)p.n);
+            const void *src = col.type == EXA_COL_I64 ? (const void *)col.idata.data() : (const void *)col.fdata.data();
+            if (p.n) HIPCHK(hipMemcpy(b.p, src, 8 * (size_t)p.n, hipMemcpyHostToDevice));
+            h.colslot[k][c] = (int)h.dcols.size();
+            h.dcols.push_back(b);
+            // the host copy is no longer needed once resident in HBM
+            std::vector<int64_t>().swap(col.idata);
+            std::vector<double>().swap(col.fdata);
+        }
+    }
+    h.dtheta.ensure(sizeof(double) * (size_t)(m.npar + 1));
+    if (m.npar) HIPCHK(hipMemcpy(h.dtheta.p, m.theta.data(), sizeof(double) * (size_t)m.npar, hipMemcpyHostToDevice));
+    h.dobj.ensure(sizeof(double));
+    HIPCHK(hipEventCreate(&h.ev0));
+    HIPCHK(hipEventCreate(&h.ev1));
+    fill_params(h);
+}
+
+void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **args) {
+    if (grid <= 0) return;
+    if (grid > 0x7fffffffLL) throw std::runtime_error("grid too large");
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, block, 1, 1, 0, h.stream, args, nullptr));
+}
+
+// ---- callbacks (device pointers, asynchronous) ------------------------------------------------------------
+void do_obj(Handle &h, const double *x, double *out_dev) {
+    const void *P = h.dP.p, *th = h.dtheta.p;
+    void *part = h.dpart.p;
+    int64_t n = h.grid[CB_OBJ];
+    if (n == 0) { HIPCHK(hipMemsetAsync(out_dev, 0, sizeof(double), h.stream)); return; }
+    void *a1[] = {&P, &x, &th, &part};
+    launch(h, h.f_obj, n, kBlock, a1);
+    void *a2[] = {&part, &n, &out_dev};
+    launch(h, h.f_red, 1, 1024, a2);
+}
+void do_grad(Handle &h, const double *x, double *g) {
+    HIPCHK(hipMemsetAsync(g, 0, sizeof(double) * (size_t)h.m->nvar, h.stream));
+    const void *P = h.dP.p, *th = h.dtheta.p;
+    void *a[] = {&P, &x, &th, &g};
+    launch(h, h.f_grad, h.grid[CB_GRAD], kBlock, a);
+}
+void do_cons(Handle &h, const double *x, double *c) {
+    if (h.m->ncon == 0) return;
+    if (h.world > 1) HIPCHK(hipMemsetAsync(c, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
+    const void *P = h.dP.p, *th = h.dtheta.p;
+    void *a[] = {&P, &x, &th, &c};
+    launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a);
+    launch(h, h.f_consaug, h.grid[CB_CONSAUG], kBlock, a);
+}
+void do_jac(Handle &h, const double *x, double *v) {
+    const void *P = h.dP.p, *th = h.dtheta.p;
+    void *a[] = {&P, &x, &th, &v};
+    launch(h, h.f_jac, h.grid[CB_JAC], kBlock, a);
+}
+void do_hess(Handle &h, const double *x, const double *y, double sigma, double *v) {
+    const void *P = h.dP.p, *th = h.dtheta.p;
+    void *a[] = {&P, &x, &y, &th, &v, &sigma};
+    launch(h, h.f_hess, h.grid[CB_HESS], kBlock, a);
+}
+void do_struct(Handle &h, bool hess, bool wide, void *rows, void *cols) {
+    const void *P = h.dP.p;
+    void *a[] = {&P, &rows, &cols};
+    hipFunction_t f = hess ? (wide ? h.f_hs64 : h.f_hs32) : (wide ? h.f_js64 : h.f_js32);
+    launch(h, f, h.grid[hess ? CB_HSTRUCT : CB_JSTRUCT], kBlock, a);
+}
+
+template <class F>
+int guard(int id, bool need_device, F &&f) {
+    Handle *h = get(id);
+    if (!h) return 1;
+    if (need_device && !h->on_device) { g_err = "model was planned without a device (exa_plan_only)"; return 1; }
+    try {
+        f(*h);
+        return 0;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return 2;
+    } catch (...) {
+        g_err = "unknown error";
+        return 2;
+    }
+}
+
+void h2d(Handle &h, DevBuf &b, const void *src, size_t bytes) {
+    b.ensure(bytes);
+    if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h.stream));
+}
+void d2h(Handle &h, void *dst, const void *src, size_t bytes) {
+    if (bytes) HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h.stream));
+    HIPCHK(hipStreamSynchronize(h.stream));
+}
+
+int create(const exa_model_desc_t *desc, int *id_out, bool device) {
+    if (!desc || !id_out) return 1;
+    try {
+        auto h = std::make_unique<Handle>();
+        h->m = plan_model(desc);
+        h->gen = generate_module(*h->m);
+        if (device) to_device(*h);
+        else fill_params(*h);
+        *id_out = put(std::move(h));
+        return 0;
+    } catch (const HipError &e) {
+        g_err = e.what();
+        return 2;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        // malformed tables are the caller's fault (status 1); build failures are internal (status 2)
+        return std::string(e.what()).rfind("hipcc failed", 0) == 0 || std::string(e.what()).rfind("cannot", 0) == 0 ? 2 : 1;
+    } catch (...) {
+        g_err = "unknown error";
+        return 2;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int exa_abi_version(void) { return EXAHIP_ABI_VERSION; }
+const char *exa_last_error(void) { return g_err.c_str(); }
+
+int exa_new_from_table(const exa_model_desc_t *desc, int *id_out) { return create(desc, id_out, true); }
+int exa_plan_only(const exa_model_desc_t *desc, int *id_out) { return create(desc, id_out, false); }
+
+int exa_compile(int id) {
+    return guard(id, false, [&](Handle &h) { h.hsaco_path = build_code_object(h.gen.source); });
+}
+const char *exa_code_object_path(int id) {
+    Handle *h = get(id);
+    return h ? h->hsaco_path.c_str() : nullptr;
+}
+
+int exa_free(int id) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (id < 1 || id > (int)g_models.size() || !g_models[id - 1]) return 1;
+    g_models[id - 1].reset();
+    return 0;
+}
+
+static int clamp32(int64_t v) { return v > 0x7fffffffLL ? -1 : (int)v; }
+int exa_nvar(int id) { Handle *h = get(id); return h ? clamp32(h->m->nvar) : -1; }
+int exa_ncon(int id) { Handle *h = get(id); return h ? clamp32(h->m->ncon) : -1; }
+int exa_nnzj(int id) { Handle *h = get(id); return h ? clamp32(h->m->nnzj) : -1; }
+int exa_nnzh(int id) { Handle *h = get(id); return h ? clamp32(h->m->nnzh) : -1; }
+int64_t exa_nvar64(int id) { Handle *h = get(id); return h ? h->m->nvar : -1; }
+int64_t exa_ncon64(int id) { Handle *h = get(id); return h ? h->m->ncon : -1; }
+int64_t exa_nnzj64(int id) { Handle *h = get(id); return h ? h->m->nnzj : -1; }
+int64_t exa_nnzh64(int id) { Handle *h = get(id); return h ? h->m->nnzh : -1; }
+int64_t exa_nnzg64(int id) { Handle *h = get(id); return h ? h->m->nnzg : -1; }
+int exa_npatterns(int id) { Handle *h = get(id); return h ? (int)h->m->pats.size() : -1; }
+
+int exa_pattern_info(int id, int p, int64_t out[9]) {
+    Handle *h = get(id);
+    if (!h || !out || p < 0 || p >= (int)h->m->pats.size()) return 1;
+    const Pattern &q = h->m->pats[p];
+    out[0] = q.kind; out[1] = q.n; out[2] = q.o0; out[3] = q.o1; out[4] = q.o2; out[5] = q.o1step; out[6] = q.o2step;
+    out[7] = (int64_t)q.comp1.size(); out[8] = (int64_t)q.comp2.size();
+    return 0;
+}
+int exa_pattern_comp(int id, int p, int order, int32_t *out) {
+    Handle *h = get(id);
+    if (!h || !out || p < 0 || p >= (int)h->m->pats.size() || (order != 1 && order != 2)) return 1;
+    const auto &c = order == 1 ? h->m->pats[p].comp1 : h->m->pats[p].comp2;
+    for (size_t i = 0; i < c.size(); i++) out[i] = c[i];
+    return 0;
+}
+int exa_meta(int id, double *x0, double *lvar, double *uvar, double *lcon, double *ucon) {
+    Handle *h = get(id);
+    if (!h) return 1;
+    const Model &m = *h->m;
+    if (x0) std::memcpy(x0, m.x0.data(), 8 * (size_t)m.nvar);
+    if (lvar) std::memcpy(lvar, m.lvar.data(), 8 * (size_t)m.nvar);
+    if (uvar) std::memcpy(uvar, m.uvar.data(), 8 * (size_t)m.nvar);
+    if (lcon) std::memcpy(lcon, m.lcon.data(), 8 * (size_t)m.ncon);
+    if (ucon) std::memcpy(ucon, m.ucon.data(), 8 * (size_t)m.ncon);
+    return 0;
+}
+const char *exa_kernel_source(int id) { Handle *h = get(id); return h ? h->gen.source.c_str() : nullptr; }
+
+int exa_set_stream(int id, void *s) { return guard(id, true, [&](Handle &h) { h.stream = (hipStream_t)s; }); }
+int exa_set_shard(int id, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) return 1;
+    return guard(id, false, [&](Handle &h) {
+        if (h.on_device) HIPCHK(hipStreamSynchronize(h.stream));
+        h.rank = rank; h.world = world;
+        fill_params(h);
+    });
+}
+int exa_set_value(int id, int64_t offset, const double *vals, int64_t len) {
+    Handle *hh = get(id);
+    if (!hh || !vals || offset < 0 || len < 0 || offset + len > hh->m->npar) return 1;
+    return guard(id, false, [&](Handle &h) {
+        std::memcpy(h.m->theta.data() + offset, vals, 8 * (size_t)len);
+        if (h.on_device && len) {
+            HIPCHK(hipMemcpyAsync((double *)h.dtheta.p + offset, h.m->theta.data() + offset, 8 * (size_t)len, hipMemcpyHostToDevice, h.stream));
+            HIPCHK(hipStreamSynchronize(h.stream));
+        }
+    });
+}
+
+int exa_obj_async(int id, const double *x, double *out_dev) {
+    if (!x || !out_dev) return 1;
+    return guard(id, true, [&](Handle &h) { do_obj(h, x, out_dev); });
+}
+int exa_obj(int id, const double *x, double *out_host) {
+    if (!x || !out_host) return 1;
+    return guard(id, true, [&](Handle &h) { do_obj(h, x, (double *)h.dobj.p); d2h(h, out_host, h.dobj.p, 8); });
+}
+int exa_grad(int id, const double *x, double *g) {
+    if (!x || !g) return 1;
+    return guard(id, true, [&](Handle &h) { do_grad(h, x, g); });
+}
+int exa_cons(int id, const double *x, double *c) {
+    if (!x) return 1;
+    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !c) throw std::runtime_error("null output"); do_cons(h, x, c); });
+}
+int exa_jac(int id, const double *x, double *v) {
+    if (!x) return 1;
+    return guard(id, true, [&](Handle &h) { if (h.m->nnzj && !v) throw std::runtime_error("null output"); do_jac(h, x, v); });
+}
+int exa_hess(int id, const double *x, const double *y, double w, double *v) {
+    if (!x) return 1;
+    return guard(id, true, [&](Handle &h) { if (h.m->nnzh && !v) throw std::runtime_error("null output"); do_hess(h, x, y, w, v); });
+}
+int exa_jac_structure(int id, int32_t *r, int32_t *c) {
+    return guard(id, true, [&](Handle &h) { if (h.m->nnzj > 0x7fffffffLL) throw std::runtime_error("nnzj exceeds int32"); do_struct(h, false, false, r, c); });
+}
+int exa_hess_structure(int id, int32_t *r, int32_t *c) {
+    return guard(id, true, [&](Handle &h) { if (h.m->nnzh > 0x7fffffffLL) throw std::runtime_error("nnzh exceeds int32"); do_struct(h, true, false, r, c); });
+}
+int exa_jac_structure64(int id, int64_t *r, int64_t *c) { return guard(id, true, [&](Handle &h) { do_struct(h, false, true, r, c); }); }
+int exa_hess_structure64(int id, int64_t *r, int64_t *c) { return guard(id, true, [&](Handle &h) { do_struct(h, true, true, r, c); }); }
+
+// ---- host-pointer variants ----------------------------------------------------------------------------
+int exa_obj_host(int id, const double *x, double *out) {
+    if (!x || !out) return 1;
+    return guard(id, true, [&](Handle &h) {
+        h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
+        do_obj(h, (const double *)h.sx.p, (double *)h.dobj.p);
+        d2h(h, out, h.dobj.p, 8);
+    });
+}
+int exa_grad_host(int id, const double *x, double *g) {
+    if (!x || !g) return 1;
+    return guard(id, true, [&](Handle &h) {
+        const size_t n = 8 * (size_t)h.m->nvar;
+        h2d(h, h.sx, x, n);
+        h.sout.ensure(n);
+        do_grad(h, (const double *)h.sx.p, (double *)h.sout.p);
+        d2h(h, g, h.sout.p, n);
+    });
+}
+int exa_cons_host(int id, const double *x, double *c) {
+    if (!x) return 1;
+    return guard(id, true, [&](Handle &h) {
+        const size_t n = 8 * (size_t)h.m->ncon;
+        if (!n) return;
+        h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
+        h.sout.ensure(n);
+        do_cons(h, (const double *)h.sx.p, (double *)h.sout.p);
+        d2h(h, c, h.sout.p, n);
+    });
+}
+int exa_jac_host(int id, const double *x, double *v) {
+    if (!x) return 1;
+    return guard(id, true, [&](Handle &h) {
+        const size_t n = 8 * (size_t)h.m->nnzj;
+        if (!n) return;
+        h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
+        h.sout.ensure(n);
+        do_jac(h, (const double *)h.sx.p, (double *)h.sout.p);
+        d2h(h, v, h.sout.p, n);
+    });
+}
+int exa_hess_host(int id, const double *x, const double *y, double w, double *v) {
+    if (!x) return 1;
+    return guard(id, true, [&](Handle &h) {
+        const size_t n = 8 * (size_t)h.m->nnzh;
+        if (!n) return;
+        h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
+        if (h.m->ncon) { if (!y) throw std::runtime_error("null multipliers"); h2d(h, h.sy, y, 8 * (size_t)h.m->ncon); }
+        else h.sy.ensure(8);
+        h.sout.ensure(n);
+        do_hess(h, (const double *)h.sx.p, (const double *)h.sy.p, w, (double *)h.sout.p);
+        d2h(h, v, h.sout.p, n);
+    });
+}
+static int struct_host(int id, bool hess, bool wide, void *r, void *c) {
+    return guard(id, true, [&](Handle &h) {
+        const int64_t nz = hess ? h.m->nnzh : h.m->nnzj;
+        if (!nz) return;
+        if (!wide && nz > 0x7fffffffLL) throw std::runtime_error("nnz exceeds int32");
+        const size_t n = (wide ? 8 : 4) * (size_t)nz;
+        h.srows.ensure(n); h.scols.ensure(n);
+        do_struct(h, hess, wide, h.srows.p, h.scols.p);
+        HIPCHK(hipMemcpyAsync(r, h.srows.p, n, hipMemcpyDeviceToHost, h.stream));
+        d2h(h, c, h.scols.p, n);
+    });
+}
+int exa_jac_structure_host(int id, int32_t *r, int32_t *c) { return struct_host(id, false, false, r, c); }
+int exa_hess_structure_host(int id, int32_t *r, int32_t *c) { return struct_host(id, true, false, r, c); }
+int exa_jac_structure64_host(int id, int64_t *r, int64_t *c) { return struct_host(id, false, true, r, c); }
+int exa_hess_structure64_host(int id, int64_t *r, int64_t *c) { return struct_host(id, true, true, r, c); }
+
+// ---- measurement ------------------------------------------------------------------------------------------
+int exa_time_callback(int id, int which, int reps, const double *x, const double *y, double w, double *out, float *ms_out) {
+    if (reps < 1 || !ms_out || which < 0 || which > 4) return 1;
+    return guard(id, true, [&](Handle &h) {
+        HIPCHK(hipEventRecord(h.ev0, h.stream));
+        for (int r = 0; r < reps; r++) {
+            switch (which) {
+            case 0: do_obj(h, x, (double *)h.dobj.p); break;
+            case 1: do_grad(h, x, out); break;
+            case 2: do_cons(h, x, out); break;
+            case 3: do_jac(h, x, out); break;
+            case 4: do_hess(h, x, y, w, out); break;
+            }
+        }
+        HIPCHK(hipEventRecord(h.ev1, h.stream));
+        HIPCHK(hipEventSynchronize(h.ev1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, h.ev0, h.ev1));
+        *ms_out = ms / (float)reps;
+    });
+}
+int exa_sync(int id) { return guard(id, true, [&](Handle &h) { HIPCHK(hipStreamSynchronize(h.stream)); }); }
+
+}  // extern "C"

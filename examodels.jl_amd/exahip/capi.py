@@ -1,0 +1,98 @@
+"""ctypes binding of libexahip.so — the C ABI declared in include/exahip.h (nothing else is called).
+
+Fails loudly if the library is missing: there is no Python or CPU fallback for evaluation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libexahip.so")
+CSRC = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
+_LIB = None
+
+# every symbol include/exahip.h declares (tests check the .so exports all of them)
+SYMBOLS = [
+    "exa_abi_version", "exa_last_error", "exa_new_from_table", "exa_plan_only", "exa_compile", "exa_code_object_path",
+    "exa_free", "exa_nvar", "exa_ncon", "exa_nnzj", "exa_nnzh", "exa_nvar64", "exa_ncon64", "exa_nnzj64", "exa_nnzh64",
+    "exa_nnzg64", "exa_npatterns", "exa_pattern_info", "exa_pattern_comp", "exa_meta", "exa_kernel_source",
+    "exa_set_stream", "exa_set_shard", "exa_set_value", "exa_obj", "exa_obj_async", "exa_grad", "exa_cons", "exa_jac",
+    "exa_hess", "exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",
+    "exa_obj_host", "exa_grad_host", "exa_cons_host", "exa_jac_host", "exa_hess_host", "exa_jac_structure_host",
+    "exa_hess_structure_host", "exa_jac_structure64_host", "exa_hess_structure64_host", "exa_time_callback", "exa_sync",
+]
+
+
+def build(force=False):
+    """Compile libexahip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hpp"))]
+    srcs += [os.path.join(CSRC, "..", "..", "include", f) for f in ("exahip.h", "exahip_ir.h")]
+    newest = max(os.path.getmtime(s) for s in srcs)
+    if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-B"])
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
+            "exahip has no CPU/Python fallback.")
+    # One HIP runtime per process: when torch is installed its bundled libamdhip64.so.7 must be the copy that
+    # libexahip.so binds to (same SONAME), otherwise device pointers/streams from torch tensors would belong to a
+    # different runtime instance.  A host without torch (e.g. the Julia shim) just uses the system ROCm.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+    L.exa_last_error.restype = ctypes.c_char_p
+    L.exa_kernel_source.restype = ctypes.c_char_p
+    L.exa_kernel_source.argtypes = [i32]
+    L.exa_code_object_path.restype = ctypes.c_char_p
+    L.exa_code_object_path.argtypes = [i32]
+    L.exa_new_from_table.argtypes = [vp, vp]
+    L.exa_plan_only.argtypes = [vp, vp]
+    L.exa_compile.argtypes = [i32]
+    L.exa_free.argtypes = [i32]
+    for f in ("exa_nvar", "exa_ncon", "exa_nnzj", "exa_nnzh", "exa_npatterns"):
+        getattr(L, f).argtypes = [i32]
+    for f in ("exa_nvar64", "exa_ncon64", "exa_nnzj64", "exa_nnzh64", "exa_nnzg64"):
+        getattr(L, f).argtypes = [i32]
+        getattr(L, f).restype = i64
+    L.exa_pattern_info.argtypes = [i32, i32, vp]
+    L.exa_pattern_comp.argtypes = [i32, i32, i32, vp]
+    L.exa_meta.argtypes = [i32, vp, vp, vp, vp, vp]
+    L.exa_set_stream.argtypes = [i32, vp]
+    L.exa_set_shard.argtypes = [i32, i32, i32]
+    L.exa_set_value.argtypes = [i32, i64, vp, i64]
+    for f in ("exa_obj", "exa_obj_async", "exa_grad", "exa_cons", "exa_jac", "exa_obj_host", "exa_grad_host",
+              "exa_cons_host", "exa_jac_host"):
+        getattr(L, f).argtypes = [i32, vp, vp]
+    L.exa_hess.argtypes = [i32, vp, vp, dbl, vp]
+    L.exa_hess_host.argtypes = [i32, vp, vp, dbl, vp]
+    for f in ("exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",
+              "exa_jac_structure_host", "exa_hess_structure_host", "exa_jac_structure64_host",
+              "exa_hess_structure64_host"):
+        getattr(L, f).argtypes = [i32, vp, vp]
+    L.exa_time_callback.argtypes = [i32, i32, i32, vp, vp, dbl, vp, vp]
+    L.exa_sync.argtypes = [i32]
+    _LIB = L
+    return L
+
+
+class ExaHipError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status == 0:
+        return
+    msg = lib().exa_last_error().decode(errors="replace") if status == 2 else "bad id or argument"
+    raise ExaHipError(f"{what}: status {status}: {msg}")

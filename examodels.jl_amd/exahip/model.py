@@ -1,0 +1,197 @@
+"""ExaModel — the NLPModels oracle surface over libexahip.so.
+
+Host-side mirror of the reference's `ExaModel <: AbstractNLPModel` (src/nlp.jl:704-716, 765-798) restricted to the
+evaluation surface: obj, cons (cons_nln!), grad (grad!), jac_structure, jac_coord (jac_coord!), hess_structure,
+hess_coord (hess_coord!), set_value (set_value!).  Method names and argument meaning follow NLPModels; the `!`
+in-place forms are expressed through the `out=` argument.  Inputs may be numpy arrays (staged through the *_host
+entry points, the WrapperNLPModel role of src/utils.jl:159-208) or torch tensors already resident in HBM
+(device-pointer entry points, asynchronous on torch's current stream).
+"""
+from __future__ import annotations
+
+import ctypes
+from types import SimpleNamespace
+
+import numpy as np
+
+from . import capi
+from .core import ExaCore, ModelIR
+
+_WHICH = {"obj": 0, "grad": 1, "cons": 2, "jac": 3, "hess": 4}
+
+
+def _is_torch(a):
+    return type(a).__module__.startswith("torch")
+
+
+class ExaModel:
+    def __init__(self, core, device=True):
+        """device=True: exa_new_from_table (needs an MI355X; raises otherwise — no CPU fallback).
+        device=False: exa_plan_only — layout + generated source only, callbacks raise."""
+        self._L = capi.lib()
+        self.ir = core if isinstance(core, ModelIR) else core.to_ir()
+        self.id = 0
+        idc = ctypes.c_int(0)
+        fn = self._L.exa_new_from_table if device else self._L.exa_plan_only
+        capi.check(fn(ctypes.addressof(self.ir.desc), ctypes.byref(idc)), "exa_new_from_table" if device else "exa_plan_only")
+        self.id = idc.value
+        self.device = device
+        L = self._L
+        nvar, ncon = L.exa_nvar64(self.id), L.exa_ncon64(self.id)
+        x0, lv, uv = np.empty(nvar), np.empty(nvar), np.empty(nvar)
+        lc, uc = np.empty(max(1, ncon)), np.empty(max(1, ncon))
+        capi.check(L.exa_meta(self.id, x0.ctypes.data, lv.ctypes.data, uv.ctypes.data, lc.ctypes.data, uc.ctypes.data), "exa_meta")
+        self.meta = SimpleNamespace(nvar=nvar, ncon=ncon, nnzj=L.exa_nnzj64(self.id), nnzh=L.exa_nnzh64(self.id),
+                                    nnzg=L.exa_nnzg64(self.id), x0=x0, lvar=lv, uvar=uv, lcon=lc[:ncon], ucon=uc[:ncon],
+                                    minimize=bool(self.ir.desc.minimize))
+        self._stream = None
+
+    def __del__(self):
+        try:
+            if self.id:
+                self._L.exa_free(self.id)
+                self.id = 0
+        except Exception:
+            pass
+
+    # ---- layout introspection -----------------------------------------------------------------------------
+    @property
+    def npatterns(self):
+        return self._L.exa_npatterns(self.id)
+
+    def pattern_info(self, k):
+        out = np.zeros(9, dtype=np.int64)
+        capi.check(self._L.exa_pattern_info(self.id, k, out.ctypes.data), "exa_pattern_info")
+        return dict(zip(["kind", "n", "o0", "o1", "o2", "o1step", "o2step", "n1", "n2"], out.tolist()))
+
+    def pattern_comp(self, k, order):
+        info = self.pattern_info(k)
+        n = info["n1"] if order == 1 else info["n2"]
+        out = np.zeros(max(1, n), dtype=np.int32)
+        capi.check(self._L.exa_pattern_comp(self.id, k, order, out.ctypes.data), "exa_pattern_comp")
+        return out[:n].tolist()
+
+    def kernel_source(self):
+        return self._L.exa_kernel_source(self.id).decode()
+
+    def compile(self):
+        capi.check(self._L.exa_compile(self.id), "exa_compile")
+        return self._L.exa_code_object_path(self.id).decode()
+
+    # ---- context ---------------------------------------------------------------------------------------------
+    def set_shard(self, rank, world):
+        capi.check(self._L.exa_set_shard(self.id, int(rank), int(world)), "exa_set_shard")
+
+    def set_value(self, par, values):
+        """set_value!(m, θ, vals): update a Parameter block without rebuilding (nlp.jl:1279-1287)."""
+        v = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.float64), (par.length,)))
+        capi.check(self._L.exa_set_value(self.id, par.offset, v.ctypes.data, v.size), "exa_set_value")
+
+    def _use_torch_stream(self, t):
+        import torch
+        s = torch.cuda.current_stream(t.device).cuda_stream
+        if s != self._stream:
+            capi.check(self._L.exa_set_stream(self.id, ctypes.c_void_p(s)), "exa_set_stream")
+            self._stream = s
+
+    def sync(self):
+        capi.check(self._L.exa_sync(self.id), "exa_sync")
+
+    @staticmethod
+    def _np(a, n, name):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.size != n:
+            raise ValueError(f"{name} has {a.size} entries, expected {n}")
+        return a
+
+    def _tcheck(self, t, n, name):
+        import torch
+        if t.dtype != torch.float64 or not t.is_contiguous() or t.numel() < n or not t.is_cuda:
+            raise ValueError(f"{name} must be a contiguous float64 CUDA tensor with >= {n} entries")
+        return t
+
+    # ---- callbacks ---------------------------------------------------------------------------------------------
+    def obj(self, x):
+        out = ctypes.c_double(0.0)
+        if _is_torch(x):
+            self._use_torch_stream(x)
+            self._tcheck(x, self.meta.nvar, "x")
+            capi.check(self._L.exa_obj(self.id, x.data_ptr(), ctypes.addressof(out)), "exa_obj")
+        else:
+            x = self._np(x, self.meta.nvar, "x")
+            capi.check(self._L.exa_obj_host(self.id, x.ctypes.data, ctypes.addressof(out)), "exa_obj_host")
+        return out.value
+
+    def _call(self, name, x, n_out, out, extra=None):
+        if _is_torch(x):
+            import torch
+            self._use_torch_stream(x)
+            self._tcheck(x, self.meta.nvar, "x")
+            if out is None:
+                out = torch.empty(n_out, dtype=torch.float64, device=x.device)
+            self._tcheck(out, n_out, "out")
+            if extra is None:
+                capi.check(getattr(self._L, "exa_" + name)(self.id, x.data_ptr(), out.data_ptr()), name)
+            else:
+                y, w = extra
+                self._tcheck(y, self.meta.ncon, "y")
+                capi.check(self._L.exa_hess(self.id, x.data_ptr(), y.data_ptr(), float(w), out.data_ptr()), name)
+            return out
+        x = self._np(x, self.meta.nvar, "x")
+        if out is None:
+            out = np.empty(n_out)
+        assert out.dtype == np.float64 and out.flags.c_contiguous and out.size >= n_out
+        if extra is None:
+            capi.check(getattr(self._L, f"exa_{name}_host")(self.id, x.ctypes.data, out.ctypes.data), name)
+        else:
+            y, w = extra
+            y = self._np(y, self.meta.ncon, "y")
+            capi.check(self._L.exa_hess_host(self.id, x.ctypes.data, y.ctypes.data if y.size else None, float(w), out.ctypes.data), name)
+        return out
+
+    def grad(self, x, out=None):
+        return self._call("grad", x, self.meta.nvar, out)
+
+    def cons(self, x, out=None):
+        return self._call("cons", x, self.meta.ncon, out)
+
+    cons_nln = cons
+
+    def jac_coord(self, x, out=None):
+        return self._call("jac", x, self.meta.nnzj, out)
+
+    def hess_coord(self, x, y, obj_weight=1.0, out=None):
+        return self._call("hess", x, self.meta.nnzh, out, extra=(y, obj_weight))
+
+    def _structure(self, which, rows, cols, nnz, dtype):
+        wide = np.dtype(dtype).itemsize == 8
+        if rows is not None and _is_torch(rows):
+            self._use_torch_stream(rows)
+            fn = getattr(self._L, f"exa_{which}_structure" + ("64" if wide else ""))
+            capi.check(fn(self.id, rows.data_ptr(), cols.data_ptr()), which + "_structure")
+            return rows, cols
+        if rows is None:
+            rows, cols = np.empty(nnz, dtype=dtype), np.empty(nnz, dtype=dtype)
+        fn = getattr(self._L, f"exa_{which}_structure" + ("64" if wide else "") + "_host")
+        capi.check(fn(self.id, rows.ctypes.data, cols.ctypes.data), which + "_structure")
+        return rows, cols
+
+    def jac_structure(self, rows=None, cols=None, dtype=np.int64):
+        if rows is not None:
+            dtype = np.int64 if (rows.element_size() if _is_torch(rows) else rows.dtype.itemsize) == 8 else np.int32
+        return self._structure("jac", rows, cols, self.meta.nnzj, dtype)
+
+    def hess_structure(self, rows=None, cols=None, dtype=np.int64):
+        if rows is not None:
+            dtype = np.int64 if (rows.element_size() if _is_torch(rows) else rows.dtype.itemsize) == 8 else np.int32
+        return self._structure("hess", rows, cols, self.meta.nnzh, dtype)
+
+    # ---- measurement (hipEvents on the model's stream, include/exahip.h exa_time_callback) -------------------
+    def time_callback(self, which, reps, x, y=None, obj_weight=1.0, out=None):
+        ms = ctypes.c_float(0.0)
+        self._use_torch_stream(x)
+        capi.check(self._L.exa_time_callback(self.id, _WHICH[which], int(reps), x.data_ptr(),
+                                             y.data_ptr() if y is not None else None, float(obj_weight),
+                                             out.data_ptr() if out is not None else None, ctypes.addressof(ms)),
+                   "exa_time_callback")
+        return ms.value

@@ -52,6 +52,10 @@ const char *exa_last_error(void);                       /* thread-local text of 
 int exa_new_from_table(const exa_model_desc_t *desc, int *id_out);
 /* Same, but only plan + generate source (no device needed): used by the CPU-side build check and tests. */
 int exa_plan_only(const exa_model_desc_t *desc, int *id_out);
+/* Compile the model's generated module for gfx950 into the on-disk cache without loading it (works without a GPU:
+ * the build check).  exa_code_object_path() then names the .hsaco. */
+int exa_compile(int id);
+const char *exa_code_object_path(int id);
 int exa_free(int id);
 
 /* ---- sizes (cnlp: P_nvar/P_ncon/P_nnzj/P_nnzh, Compiler :1564-1582) ---------------------------- */

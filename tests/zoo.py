@@ -1,0 +1,60 @@
+"""Model zoo shared by the parity tests: (name, core builder, evaluation point builder)."""
+import numpy as np
+
+from exahip import ExaCore, Table, models, product, rng
+from exahip.graph import cos, exp, log, sin, sqrt, tanh
+
+
+def point(meta_x0, ncon, seed=0, spread=0.1):
+    """x = x0 + 0.1 u, u ~ U(-1,1) PCG64 seed 0; y ~ N(0,1) seed 1; sigma = 0.5."""
+    x = np.asarray(meta_x0) + spread * np.random.default_rng(seed).uniform(-1, 1, len(meta_x0))
+    y = np.random.default_rng(seed + 1).standard_normal(ncon)
+    return x, y, 0.5
+
+
+def mixed_model():
+    """Small model exercising parameters, data columns (Int and Float), non-unit ranges, several patterns."""
+    c = ExaCore()
+    x = c.add_var(12, start=np.linspace(0.5, 1.5, 12))
+    z = c.add_var(rng(0, 5), start=0.7)
+    th = c.add_par(rng(2, 4), value=[10.0, 20.0, 30.0])
+    tab = Table(i=np.array([1, 3, 5, 7]), j=np.array([2, 4, 6, 8]), w=np.array([0.5, 1.5, -2.0, 3.0]), e=np.array([2, 3, 4, 5]))
+    c.add_obj(lambda d: d.w * (x[d.i] - x[d.j]) ** 2 + sin(x[d.i] * x[d.j]), tab)
+    c.add_obj(lambda i: exp(-z[i]) * z[i] ** 3 + th[2] * z[i], rng(0, 5))
+    c.add_con(lambda j: th[j] * x[1] * x[j] + log(x[j + 1]), rng(2, 4))
+    g = c.add_con(lambda d: x[d.i] / x[d.j] - d.w * sqrt(x[d.j]) + x[d.i] ** d.e, tab, lcon=-1.0, ucon=1.0)
+    c.add_con_aug(g, lambda k: (k, tanh(x[k] * x[k + 4]) - 3 * x[k + 8]), rng(1, 4))
+    c.add_con(lambda i: z[i] * z[i - 1] - cos(z[i] - x[12]) + 2.0 ** z[i], rng(1, 5))
+    return c
+
+
+def conaug2d_model():
+    """test/NLPTest/conaug_test.jl:200-213 shape: two augmentations on a 2-D empty constraint."""
+    N, M = 4, 5
+    c = ExaCore()
+    x = c.add_var(N, M, start=np.arange(1.0, N * M + 1))
+    g = c.add_con(N, M, lcon=-np.inf, ucon=np.inf)
+    fwd = [(i, j) for j in range(1, M + 1) for i in range(1, N)]
+    bwd = [(i, j) for j in range(1, M + 1) for i in range(2, N + 1)]
+    c.add_con_aug(g, lambda p: g[p[0], p[1]] + (x[p[0], p[1]] * x[p[0] + 1, p[1]]), fwd)
+    c.add_con_aug(g, lambda p: g[p[0], p[1]] + (x[p[0] - 1, p[1]] - x[p[0], p[1]] ** 2), bwd)
+    c.add_obj(lambda p: x[p[0], p[1]] ** 2, product(rng(1, N), rng(1, M)))
+    return c
+
+
+def small_acopf():
+    return models.ac_power_model(models.synthetic_power_data(nbus=30, nbr=41, ngen=6, seed=3))
+
+
+ZOO = {
+    "lv3": lambda: models.luksan_vlcek_model(3),
+    "lv20": lambda: models.luksan_vlcek_model(20),
+    "lv20_objfirst": lambda: models.luksan_vlcek_model(20, obj_first=True),
+    "lv_split_20x1": lambda: models.luksan_vlcek_split_model(20, 1),
+    "lv_split_20x2": lambda: models.luksan_vlcek_split_model(20, 2),
+    "lv1000": lambda: models.luksan_vlcek_model(1000),
+    "rocket50": lambda: models.rocket_model(50),
+    "acopf30": small_acopf,
+    "mixed": mixed_model,
+    "conaug2d": conaug2d_model,
+}
