@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py — sparse Lagrangian Hessian evaluation throughput on MI355X (BASELINE.json metric).
+
+A "step" is one hess_coord!(m, x, y, H; obj_weight) of the Luksan-Vlcek model (BASELINE.json configs[1],
+benchmark/runbenchmark.jl:163-169) with x, y and H already resident in HBM.  Per-GPU work is fixed
+(--points data points of each pattern per GPU, default 1e7): with N GPUs the model is LV(N * points) and every
+rank evaluates its contiguous shard of each pattern's iterator, writing its disjoint slice of the global COO
+vector — no data-path collective => "scaling": "weak", value = aggregate Hessian nonzeros / s.
+
+    python bench.py                       # 1 GPU, LV N=1e7
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus 8 --steps K --warmup W
+
+One JSON line on rank 0.  Extra objects: "roofline" (algorithmic HBM bytes / measured kernel time against the
+8 TB/s peak) and "cpu_baseline" (the C restatement of the reference CPU algorithm, oracle/, timed on this host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "examodels.jl_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(sample_n, threads_all):
+    """Times oracle/ (C restatement of src/hessian.jl + src/nlp.jl:1906-1940: zero-fill + one `+=` per
+    contribution) on a bounded sample of the same workload.  kind = "port": the real reference is Julia and
+    cannot run here."""
+    import numpy as np
+    import oracle
+    from exahip import models
+    core = models.luksan_vlcek_model(sample_n)
+    ir = core.to_ir()
+    o = oracle.OracleModel(ir, threads=1)
+    r = np.random.default_rng(0)
+    x = ir.x0 + 0.1 * r.uniform(-1, 1, o.nvar)
+    y = np.random.default_rng(1).standard_normal(o.ncon)
+    out = np.empty(o.nnzh)
+    o.hess_coord(x, y, 0.5, out=out)   # warm
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        o.hess_coord(x, y, 0.5, out=out)
+    t1 = (time.perf_counter() - t0) / reps
+    res = {"value": o.nnzh / t1, "unit": "nnz/s", "cores": 1, "kind": "port",
+           "sample": f"LuksanVlcek N={sample_n} hess_coord!, {reps} evals, single thread (proxy for backend=nothing)",
+           "evals_per_s_at_sample": 1.0 / t1}
+    if threads_all > 1:
+        o.set_threads(threads_all)
+        o.hess_coord(x, y, 0.5, out=out)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o.hess_coord(x, y, 0.5, out=out)
+        tn = (time.perf_counter() - t0) / reps
+        res["all_cores"] = {"value": o.nnzh / tn, "cores": threads_all,
+                            "note": "OpenMP over data points (proxy for the KernelAbstractions CPU() backend)"}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--points", type=float, default=1e7, help="LV size per GPU (N)")
+    ap.add_argument("--cpu-sample", type=float, default=1e6)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--all-callbacks", action="store_true", help="also time obj/cons/grad/jac (secondary)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from exahip import ExaModel, models
+    per_gpu = int(args.points)
+    N = per_gpu * world
+    core = models.luksan_vlcek_model(N)
+    m = ExaModel(core)
+    m.set_shard(rank, world)
+
+    r = np.random.default_rng(0)
+    x = m.meta.x0 + 0.1 * r.uniform(-1, 1, m.meta.nvar)
+    y = np.random.default_rng(1).standard_normal(m.meta.ncon)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.from_numpy(y).to(dev)
+    del x, y
+    h = torch.empty(m.meta.nnzh, dtype=torch.float64, device=dev)
+    sigma = 0.5
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        m.hess_coord(xd, yd, sigma, out=h)
+    barrier()
+    t0 = time.perf_counter()
+    # exactly K steps; the same K launches are bracketed by hipEvents on the launch stream inside libexahip
+    kernel_ms = m.time_callback("hess", args.steps, xd, yd, sigma, out=h)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = t[0].item(), t[1].item()
+
+    nnzh = m.meta.nnzh
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = nnzh * args.steps / elapsed
+    # algorithmic HBM bytes of one launch on one GPU: write each COO slot once, read x and y once;
+    # the LV iterators are UnitRanges (no iterator bytes)
+    shard_nnzh = nnzh / world
+    alg_bytes = 8.0 * shard_nnzh + 8.0 * (m.meta.nvar / world) + 8.0 * (m.meta.ncon / world)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    out = {
+        "metric": "sparse Lagrangian Hessian throughput (hess_coord!), nonzeros/s; evals/s in evals_per_s",
+        "value": value, "unit": "nnz/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"LuksanVlcek N={per_gpu:.0e} per GPU (global N={N:.0e}), hess_coord! sharded-output",
+                   "nvar": m.meta.nvar, "ncon": m.meta.ncon, "nnzh": nnzh, "obj_weight": sigma,
+                   "parallelism": f"iterator-shard x{world}, no data-path collective"},
+        "evals_per_s": args.steps / elapsed,
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "exa_hess", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+    }
+    if args.all_callbacks:
+        g = torch.empty(m.meta.nvar, dtype=torch.float64, device=dev)
+        c = torch.empty(m.meta.ncon, dtype=torch.float64, device=dev)
+        j = torch.empty(m.meta.nnzj, dtype=torch.float64, device=dev)
+        sec = {}
+        for name, buf in (("obj", None), ("cons", c), ("grad", g), ("jac", j)):
+            m.time_callback(name, 3, xd, out=buf)
+            sec[name + "_ms"] = m.time_callback(name, 20, xd, out=buf)
+        out["secondary_callbacks"] = sec
+    if rank == 0 and world == 1 and not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample), os.cpu_count() or 1)
+        out["cpu_baseline"]["gpu_over_cpu_1thread"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
