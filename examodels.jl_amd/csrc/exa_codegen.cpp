@@ -12,6 +12,7 @@
 //     sub-expressions (one sincos per argument, exp reused for f=f'=f'') are shared by construction.
 // Derivative formulas follow src/functionlist.jl:6-81 (algebraically identical, a few rewritten through the
 // already-computed primal to save FP64 divides; parity bar 1e-10 relative).
+#include <algorithm>
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -617,6 +618,24 @@ static __device__ double exa_powi(double x, long n) {
     while (n > 1) { if (n & 1) y *= x; x *= x; n >>= 1; }
     return x * y;
 }
+// COO store epilogue.  A wavefront owns 64*S CONTIGUOUS output doubles (lane l owns S of them).  Storing them
+// lane-by-lane is a 8*S-byte-strided pattern (3.8 TB/s measured); instead the wavefront stages its block in LDS
+// slot-major (conflict-free ds_write_b64) and streams it out lane-interleaved: every store instruction is one
+// fully coalesced 512 B burst, non-temporal (measured 5.7 TB/s, tools/store_bench.hip).
+#define EXA_TILE_LD 65
+template <int S>
+static __device__ __forceinline__ void exa_flush_tile(double* __restrict__ out, long o, long lim, const double* tile, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const int j = k * 64 + lane;
+        const int l2 = j / S, s2 = j - l2 * S;
+        const double v = tile[s2 * EXA_TILE_LD + l2];
+        if (o + j < lim) __builtin_nontemporal_store(v, out + o + j);
+    }
+}
 // sum over the 256-thread workgroup: 64-lane wavefront butterflies, then 4 partials through LDS
 static __device__ __forceinline__ double exa_block_sum(double v) {
     __shared__ double red[EXA_BLOCK / 64];
@@ -639,6 +658,32 @@ extern "C" __global__ void __launch_bounds__(1024) exa_reduce_partials(const dou
     if (threadIdx.x == 0) { double s = 0.0; for (int w = 0; w < 16; w++) s += red[w]; out[0] = s; }
 }
 )HIP";
+
+constexpr int kMaxTileS = 24;
+bool use_tile(int S) { return S >= 2 && S <= kMaxTileS; }
+
+// prologue of a COO-writing pattern function: tail lanes are clamped (they recompute the last point and their
+// stores are masked) so that the whole wavefront reaches the cooperative store epilogue
+void emit_coo_prologue(std::ostringstream &os, const Body &b, const ParamLayout &L, int pi, bool tile) {
+    os << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n";
+    if (tile) {
+        os << "    const int lane = threadIdx.x & 63;\n    if (I0 - lane >= hi) return;\n"
+           << "    const long I = I0 < hi ? I0 : hi - 1;\n";
+    } else {
+        os << "    if (I0 >= hi) return;\n    const long I = I0;\n";
+    }
+}
+void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, const std::vector<std::string> &vals, bool tile) {
+    if (tile) {
+        os << "    double* tile = lds + (threadIdx.x >> 6) * (" << S << " * EXA_TILE_LD);\n";
+        for (int s = 0; s < S; s++) os << "    tile[" << s << " * EXA_TILE_LD + lane] = " << vals[s] << ";\n";
+        os << "    exa_flush_tile<" << S << ">(out, " << b.P(word_o) << " + " << S << "L * (I0 - lane), " << b.P(word_o) << " + " << S
+           << "L * hi, tile, lane);\n";
+    } else {
+        os << "    const long o = " << b.P(word_o) << " + " << S << "L * I;\n";
+        for (int s = 0; s < S; s++) os << "    out[o + " << s << "] = " << vals[s] << ";\n";
+    }
+}
 
 std::string fn_name(int pi, const char *cb) { return "p" + std::to_string(pi) + "_" + cb; }
 
@@ -671,23 +716,23 @@ void gen_first_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     b.forward(p.ad_root, 1, false);
     GenAlg a(b, p.comp1, p.o1step);
     grpass(p, p.ad_root, a, Emitter::litf(1.0));
+    const bool tile = !grad && use_tile(p.o1step);
     os << "static __device__ __forceinline__ void " << fn_name(pi, grad ? "grad" : "jac")
-       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ out, long tid) {\n"
-       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
-    // stores are emitted after the body; index texts are computed first so that they land in e.lines
-    std::vector<std::string> stores;
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ out, long tid"
+       << (grad ? "" : ", double* lds") << ") {\n";
+    emit_coo_prologue(os, b, L, pi, tile);
+    // index texts are computed first so that they land in e.lines
+    std::vector<std::string> stores, vals;
     for (int s = 0; s < p.o1step; s++) {
         if (grad) {
             if (a.acc[s].lit_eq(0)) continue;
             Val vi = b.fv[p.slotvar1[s]].vidx;
             stores.push_back("unsafeAtomicAdd(&out[" + b.e.s(b.e.sub(vi, Emitter::liti(1))) + "], " + b.e.sd(a.acc[s]) + ");");
-        } else {
-            stores.push_back("out[o + " + std::to_string(s) + "] = " + b.e.sd(a.acc[s]) + ";");
-        }
+        } else vals.push_back(b.e.sd(a.acc[s]));
     }
     emit_lines(os, b.e);
-    if (!grad) os << "    const long o = " << b.P(L.pat[pi].o1) << " + " << p.o1step << "L * I;\n";
-    for (auto &s : stores) os << "    " << s << "\n";
+    if (grad) { for (auto &s : stores) os << "    " << s << "\n"; }
+    else emit_coo_stores(os, b, L.pat[pi].o1, p.o1step, vals, tile);
     os << "}\n";
 }
 
@@ -700,13 +745,15 @@ void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     else adj = b.e.raw("y[" + b.row0() + "]", false);
     GenAlg a(b, p.comp2, p.o2step);
     hrpass0(p, p.ad_root, a, adj, Emitter::litf(0.0));
+    const bool tile = use_tile(p.o2step);
     os << "static __device__ __forceinline__ void " << fn_name(pi, "hess")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
-          "double* __restrict__ out, double sigma, long tid) {\n"
-       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
+          "double* __restrict__ out, double sigma, long tid, double* lds) {\n";
+    emit_coo_prologue(os, b, L, pi, tile);
     emit_lines(os, b.e);
-    os << "    const long o = " << b.P(L.pat[pi].o2) << " + " << p.o2step << "L * I;\n";
-    for (int s = 0; s < p.o2step; s++) os << "    out[o + " << s << "] = " << b.e.sd(a.acc[s]) << ";\n";
+    std::vector<std::string> vals;
+    for (int s = 0; s < p.o2step; s++) vals.push_back(b.e.sd(a.acc[s]));
+    emit_coo_stores(os, b, L.pat[pi].o2, p.o2step, vals, tile);
     os << "}\n";
 }
 
@@ -740,14 +787,15 @@ void gen_struct_fn(std::ostringstream &os, const Model &m, int pi, const ParamLa
 }
 
 // ---- fused kernels: blockIdx -> (pattern, tile) ------------------------------------------------------
-void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const std::string &call_prefix, const std::string &call_args) {
+void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const std::string &call_prefix, const std::string &call_args,
+                  const std::string &tail_args = "") {
     const auto &act = L.active[cb];
     os << "    const long b = blockIdx.x;\n";
     for (size_t k = 0; k < act.size(); k++) {
         const std::string end = "P[" + std::to_string(L.blk[cb] + (int)k) + "]";
         const std::string beg = k == 0 ? "0L" : "P[" + std::to_string(L.blk[cb] + (int)k - 1) + "]";
         os << "    " << (k ? "else " : "") << "if (b < " << end << ") { const long tid = (b - " << beg << ") * EXA_BLOCK + threadIdx.x; "
-           << "p" << act[k] << "_" << call_prefix << "(" << call_args << ", tid); }\n";
+           << "p" << act[k] << "_" << call_prefix << "(" << call_args << ", tid" << tail_args << "); }\n";
     }
 }
 
@@ -821,13 +869,21 @@ Generated generate_module(const Model &m) {
           "const double* __restrict__ th, double* __restrict__ out) {\n";
     gen_dispatch(os, L, CB_CONSAUG, "cons", "P, x, th, out");
     os << "}\n";
+    auto lds_decl = [&](int cb, bool hess) {
+        int mx = 0;
+        for (int k : L.active[cb]) { const int S = hess ? m.pats[k].o2step : m.pats[k].o1step; if (use_tile(S)) mx = std::max(mx, S); }
+        if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << " * EXA_TILE_LD];\n    double* lds = lds_all;\n";
+        else os << "    double* lds = nullptr;\n";
+    };
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jac(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out) {\n";
-    gen_dispatch(os, L, CB_JAC, "jac", "P, x, th, out");
+    lds_decl(CB_JAC, false);
+    gen_dispatch(os, L, CB_JAC, "jac", "P, x, th, out", ", lds");
     os << "}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hess(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma) {\n";
-    gen_dispatch(os, L, CB_HESS, "hess", "P, x, y, th, out, sigma");
+    lds_decl(CB_HESS, true);
+    gen_dispatch(os, L, CB_HESS, "hess", "P, x, y, th, out, sigma", ", lds");
     os << "}\n";
     for (int wide = 0; wide < 2; wide++) {
         const char *it = wide ? "long" : "int";
