@@ -333,6 +333,7 @@ typedef struct {
     double *theta;
     double *x0, *lvar, *uvar, *lcon, *ucon;
     int nthreads;
+    int rank, world;   /* iterator shard of every pattern: [n*rank/world, n*(rank+1)/world) (tests of the N>1 host logic) */
 } ora_model;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -665,7 +666,7 @@ static double *dupd(const double *src, int64_t n, double fill) {
 void *ora_new(const exa_model_desc_t *d) {
     ora_handle *h = (ora_handle *)calloc(1, sizeof(ora_handle));
     ora_model *m = &h->m;
-    m->nvar = d->nvar; m->npar = d->npar; m->npat = d->n_patterns; m->nthreads = 1;
+    m->nvar = d->nvar; m->npar = d->npar; m->npat = d->n_patterns; m->nthreads = 1; m->rank = 0; m->world = 1;
     m->pat = (pattern *)calloc(m->npat ? m->npat : 1, sizeof(pattern));
     h->tmpl = (adnode **)calloc(m->npat ? m->npat : 1, sizeof(adnode *));
     m->theta = dupd(d->theta0, d->npar, 0.0);
@@ -722,6 +723,9 @@ int64_t ora_nnzj(void *h) { return ((ora_handle *)h)->m.nnzj; }
 int64_t ora_nnzh(void *h) { return ((ora_handle *)h)->m.nnzh; }
 int64_t ora_nnzg(void *h) { return ((ora_handle *)h)->m.nnzg; }
 int ora_npatterns(void *h) { return ((ora_handle *)h)->m.npat; }
+static inline int64_t shard_lo(const ora_model *m, const pattern *p) { return (int64_t)((__int128)p->n * m->rank / m->world); }
+static inline int64_t shard_hi(const ora_model *m, const pattern *p) { return (int64_t)((__int128)p->n * (m->rank + 1) / m->world); }
+void ora_set_shard(void *h, int rank, int world) { ((ora_handle *)h)->m.rank = rank; ((ora_handle *)h)->m.world = world; }
 void ora_set_threads(void *h, int n) { ((ora_handle *)h)->m.nthreads = n < 1 ? 1 : n; }
 void ora_set_theta(void *h, int64_t off, const double *v, int64_t len) { memcpy(((ora_handle *)h)->m.theta + off, v, sizeof(double) * len); }
 
@@ -754,7 +758,7 @@ double ora_obj(void *hh, const double *x) {
     for (int k = 0; k < m->npat; k++) {
         pattern *p = &m->pat[k];
         if (p->kind != EXA_PAT_OBJ) continue;
-        for (int64_t I = 0; I < p->n; I++) s += asf(ev(p, p->root, I, x, m->theta));
+        for (int64_t I = shard_lo(m, p); I < shard_hi(m, p); I++) s += asf(ev(p, p->root, I, x, m->theta));
     }
     return s;
 }
@@ -766,7 +770,7 @@ void ora_cons(void *hh, const double *x, double *g) {
     for (int k = 0; k < m->npat; k++) {
         pattern *p = &m->pat[k];
         if (p->kind == EXA_PAT_OBJ) continue;
-        for (int64_t I = 0; I < p->n; I++) g[row_of(p, I, m->theta)] += asf(ev(p, p->root, I, x, m->theta));
+        for (int64_t I = shard_lo(m, p); I < shard_hi(m, p); I++) g[row_of(p, I, m->theta)] += asf(ev(p, p->root, I, x, m->theta));
     }
 }
 
@@ -776,9 +780,10 @@ static void drive(ora_handle *h, int k, const double *x, point_fn fn, void *user
     ora_model *m = &h->m;
     pattern *p = &m->pat[k];
     int nt = parallel ? m->nthreads : 1;
+    const int64_t lo = shard_lo(m, p), hi = shard_hi(m, p);
     if (nt <= 1) {
         adnode *t = h->tmpl[k];
-        for (int64_t I = 0; I < p->n; I++) { ctx c = {p, I, x, m->theta}; fn(p, t, &c, user); }
+        for (int64_t I = lo; I < hi; I++) { ctx c = {p, I, x, m->theta}; fn(p, t, &c, user); }
         return;
     }
 #ifdef _OPENMP
@@ -786,11 +791,11 @@ static void drive(ora_handle *h, int k, const double *x, point_fn fn, void *user
     {
         adnode *t = clone_ad(h->tmpl[k]);
 #pragma omp for schedule(static)
-        for (int64_t I = 0; I < p->n; I++) { ctx c = {p, I, x, m->theta}; fn(p, t, &c, user); }
+        for (int64_t I = lo; I < hi; I++) { ctx c = {p, I, x, m->theta}; fn(p, t, &c, user); }
         free_ad(t);
     }
 #else
-    { adnode *t = h->tmpl[k]; for (int64_t I = 0; I < p->n; I++) { ctx c = {p, I, x, m->theta}; fn(p, t, &c, user); } }
+    { adnode *t = h->tmpl[k]; for (int64_t I = lo; I < hi; I++) { ctx c = {p, I, x, m->theta}; fn(p, t, &c, user); } }
 #endif
 }
 

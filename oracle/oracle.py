@@ -35,6 +35,7 @@ def lib():
             getattr(L, f).argtypes = [vp]
         L.ora_npatterns.argtypes = [vp]
         L.ora_set_threads.argtypes = [vp, ctypes.c_int]
+        L.ora_set_shard.argtypes = [vp, ctypes.c_int, ctypes.c_int]
         L.ora_set_theta.argtypes = [vp, i64, vp, i64]
         L.ora_pattern_info.argtypes = [vp, ctypes.c_int, vp]
         L.ora_pattern_comp.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
@@ -87,6 +88,9 @@ class OracleModel:
 
     def set_threads(self, n):
         self._L.ora_set_threads(self._h, int(n))
+
+    def set_shard(self, rank, world):
+        self._L.ora_set_shard(self._h, int(rank), int(world))
 
     def set_value(self, offset, vals):
         v = _f64(vals)

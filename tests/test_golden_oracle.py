@@ -1,0 +1,83 @@
+"""Pins the TEST ORACLE (oracle/exa_oracle.c) against the golden vectors of tests/golden/ad_golden.json
+(symbolic derivatives by sympy, 40-digit evaluation; generator: tests/golden/make_golden.py).
+
+This is the in-container stand-in for the reference's own differential test against ForwardDiff
+(test/ADTest/ADTest.jl:344-373).  CPU only.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from exprs import EXPRS, NPAR, NVAR  # noqa: E402
+
+from exahip import ExaCore, graph, rng  # noqa: E402
+
+with open(os.path.join(HERE, "golden", "ad_golden.json")) as fh:
+    GOLD = json.load(fh)
+CASES = {c["name"]: c for c in GOLD["cases"]}
+X0, T0 = np.array(GOLD["x"]), np.array(GOLD["theta"])
+
+TOL = 1e-11   # oracle (glibc libm, double) vs 40-digit symbolic truth
+
+
+class NodeF:
+    """exahip namespace for exprs.py."""
+    abs = staticmethod(abs)
+
+    def __getattr__(self, k):
+        return getattr(graph, k)
+
+
+def close(a, ref, tol=TOL):
+    a, ref = np.asarray(a, dtype=float), np.asarray(ref, dtype=float)
+    scale = np.maximum(np.abs(ref), max(1.0, float(np.max(np.abs(ref)))) * 1e-3)
+    return float(np.max(np.abs(a - ref) / scale)) <= tol
+
+
+def dense_lower(rows, cols, vals, n):
+    H = np.zeros((n, n))
+    np.add.at(H, (rows - 1, cols - 1), vals)
+    return H
+
+
+def build_case(f, as_constraint):
+    c = ExaCore()
+    x = c.add_var(NVAR, start=X0)
+    th = c.add_par(NPAR, value=T0)
+    e = f(x, th, NodeF())
+    if as_constraint:
+        c.add_con(e)
+    else:
+        c.add_obj(e)
+    return c
+
+
+@pytest.mark.parametrize("name", [n for n, _ in EXPRS])
+def test_oracle_matches_symbolic_derivatives(libs, name):
+    import oracle
+    f = dict(EXPRS)[name]
+    g = CASES[name]
+    gold_H = np.tril(np.array(g["hess"]))
+    # as an objective: obj / grad! / hess_coord!(obj_weight)
+    o = oracle.OracleModel(build_case(f, False).to_ir())
+    assert close(o.obj(X0), g["value"])
+    assert close(o.grad(X0), g["grad"])
+    r, c = o.hess_structure()
+    assert np.all(r >= c)
+    H = dense_lower(r, c, o.hess_coord(X0, np.zeros(0), 1.0), NVAR)
+    assert close(H, gold_H)
+    # as a constraint row: cons! / jac_coord! / hess_coord!(y)
+    o = oracle.OracleModel(build_case(f, True).to_ir())
+    assert close(o.cons(X0), [g["value"]])
+    jr, jc = o.jac_structure()
+    J = np.zeros(NVAR)
+    np.add.at(J, jc - 1, o.jac_coord(X0))
+    assert np.all(jr == 1) and close(J, g["grad"])
+    r, c = o.hess_structure()
+    H = dense_lower(r, c, o.hess_coord(X0, np.array([-1.75]), 0.0), NVAR)
+    assert close(H, -1.75 * gold_H)

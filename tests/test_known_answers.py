@@ -1,0 +1,253 @@
+"""Known-answer tests the reference's own suite holds for this path, replayed on the test oracle (CPU).
+
+Each test cites the reference test whose expected values it restates.  The same model builders are evaluated by
+the HIP path in tests/test_gpu_known_answers.py.
+"""
+import numpy as np
+import pytest
+
+from exahip import ExaCore, Table, graph, models, product, rng
+from exahip.graph import Constant
+
+
+def oracle_model(core):
+    import oracle
+    return oracle.OracleModel(core.to_ir())
+
+
+# ---- model builders (shared with the GPU test) -----------------------------------------------------------------
+def conaug_1d_sugar(N=9):
+    """conaug_test.jl:37-48: `@add_con(c, g, Constant(0) for _ = 1:N)`, `@add_con!(c, g[i] += x[i] + x[i+1])`; x = ones -> all 2."""
+    c = ExaCore()
+    x = c.add_var(N + 1)
+    g = c.add_con(lambda _: Constant(0), rng(1, N), lcon=-1.0, ucon=1.0)
+    c.add_con_aug(None, lambda i: g[i] + (x[i] + x[i + 1]), rng(1, N))
+    return c, np.ones(N + 1), np.full(N, 2.0)
+
+
+def conaug_2d_int(N=3, M=4):
+    """conaug_test.jl:73-95"""
+    c = ExaCore()
+    x = c.add_var(N, M)
+    g = c.add_con(N, M, lcon=-np.inf, ucon=0.0)
+    itr = [(i, j) for j in range(1, M + 1) for i in range(1, N)]
+    c.add_con_aug(None, lambda p: g[p[0], p[1]] + (x[p[0], p[1]] - x[p[0] + 1, p[1]]), itr)
+    x0 = np.arange(1.0, N * M + 1)
+    exp = np.array([(float((j - 1) * N + i) - float((j - 1) * N + i + 1)) if i < N else 0.0
+                    for j in range(1, M + 1) for i in range(1, N + 1)])
+    return c, x0, exp, len(itr) * 2
+
+
+def conaug_2d_range(N=3, M=4):
+    """conaug_test.jl:97-123: range-based dims with a non-unit start (r2 = 2:M+1)."""
+    c = ExaCore()
+    x = c.add_var(N, M + 1)
+    g = c.add_con(rng(1, N), rng(2, M + 1), lcon=-np.inf, ucon=0.0)
+    itr = [(i, j) for j in range(2, M + 2) for i in range(1, N)]
+    c.add_con_aug(None, lambda p: g[p[0], p[1]] + (x[p[0], p[1]] - x[p[0] + 1, p[1]]), itr)
+    x0 = np.arange(1.0, N * (M + 1) + 1)
+    exp = np.array([-1.0 if i < N else 0.0 for _ in range(1, M + 1) for i in range(1, N + 1)])
+    return c, x0, exp, len(itr) * 2
+
+
+def conaug_3d(N=2, M=3, K=4):
+    """conaug_test.jl:125-143"""
+    c = ExaCore()
+    x = c.add_var(N * M * K)
+    g = c.add_con(N, M, K, lcon=0.0, ucon=0.0)
+    itr = [(i, j, k) for k in range(1, K + 1) for j in range(1, M + 1) for i in range(1, N + 1)]
+    c.add_con_aug(None, lambda p: g[p[0], p[1], p[2]] + x[(p[2] - 1) * N * M + (p[1] - 1) * N + p[0]] * 2, itr)
+    return c, np.ones(N * M * K), np.full(N * M * K, 2.0), len(itr)
+
+
+def conaug_multi(N=4, M=5):
+    """conaug_test.jl:180-214: forward and backward differences on one 2-D constraint."""
+    c = ExaCore()
+    x = c.add_var(N, M)
+    g = c.add_con(N, M, lcon=-np.inf, ucon=np.inf)
+    fwd = [(i, j) for j in range(1, M + 1) for i in range(1, N)]
+    bwd = [(i, j) for j in range(1, M + 1) for i in range(2, N + 1)]
+    c.add_con_aug(None, lambda p: g[p[0], p[1]] + (x[p[0], p[1]] - x[p[0] + 1, p[1]]), fwd)
+    c.add_con_aug(None, lambda p: g[p[0], p[1]] + (x[p[0] - 1, p[1]] - x[p[0], p[1]]), bwd)
+    x0 = np.arange(1.0, N * M + 1)
+    exp = []
+    for j in range(1, M + 1):
+        for i in range(1, N + 1):
+            b = (j - 1) * N
+            exp.append(float(b + 1) - float(b + 2) if i == 1 else (float(b + N - 1) - float(b + N) if i == N else float(b + i - 1) - float(b + i + 1)))
+    return c, x0, np.array(exp), (len(fwd) + len(bwd)) * 2
+
+
+def par_nonunit():
+    """feature_test.jl:100-112: add_par(core, 2:4; value=[10,20,30]); θ[j]*x[1] for j in 2:4; x = ones."""
+    c = ExaCore()
+    x = c.add_var(5)
+    th = c.add_par(rng(2, 4), value=[10.0, 20.0, 30.0])
+    c.add_con(lambda j: th[j] * x[1], rng(2, 4))
+    return c, np.ones(5), np.array([10.0, 20.0, 30.0])
+
+
+def par_multidim():
+    """feature_test.jl:114-126: add_par(core, 3, 2:5; value=1:12); θ[i,j]*x[1] for (1,2),(2,3),(3,4)."""
+    c = ExaCore()
+    x = c.add_var(12)
+    th = c.add_par(3, rng(2, 5), value=np.arange(1.0, 13.0))
+    c.add_con(lambda p: th[p[0], p[1]] * x[1], [(1, 2), (2, 3), (3, 4)])
+    return c, np.ones(12), np.array([1.0, 5.0, 9.0])
+
+
+def par_set_value():
+    """feature_test.jl:159-168: set_value! before the model is built."""
+    c = ExaCore()
+    th = c.add_par(rng(2, 4), value=np.ones(3))
+    c.set_value(th, [5.0, 6.0, 7.0])
+    x = c.add_var(1)
+    c.add_con(lambda j: th[j] * x[1], rng(2, 4))
+    return c, np.ones(1), np.array([5.0, 6.0, 7.0])
+
+
+def expr_nonunit():
+    """feature_test.jl:171-182: add_expr(x[i]^2 for i in 2:4); s[j] for j in 2:4; x = 1:5 -> [4,9,16]."""
+    c = ExaCore()
+    x = c.add_var(5)
+    s = c.add_expr(lambda i: x[i] ** 2, rng(2, 4))
+    c.add_con(lambda j: s[j], rng(2, 4))
+    return c, np.arange(1.0, 6.0), np.array([4.0, 9.0, 16.0])
+
+
+def data_axis():
+    """feature_test.jl:128-157 (zip axis): y[i] - v for (i, v) in zip(2:4, [5,45,0]); y = 0."""
+    c = ExaCore()
+    y = c.add_var(6, start=0.0)
+    c.add_con(lambda p: y[p[0]] - p[1], [(2, 5.0), (3, 45.0), (4, 0.0)])
+    return c, np.zeros(6), np.array([-5.0, -45.0, 0.0])
+
+
+CONS_CASES = {
+    "conaug_1d_sugar": lambda: conaug_1d_sugar()[:3],
+    "conaug_2d_int": lambda: conaug_2d_int()[:3],
+    "conaug_2d_range": lambda: conaug_2d_range()[:3],
+    "conaug_3d": lambda: conaug_3d()[:3],
+    "conaug_multi": lambda: conaug_multi()[:3],
+    "par_nonunit": par_nonunit,
+    "par_multidim": par_multidim,
+    "par_set_value": par_set_value,
+    "expr_nonunit": expr_nonunit,
+    "data_axis": data_axis,
+}
+
+
+@pytest.mark.parametrize("name", list(CONS_CASES))
+def test_cons_known_answers(libs, name):
+    core, x0, expected = CONS_CASES[name]()
+    o = oracle_model(core)
+    assert o.ncon == len(expected)
+    np.testing.assert_allclose(o.cons(x0), expected, rtol=0, atol=1e-14)
+
+
+def test_conaug_nnzj_counts(libs):
+    for mk in (conaug_2d_int, conaug_2d_range, conaug_3d, conaug_multi):
+        core, _, exp, nnzj = mk()
+        o = oracle_model(core)
+        assert o.nnzj == nnzj and o.ncon == len(exp)
+
+
+def test_conaug_old_and_sugar_syntax_agree(libs):
+    """conaug_test.jl:11-35"""
+    N = 9
+    c1 = ExaCore()
+    x1 = c1.add_var(N + 1)
+    g1 = c1.add_con(N, lcon=-1.0, ucon=1.0)
+    c1.add_con_aug(g1, lambda i: (i, x1[i] + x1[i + 1]), rng(1, N))
+    c2 = ExaCore()
+    x2 = c2.add_var(N + 1)
+    g2 = c2.add_con(N, lcon=-1.0, ucon=1.0)
+    c2.add_con_aug(None, lambda i: g2[i] + (x2[i] + x2[i + 1]), rng(1, N))
+    o1, o2 = oracle_model(c1), oracle_model(c2)
+    assert (o1.nnzj, o1.nnzh) == (o2.nnzj, o2.nnzh)
+    x0 = np.random.default_rng(0).uniform(size=N + 1)
+    np.testing.assert_array_equal(o1.cons(x0), o2.cons(x0))
+
+
+def test_concrete_mode_known_objective(libs):
+    """test/ConcreteModeTest.jl:58-64: sum (x_i - 1)^2 at x = 1.5, N = 4 -> 1.0;
+    ExaModelsCompiler/test/runtests.jl:305-306 analogue: obj at ones of sum x_i^2 is N."""
+    c = ExaCore()
+    x = c.add_var(4, start=1.5)
+    c.add_obj(lambda i: (x[i] - 1) ** 2, rng(1, 4))
+    o = oracle_model(c)
+    x0 = o.meta()[0]
+    assert o.obj(x0) == 1.0
+    c = ExaCore()
+    x = c.add_var(7)
+    c.add_obj(lambda i: x[i] ** 2, rng(1, 7))
+    assert oracle_model(c).obj(np.ones(7)) == 7.0
+
+
+# ---- Luksan-Vlcek: layout tables and the published KKT point ---------------------------------------------------
+XSTAR = np.array([-0.9505563573613093, 0.9139008176388945, 0.9890905176644905, 0.9985592422681151, 0.9998087408802769,
+                  0.9999745932450963, 0.9999966246997642, 0.9999995512524277, 0.999999944919307, 0.999999930070643])
+LSTAR = np.array([4.1358568305002255, -1.876494903703342, -0.06556333356358675, -0.021931863018312875,
+                  -0.0019537261317119302, -0.00032910445671233547, -3.8788212776372465e-5, -7.376592164341867e-6])
+
+
+def test_lv10_published_kkt_point(libs):
+    """docs/src/develop.md:84-106: Ipopt solution and multipliers of luksan_vlcek_model(10).  With only the
+    evaluators: c(x*) = 0 and grad f(x*) + J(x*)^T lambda* = 0 — pins obj-grad / cons / jac sign conventions and
+    the COO layout end to end without a solver."""
+    o = oracle_model(models.luksan_vlcek_model(10))
+    assert np.max(np.abs(o.cons(XSTAR))) < 1e-8
+    jr, jc = o.jac_structure()
+    J = np.zeros((o.ncon, o.nvar))
+    np.add.at(J, (jr - 1, jc - 1), o.jac_coord(XSTAR))
+    assert np.max(np.abs(o.grad(XSTAR) + J.T @ LSTAR)) < 1e-6
+
+
+def test_lv_layout_tables(libs):
+    """SURVEY App. B (derived from hessian.jl / simdfunction.jl rules): LV objective comp1=(1,2,1), comp2=(1,2,3,1),
+    o2step=3; constraint 10 first-order visits -> o1step 3, 17 second-order visits -> o2step 6 with keys
+    (a,a),(b,b),(a,b),(b,a),(c,c),(c,a); nnzh = 9N-15; the constraint block comes first in the Hessian."""
+    N = 20
+    o = oracle_model(models.luksan_vlcek_model(N))
+    assert (o.nvar, o.ncon, o.nnzj, o.nnzh, o.nnzg) == (N, N - 2, 3 * (N - 2), 9 * N - 15, 2 * (N - 1))
+    con, obj = o.pattern_info(0), o.pattern_info(1)
+    assert (con["o1step"], con["o2step"], con["n1"], con["n2"], con["o2"]) == (3, 6, 10, 17, 0)
+    assert (obj["o1step"], obj["o2step"], obj["n1"], obj["n2"], obj["o2"]) == (2, 3, 3, 4, 6 * (N - 2))
+    assert o.pattern_comp(1, 1) == [1, 2, 1] and o.pattern_comp(1, 2) == [1, 2, 3, 1]
+    r, c = o.hess_structure()
+    i = 1   # first data point of the constraint: a = x[2], b = x[3], c = x[1]
+    assert list(zip(r[:6], c[:6])) == [(i + 1, i + 1), (i + 2, i + 2), (i + 2, i + 1), (i + 2, i + 1), (i, i), (i + 1, i)]
+    k = 6 * (N - 2)   # first data point of the objective, i = 2: slots (1,1), (2,2), (2,1)
+    assert list(zip(r[k:k + 3], c[k:k + 3])) == [(1, 1), (2, 2), (2, 1)]
+    # insertion order decides the ranges (docs/src/performance.jl:13-17 adds the objective first)
+    o2 = oracle_model(models.luksan_vlcek_model(N, obj_first=True))
+    assert o2.pattern_info(0)["o2"] == 0 and o2.pattern_info(1)["o2"] == 3 * (N - 1)
+
+
+def test_lv_split_variant_layout(libs):
+    """test/NLPTest/luksan.jl:17-26: base con1 (o2step 1) + augmentation con2 (o2step 6), 2-D variables."""
+    N, M = 20, 2
+    o = oracle_model(models.luksan_vlcek_split_model(N, M))
+    assert o.ncon == (N - 2) * M
+    assert o.pattern_info(0)["o2step"] == 1 and o.pattern_info(1)["o2step"] == 6
+    assert o.pattern_info(1)["o0"] == o.pattern_info(0)["o0"]          # augmentation rows land on the base block
+    # same numbers as the merged 1-D model when M == 1
+    o1 = oracle_model(models.luksan_vlcek_split_model(N, 1))
+    om = oracle_model(models.luksan_vlcek_model(N))
+    x = models.lv_x0(N) + 0.05
+    np.testing.assert_allclose(o1.cons(x), om.cons(x), rtol=1e-14)
+    np.testing.assert_allclose(o1.obj(x), om.obj(x), rtol=1e-14)
+
+
+def test_acopf_layout_table(libs):
+    """SURVEY App. B / test/NLPTest/power.jl:112-213: per-block strides of the 15 ACOPF blocks and the totals
+    nnzj = nref + 30 nbr + 2 nbus + 2 ngen, nnzh = ngen + 44 nbr + 2 nbus."""
+    nbus, nbr, ngen = 30, 41, 6
+    o = oracle_model(models.ac_power_model(models.synthetic_power_data(nbus, nbr, ngen, seed=3)))
+    steps = [(o.pattern_info(k)["o1step"], o.pattern_info(k)["o2step"]) for k in range(o.npatterns)]
+    assert steps == [(1, 1), (1, 0), (5, 10), (5, 10), (5, 10), (5, 10), (2, 0), (2, 2), (2, 2), (1, 1), (1, 1),
+                     (1, 0), (1, 0), (1, 0), (1, 0)]
+    assert o.nvar == 2 * nbus + 2 * ngen + 4 * nbr
+    assert o.ncon == 1 + 7 * nbr + 2 * nbus
+    assert o.nnzj == 1 + 30 * nbr + 2 * nbus + 2 * ngen
+    assert o.nnzh == ngen + 44 * nbr + 2 * nbus

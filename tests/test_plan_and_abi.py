@@ -1,0 +1,146 @@
+"""-m "not gpu": host logic of libexahip.so without a device.
+
+* the library loads and exports every symbol include/exahip.h declares;
+* status codes: 0 ok / 1 bad id or argument / 2 internal error, never an exception across the boundary
+  (cnlp ABI convention, ExaModelsCompiler/src/ExaModelsCompiler.jl:1560-1732);
+* the PLANNER (slot maps comp1/comp2, o1step/o2step, running offsets) agrees with the test oracle's independent
+  implementation on every zoo model and every golden expression;
+* the generated HIP module of representative models compiles for gfx950 (hipcc cross-compiles without a GPU);
+* no compute entry point works without a device: they return status 1 on a plan-only model, and
+  exa_new_from_table fails with status 2 ("no HIP device") instead of falling back to the CPU.
+"""
+import ctypes
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+from conftest import has_gpu  # noqa: E402
+from zoo import ZOO  # noqa: E402
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "exahip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(exa_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(libs):
+    from exahip import capi
+    L = capi.lib()
+    declared = header_symbols()
+    assert len(declared) >= 40
+    for s in declared:
+        assert hasattr(L, s), f"libexahip.so does not export {s}"
+    assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS and include/exahip.h disagree"
+    assert L.exa_abi_version() == 1
+
+
+def test_bad_ids_and_arguments_return_status_1(libs):
+    from exahip import capi
+    L = capi.lib()
+    assert L.exa_nvar(12345) == -1 and L.exa_nnzh64(0) == -1
+    buf = (ctypes.c_double * 4)()
+    assert L.exa_obj_host(999, buf, buf) == 1
+    assert L.exa_hess(999, buf, buf, 1.0, buf) == 1
+    assert L.exa_free(999) == 1
+    assert L.exa_set_shard(999, 0, 1) == 1
+    idc = ctypes.c_int(0)
+    assert L.exa_new_from_table(None, ctypes.byref(idc)) == 1
+    assert L.exa_plan_only(None, ctypes.byref(idc)) == 1
+
+
+def test_malformed_table_is_rejected_not_crashed(libs):
+    from exahip import ExaCore, capi, rng
+    from exahip.core import CNode
+    L = capi.lib()
+    c = ExaCore()
+    x = c.add_var(3)
+    c.add_con(lambda i: x[i] * x[i], rng(1, 3))
+    ir = c.to_ir()
+    # corrupt: make the root point past the node array
+    ir.patterns[0].root = 10_000
+    idc = ctypes.c_int(0)
+    assert L.exa_plan_only(ctypes.addressof(ir.desc), ctypes.byref(idc)) == 1
+    ir = c.to_ir()
+    nodes = ctypes.cast(ir.patterns[0].nodes, ctypes.POINTER(CNode))
+    nodes[ir.patterns[0].n_nodes - 1].fn = 99      # unknown function id
+    assert L.exa_plan_only(ctypes.addressof(ir.desc), ctypes.byref(idc)) == 1
+
+
+def test_plan_only_model_cannot_compute_and_shards(libs):
+    from exahip import ExaModel, capi, models
+    m = ExaModel(models.luksan_vlcek_model(10), device=False)
+    L = capi.lib()
+    buf = (ctypes.c_double * 100)()
+    assert L.exa_obj_host(m.id, buf, buf) == 1
+    assert L.exa_hess_host(m.id, buf, buf, 1.0, buf) == 1
+    assert L.exa_set_shard(m.id, 1, 2) == 0 and L.exa_set_shard(m.id, 2, 2) == 1 and L.exa_set_shard(m.id, 0, 0) == 1
+    x0, lv, uv = np.zeros(10), np.zeros(10), np.zeros(10)
+    assert L.exa_meta(m.id, x0.ctypes.data, lv.ctypes.data, uv.ctypes.data, None, None) == 0
+    assert x0[0] == -1.2 and x0[1] == 1.0 and np.all(np.isinf(lv))
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_cpu_fallback_without_device(libs):
+    from exahip import ExaModel, models
+    from exahip.capi import ExaHipError
+    with pytest.raises(ExaHipError, match="status 2"):
+        ExaModel(models.luksan_vlcek_model(10), device=True)
+
+
+@pytest.mark.parametrize("name", list(ZOO))
+def test_planner_matches_oracle_on_zoo(libs, name):
+    from exahip import ExaModel
+    import oracle
+    m = ExaModel(ZOO[name](), device=False)
+    o = oracle.OracleModel(m.ir)
+    assert (m.meta.nvar, m.meta.ncon, m.meta.nnzj, m.meta.nnzh, m.meta.nnzg) == (o.nvar, o.ncon, o.nnzj, o.nnzh, o.nnzg)
+    assert m.npatterns == o.npatterns
+    for k in range(m.npatterns):
+        assert m.pattern_info(k) == o.pattern_info(k), k
+        assert m.pattern_comp(k, 1) == o.pattern_comp(k, 1), k
+        assert m.pattern_comp(k, 2) == o.pattern_comp(k, 2), k
+    mx0, mlv, muv = m.meta.x0, m.meta.lvar, m.meta.uvar
+    ox0, olv, ouv, olc, ouc = o.meta()
+    assert np.array_equal(mx0, ox0) and np.array_equal(mlv, olv) and np.array_equal(muv, ouv)
+    assert np.array_equal(m.meta.lcon, olc) and np.array_equal(m.meta.ucon, ouc)
+
+
+def test_planner_matches_oracle_on_golden_expressions(libs):
+    from exprs import EXPRS
+    from test_golden_oracle import build_case
+    from exahip import ExaModel
+    import oracle
+    for name, f in EXPRS:
+        for as_con in (False, True):
+            m = ExaModel(build_case(f, as_con), device=False)
+            o = oracle.OracleModel(m.ir)
+            assert m.pattern_info(0) == o.pattern_info(0), name
+            assert m.pattern_comp(0, 1) == o.pattern_comp(0, 1), name
+            assert m.pattern_comp(0, 2) == o.pattern_comp(0, 2), name
+
+
+@pytest.mark.parametrize("name", ["lv20", "mixed", "acopf30"])
+def test_generated_module_compiles_for_gfx950(libs, name):
+    from exahip import ExaModel
+    m = ExaModel(ZOO[name](), device=False)
+    src = m.kernel_source()
+    assert 'extern "C" __global__' in src and "exa_hess" in src
+    path = m.compile()
+    assert os.path.exists(path) and os.path.getsize(path) > 1000
+
+
+def test_module_source_is_size_independent(libs):
+    """One compiled module serves every N of the same model (sizes/offsets are run-time parameters)."""
+    from exahip import ExaModel, models
+    a = ExaModel(models.luksan_vlcek_model(10), device=False).kernel_source()
+    b = ExaModel(models.luksan_vlcek_model(12345), device=False).kernel_source()
+    assert a == b
