@@ -16,6 +16,7 @@
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <stdexcept>
@@ -622,19 +623,26 @@ static __device__ double exa_powi(double x, long n) {
 // lane-by-lane is a 8*S-byte-strided pattern (3.8 TB/s measured); instead the wavefront stages its block in LDS
 // slot-major (conflict-free ds_write_b64) and streams it out lane-interleaved: every store instruction is one
 // fully coalesced 512 B burst, non-temporal (measured 5.7 TB/s, tools/store_bench.hip).
-#define EXA_TILE_LD 65
-template <int S>
-static __device__ __forceinline__ void exa_flush_tile(double* __restrict__ out, long o, long lim, const double* tile, int lane) {
+// Flushes the S slots of PP consecutive points (point group g of the wavefront): one CONTIGUOUS run of PP*S doubles,
+// so every store instruction is a full 512-B burst.  PP = 64 stages the whole wavefront at once; wide patterns use
+// PP = 32/16/8 (several passes) to bound LDS per workgroup.  tile is slot-major with leading dimension PP+1.
+template <int S, int PP>
+static __device__ __forceinline__ void exa_flush_points(double* __restrict__ out, long obase, long npts, const double* tile, int lane, int g) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int CNT = S * PP;
 #pragma unroll
-    for (int k = 0; k < S; k++) {
+    for (int k = 0; k * 64 < CNT; k++) {
         const int j = k * 64 + lane;
         const int l2 = j / S, s2 = j - l2 * S;
-        const double v = tile[s2 * EXA_TILE_LD + l2];
-        if (o + j < lim) __builtin_nontemporal_store(v, out + o + j);
+        if (j < CNT && g * PP + l2 < npts) {
+            const double v = tile[s2 * (PP + 1) + l2];
+            __builtin_nontemporal_store(v, out + obase + (long)CNT * g + j);
+        }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 // sum over the 256-thread workgroup: 64-lane wavefront butterflies, then 4 partials through LDS
 static __device__ __forceinline__ double exa_block_sum(double v) {
@@ -659,8 +667,17 @@ extern "C" __global__ void __launch_bounds__(1024) exa_reduce_partials(const dou
 }
 )HIP";
 
-constexpr int kMaxTileS = 24;
-bool use_tile(int S) { return S >= 2 && S <= kMaxTileS; }
+int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
+// LDS budget per 256-thread workgroup for the store staging (tuning knob; changes the source and so the cache key)
+int lds_budget() { return env_int("EXAHIP_LDS_BUDGET", 40960); }
+bool use_tile(int S) { return S >= 2; }
+// points staged per pass: the largest of 64/32/16/8 whose tile (4 wavefronts) fits the budget
+int tile_pp(int S) {
+    for (int pp = 64; pp > 8; pp >>= 1)
+        if (4 * S * (pp + 1) * 8 <= lds_budget()) return pp;
+    return 8;
+}
+int tile_doubles(int S) { return S * (tile_pp(S) + 1); }   // per wavefront
 
 // prologue of a COO-writing pattern function: tail lanes are clamped (they recompute the last point and their
 // stores are masked) so that the whole wavefront reaches the cooperative store epilogue
@@ -675,10 +692,19 @@ void emit_coo_prologue(std::ostringstream &os, const Body &b, const ParamLayout 
 }
 void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, const std::vector<std::string> &vals, bool tile) {
     if (tile) {
-        os << "    double* tile = lds + (threadIdx.x >> 6) * (" << S << " * EXA_TILE_LD);\n";
-        for (int s = 0; s < S; s++) os << "    tile[" << s << " * EXA_TILE_LD + lane] = " << vals[s] << ";\n";
-        os << "    exa_flush_tile<" << S << ">(out, " << b.P(word_o) << " + " << S << "L * (I0 - lane), " << b.P(word_o) << " + " << S
-           << "L * hi, tile, lane);\n";
+        const int pp = tile_pp(S);
+        os << "    double* tile = lds + (threadIdx.x >> 6) * " << tile_doubles(S) << ";\n"
+           << "    const long obase = " << b.P(word_o) << " + " << S << "L * (I0 - lane);\n    const long npts = hi - (I0 - lane);\n";
+        for (int g = 0; g < 64 / pp; g++) {
+            if (pp == 64) {
+                for (int s = 0; s < S; s++) os << "    tile[" << s * (pp + 1) << " + lane] = " << vals[s] << ";\n";
+            } else {
+                os << "    if ((lane / " << pp << ") == " << g << ") {\n";
+                for (int s = 0; s < S; s++) os << "        tile[" << s * (pp + 1) << " + (lane % " << pp << ")] = " << vals[s] << ";\n";
+                os << "    }\n";
+            }
+            os << "    exa_flush_points<" << S << ", " << pp << ">(out, obase, npts, tile, lane, " << g << ");\n";
+        }
     } else {
         os << "    const long o = " << b.P(word_o) << " + " << S << "L * I;\n";
         for (int s = 0; s < S; s++) os << "    out[o + " << s << "] = " << vals[s] << ";\n";
@@ -871,8 +897,8 @@ Generated generate_module(const Model &m) {
     os << "}\n";
     auto lds_decl = [&](int cb, bool hess) {
         int mx = 0;
-        for (int k : L.active[cb]) { const int S = hess ? m.pats[k].o2step : m.pats[k].o1step; if (use_tile(S)) mx = std::max(mx, S); }
-        if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << " * EXA_TILE_LD];\n    double* lds = lds_all;\n";
+        for (int k : L.active[cb]) { const int S = hess ? m.pats[k].o2step : m.pats[k].o1step; if (use_tile(S)) mx = std::max(mx, tile_doubles(S)); }
+        if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all;\n";
         else os << "    double* lds = nullptr;\n";
     };
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jac(const long* __restrict__ P, const double* __restrict__ x, "

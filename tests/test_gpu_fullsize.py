@@ -1,0 +1,91 @@
+"""-m gpu: parity at BASELINE.json's full sizes (configs 2-4).
+
+The oracle is an interpreter, but with OpenMP over data points it still finishes each of these in seconds on the GPU
+box's host cores, so the whole COO vector is compared — plus the size-independent properties the domain offers:
+linearity of the Lagrangian Hessian in (obj_weight, y), shard tiling, and window locality of Luksan-Vlcek.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from zoo import point
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+RTOL = 1e-10
+THREADS = max(1, min(32, (os.cpu_count() or 2) // 2))
+
+
+def maxrel(a, ref):
+    scale = np.maximum(np.abs(ref), 1e-3 * max(1.0, float(np.max(np.abs(ref)))))
+    return float(np.max(np.abs(a - ref) / scale))
+
+
+def full_compare(core, seed):
+    import torch
+    from exahip import ExaModel
+    import oracle
+    m = ExaModel(core)
+    o = oracle.OracleModel(m.ir, threads=THREADS)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=seed)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    h = m.hess_coord(xd, yd, sigma)
+    j = m.jac_coord(xd)
+    c = m.cons(xd)
+    g = m.grad(xd)
+    f = m.obj(xd)
+    torch.cuda.synchronize()
+    assert maxrel(h.cpu().numpy(), o.hess_coord(x, y, sigma)) <= RTOL
+    assert maxrel(j.cpu().numpy(), o.jac_coord(x)) <= RTOL
+    assert maxrel(c.cpu().numpy(), o.cons(x)) <= RTOL
+    assert maxrel(g.cpu().numpy(), o.grad(x)) <= RTOL
+    fo = o.obj(x)
+    assert abs(f - fo) <= RTOL * max(1.0, abs(fo))
+    # linearity in (sigma, y): H(x, a*y, a*sigma) = a*H and additivity
+    y2 = torch.from_numpy(np.random.default_rng(11).standard_normal(m.meta.ncon)).to(dev)
+    h2 = m.hess_coord(xd, y2, 1.25)
+    hs = m.hess_coord(xd, yd + y2, sigma + 1.25)
+    torch.cuda.synchronize()
+    num = (hs - (h + h2)).abs().max().item()
+    den = max(1.0, hs.abs().max().item())
+    assert num / den <= 1e-12
+    return m, o, (x, y, sigma), (xd, yd)
+
+
+def test_config2_lv_1e7_full_vector(libs):
+    import torch
+    from exahip import ExaModel, models
+    import oracle
+    N = 10_000_000
+    m, o, (x, y, sigma), (xd, yd) = full_compare(models.luksan_vlcek_model(N), seed=0)
+    assert m.meta.nnzh == 9 * N - 15
+    # structure at full size: int32 rows/cols, lower triangle, equal to the oracle's
+    rows = torch.empty(m.meta.nnzh, dtype=torch.int32, device=xd.device)
+    cols = torch.empty(m.meta.nnzh, dtype=torch.int32, device=xd.device)
+    m.hess_structure(rows, cols)
+    torch.cuda.synchronize()
+    orr, oc = o.hess_structure()
+    assert torch.all(rows >= cols).item()
+    assert np.array_equal(rows.cpu().numpy(), orr.astype(np.int32)) and np.array_equal(cols.cpu().numpy(), oc.astype(np.int32))
+    # window locality: the slots of data points [a, a+n) equal those of a small model built on x[a : a+n+2]
+    a, n = 4_321_000, 500
+    small = ExaModel(models.luksan_vlcek_model(n + 2))
+    hw = small.hess_coord(x[a:a + n + 2], y[a:a + n], sigma)
+    big = m.hess_coord(xd, yd, sigma).cpu().numpy()
+    np.testing.assert_allclose(big[6 * a:6 * (a + n)], hw[:6 * n], rtol=1e-13, atol=0)
+
+
+def test_config3_rocket_1e6(libs):
+    from exahip import models
+    m, o, _, _ = full_compare(models.rocket_model(1_000_000), seed=1)
+    assert m.meta.nvar == 4 * 1_000_001 + 1 and m.meta.ncon == 3 * 1_000_000 + 4
+
+
+def test_config4_acopf_78k_synthetic(libs):
+    from exahip import models
+    nbus, nbr, ngen = 78_484, 126_015, 6_800
+    data = models.synthetic_power_data(nbus, nbr, ngen, seed=0)
+    m, o, _, _ = full_compare(models.ac_power_model(data), seed=2)
+    assert m.meta.nnzh == ngen + 44 * nbr + 2 * nbus

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Times all five callbacks on BASELINE.json configs 2-4 (1 GPU) with hipEvents on the launch stream and prints one
+JSON object per config: ms per call, algorithmic bytes, achieved GB/s, fraction of the 8 TB/s HBM peak.
+Secondary to bench.py (which is the contract line for config 2)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "examodels.jl_amd"), os.path.join(ROOT, "oracle")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from exahip import ExaModel, models  # noqa: E402
+
+PEAK = 8000.0
+
+
+def iterator_bytes(m):
+    """bytes of iterator columns read per full pass (8 B per stored column entry)."""
+    tot = 0
+    for k in range(m.npatterns):
+        pat = m.ir.patterns[k]
+        for c in range(pat.n_cols):
+            if pat.cols[c].type != 2:
+                tot += 8 * pat.n
+    return tot
+
+
+def run(name, core, reps=50):
+    m = ExaModel(core)
+    dev = torch.device("cuda:0")
+    r = np.random.default_rng(0)
+    x = torch.from_numpy(m.meta.x0 + 0.1 * r.uniform(-1, 1, m.meta.nvar)).to(dev)
+    y = torch.from_numpy(np.random.default_rng(1).standard_normal(m.meta.ncon)).to(dev)
+    bufs = {"obj": None, "cons": torch.empty(m.meta.ncon, dtype=torch.float64, device=dev),
+            "grad": torch.empty(m.meta.nvar, dtype=torch.float64, device=dev),
+            "jac": torch.empty(m.meta.nnzj, dtype=torch.float64, device=dev),
+            "hess": torch.empty(m.meta.nnzh, dtype=torch.float64, device=dev)}
+    itb = iterator_bytes(m)
+    alg = {"obj": 8 * m.meta.nvar + itb, "cons": 8 * m.meta.ncon + 8 * m.meta.nvar + itb,
+           "grad": 16 * m.meta.nvar + itb, "jac": 8 * m.meta.nnzj + 8 * m.meta.nvar + itb,
+           "hess": 8 * m.meta.nnzh + 8 * m.meta.nvar + 8 * m.meta.ncon + itb}
+    out = {"config": name, "nvar": m.meta.nvar, "ncon": m.meta.ncon, "nnzj": m.meta.nnzj, "nnzh": m.meta.nnzh,
+           "npatterns": m.npatterns, "callbacks": {}}
+    for cb in ("obj", "cons", "grad", "jac", "hess"):
+        m.time_callback(cb, 5, x, y, 0.5, out=bufs[cb])
+        ms = min(m.time_callback(cb, reps, x, y, 0.5, out=bufs[cb]) for _ in range(3))
+        gbs = alg[cb] / (ms * 1e-3) / 1e9
+        out["callbacks"][cb] = {"ms": ms, "algorithmic_bytes": alg[cb], "GBps": gbs, "frac_of_8TBps": gbs / PEAK,
+                                "evals_per_s": 1e3 / ms}
+    out["hess_nnz_per_s"] = m.meta.nnzh * out["callbacks"]["hess"]["evals_per_s"]
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["lv", "rocket", "acopf"]
+    if "lv" in which:
+        run("config2: LuksanVlcek N=1e7", models.luksan_vlcek_model(10_000_000))
+    if "rocket" in which:
+        run("config3: Goddard rocket nh=1e6", models.rocket_model(1_000_000))
+    if "acopf" in which:
+        run("config4: ACOPF 78484-bus-scale synthetic", models.ac_power_model(models.synthetic_power_data(78_484, 126_015, 6_800, seed=0)))
