@@ -86,10 +86,19 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    # one rank per GPU.  (EXAHIP_DIST_BACKEND=gloo lets the launch path be exercised on a box with fewer GPUs than
+    # ranks — ranks then share GPUs and the number is meaningless; never set by the driver.)
+    backend = os.environ.get("EXAHIP_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"{world} ranks need {world} GPUs, found {ndev}")
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from exahip import ExaModel, models
     per_gpu = int(args.points)
@@ -121,7 +130,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = t[0].item(), t[1].item()
 

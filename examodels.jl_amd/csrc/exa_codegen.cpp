@@ -625,8 +625,9 @@ static __device__ double exa_powi(double x, long n) {
 // fully coalesced 512 B burst, non-temporal (measured 5.7 TB/s, tools/store_bench.hip).
 // Flushes the S slots of PP consecutive points (point group g of the wavefront): one CONTIGUOUS run of PP*S doubles,
 // so every store instruction is a full 512-B burst.  PP = 64 stages the whole wavefront at once; wide patterns use
-// PP = 32/16/8 (several passes) to bound LDS per workgroup.  tile is slot-major with leading dimension PP+1.
-template <int S, int PP>
+// PP = 32/16/8 (several passes) to bound LDS per workgroup.  tile is slot-major with leading dimension LD, chosen by
+// the generator so that the transposed ds_read_b64 of a 32-lane half hits 32 distinct bank pairs.
+template <int S, int PP, int LD>
 static __device__ __forceinline__ void exa_flush_points(double* __restrict__ out, long obase, long npts, const double* tile, int lane, int g) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -637,7 +638,7 @@ static __device__ __forceinline__ void exa_flush_points(double* __restrict__ out
         const int j = k * 64 + lane;
         const int l2 = j / S, s2 = j - l2 * S;
         if (j < CNT && g * PP + l2 < npts) {
-            const double v = tile[s2 * (PP + 1) + l2];
+            const double v = tile[s2 * LD + l2];
             __builtin_nontemporal_store(v, out + obase + (long)CNT * g + j);
         }
     }
@@ -677,7 +678,32 @@ int tile_pp(int S) {
         if (4 * S * (pp + 1) * 8 <= lds_budget()) return pp;
     return 8;
 }
-int tile_doubles(int S) { return S * (tile_pp(S) + 1); }   // per wavefront
+// Leading dimension of the slot-major tile.  Writes (lane-consecutive) are conflict-free for any LD; the transposed
+// read of lane j fetches element (j % S) * LD + j / S, and a ds_read_b64 is serviced per 32-lane half with 32 bank
+// pairs (MI355X_MICROARCH.md §LDS) — pick the LD in [PP, PP+32] with the fewest extra cycles.
+int tile_ld(int S) {
+    const int pp = tile_pp(S), cnt = S * pp;
+    int best = pp + 1;
+    long best_cost = -1;
+    for (int ld = pp; ld <= pp + 32; ld++) {
+        long cost = 0;
+        for (int k = 0; k * 64 < cnt; k++)
+            for (int half = 0; half < 2; half++) {
+                int mult[32] = {0};
+                int mx = 0;
+                for (int l = 0; l < 32; l++) {
+                    const int j = k * 64 + half * 32 + l;
+                    if (j >= cnt) continue;
+                    const int d = (j % S) * ld + j / S;
+                    mx = std::max(mx, ++mult[d & 31]);
+                }
+                cost += mx > 0 ? mx - 1 : 0;
+            }
+        if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = ld; }
+    }
+    return best;
+}
+int tile_doubles(int S) { return S * tile_ld(S); }   // per wavefront
 
 // prologue of a COO-writing pattern function: tail lanes are clamped (they recompute the last point and their
 // stores are masked) so that the whole wavefront reaches the cooperative store epilogue
@@ -692,18 +718,18 @@ void emit_coo_prologue(std::ostringstream &os, const Body &b, const ParamLayout 
 }
 void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, const std::vector<std::string> &vals, bool tile) {
     if (tile) {
-        const int pp = tile_pp(S);
+        const int pp = tile_pp(S), ld = tile_ld(S);
         os << "    double* tile = lds + (threadIdx.x >> 6) * " << tile_doubles(S) << ";\n"
            << "    const long obase = " << b.P(word_o) << " + " << S << "L * (I0 - lane);\n    const long npts = hi - (I0 - lane);\n";
         for (int g = 0; g < 64 / pp; g++) {
             if (pp == 64) {
-                for (int s = 0; s < S; s++) os << "    tile[" << s * (pp + 1) << " + lane] = " << vals[s] << ";\n";
+                for (int s = 0; s < S; s++) os << "    tile[" << s * ld << " + lane] = " << vals[s] << ";\n";
             } else {
                 os << "    if ((lane / " << pp << ") == " << g << ") {\n";
-                for (int s = 0; s < S; s++) os << "        tile[" << s * (pp + 1) << " + (lane % " << pp << ")] = " << vals[s] << ";\n";
+                for (int s = 0; s < S; s++) os << "        tile[" << s * ld << " + (lane % " << pp << ")] = " << vals[s] << ";\n";
                 os << "    }\n";
             }
-            os << "    exa_flush_points<" << S << ", " << pp << ">(out, obase, npts, tile, lane, " << g << ");\n";
+            os << "    exa_flush_points<" << S << ", " << pp << ", " << ld << ">(out, obase, npts, tile, lane, " << g << ");\n";
         }
     } else {
         os << "    const long o = " << b.P(word_o) << " + " << S << "L * I;\n";
@@ -816,7 +842,12 @@ void gen_struct_fn(std::ostringstream &os, const Model &m, int pi, const ParamLa
 void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const std::string &call_prefix, const std::string &call_args,
                   const std::string &tail_args = "") {
     const auto &act = L.active[cb];
-    os << "    const long b = blockIdx.x;\n";
+    if (env_int("EXAHIP_XCD_REMAP", 0))
+        // workgroup b runs on XCD b % 8 (observed placement): give every XCD one contiguous range of tiles
+        os << "    const long nb_ = gridDim.x, q_ = nb_ >> 3, r_ = nb_ & 7, xcd_ = blockIdx.x & 7, i_ = blockIdx.x >> 3;\n"
+              "    const long b = xcd_ * q_ + (xcd_ < r_ ? xcd_ : r_) + i_;\n";
+    else
+        os << "    const long b = blockIdx.x;\n";
     for (size_t k = 0; k < act.size(); k++) {
         const std::string end = "P[" + std::to_string(L.blk[cb] + (int)k) + "]";
         const std::string beg = k == 0 ? "0L" : "P[" + std::to_string(L.blk[cb] + (int)k - 1) + "]";
