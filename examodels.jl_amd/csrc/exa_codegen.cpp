@@ -656,6 +656,17 @@ static __device__ __forceinline__ double exa_block_sum(double v) {
     if (threadIdx.x == 0) { for (int w = 0; w < EXA_BLOCK / 64; w++) s += red[w]; }
     return s;
 }
+// cons_nln! augmentation, second stage (the reference's compress_to_dense, KA ext :691-697): one thread per distinct
+// target row adds its contributions, listed in insertion order, to the base value written by exa_cons.
+extern "C" __global__ void __launch_bounds__(EXA_BLOCK) exa_aug_gather(const long* __restrict__ rows, const long* __restrict__ ptr,
+        const long* __restrict__ perm, const double* __restrict__ buf, double* __restrict__ c, long nrows) {
+    const long t = (long)blockIdx.x * EXA_BLOCK + threadIdx.x;
+    if (t >= nrows) return;
+    const long r = rows[t];
+    double s = c[r];
+    for (long j = ptr[t]; j < ptr[t + 1]; j++) s += buf[perm[j]];
+    c[r] = s;
+}
 // second stage of obj: one workgroup folds the per-workgroup partial sums in a fixed order (deterministic)
 extern "C" __global__ void __launch_bounds__(1024) exa_reduce_partials(const double* __restrict__ part, long n, double* __restrict__ out) {
     __shared__ double red[16];
@@ -751,14 +762,13 @@ void gen_value_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
 
 void gen_cons_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
     Body b(m, pi, L);
-    const std::string row = b.row0();
     os << "static __device__ __forceinline__ void " << fn_name(pi, "cons")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ c, long tid) {\n"
        << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n"
        << "    const double v = " << fn_name(pi, "val") << "(P, x, th, I);\n";
-    emit_lines(os, b.e);
-    if (b.p.kind == EXA_PAT_CONAUG) os << "    unsafeAtomicAdd(&c[" << row << "], v);\n";
-    else os << "    c[" << row << "] = v;\n";
+    // base rows: plain store into c; augmentation terms: into the value buffer, gathered per row by exa_aug_gather
+    if (b.p.kind == EXA_PAT_CONAUG) os << "    c[" << b.P(L.pat[pi].oa) << " + I] = v;\n";
+    else os << "    c[" << b.P(L.pat[pi].o0) << " + I] = v;\n";
     os << "}\n";
 }
 
@@ -842,8 +852,10 @@ void gen_struct_fn(std::ostringstream &os, const Model &m, int pi, const ParamLa
 void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const std::string &call_prefix, const std::string &call_args,
                   const std::string &tail_args = "") {
     const auto &act = L.active[cb];
+    const int ppt = L.ppt[cb];
     if (env_int("EXAHIP_XCD_REMAP", 0))
         // workgroup b runs on XCD b % 8 (observed placement): give every XCD one contiguous range of tiles
+        // (measured SLOWER than the default interleaving on all three configs; kept only as an experiment knob)
         os << "    const long nb_ = gridDim.x, q_ = nb_ >> 3, r_ = nb_ & 7, xcd_ = blockIdx.x & 7, i_ = blockIdx.x >> 3;\n"
               "    const long b = xcd_ * q_ + (xcd_ < r_ ? xcd_ : r_) + i_;\n";
     else
@@ -851,8 +863,12 @@ void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const st
     for (size_t k = 0; k < act.size(); k++) {
         const std::string end = "P[" + std::to_string(L.blk[cb] + (int)k) + "]";
         const std::string beg = k == 0 ? "0L" : "P[" + std::to_string(L.blk[cb] + (int)k - 1) + "]";
-        os << "    " << (k ? "else " : "") << "if (b < " << end << ") { const long tid = (b - " << beg << ") * EXA_BLOCK + threadIdx.x; "
-           << "p" << act[k] << "_" << call_prefix << "(" << call_args << ", tid" << tail_args << "); }\n";
+        os << "    " << (k ? "else " : "") << "if (b < " << end << ") {\n        const long tid0 = (b - " << beg << ") * (EXA_BLOCK * " << ppt
+           << ") + threadIdx.x;\n";
+        if (ppt > 1) os << "#pragma unroll\n        for (int u = 0; u < " << ppt << "; u++) ";
+        else os << "        { const int u = 0; ";
+        os << "p" << act[k] << "_" << call_prefix << "(" << call_args << ", tid0 + u * EXA_BLOCK" << tail_args << ");" << (ppt > 1 ? "" : " }")
+           << "\n    }\n";
     }
 }
 
@@ -866,7 +882,7 @@ Generated generate_module(const Model &m) {
     L.pat.resize(np);
     for (int k = 0; k < np; k++) {
         auto &pp = L.pat[k];
-        pp.lo = w++; pp.hi = w++; pp.o0 = w++; pp.o1 = w++; pp.o2 = w++;
+        pp.lo = w++; pp.hi = w++; pp.o0 = w++; pp.o1 = w++; pp.o2 = w++; pp.oa = w++;
         for (size_t c = 0; c < m.pats[k].cols.size(); c++) pp.col.push_back(w++);
     }
     for (int k = 0; k < np; k++) {
@@ -882,7 +898,13 @@ Generated generate_module(const Model &m) {
         }
         if (p.o2step > 0) { L.active[CB_HESS].push_back(k); L.active[CB_HSTRUCT].push_back(k); }
     }
-    for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w; w += (int)L.active[cb].size(); }
+    for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w; w += (int)L.active[cb].size(); L.ppt[cb] = 1; }
+    // streaming value kernels keep more loads in flight per wavefront with several points per thread (measured)
+    L.ppt[CB_OBJ] = env_int("EXAHIP_PPT_OBJ", 4);
+    L.ppt[CB_CONS] = env_int("EXAHIP_PPT_CONS", 2);
+    L.ppt[CB_GRAD] = env_int("EXAHIP_PPT_GRAD", 1);
+    L.ppt[CB_JAC] = env_int("EXAHIP_PPT_JAC", 1);
+    L.ppt[CB_HESS] = env_int("EXAHIP_PPT_HESS", 1);
     L.nwords = w;
 
     std::ostringstream os;
@@ -905,12 +927,14 @@ Generated generate_module(const Model &m) {
           "const double* __restrict__ th, double* __restrict__ part) {\n    const long b = blockIdx.x;\n    double v = 0.0;\n";
     {
         const auto &act = L.active[CB_OBJ];
+        const int ppt = L.ppt[CB_OBJ];
         for (size_t k = 0; k < act.size(); k++) {
             const std::string end = "P[" + std::to_string(L.blk[CB_OBJ] + (int)k) + "]";
             const std::string beg = k == 0 ? "0L" : "P[" + std::to_string(L.blk[CB_OBJ] + (int)k - 1) + "]";
             const auto &pp = L.pat[act[k]];
-            os << "    " << (k ? "else " : "") << "if (b < " << end << ") { const long I = P[" << pp.lo << "] + (b - " << beg
-               << ") * EXA_BLOCK + threadIdx.x; if (I < P[" << pp.hi << "]) v = p" << act[k] << "_val(P, x, th, I); }\n";
+            os << "    " << (k ? "else " : "") << "if (b < " << end << ") {\n        const long I0 = P[" << pp.lo << "] + (b - " << beg
+               << ") * (EXA_BLOCK * " << ppt << ") + threadIdx.x;\n#pragma unroll\n        for (int u = 0; u < " << ppt
+               << "; u++) { const long I = I0 + u * EXA_BLOCK; if (I < P[" << pp.hi << "]) v += p" << act[k] << "_val(P, x, th, I); }\n    }\n";
         }
     }
     os << "    const double s = exa_block_sum(v);\n    if (threadIdx.x == 0) part[b] = s;\n}\n";

@@ -52,6 +52,7 @@ struct Pattern {
     std::vector<std::pair<int, int>> slotvar2;      // per 2nd-order slot: ordered pair of AD leaves
     int o1step = 0, o2step = 0;
     int64_t o0 = 0, o1 = 0, o2 = 0;
+    int64_t oa = 0;                 // CONAUG: first entry of this pattern in the augmentation value buffer (nlp.jl:1731)
 };
 
 struct Model {
@@ -59,6 +60,9 @@ struct Model {
     int minimize = 1;
     std::vector<Pattern> pats;
     std::vector<double> x0, lvar, uvar, theta, y0, lcon, ucon;
+    // Augmentation gather lists (the reference's conaugsparsity sorted by target row + conaugptr, KA ext :79-101):
+    // target row aug_rows[t] receives buffer entries aug_perm[aug_ptr[t] .. aug_ptr[t+1])
+    std::vector<int64_t> aug_rows, aug_ptr, aug_perm;
 };
 
 // Planner (exa_plan.cpp): copies the description, builds AD trees, slot maps and running offsets.
@@ -72,12 +76,13 @@ enum Callback { CB_OBJ = 0, CB_GRAD, CB_CONS, CB_CONSAUG, CB_JAC, CB_HESS, CB_JS
 struct ParamLayout {
     // word indices into the int64 parameter table P that every kernel receives
     struct Pat {
-        int lo = -1, hi = -1, o0 = -1, o1 = -1, o2 = -1;
+        int lo = -1, hi = -1, o0 = -1, o1 = -1, o2 = -1, oa = -1;
         std::vector<int> col;   // per column: device pointer (I64/F64) or range start (RANGE)
     };
     std::vector<Pat> pat;
     std::vector<int> active[CB_COUNT];   // patterns handled by each callback, in dispatch order
     int blk[CB_COUNT];                   // first word of the cumulative block-end list of each callback
+    int ppt[CB_COUNT];                   // data points per thread (a workgroup covers kBlock * ppt points)
     int nwords = 0;
 };
 

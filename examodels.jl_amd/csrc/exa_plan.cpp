@@ -4,6 +4,7 @@
 // identity-dedup -> Compressor tuples, o1step/o2step) and the counter bookkeeping of src/nlp.jl:1474-1482
 // (_add_obj), :1597-1611 (_add_con), :1730-1738 (_add_con!).  Instead of probing with NaNs it classifies every
 // IR subtree statically (constant for AD <=> contains no VAR) and replays the traversal order symbolically.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <sstream>
@@ -175,6 +176,56 @@ void plan_pattern(Pattern &p, int pi) {
     for (int v : fv) p.slotvar2.push_back(a2.leaf2s[v]);
 }
 
+// host evaluation of an integer-typed expression of the data point (index arithmetic only)
+int64_t eval_int(const Pattern &p, int k, int64_t I) {
+    const exa_node_t &nd = p.nodes[k];
+    switch (nd.op) {
+    case EXA_OP_CONST_I: return nd.ival;
+    case EXA_OP_DATA: {
+        const Column &c = p.cols[nd.a];
+        return c.type == EXA_COL_RANGE ? c.start + c.step * I : c.idata[(size_t)I];
+    }
+    case EXA_OP_UN: {
+        const int64_t a = eval_int(p, nd.a, I);
+        switch (nd.fn) { case EXA_U_PLUS: return a; case EXA_U_MINUS: return -a; case EXA_U_ABS: return a < 0 ? -a : a; case EXA_U_ABS2: return a * a; }
+        break;
+    }
+    case EXA_OP_BIN: {
+        const int64_t a = eval_int(p, nd.a, I), b = eval_int(p, nd.b, I);
+        switch (nd.fn) {
+        case EXA_B_ADD: return a + b; case EXA_B_SUB: return a - b; case EXA_B_MUL: return a * b;
+        case EXA_B_MAX: return a > b ? a : b; case EXA_B_MIN: return a < b ? a : b;
+        }
+        break;
+    }
+    default: break;
+    }
+    fail("non-integer node inside an index expression");
+}
+
+// sorted (target row -> contributing buffer entries) lists for the constraint augmentations
+void build_aug_lists(Model &m) {
+    if (m.nconaug == 0) return;
+    std::vector<int64_t> row((size_t)m.nconaug);
+    for (const Pattern &p : m.pats) {
+        if (p.kind != EXA_PAT_CONAUG) continue;
+        const int64_t nbase = m.pats[p.base].n;
+        for (int64_t I = 0; I < p.n; I++) {
+            const int64_t t = eval_int(p, p.target, I);
+            if (t < 1 || t > nbase) fail("augmentation target row outside the base constraint block");
+            row[(size_t)(p.oa + I)] = p.o0 + t - 1;
+        }
+    }
+    m.aug_perm.resize((size_t)m.nconaug);
+    for (int64_t q = 0; q < m.nconaug; q++) m.aug_perm[(size_t)q] = q;
+    std::stable_sort(m.aug_perm.begin(), m.aug_perm.end(), [&](int64_t a, int64_t b) { return row[(size_t)a] < row[(size_t)b]; });
+    for (int64_t j = 0; j < m.nconaug; j++) {
+        const int64_t r = row[(size_t)m.aug_perm[(size_t)j]];
+        if (m.aug_rows.empty() || m.aug_rows.back() != r) { m.aug_rows.push_back(r); m.aug_ptr.push_back(j); }
+    }
+    m.aug_ptr.push_back(m.nconaug);
+}
+
 template <class T>
 std::vector<T> copy_or(const T *src, int64_t n, T fill) {
     std::vector<T> v((size_t)n, fill);
@@ -229,10 +280,11 @@ std::unique_ptr<Model> plan_model(const exa_model_desc_t *d) {
             m->ncon += p.n; m->nnzj += p.n * p.o1step; m->nnzh += p.n * p.o2step;
         } else {
             p.o0 = m->pats[p.base].o0;   // offset0(c1, 0) (nlp.jl:1683)
-            p.o1 = m->nnzj; p.o2 = m->nnzh;
+            p.o1 = m->nnzj; p.o2 = m->nnzh; p.oa = m->nconaug;
             m->nconaug += p.n; m->nnzj += p.n * p.o1step; m->nnzh += p.n * p.o2step;
         }
     }
+    build_aug_lists(*m);
     m->y0 = copy_or<double>(d->y0, m->ncon, 0.0);
     m->lcon = copy_or<double>(d->lcon, m->ncon, 0.0);
     m->ucon = copy_or<double>(d->ucon, m->ncon, 0.0);

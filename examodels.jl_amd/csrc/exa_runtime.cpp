@@ -56,11 +56,11 @@ struct Handle {
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_consaug = nullptr, f_jac = nullptr,
+    hipFunction_t f_auggather = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_consaug = nullptr, f_jac = nullptr,
                   f_hess = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
-    DevBuf dP, dtheta, dpart, dobj;
+    DevBuf dP, dtheta, dpart, dobj, daugbuf, daugrows, daugptr, daugperm;
     std::vector<DevBuf> dcols;              // flattened over patterns
     std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
     DevBuf sx, sy, sout, srows, scols;      // scratch of the *_host variants
@@ -69,6 +69,7 @@ struct Handle {
     ~Handle() {
         if (on_device) {
             dP.release(); dtheta.release(); dpart.release(); dobj.release();
+            daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release();
             for (auto &b : dcols) b.release();
             sx.release(); sy.release(); sout.release(); srows.release(); scols.release();
             if (ev0) (void)hipEventDestroy(ev0);
@@ -176,7 +177,7 @@ void fill_params(Handle &h) {
         const Pattern &p = m.pats[k];
         const auto &pp = L.pat[k];
         const int64_t lo = (int64_t)((__int128)p.n * h.rank / h.world), hi = (int64_t)((__int128)p.n * (h.rank + 1) / h.world);
-        h.P[pp.lo] = lo; h.P[pp.hi] = hi; h.P[pp.o0] = p.o0; h.P[pp.o1] = p.o1; h.P[pp.o2] = p.o2;
+        h.P[pp.lo] = lo; h.P[pp.hi] = hi; h.P[pp.o0] = p.o0; h.P[pp.o1] = p.o1; h.P[pp.o2] = p.o2; h.P[pp.oa] = p.oa;
         for (size_t c = 0; c < p.cols.size(); c++) {
             if (p.cols[c].type == EXA_COL_RANGE) h.P[pp.col[c]] = p.cols[c].start;
             else h.P[pp.col[c]] = h.on_device ? (int64_t)(uintptr_t)h.dcols[h.colslot[k][c]].p : 0;
@@ -187,7 +188,8 @@ void fill_params(Handle &h) {
         for (size_t j = 0; j < L.active[cb].size(); j++) {
             const auto &pp = L.pat[L.active[cb][j]];
             const int64_t cnt = h.P[pp.hi] - h.P[pp.lo];
-            cum += (cnt + kBlock - 1) / kBlock;
+            const int64_t tile = (int64_t)kBlock * L.ppt[cb];
+            cum += (cnt + tile - 1) / tile;
             h.P[L.blk[cb] + (int)j] = cum;
         }
         h.grid[cb] = cum;
@@ -210,7 +212,7 @@ void to_device(Handle &h) {
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
     h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
-    h.f_consaug = fn("exa_consaug"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
+    h.f_consaug = fn("exa_consaug"); h.f_auggather = fn("exa_aug_gather"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
     h.on_device = true;
     h.colslot.resize(m.pats.size());
@@ -234,6 +236,14 @@ void to_device(Handle &h) {
     h.dtheta.ensure(sizeof(double) * (size_t)(m.npar + 1));
     if (m.npar) HIPCHK(hipMemcpy(h.dtheta.p, m.theta.data(), sizeof(double) * (size_t)m.npar, hipMemcpyHostToDevice));
     h.dobj.ensure(sizeof(double));
+    if (m.nconaug) {
+        auto up = [&](DevBuf &b, const std::vector<int64_t> &v) {
+            b.ensure(8 * v.size());
+            HIPCHK(hipMemcpy(b.p, v.data(), 8 * v.size(), hipMemcpyHostToDevice));
+        };
+        up(h.daugrows, m.aug_rows); up(h.daugptr, m.aug_ptr); up(h.daugperm, m.aug_perm);
+        h.daugbuf.ensure(8 * (size_t)m.nconaug);
+    }
     HIPCHK(hipEventCreate(&h.ev0));
     HIPCHK(hipEventCreate(&h.ev1));
     fill_params(h);
@@ -268,7 +278,16 @@ void do_cons(Handle &h, const double *x, double *c) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &th, &c};
     launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a);
-    launch(h, h.f_consaug, h.grid[CB_CONSAUG], kBlock, a);
+    if (h.m->nconaug == 0) return;
+    // augmentation: values into the buffer (coalesced), then one deterministic gather per target row
+    void *buf = h.daugbuf.p;
+    if (h.world > 1) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
+    void *a2[] = {&P, &x, &th, &buf};
+    launch(h, h.f_consaug, h.grid[CB_CONSAUG], kBlock, a2);
+    const void *rows = h.daugrows.p, *ptr = h.daugptr.p, *perm = h.daugperm.p;
+    int64_t nrows = (int64_t)h.m->aug_rows.size();
+    void *a3[] = {&rows, &ptr, &perm, &buf, &c, &nrows};
+    launch(h, h.f_auggather, (nrows + kBlock - 1) / kBlock, kBlock, a3);
 }
 void do_jac(Handle &h, const double *x, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
