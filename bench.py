@@ -142,6 +142,13 @@ def main():
     shard_nnzh = nnzh / world
     alg_bytes = 8.0 * shard_nnzh + 8.0 * (m.meta.nvar / world) + 8.0 * (m.meta.ncon / world)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    # HBM traffic per launch from the PMC counters: measured in separate rocprofv3 passes (cannot run inside the timed
+    # process), committed under profiles/ and attached only when the workload is the one that was profiled
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1_traffic_lv1e7.json")
+    if world == 1 and per_gpu == 10_000_000 and os.path.exists(tpath):
+        with open(tpath) as fh:
+            traffic = json.load(fh)["hbm_bytes_per_launch"]
     out = {
         "metric": "sparse Lagrangian Hessian throughput (hess_coord!), nonzeros/s; evals/s in evals_per_s",
         "value": value, "unit": "nnz/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,7 +159,7 @@ def main():
                    "parallelism": f"iterator-shard x{world}, no data-path collective"},
         "evals_per_s": args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "exa_hess", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
     }
     if args.all_callbacks:

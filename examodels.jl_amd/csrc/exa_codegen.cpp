@@ -860,11 +860,12 @@ void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const st
               "    const long b = xcd_ * q_ + (xcd_ < r_ ? xcd_ : r_) + i_;\n";
     else
         os << "    const long b = blockIdx.x;\n";
+    // block map: which pattern and which tile this workgroup evaluates (interleaved by the runtime so that patterns
+    // reading the same x ranges run on the same XCD at about the same time)
+    os << "    const long e_ = ((const long*)P[" << L.blk[cb] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
+          "    const long tid0 = (e_ & ((1L << 40) - 1)) * (EXA_BLOCK * " << ppt << ") + threadIdx.x;\n";
     for (size_t k = 0; k < act.size(); k++) {
-        const std::string end = "P[" + std::to_string(L.blk[cb] + (int)k) + "]";
-        const std::string beg = k == 0 ? "0L" : "P[" + std::to_string(L.blk[cb] + (int)k - 1) + "]";
-        os << "    " << (k ? "else " : "") << "if (b < " << end << ") {\n        const long tid0 = (b - " << beg << ") * (EXA_BLOCK * " << ppt
-           << ") + threadIdx.x;\n";
+        os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n";
         if (ppt > 1) os << "#pragma unroll\n        for (int u = 0; u < " << ppt << "; u++) ";
         else os << "        { const int u = 0; ";
         os << "p" << act[k] << "_" << call_prefix << "(" << call_args << ", tid0 + u * EXA_BLOCK" << tail_args << ");" << (ppt > 1 ? "" : " }")
@@ -898,10 +899,10 @@ Generated generate_module(const Model &m) {
         }
         if (p.o2step > 0) { L.active[CB_HESS].push_back(k); L.active[CB_HSTRUCT].push_back(k); }
     }
-    for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w; w += (int)L.active[cb].size(); L.ppt[cb] = 1; }
+    for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w++; L.ppt[cb] = 1; }
     // streaming value kernels keep more loads in flight per wavefront with several points per thread (measured)
     L.ppt[CB_OBJ] = env_int("EXAHIP_PPT_OBJ", 4);
-    L.ppt[CB_CONS] = env_int("EXAHIP_PPT_CONS", 2);
+    L.ppt[CB_CONS] = env_int("EXAHIP_PPT_CONS", 1);
     L.ppt[CB_GRAD] = env_int("EXAHIP_PPT_GRAD", 1);
     L.ppt[CB_JAC] = env_int("EXAHIP_PPT_JAC", 1);
     L.ppt[CB_HESS] = env_int("EXAHIP_PPT_HESS", 1);
@@ -928,13 +929,13 @@ Generated generate_module(const Model &m) {
     {
         const auto &act = L.active[CB_OBJ];
         const int ppt = L.ppt[CB_OBJ];
+        os << "    const long e_ = ((const long*)P[" << L.blk[CB_OBJ] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
+              "    const long t0_ = (e_ & ((1L << 40) - 1)) * (EXA_BLOCK * " << ppt << ") + threadIdx.x;\n";
         for (size_t k = 0; k < act.size(); k++) {
-            const std::string end = "P[" + std::to_string(L.blk[CB_OBJ] + (int)k) + "]";
-            const std::string beg = k == 0 ? "0L" : "P[" + std::to_string(L.blk[CB_OBJ] + (int)k - 1) + "]";
             const auto &pp = L.pat[act[k]];
-            os << "    " << (k ? "else " : "") << "if (b < " << end << ") {\n        const long I0 = P[" << pp.lo << "] + (b - " << beg
-               << ") * (EXA_BLOCK * " << ppt << ") + threadIdx.x;\n#pragma unroll\n        for (int u = 0; u < " << ppt
-               << "; u++) { const long I = I0 + u * EXA_BLOCK; if (I < P[" << pp.hi << "]) v += p" << act[k] << "_val(P, x, th, I); }\n    }\n";
+            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n        const long I0 = P[" << pp.lo << "] + t0_;\n#pragma unroll\n"
+               << "        for (int u = 0; u < " << ppt << "; u++) { const long I = I0 + u * EXA_BLOCK; if (I < P[" << pp.hi << "]) v += p"
+               << act[k] << "_val(P, x, th, I); }\n    }\n";
         }
     }
     os << "    const double s = exa_block_sum(v);\n    if (threadIdx.x == 0) part[b] = s;\n}\n";

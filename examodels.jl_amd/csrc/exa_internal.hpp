@@ -81,7 +81,8 @@ struct ParamLayout {
     };
     std::vector<Pat> pat;
     std::vector<int> active[CB_COUNT];   // patterns handled by each callback, in dispatch order
-    int blk[CB_COUNT];                   // first word of the cumulative block-end list of each callback
+    int blk[CB_COUNT];                   // word holding the device address of the callback's block map: entry b =
+                                         // (slot in active[cb] << 40) | tile index, built by the runtime (interleaved)
     int ppt[CB_COUNT];                   // data points per thread (a workgroup covers kBlock * ppt points)
     int nwords = 0;
 };

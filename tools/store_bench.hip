@@ -52,6 +52,15 @@ __global__ void __launch_bounds__(256) k_lds(double* __restrict__ out, const dou
         if (base + j < lim) { if (NT) __builtin_nontemporal_store(val, out + base + j); else out[base + j] = val; }
     }
 }
+// read-side calibration for the FETCH_SIZE counter: the access pattern of exa_hess on Luksan-Vlcek
+// (three overlapping 8-B/lane loads of x, one of y), nothing written but one double per workgroup
+__global__ void __launch_bounds__(256) k_read8(const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ part, long n) {
+    const long I = (long)blockIdx.x * 256 + threadIdx.x;
+    double v = 0.0;
+    if (I + 2 < n) v = x[I] + x[I + 1] * 0.5 + x[I + 2] * 0.25 + y[I];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) part[blockIdx.x * 4 + (threadIdx.x >> 6)] = v;
+}
 int main(int argc, char** argv) {
     const long n = argc > 1 ? atol(argv[1]) : 15000000;    // points; 15e6*6 doubles = 720 MB
     double *out, *x;
@@ -75,6 +84,19 @@ int main(int argc, char** argv) {
     timeit("v2 direct nt", [&] { k_direct<true><<<grid, 256>>>(out, x, n); });
     timeit("v3 lds transpose", [&] { k_lds<false><<<grid, 256>>>(out, x, n); });
     timeit("v4 lds transpose nt", [&] { k_lds<true><<<grid, 256>>>(out, x, n); });
+    {
+        const long nr = 10000000;
+        double *xr, *yr, *pr;
+        CHECK(hipMalloc(&xr, 8 * nr)); CHECK(hipMalloc(&yr, 8 * nr)); CHECK(hipMalloc(&pr, 8 * (nr / 64 + 8)));
+        CHECK(hipMemset(xr, 0, 8 * nr)); CHECK(hipMemset(yr, 0, 8 * nr));
+        const unsigned g = (unsigned)((nr + 255) / 256);
+        for (int i = 0; i < 5; i++) k_read8<<<g, 256>>>(xr, yr, pr, nr);
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < reps; i++) k_read8<<<g, 256>>>(xr, yr, pr, nr);
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        printf("%-28s %8.3f ms  %8.1f GB/s (reads 2 x 80 MB = 160 MB known bytes; FETCH_SIZE calibration)\n", "k_read8", ms, 16.0 * nr / ms / 1e6);
+    }
     timeit("memset 720MB", [&] { CHECK(hipMemsetAsync(out, 0, sizeof(double) * n * S, 0)); });
     return 0;
 }
