@@ -892,3 +892,83 @@ int ora_has_openmp(void) {
     return 0;
 #endif
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Luksan-Vlcek hess_coord!, hand-specialised straight-line C — TEST/BASELINE ONLY.                    */
+/* What Julia's compiler makes of shessian! for the two LV patterns (benchmark/runbenchmark.jl:163-169):*/
+/* the generic interpreter above pays tree-walking overhead per node that compiled Julia does not, so   */
+/* bench.py's cpu_baseline times THIS as the proxy for `backend = nothing`.  Same algorithm: zero-fill  */
+/* (nlp.jl:1913) then one `+=` per contribution in hrpass0/hrpass/hdrpass order (hessian.jl), constraint*/
+/* block first.  Checked against the interpreter in tests/test_known_answers.py.                        */
+/* ------------------------------------------------------------------------------------------------ */
+void ora_lv_hess_compiled(int64_t N, const double *x, const double *y, double sigma, double *H, int threads) {
+    const int64_t ncon = N - 2, nobj = N - 1;
+    const int64_t nnzh = 6 * ncon + 3 * nobj;
+    (void)threads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t k = 0; k < nnzh; k++) H[k] = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t I = 0; I < ncon; I++) {            /* i = I+1: a = x[i+1], b = x[i+2], c = x[i] */
+        const double a = x[I + 1], b = x[I + 2], c = x[I], lam = y[I];
+        double *h = H + 6 * I;
+        /* 3a^3: FirstFixed{*}(3, a^3): adj = 3 lam; a^3: y = 3a^2, h = 6a */
+        const double y3 = 3.0 * (a * a), h3 = (2 * 3) * a;
+        h[0] += 0.0 * (y3 * y3) + (lam * 3.0) * h3;                                   /* (a,a) */
+        /* sin(a-b) * sin(a+b) */
+        const double u = a - b, v = a + b;
+        const double su = sin(u), cu = cos(u), sv = sin(v), cv = cos(v);
+        /* Node2{*}(S1, S2): y1 = S2.x, y2 = S1.x, h12 = 1 */
+        const double adj1 = lam * sv, adj2 = lam * su;
+        /* hrpass(S1 = sin(u)): child u = a - b with adj = adj1*cu, adj2' = 0*.. + adj1*(-su) */
+        { const double ad = adj1 * cu, a2 = 0.0 * (cu * cu) + adj1 * (-su);
+          /* u = a - b (Node2{-}): hrpass(a, ad*1, a2*1 + ad*0), hrpass(b, ad*-1, a2*1 + ad*0), hdrpass(a,b, a2*1*-1 + ad*0) */
+          h[0] += a2 * (1.0 * 1.0) + (ad * 1.0) * 0.0;                                 /* (a,a) */
+          h[1] += a2 * (-1.0 * -1.0) + (ad * -1.0) * 0.0;                              /* (b,b) */
+          h[2] += a2 * 1.0 * -1.0 + ad * 0.0; }                                        /* (a,b) */
+        { const double ad = adj2 * cv, a2 = 0.0 * (cv * cv) + adj2 * (-sv);
+          h[0] += a2 * (1.0 * 1.0) + (ad * 1.0) * 0.0;                                 /* (a,a) */
+          h[1] += a2 * (1.0 * 1.0) + (ad * 1.0) * 0.0;                                 /* (b,b) */
+          h[2] += a2 * 1.0 * 1.0 + ad * 0.0; }                                         /* (a,b) */
+        /* hdrpass(S1, S2, adj = 0*.. + lam*1): (u-leaves) x (v-leaves) with adj*cu*cv */
+        { const double ad = (0.0 * sv * su + lam * 1.0) * cu * cv;
+          h[0] += 2.0 * (ad * 1.0 * 1.0);                                              /* (a,a): i == j -> 2 adj */
+          h[2] += ad * 1.0 * 1.0;                                                      /* (a,b) */
+          h[3] += ad * -1.0 * 1.0;                                                     /* (b,a) */
+          h[1] += 2.0 * (ad * -1.0 * 1.0); }                                           /* (b,b) */
+        /* - c * exp(c - a): binary '-' at the top passes -lam to Node2{*}(c, E) */
+        { const double e = exp(c - a), nl = -lam;
+          /* hrpass(c, nl*e, 0*e*e + nl*0) */
+          h[4] += 0.0 * (e * e) + nl * 0.0;                                            /* (c,c) */
+          /* hrpass(E = exp(w), adj = nl*c, adj2 = 0*c*c + nl*0) -> w = c - a: ad = adj*e, a2 = adj2*e*e + adj*e */
+          const double adE = nl * c, a2E = 0.0 * (c * c) + nl * 0.0;
+          const double ad = adE * e, a2 = a2E * (e * e) + adE * e;
+          h[4] += a2 * (1.0 * 1.0) + (ad * 1.0) * 0.0;                                 /* (c,c) */
+          h[0] += a2 * (-1.0 * -1.0) + (ad * -1.0) * 0.0;                              /* (a,a) */
+          h[5] += a2 * 1.0 * -1.0 + ad * 0.0;                                          /* (c,a) */
+          /* hdrpass(c, E, adj = 0*e*c + nl*1): var x unary -> adj*e; then var x Node2{-}: (c,c) 2adj, (c,a) -adj */
+          const double adx = (0.0 * e * c + nl * 1.0) * e;
+          h[4] += 2.0 * (adx * 1.0);                                                   /* (c,c) */
+          h[5] += adx * -1.0; }                                                        /* (c,a) */
+    }
+    double *Ho = H + 6 * ncon;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (int64_t I = 0; I < nobj; I++) {            /* i = I+2: p = x[i-1], q = x[i] */
+        const double p = x[I], q = x[I + 1];
+        double *h = Ho + 3 * I;
+        /* 100 * (p^2 - q)^2: FirstFixed{*} -> adj = 100 sigma; abs2(w): y = 2w, h = 2; w = abs2(p) - q */
+        const double w = p * p - q, adj = sigma * 100.0;
+        const double ad = adj * (2.0 * w), a2 = 0.0 * ((2.0 * w) * (2.0 * w)) + adj * 2.0;
+        /* Node2{-}(abs2(p), q): hrpass(abs2(p), ad, a2) -> p: adj2 = a2*(2p)^2 + ad*2 ; hrpass(q, -ad, a2) ; hdrpass -> -a2 * 2p */
+        h[0] += a2 * ((2.0 * p) * (2.0 * p)) + ad * 2.0;                               /* (p,p) */
+        h[1] += a2 * (-1.0 * -1.0) + (ad * -1.0) * 0.0;                                /* (q,q) */
+        h[2] += (a2 * 1.0 * -1.0 + ad * 0.0) * (2.0 * p);                              /* (p,q) -> (i, i-1) */
+        /* (p - 1)^2 */
+        h[0] += 0.0 * ((2.0 * (p - 1.0)) * (2.0 * (p - 1.0))) + sigma * 2.0;           /* (p,p) */
+    }
+}

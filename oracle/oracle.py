@@ -49,6 +49,7 @@ def lib():
         L.ora_hess.argtypes = [vp, vp, vp, dbl, vp]
         L.ora_jac_structure.argtypes = [vp, vp, vp]
         L.ora_hess_structure.argtypes = [vp, vp, vp]
+        L.ora_lv_hess_compiled.argtypes = [i64, vp, vp, dbl, vp, ctypes.c_int]
         L.ora_un_table.argtypes = [ctypes.c_int, dbl, vp]
         L.ora_bin_table.argtypes = [ctypes.c_int, dbl, dbl, vp]
         _LIB = L
@@ -168,4 +169,13 @@ def un_table(fn_id, x):
 def bin_table(fn_id, x1, x2):
     out = np.zeros(6)
     lib().ora_bin_table(int(fn_id), float(x1), float(x2), _p(out))
+    return out
+
+
+def lv_hess_compiled(N, x, y, sigma, out=None, threads=1):
+    """Hand-specialised LV hess_coord! (proxy for Julia-compiled `backend = nothing`), see exa_oracle.c."""
+    x, y = _f64(x), _f64(y)
+    if out is None:
+        out = np.empty(9 * N - 15)
+    lib().ora_lv_hess_compiled(int(N), _p(x), _p(y), float(sigma), _p(out), int(threads))
     return out

@@ -251,3 +251,16 @@ def test_acopf_layout_table(libs):
     assert o.ncon == 1 + 7 * nbr + 2 * nbus
     assert o.nnzj == 1 + 30 * nbr + 2 * nbus + 2 * ngen
     assert o.nnzh == ngen + 44 * nbr + 2 * nbus
+
+
+def test_lv_compiled_baseline_equals_interpreter(libs):
+    """bench.py's cpu_baseline times a hand-specialised straight-line C version of the LV Hessian (what Julia's
+    compiler makes of shessian!); it must produce exactly the interpreter's numbers."""
+    import oracle
+    N = 5000
+    o = oracle_model(models.luksan_vlcek_model(N))
+    x = models.lv_x0(N) + 0.1 * np.random.default_rng(0).uniform(-1, 1, N)
+    y = np.random.default_rng(1).standard_normal(N - 2)
+    ref = o.hess_coord(x, y, 0.5)
+    np.testing.assert_allclose(oracle.lv_hess_compiled(N, x, y, 0.5), ref, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(oracle.lv_hess_compiled(N, x, y, 0.5, threads=4), ref, rtol=1e-14, atol=0)
