@@ -798,6 +798,82 @@ void gen_first_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     os << "}\n";
 }
 
+// ---- gather ("pull") formulation of the objective gradient ------------------------------------------------
+// index expression == a * (RANGE column) + c ?
+struct Affine { bool ok = false; int col = -1; int64_t a = 0, c = 0; };
+Affine affine(const Pattern &p, int k) {
+    const exa_node_t &nd = p.nodes[k];
+    Affine r;
+    if (nd.op == EXA_OP_CONST_I) { r.ok = true; r.c = nd.ival; return r; }
+    if (nd.op == EXA_OP_DATA) {
+        if (p.cols[nd.a].type != EXA_COL_RANGE) return r;
+        r.ok = true; r.col = nd.a; r.a = 1; return r;
+    }
+    if (nd.op == EXA_OP_UN && (nd.fn == EXA_U_PLUS || nd.fn == EXA_U_MINUS)) {
+        Affine x = affine(p, nd.a);
+        if (!x.ok) return r;
+        if (nd.fn == EXA_U_MINUS) { x.a = -x.a; x.c = -x.c; }
+        return x;
+    }
+    if (nd.op == EXA_OP_BIN && (nd.fn == EXA_B_ADD || nd.fn == EXA_B_SUB || nd.fn == EXA_B_MUL)) {
+        Affine x = affine(p, nd.a), y = affine(p, nd.b);
+        if (!x.ok || !y.ok) return r;
+        if (nd.fn == EXA_B_MUL) {
+            if (x.col >= 0 && y.col >= 0) return r;
+            if (y.col >= 0) std::swap(x, y);
+            r.ok = true; r.col = x.col; r.a = x.a * y.c; r.c = x.c * y.c; return r;
+        }
+        const int64_t sg = nd.fn == EXA_B_ADD ? 1 : -1;
+        if (x.col >= 0 && y.col >= 0 && x.col != y.col) return r;
+        r.ok = true; r.col = x.col >= 0 ? x.col : y.col; r.a = x.a + sg * y.a; r.c = x.c + sg * y.c;
+        if (r.a == 0) r.col = -1;
+        return r;
+    }
+    return r;
+}
+
+// An objective pattern can be gathered when every first-order slot's variable index is (range value) + c: variable
+// v then receives slot s from exactly one data point, I = (v - c_s - start) / step.  One thread per VARIABLE
+// re-evaluates the (cheap) pattern at those points: coalesced store, no zero-fill, no atomics, deterministic.
+// (The reference's KA path resolves the same contention with a sorted gather list, KA ext :310-336.)
+bool pull_ok(const Pattern &p, std::vector<Affine> &slots) {
+    if (p.kind != EXA_PAT_OBJ || p.n == 0 || p.o1step < 1 || p.o1step > env_int("EXAHIP_PULL_MAX_SLOTS", 4)) return false;
+    if (!env_int("EXAHIP_GRAD_PULL", 1)) return false;
+    slots.clear();
+    int col = -1;
+    for (int s = 0; s < p.o1step; s++) {
+        Affine a = affine(p, p.ad[p.slotvar1[s]].ir);
+        if (!a.ok || a.col < 0 || a.a != 1) return false;
+        if (col >= 0 && a.col != col) return false;
+        col = a.col;
+        if (p.cols[col].step < 1) return false;
+        slots.push_back(a);
+    }
+    return true;
+}
+
+void gen_pull_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
+    const Pattern &p = m.pats[pi];
+    std::vector<Affine> slots;
+    pull_ok(p, slots);
+    os << "static __device__ __forceinline__ double " << fn_name(pi, "pull")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, long v) {\n    double g = 0.0;\n";
+    for (int s = 0; s < p.o1step; s++) {
+        Body b(m, pi, L);
+        b.forward(p.ad_root, 1, false);
+        GenAlg a(b, p.comp1, p.o1step);
+        grpass(p, p.ad_root, a, Emitter::litf(1.0));
+        const int64_t step = p.cols[slots[s].col].step;
+        os << "    {   // slot " << s << ": x[range" << (slots[s].c >= 0 ? " + " : " - ") << std::llabs(slots[s].c) << "]\n"
+           << "        const long r = v - (" << slots[s].c << "L) - " << b.P(L.pat[pi].col[slots[s].col]) << ";\n"
+           << "        const long I = r / " << step << "L;\n"
+           << "        if (r >= 0 && I * " << step << "L == r && I >= " << b.P(L.pat[pi].lo) << " && I < " << b.P(L.pat[pi].hi) << ") {\n";
+        emit_lines(os, b.e, "            ");
+        os << "            g += " << b.e.sd(a.acc[s]) << ";\n        }\n    }\n";
+    }
+    os << "    return g;\n}\n";
+}
+
 void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
     Body b(m, pi, L);
     const Pattern &p = b.p;
@@ -891,7 +967,9 @@ Generated generate_module(const Model &m) {
         if (p.n == 0) continue;
         if (p.kind == EXA_PAT_OBJ) {
             L.active[CB_OBJ].push_back(k);
-            if (p.o1step > 0) L.active[CB_GRAD].push_back(k);
+            std::vector<Affine> sl;
+            if (pull_ok(p, sl)) L.pull.push_back(k);
+            else if (p.o1step > 0) L.active[CB_GRAD].push_back(k);
         } else {
             if (p.kind == EXA_PAT_CON) L.active[CB_CONS].push_back(k);
             else L.active[CB_CONSAUG].push_back(k);
@@ -916,7 +994,10 @@ Generated generate_module(const Model &m) {
         if (p.n == 0) continue;
         os << "// ---- pattern " << k << ": kind=" << p.kind << " o1step=" << p.o1step << " o2step=" << p.o2step << " ----\n";
         gen_value_fn(os, m, k, L);
-        if (p.kind == EXA_PAT_OBJ) { if (p.o1step > 0) gen_first_fn(os, m, k, L, true); }
+        if (p.kind == EXA_PAT_OBJ) {
+            if (std::find(L.pull.begin(), L.pull.end(), k) != L.pull.end()) gen_pull_fn(os, m, k, L);
+            else if (p.o1step > 0) gen_first_fn(os, m, k, L, true);
+        }
         else {
             gen_cons_fn(os, m, k, L);
             if (p.o1step > 0) { gen_first_fn(os, m, k, L, false); gen_struct_fn(os, m, k, L, false); }
@@ -943,6 +1024,12 @@ Generated generate_module(const Model &m) {
           "const double* __restrict__ th, double* __restrict__ out) {\n";
     gen_dispatch(os, L, CB_GRAD, "grad", "P, x, th, out");
     os << "}\n";
+    // grad!, gather part: one thread per variable; also provides the zero of untouched variables (no memset)
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_grad_pull(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ th, double* __restrict__ out, long nvar) {\n"
+          "    const long v = (long)blockIdx.x * EXA_BLOCK + threadIdx.x;\n    if (v >= nvar) return;\n    double g = 0.0;\n";
+    for (int k : L.pull) os << "    g += p" << k << "_pull(P, x, th, v + 1);\n";
+    os << "    out[v] = g;\n}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_cons(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out) {\n";
     gen_dispatch(os, L, CB_CONS, "cons", "P, x, th, out");

@@ -85,6 +85,7 @@ struct ParamLayout {
                                          // (slot in active[cb] << 40) | tile index, built by the runtime (interleaved)
     int ppt[CB_COUNT];                   // data points per thread (a workgroup covers kBlock * ppt points)
     int nwords = 0;
+    std::vector<int> pull;               // objective patterns whose gradient is GATHERED per variable (exa_grad_pull)
 };
 
 struct Generated {

@@ -56,7 +56,7 @@ struct Handle {
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_auggather = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_consaug = nullptr, f_jac = nullptr,
+    hipFunction_t f_auggather = nullptr, f_gradpull = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_consaug = nullptr, f_jac = nullptr,
                   f_hess = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
@@ -239,7 +239,7 @@ void to_device(Handle &h) {
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
     h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
-    h.f_consaug = fn("exa_consaug"); h.f_auggather = fn("exa_aug_gather"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
+    h.f_consaug = fn("exa_consaug"); h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
     h.on_device = true;
     h.colslot.resize(m.pats.size());
@@ -294,10 +294,17 @@ void do_obj(Handle &h, const double *x, double *out_dev) {
     launch(h, h.f_red, 1, 1024, a2);
 }
 void do_grad(Handle &h, const double *x, double *g) {
-    HIPCHK(hipMemsetAsync(g, 0, sizeof(double) * (size_t)h.m->nvar, h.stream));
     const void *P = h.dP.p, *th = h.dtheta.p;
+    int64_t nvar = h.m->nvar;
+    if (!h.gen.layout.pull.empty()) {
+        // gathered patterns: plain coalesced store of every g[v] (zero where nothing contributes)
+        void *a0[] = {&P, &x, &th, &g, &nvar};
+        launch(h, h.f_gradpull, (nvar + kBlock - 1) / kBlock, kBlock, a0);
+    } else {
+        HIPCHK(hipMemsetAsync(g, 0, sizeof(double) * (size_t)nvar, h.stream));
+    }
     void *a[] = {&P, &x, &th, &g};
-    launch(h, h.f_grad, h.grid[CB_GRAD], kBlock, a);
+    launch(h, h.f_grad, h.grid[CB_GRAD], kBlock, a);   // scattered patterns: FP64 hardware atomics on top
 }
 void do_cons(Handle &h, const double *x, double *c) {
     if (h.m->ncon == 0) return;
