@@ -27,7 +27,7 @@
 namespace exa {
 namespace {
 
-[[noreturn]] void fail(const std::string &m) { throw std::runtime_error(m); }
+[[noreturn]] void fail(const std::string &m) { throw BadInput(m); }
 
 // ---------------------------------------------------------------------------------------------------
 // symbolic values
@@ -633,13 +633,21 @@ static __device__ __forceinline__ void exa_flush_points(double* __restrict__ out
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     constexpr int CNT = S * PP;
+    double* __restrict__ dst = out + obase + (long)CNT * g;
+    if (npts >= (long)(g + 1) * PP) {
+        // all PP points of the group are in range (every wavefront but the last of a pattern): no per-element test
 #pragma unroll
-    for (int k = 0; k * 64 < CNT; k++) {
-        const int j = k * 64 + lane;
-        const int l2 = j / S, s2 = j - l2 * S;
-        if (j < CNT && g * PP + l2 < npts) {
-            const double v = tile[s2 * LD + l2];
-            __builtin_nontemporal_store(v, out + obase + (long)CNT * g + j);
+        for (int k = 0; k * 64 < CNT; k++) {
+            const int j = k * 64 + lane;
+            const int l2 = j / S, s2 = j - l2 * S;
+            if ((k + 1) * 64 <= CNT || j < CNT) __builtin_nontemporal_store(tile[s2 * LD + l2], dst + j);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k * 64 < CNT; k++) {
+            const int j = k * 64 + lane;
+            const int l2 = j / S, s2 = j - l2 * S;
+            if (j < CNT && g * PP + l2 < npts) __builtin_nontemporal_store(tile[s2 * LD + l2], dst + j);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -3,12 +3,16 @@
 #include <cstdint>
 #include <map>
 #include <memory>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
 #include "../../include/exahip.h"
 
 namespace exa {
+
+// malformed pattern table / unsupported construct: the caller's fault -> C-ABI status 1 (everything else -> 2)
+struct BadInput : std::runtime_error { using std::runtime_error::runtime_error; };
 
 // ---------------------------------------------------------------------------------------------------
 // Deep copy of the wire model (include/exahip_ir.h)

@@ -17,7 +17,7 @@ namespace exa {
 
 namespace {
 
-[[noreturn]] void fail(const std::string &msg) { throw std::runtime_error(msg); }
+[[noreturn]] void fail(const std::string &msg) { throw BadInput(msg); }
 
 void check_pattern(const Pattern &p, int pi) {
     const int n = (int)p.nodes.size();

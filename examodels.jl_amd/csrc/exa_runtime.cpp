@@ -236,12 +236,12 @@ void to_device(Handle &h) {
         throw HipError("no HIP device available (libexahip has no CPU fallback): " + std::string(hipGetErrorString(e)));
     h.hsaco_path = build_code_object(h.gen.source);
     std::vector<char> image = read_file(h.hsaco_path);
+    h.on_device = true;   // from here on the destructor releases whatever was acquired
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
     h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
     h.f_consaug = fn("exa_consaug"); h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
-    h.on_device = true;
     h.colslot.resize(m.pats.size());
     for (size_t k = 0; k < m.pats.size(); k++) {
         Pattern &p = m.pats[k];
@@ -376,13 +376,12 @@ int create(const exa_model_desc_t *desc, int *id_out, bool device) {
         else fill_params(*h);
         *id_out = put(std::move(h));
         return 0;
-    } catch (const HipError &e) {
-        g_err = e.what();
-        return 2;
+    } catch (const BadInput &e) {
+        g_err = e.what();      // malformed table: the caller's fault
+        return 1;
     } catch (const std::exception &e) {
-        g_err = e.what();
-        // malformed tables are the caller's fault (status 1); build failures are internal (status 2)
-        return std::string(e.what()).rfind("hipcc failed", 0) == 0 || std::string(e.what()).rfind("cannot", 0) == 0 ? 2 : 1;
+        g_err = e.what();      // HIP failure, hipcc failure, I/O failure: internal
+        return 2;
     } catch (...) {
         g_err = "unknown error";
         return 2;
