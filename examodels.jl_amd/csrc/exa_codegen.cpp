@@ -903,6 +903,112 @@ void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     os << "}\n";
 }
 
+// ---- matrix-free products: same sweeps, different leaf actions ---------------------------------
+// Jv: row value = sum_s acc_s * v[k_s] (jacobian.jl:41-54) — a base row is owned by one data point (plain store),
+// augmentation terms go through the value buffer + exa_aug_gather like cons_nln!.
+void gen_jprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
+    Body b(m, pi, L);
+    const Pattern &p = b.p;
+    Val sum = Emitter::litf(0.0);
+    if (p.o1step > 0) {
+        b.forward(p.ad_root, 1, false);
+        GenAlg a(b, p.comp1, p.o1step);
+        grpass(p, p.ad_root, a, Emitter::litf(1.0));
+        for (int s = 0; s < p.o1step; s++) {
+            Val vi = b.fv[p.slotvar1[s]].vidx;
+            Val vv = b.e.raw("v[" + b.e.s(b.e.sub(vi, Emitter::liti(1))) + "]", false);
+            sum = b.e.add(sum, b.e.mul(a.acc[s], vv));
+        }
+    }
+    const std::string dst = p.kind == EXA_PAT_CONAUG ? b.P(L.pat[pi].oa) + " + I" : b.P(L.pat[pi].o0) + " + I";
+    os << "static __device__ __forceinline__ void " << fn_name(pi, "jprod")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, const double* __restrict__ v, "
+          "double* __restrict__ out, long tid) {\n"
+       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
+    emit_lines(os, b.e);
+    os << "    out[" << dst << "] = " << b.e.sd(sum) << ";\n}\n";
+}
+
+// J'v: out[k_s] += acc_s * v[row] (jacobian.jl:55-68) — shared targets, FP64 hardware atomics on a zeroed vector
+void gen_jtprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
+    Body b(m, pi, L);
+    const Pattern &p = b.p;
+    b.forward(p.ad_root, 1, false);
+    GenAlg a(b, p.comp1, p.o1step);
+    grpass(p, p.ad_root, a, Emitter::litf(1.0));
+    Val w = b.e.raw("v[" + b.row0() + "]", false);
+    std::vector<std::string> stores;
+    for (int s = 0; s < p.o1step; s++) {
+        Val vi = b.fv[p.slotvar1[s]].vidx;
+        Val t = b.e.mul(a.acc[s], w);
+        if (t.lit_eq(0)) continue;
+        stores.push_back("unsafeAtomicAdd(&out[" + b.e.s(b.e.sub(vi, Emitter::liti(1))) + "], " + b.e.sd(t) + ");");
+    }
+    os << "static __device__ __forceinline__ void " << fn_name(pi, "jtprod")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, const double* __restrict__ v, "
+          "double* __restrict__ out, long tid) {\n"
+       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
+    emit_lines(os, b.e);
+    for (auto &st : stores) os << "    " << st << "\n";
+    os << "}\n";
+}
+
+// Hv: for a lower-triangular COO entry (i, j, A): i == j -> Hv[i] += A v[i]; else Hv[i] += A v[j], Hv[j] += A v[i]
+// (hessian.jl:291-315, 566-579).  Contributions are merged per variable in registers first: one atomic per
+// distinct variable of the data point instead of one or two per slot.
+void gen_hprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
+    Body b(m, pi, L);
+    const Pattern &p = b.p;
+    b.forward(p.ad_root, 2, false);
+    Val adj;
+    if (p.kind == EXA_PAT_OBJ) adj = b.e.raw("sigma", false);
+    else adj = b.e.raw("y[" + b.row0() + "]", false);
+    GenAlg a(b, p.comp2, p.o2step);
+    hrpass0(p, p.ad_root, a, adj, Emitter::litf(0.0));
+    const int nk = (int)p.keys.size();
+    std::vector<int> rep(nk, -1);
+    for (size_t n = 0; n < p.ad.size(); n++)
+        if (p.ad[n].kind == AD_VAR && rep[p.ad[n].key] < 0) rep[p.ad[n].key] = (int)n;
+    std::vector<Val> hv(nk, Emitter::litf(0.0)), vv(nk);
+    std::vector<char> used(nk, 0);
+    auto vload = [&](int key) {
+        Val vi = b.fv[rep[key]].vidx;
+        return b.e.raw("v[" + b.e.s(b.e.sub(vi, Emitter::liti(1))) + "]", false);
+    };
+    for (int s = 0; s < p.o2step; s++) {
+        const int k1 = p.ad[p.slotvar2[s].first].key, k2 = p.ad[p.slotvar2[s].second].key;
+        Val A = a.acc[s];
+        if (A.lit_eq(0)) continue;
+        if (k1 == k2) {
+            hv[k1] = b.e.add(hv[k1], b.e.mul(A, vload(k1)));
+            used[k1] = 1;
+        } else {
+            // A already carries the i == j ? 2adj : adj rule; when the two keys alias at run time only one update applies
+            Val i = b.fv[rep[k1]].vidx, j = b.fv[rep[k2]].vidx;
+            hv[k1] = b.e.add(hv[k1], b.e.mul(A, vload(k2)));
+            Val second = b.e.mul(A, vload(k1));
+            if (!(i.is_lit() && j.is_lit()))
+                second = b.e.raw("(" + b.e.s(i) + " == " + b.e.s(j) + " ? 0.0 : " + b.e.sd(second) + ")", false);
+            else if (i.i == j.i) second = Emitter::litf(0.0);
+            hv[k2] = b.e.add(hv[k2], second);
+            used[k1] = used[k2] = 1;
+        }
+    }
+    std::vector<std::string> stores;
+    for (int k = 0; k < nk; k++) {
+        if (!used[k] || hv[k].lit_eq(0)) continue;
+        Val vi = b.fv[rep[k]].vidx;
+        stores.push_back("unsafeAtomicAdd(&out[" + b.e.s(b.e.sub(vi, Emitter::liti(1))) + "], " + b.e.sd(hv[k]) + ");");
+    }
+    os << "static __device__ __forceinline__ void " << fn_name(pi, "hprod")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
+          "const double* __restrict__ v, double* __restrict__ out, double sigma, long tid) {\n"
+       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
+    emit_lines(os, b.e);
+    for (auto &st : stores) os << "    " << st << "\n";
+    os << "}\n";
+}
+
 void gen_struct_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L, bool hess) {
     Body b(m, pi, L);
     const Pattern &p = b.p;
@@ -979,11 +1085,12 @@ Generated generate_module(const Model &m) {
             if (pull_ok(p, sl)) L.pull.push_back(k);
             else if (p.o1step > 0) L.active[CB_GRAD].push_back(k);
         } else {
-            if (p.kind == EXA_PAT_CON) L.active[CB_CONS].push_back(k);
-            else L.active[CB_CONSAUG].push_back(k);
+            if (p.kind == EXA_PAT_CON) { L.active[CB_CONS].push_back(k); L.active[CB_JPROD].push_back(k); }
+            else { L.active[CB_CONSAUG].push_back(k); L.active[CB_JPRODAUG].push_back(k); }
+            if (p.o1step > 0) L.active[CB_JTPROD].push_back(k);
             if (p.o1step > 0) { L.active[CB_JAC].push_back(k); L.active[CB_JSTRUCT].push_back(k); }
         }
-        if (p.o2step > 0) { L.active[CB_HESS].push_back(k); L.active[CB_HSTRUCT].push_back(k); }
+        if (p.o2step > 0) { L.active[CB_HESS].push_back(k); L.active[CB_HSTRUCT].push_back(k); L.active[CB_HPROD].push_back(k); }
     }
     for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w++; L.ppt[cb] = 1; }
     // streaming value kernels keep more loads in flight per wavefront with several points per thread (measured)
@@ -1008,9 +1115,10 @@ Generated generate_module(const Model &m) {
         }
         else {
             gen_cons_fn(os, m, k, L);
-            if (p.o1step > 0) { gen_first_fn(os, m, k, L, false); gen_struct_fn(os, m, k, L, false); }
+            gen_jprod_fn(os, m, k, L);
+            if (p.o1step > 0) { gen_first_fn(os, m, k, L, false); gen_struct_fn(os, m, k, L, false); gen_jtprod_fn(os, m, k, L); }
         }
-        if (p.o2step > 0) { gen_hess_fn(os, m, k, L); gen_struct_fn(os, m, k, L, true); }
+        if (p.o2step > 0) { gen_hess_fn(os, m, k, L); gen_struct_fn(os, m, k, L, true); gen_hprod_fn(os, m, k, L); }
     }
     // obj: per-workgroup partial sums
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_obj(const long* __restrict__ P, const double* __restrict__ x, "
@@ -1061,6 +1169,21 @@ Generated generate_module(const Model &m) {
           "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma) {\n";
     lds_decl(CB_HESS, true);
     gen_dispatch(os, L, CB_HESS, "hess", "P, x, y, th, out, sigma", ", lds");
+    os << "}\n";
+    const char *prod_sig = "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, "
+                           "const double* __restrict__ v, double* __restrict__ out) {\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jprod" << prod_sig;
+    gen_dispatch(os, L, CB_JPROD, "jprod", "P, x, th, v, out");
+    os << "}\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jprodaug" << prod_sig;
+    gen_dispatch(os, L, CB_JPRODAUG, "jprod", "P, x, th, v, out");
+    os << "}\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jtprod" << prod_sig;
+    gen_dispatch(os, L, CB_JTPROD, "jtprod", "P, x, th, v, out");
+    os << "}\n";
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hprod(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ y, const double* __restrict__ th, const double* __restrict__ v, double* __restrict__ out, double sigma) {\n";
+    gen_dispatch(os, L, CB_HPROD, "hprod", "P, x, y, th, v, out, sigma");
     os << "}\n";
     for (int wide = 0; wide < 2; wide++) {
         const char *it = wide ? "long" : "int";

@@ -56,7 +56,7 @@ struct Handle {
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_auggather = nullptr, f_gradpull = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_consaug = nullptr, f_jac = nullptr,
+    hipFunction_t f_auggather = nullptr, f_gradpull = nullptr, f_jprod = nullptr, f_jprodaug = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_consaug = nullptr, f_jac = nullptr,
                   f_hess = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
@@ -64,7 +64,7 @@ struct Handle {
     DevBuf dmap[CB_COUNT];                  // per-callback block maps
     std::vector<DevBuf> dcols;              // flattened over patterns
     std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
-    DevBuf sx, sy, sout, srows, scols;      // scratch of the *_host variants
+    DevBuf sx, sy, sv, sout, srows, scols;  // scratch of the *_host variants
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     ~Handle() {
@@ -73,7 +73,7 @@ struct Handle {
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release();
             for (auto &b : dmap) b.release();
             for (auto &b : dcols) b.release();
-            sx.release(); sy.release(); sout.release(); srows.release(); scols.release();
+            sx.release(); sy.release(); sv.release(); sout.release(); srows.release(); scols.release();
             if (ev0) (void)hipEventDestroy(ev0);
             if (ev1) (void)hipEventDestroy(ev1);
             if (module) (void)hipModuleUnload(module);
@@ -240,7 +240,8 @@ void to_device(Handle &h) {
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
     h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
-    h.f_consaug = fn("exa_consaug"); h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
+    h.f_consaug = fn("exa_consaug"); h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull");
+    h.f_jprod = fn("exa_jprod"); h.f_jprodaug = fn("exa_jprodaug"); h.f_jtprod = fn("exa_jtprod"); h.f_hprod = fn("exa_hprod"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
     h.colslot.resize(m.pats.size());
     for (size_t k = 0; k < m.pats.size(); k++) {
@@ -332,6 +333,35 @@ void do_hess(Handle &h, const double *x, const double *y, double sigma, double *
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &y, &th, &v, &sigma};
     launch(h, h.f_hess, h.grid[CB_HESS], kBlock, a);
+}
+// matrix-free products (jprod_nln! / jtprod_nln! / hprod!, nlp.jl:1882-1978)
+void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
+    if (h.m->ncon == 0) return;
+    if (h.world > 1) HIPCHK(hipMemsetAsync(Jv, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
+    const void *P = h.dP.p, *th = h.dtheta.p;
+    void *a[] = {&P, &x, &th, &v, &Jv};
+    launch(h, h.f_jprod, h.grid[CB_JPROD], kBlock, a);
+    if (h.m->nconaug == 0) return;
+    void *buf = h.daugbuf.p;
+    if (h.world > 1) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
+    void *a2[] = {&P, &x, &th, &v, &buf};
+    launch(h, h.f_jprodaug, h.grid[CB_JPRODAUG], kBlock, a2);
+    const void *rows = h.daugrows.p, *ptr = h.daugptr.p, *perm = h.daugperm.p;
+    int64_t nrows = (int64_t)h.m->aug_rows.size();
+    void *a3[] = {&rows, &ptr, &perm, &buf, &Jv, &nrows};
+    launch(h, h.f_auggather, (nrows + kBlock - 1) / kBlock, kBlock, a3);
+}
+void do_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
+    HIPCHK(hipMemsetAsync(Jtv, 0, sizeof(double) * (size_t)h.m->nvar, h.stream));
+    const void *P = h.dP.p, *th = h.dtheta.p;
+    void *a[] = {&P, &x, &th, &v, &Jtv};
+    launch(h, h.f_jtprod, h.grid[CB_JTPROD], kBlock, a);
+}
+void do_hprod(Handle &h, const double *x, const double *y, const double *v, double sigma, double *Hv) {
+    HIPCHK(hipMemsetAsync(Hv, 0, sizeof(double) * (size_t)h.m->nvar, h.stream));
+    const void *P = h.dP.p, *th = h.dtheta.p;
+    void *a[] = {&P, &x, &y, &th, &v, &Hv, &sigma};
+    launch(h, h.f_hprod, h.grid[CB_HPROD], kBlock, a);
 }
 void do_struct(Handle &h, bool hess, bool wide, void *rows, void *cols) {
     const void *P = h.dP.p;
@@ -498,6 +528,18 @@ int exa_hess(int id, const double *x, const double *y, double w, double *v) {
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) { if (h.m->nnzh && !v) throw std::runtime_error("null output"); do_hess(h, x, y, w, v); });
 }
+int exa_jprod(int id, const double *x, const double *v, double *Jv) {
+    if (!x || !v) return 1;
+    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !Jv) throw std::runtime_error("null output"); do_jprod(h, x, v, Jv); });
+}
+int exa_jtprod(int id, const double *x, const double *v, double *Jtv) {
+    if (!x || !Jtv) return 1;
+    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !v) throw std::runtime_error("null input"); do_jtprod(h, x, v, Jtv); });
+}
+int exa_hprod(int id, const double *x, const double *y, const double *v, double w, double *Hv) {
+    if (!x || !v || !Hv) return 1;
+    return guard(id, true, [&](Handle &h) { do_hprod(h, x, y, v, w, Hv); });
+}
 int exa_jac_structure(int id, int32_t *r, int32_t *c) {
     return guard(id, true, [&](Handle &h) { if (h.m->nnzj > 0x7fffffffLL) throw std::runtime_error("nnzj exceeds int32"); do_struct(h, false, false, r, c); });
 }
@@ -559,6 +601,43 @@ int exa_hess_host(int id, const double *x, const double *y, double w, double *v)
         h.sout.ensure(n);
         do_hess(h, (const double *)h.sx.p, (const double *)h.sy.p, w, (double *)h.sout.p);
         d2h(h, v, h.sout.p, n);
+    });
+}
+int exa_jprod_host(int id, const double *x, const double *v, double *Jv) {
+    if (!x || !v) return 1;
+    return guard(id, true, [&](Handle &h) {
+        const size_t n = 8 * (size_t)h.m->ncon;
+        if (!n) return;
+        h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
+        h2d(h, h.sv, v, 8 * (size_t)h.m->nvar);
+        h.sout.ensure(n);
+        do_jprod(h, (const double *)h.sx.p, (const double *)h.sv.p, (double *)h.sout.p);
+        d2h(h, Jv, h.sout.p, n);
+    });
+}
+int exa_jtprod_host(int id, const double *x, const double *v, double *Jtv) {
+    if (!x || !Jtv) return 1;
+    return guard(id, true, [&](Handle &h) {
+        const size_t n = 8 * (size_t)h.m->nvar;
+        h2d(h, h.sx, x, n);
+        if (h.m->ncon) { if (!v) throw std::runtime_error("null input"); h2d(h, h.sv, v, 8 * (size_t)h.m->ncon); }
+        else h.sv.ensure(8);
+        h.sout.ensure(n);
+        do_jtprod(h, (const double *)h.sx.p, (const double *)h.sv.p, (double *)h.sout.p);
+        d2h(h, Jtv, h.sout.p, n);
+    });
+}
+int exa_hprod_host(int id, const double *x, const double *y, const double *v, double w, double *Hv) {
+    if (!x || !v || !Hv) return 1;
+    return guard(id, true, [&](Handle &h) {
+        const size_t n = 8 * (size_t)h.m->nvar;
+        h2d(h, h.sx, x, n);
+        h2d(h, h.sv, v, n);
+        if (h.m->ncon) { if (!y) throw std::runtime_error("null multipliers"); h2d(h, h.sy, y, 8 * (size_t)h.m->ncon); }
+        else h.sy.ensure(8);
+        h.sout.ensure(n);
+        do_hprod(h, (const double *)h.sx.p, (const double *)h.sy.p, (const double *)h.sv.p, w, (double *)h.sout.p);
+        d2h(h, Hv, h.sout.p, n);
     });
 }
 static int struct_host(int id, bool hess, bool wide, void *r, void *c) {

@@ -19,7 +19,7 @@ SYMBOLS = [
     "exa_free", "exa_nvar", "exa_ncon", "exa_nnzj", "exa_nnzh", "exa_nvar64", "exa_ncon64", "exa_nnzj64", "exa_nnzh64",
     "exa_nnzg64", "exa_npatterns", "exa_pattern_info", "exa_pattern_comp", "exa_meta", "exa_kernel_source",
     "exa_set_stream", "exa_set_shard", "exa_set_value", "exa_obj", "exa_obj_async", "exa_grad", "exa_cons", "exa_jac",
-    "exa_hess", "exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",
+    "exa_hess", "exa_jprod", "exa_jtprod", "exa_hprod", "exa_jprod_host", "exa_jtprod_host", "exa_hprod_host", "exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",
     "exa_obj_host", "exa_grad_host", "exa_cons_host", "exa_jac_host", "exa_hess_host", "exa_jac_structure_host",
     "exa_hess_structure_host", "exa_jac_structure64_host", "exa_hess_structure64_host", "exa_time_callback", "exa_sync",
 ]
@@ -75,6 +75,10 @@ def lib():
     for f in ("exa_obj", "exa_obj_async", "exa_grad", "exa_cons", "exa_jac", "exa_obj_host", "exa_grad_host",
               "exa_cons_host", "exa_jac_host"):
         getattr(L, f).argtypes = [i32, vp, vp]
+    for f in ("exa_jprod", "exa_jtprod", "exa_jprod_host", "exa_jtprod_host"):
+        getattr(L, f).argtypes = [i32, vp, vp, vp]
+    L.exa_hprod.argtypes = [i32, vp, vp, vp, dbl, vp]
+    L.exa_hprod_host.argtypes = [i32, vp, vp, vp, dbl, vp]
     L.exa_hess.argtypes = [i32, vp, vp, dbl, vp]
     L.exa_hess_host.argtypes = [i32, vp, vp, dbl, vp]
     for f in ("exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",

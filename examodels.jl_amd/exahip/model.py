@@ -163,6 +163,40 @@ class ExaModel:
     def hess_coord(self, x, y, obj_weight=1.0, out=None):
         return self._call("hess", x, self.meta.nnzh, out, extra=(y, obj_weight))
 
+    # ---- matrix-free products: jprod_nln! / jtprod_nln! / hprod! (nlp.jl:1882-1978) -----------------------------
+    def _prod(self, name, x, v, nv, n_out, out, y=None, w=1.0):
+        if _is_torch(x):
+            import torch
+            self._use_torch_stream(x)
+            self._tcheck(x, self.meta.nvar, "x")
+            self._tcheck(v, nv, "v")
+            if out is None:
+                out = torch.empty(n_out, dtype=torch.float64, device=x.device)
+            if name == "hprod":
+                capi.check(self._L.exa_hprod(self.id, x.data_ptr(), y.data_ptr(), v.data_ptr(), float(w), out.data_ptr()), name)
+            else:
+                capi.check(getattr(self._L, "exa_" + name)(self.id, x.data_ptr(), v.data_ptr(), out.data_ptr()), name)
+            return out
+        x = self._np(x, self.meta.nvar, "x")
+        v = self._np(v, nv, "v")
+        if out is None:
+            out = np.empty(n_out)
+        if name == "hprod":
+            y = self._np(y, self.meta.ncon, "y")
+            capi.check(self._L.exa_hprod_host(self.id, x.ctypes.data, y.ctypes.data if y.size else None, v.ctypes.data, float(w), out.ctypes.data), name)
+        else:
+            capi.check(getattr(self._L, f"exa_{name}_host")(self.id, x.ctypes.data, v.ctypes.data if v.size else None, out.ctypes.data), name)
+        return out
+
+    def jprod(self, x, v, out=None):
+        return self._prod("jprod", x, v, self.meta.nvar, self.meta.ncon, out)
+
+    def jtprod(self, x, v, out=None):
+        return self._prod("jtprod", x, v, self.meta.ncon, self.meta.nvar, out)
+
+    def hprod(self, x, y, v, obj_weight=1.0, out=None):
+        return self._prod("hprod", x, v, self.meta.nvar, self.meta.nvar, out, y=y, w=obj_weight)
+
     def _structure(self, which, rows, cols, nnz, dtype):
         wide = np.dtype(dtype).itemsize == 8
         if rows is not None and _is_torch(rows):

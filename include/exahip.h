@@ -11,6 +11,9 @@
  *   exa_jac             <- jac_coord!     (KA ext :338-351,  CPU src/nlp.jl:1870-1880)
  *   exa_hess_structure  <- hess_structure!(KA ext :232-250,  CPU src/nlp.jl:1809-1825)
  *   exa_hess            <- hess_coord!    (KA ext :515-547,  CPU src/nlp.jl:1906-1940)
+ *   exa_jprod           <- jprod_nln!     (KA ext :369-387,  CPU src/nlp.jl:1882-1892)   matrix-free: no COO buffer
+ *   exa_jtprod          <- jtprod_nln!    (KA ext :389-407,  CPU src/nlp.jl:1894-1904)
+ *   exa_hprod           <- hprod!         (KA ext :409-511,  CPU src/nlp.jl:1942-1978)
  *   exa_set_value       <- set_value!     (src/nlp.jl:1279-1287)
  *   exa_new_from_table  <- build_extension (KA ext :33-191) + the pattern records of src/simdfunction.jl:78-100
  *
@@ -97,6 +100,9 @@ int exa_grad(int id, const double *x, double *g);
 int exa_cons(int id, const double *x, double *c);
 int exa_jac (int id, const double *x, double *vals);
 int exa_hess(int id, const double *x, const double *y, double obj_weight, double *vals);
+int exa_jprod (int id, const double *x, const double *v, double *Jv);             /* Jv [ncon]  = J(x) v,   v [nvar] */
+int exa_jtprod(int id, const double *x, const double *v, double *Jtv);            /* Jtv [nvar] = J(x)' v,  v [ncon] */
+int exa_hprod (int id, const double *x, const double *y, const double *v, double obj_weight, double *Hv);  /* Hv [nvar] */
 int exa_jac_structure  (int id, int32_t *rows, int32_t *cols);
 int exa_hess_structure (int id, int32_t *rows, int32_t *cols);
 int exa_jac_structure64 (int id, int64_t *rows, int64_t *cols);               /* Julia Vector{Int} */
@@ -108,6 +114,9 @@ int exa_grad_host(int id, const double *x, double *g);
 int exa_cons_host(int id, const double *x, double *c);
 int exa_jac_host (int id, const double *x, double *vals);
 int exa_hess_host(int id, const double *x, const double *y, double obj_weight, double *vals);
+int exa_jprod_host (int id, const double *x, const double *v, double *Jv);
+int exa_jtprod_host(int id, const double *x, const double *v, double *Jtv);
+int exa_hprod_host (int id, const double *x, const double *y, const double *v, double obj_weight, double *Hv);
 int exa_jac_structure_host  (int id, int32_t *rows, int32_t *cols);
 int exa_hess_structure_host (int id, int32_t *rows, int32_t *cols);
 int exa_jac_structure64_host (int id, int64_t *rows, int64_t *cols);

@@ -500,13 +500,14 @@ static void fwd(adnode *a, const ctx *c, int order) {
 /* ------------------------------------------------------------------------------------------------ */
 /* reverse sweeps with pluggable leaf actions                                                         */
 /* ------------------------------------------------------------------------------------------------ */
-enum { S_COLLECT, S_VALUES, S_DENSE, S_STRUCT };
+enum { S_COLLECT, S_VALUES, S_DENSE, S_STRUCT, S_JV, S_JTV, S_HV };
 typedef struct {
     int mode; int cnt;
     /* S_COLLECT */ int *raw; int nraw, capraw;             /* 1st order: key; 2nd order: key1*65536+key2 */
     /* S_VALUES  */ double *out; int64_t base; const int *comp;
     /* S_DENSE   */ double *dense;
     /* S_STRUCT  */ int64_t *rows, *cols; int64_t row;
+    /* S_JV/S_JTV/S_HV: matrix-free products (jacobian.jl:41-68, hessian.jl:291-315, 566-579) */ double *py; const double *pv;
 } sink;
 
 static void push_raw(sink *s, int v) {
@@ -520,6 +521,9 @@ static void leaf1(sink *s, adnode *v, double adj) {
     case S_VALUES: s->out[s->base + s->comp[s->cnt++] - 1] += adj; break;                 /* gradient.jl:83-86, jacobian.jl:37-40 */
     case S_DENSE: s->dense[v->vi - 1] += adj; s->cnt++; break;                              /* gradient.jl:23-26 */
     case S_STRUCT: { int64_t ind = s->base + s->comp[s->cnt++] - 1; s->rows[ind] = s->row; s->cols[ind] = v->vi; break; } /* jacobian.jl:69-83 */
+    case S_JV: s->py[s->row - 1] += adj * s->pv[v->vi - 1]; s->cnt++; break;      /* jacobian.jl:41-54 */
+    case S_JTV: s->py[v->vi - 1] += adj * s->pv[s->row - 1]; s->cnt++; break;     /* jacobian.jl:55-68 */
+    default: break;
     }
 }
 
@@ -540,6 +544,14 @@ static void leaf2(sink *s, adnode *v1, adnode *v2, double val) {
     case S_STRUCT: {                                                                         /* hessian.jl:593-642 */
         int64_t ind = s->base + s->comp[s->cnt++] - 1, i = v1->vi, j = v2->vi;
         if (i >= j) { s->rows[ind] = i; s->cols[ind] = j; } else { s->rows[ind] = j; s->cols[ind] = i; }
+        break;
+    }
+    case S_HV: {   /* hessian.jl:291-315 (cross) / 566-579 (leaf): val is adj (cross) or adj2 (leaf) */
+        const int64_t i = v1->vi, j = v2->vi;
+        if (v1 == v2) s->py[i - 1] += val * s->pv[i - 1];
+        else if (i == j) s->py[i - 1] += 2 * val * s->pv[i - 1];
+        else { s->py[i - 1] += val * s->pv[j - 1]; s->py[j - 1] += val * s->pv[i - 1]; }
+        s->cnt++;
         break;
     }
     default: break;
@@ -580,7 +592,7 @@ static void hdrpass(adnode *t1, adnode *t2, sink *s, double adj) {
         return;
     }
     /* VAR x VAR (hessian.jl:251-268) */
-    leaf2(s, t1, t2, (s->mode == S_VALUES && t1->vi == t2->vi) ? 2 * adj : adj);
+    leaf2(s, t1, t2, (s->mode == S_VALUES && t1->vi == t2->vi) ? 2 * adj : adj);   /* S_HV applies the 2x itself */
 }
 
 /* hessian.jl:337-380, 580-592 */
@@ -847,6 +859,41 @@ void ora_hess(void *hh, const double *x, const double *y, double sigma, double *
     hess_user u = {hess, y, sigma, m->theta};
     for (int k = 0; k < m->npat; k++) if (m->pat[k].kind == EXA_PAT_OBJ) drive(h, k, x, pt_hess, &u, 1);
     for (int k = 0; k < m->npat; k++) if (m->pat[k].kind != EXA_PAT_OBJ) drive(h, k, x, pt_hess, &u, 1);
+}
+
+/* jprod_nln! / jtprod_nln! (nlp.jl:1882-1904) and hprod! (nlp.jl:1942-1978): sequential, shared targets */
+typedef struct { double *out; const double *v; const double *y; double sigma; const double *theta; int mode; } prod_user;
+static void pt_jprod(const pattern *p, adnode *t, const ctx *c, void *user) {
+    prod_user *u = (prod_user *)user;
+    fwd(t, c, 1);
+    sink s; memset(&s, 0, sizeof s); s.mode = u->mode; s.py = u->out; s.pv = u->v; s.row = row_of(p, c->I, u->theta) + 1;
+    grpass(t, &s, 1.0);
+}
+void ora_jprod(void *hh, const double *x, const double *v, double *Jv) {
+    ora_handle *h = (ora_handle *)hh; ora_model *m = &h->m;
+    for (int64_t i = 0; i < m->ncon; i++) Jv[i] = 0.0;
+    prod_user u = {Jv, v, NULL, 0.0, m->theta, S_JV};
+    for (int k = 0; k < m->npat; k++) if (m->pat[k].kind != EXA_PAT_OBJ) drive(h, k, x, pt_jprod, &u, 0);
+}
+void ora_jtprod(void *hh, const double *x, const double *v, double *Jtv) {
+    ora_handle *h = (ora_handle *)hh; ora_model *m = &h->m;
+    for (int64_t i = 0; i < m->nvar; i++) Jtv[i] = 0.0;
+    prod_user u = {Jtv, v, NULL, 0.0, m->theta, S_JTV};
+    for (int k = 0; k < m->npat; k++) if (m->pat[k].kind != EXA_PAT_OBJ) drive(h, k, x, pt_jprod, &u, 0);
+}
+static void pt_hprod(const pattern *p, adnode *t, const ctx *c, void *user) {
+    prod_user *u = (prod_user *)user;
+    fwd(t, c, 2);
+    sink s; memset(&s, 0, sizeof s); s.mode = S_HV; s.py = u->out; s.pv = u->v;
+    double adj = (p->kind == EXA_PAT_OBJ) ? u->sigma : u->y[row_of(p, c->I, u->theta)];
+    hrpass0(t, &s, adj, 0.0);
+}
+void ora_hprod(void *hh, const double *x, const double *y, const double *v, double sigma, double *Hv) {
+    ora_handle *h = (ora_handle *)hh; ora_model *m = &h->m;
+    for (int64_t i = 0; i < m->nvar; i++) Hv[i] = 0.0;
+    prod_user u = {Hv, v, y, sigma, m->theta, S_HV};
+    for (int k = 0; k < m->npat; k++) if (m->pat[k].kind == EXA_PAT_OBJ) drive(h, k, x, pt_hprod, &u, 0);
+    for (int k = 0; k < m->npat; k++) if (m->pat[k].kind != EXA_PAT_OBJ) drive(h, k, x, pt_hprod, &u, 0);
 }
 
 /* structures (nlp.jl:1798-1825) */

@@ -47,6 +47,9 @@ def lib():
         L.ora_sgrad.argtypes = [vp, vp, vp]
         L.ora_jac.argtypes = [vp, vp, vp]
         L.ora_hess.argtypes = [vp, vp, vp, dbl, vp]
+        L.ora_jprod.argtypes = [vp, vp, vp, vp]
+        L.ora_jtprod.argtypes = [vp, vp, vp, vp]
+        L.ora_hprod.argtypes = [vp, vp, vp, vp, dbl, vp]
         L.ora_jac_structure.argtypes = [vp, vp, vp]
         L.ora_hess_structure.argtypes = [vp, vp, vp]
         L.ora_lv_hess_compiled.argtypes = [i64, vp, vp, dbl, vp, ctypes.c_int]
@@ -148,6 +151,24 @@ class OracleModel:
         v = np.empty(self.nnzh) if out is None else out
         self._L.ora_hess(self._h, _p(x), _p(y), float(obj_weight), _p(v))
         return v
+
+    def jprod(self, x, v):
+        x, v = _f64(x), _f64(v)
+        out = np.empty(self.ncon)
+        self._L.ora_jprod(self._h, _p(x), _p(v), _p(out))
+        return out
+
+    def jtprod(self, x, v):
+        x, v = _f64(x), _f64(v)
+        out = np.empty(self.nvar)
+        self._L.ora_jtprod(self._h, _p(x), _p(v), _p(out))
+        return out
+
+    def hprod(self, x, y, v, obj_weight=1.0):
+        x, y, v = _f64(x), _f64(y), _f64(v)
+        out = np.empty(self.nvar)
+        self._L.ora_hprod(self._h, _p(x), _p(y), _p(v), float(obj_weight), _p(out))
+        return out
 
     def jac_structure(self):
         r, c = np.zeros(self.nnzj, dtype=np.int64), np.zeros(self.nnzj, dtype=np.int64)
