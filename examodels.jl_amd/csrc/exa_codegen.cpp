@@ -604,7 +604,7 @@ const char *kPrelude = R"HIP(// Generated by libexahip (examodels.jl_amd/csrc/ex
 #define EXA_PI 3.14159265358979323846
 #define EXA_D2R (EXA_PI / 180.0)
 #define EXA_R2D (180.0 / EXA_PI)
-#define EXA_BLOCK 256
+#define EXA_BLOCK @BLOCK@
 static __device__ __forceinline__ double exa_sq(double x) { return x * x; }
 static __device__ __forceinline__ double exa_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : x); }
 static __device__ __forceinline__ double exa_sind(double x) { return sin(EXA_D2R * fmod(x, 360.0)); }
@@ -694,7 +694,7 @@ bool use_tile(int S) { return S >= 2; }
 // points staged per pass: the largest of 64/32/16/8 whose tile (4 wavefronts) fits the budget
 int tile_pp(int S) {
     for (int pp = 64; pp > 8; pp >>= 1)
-        if (4 * S * (pp + 1) * 8 <= lds_budget()) return pp;
+        if ((kBlock / 64) * S * (pp + 1) * 8 <= lds_budget()) return pp;
     return 8;
 }
 // Leading dimension of the slot-major tile.  Writes (lane-consecutive) are conflict-free for any LD; the transposed
@@ -1102,7 +1102,7 @@ Generated generate_module(const Model &m) {
     L.nwords = w;
 
     std::ostringstream os;
-    os << kPrelude;
+    { std::string pre = kPrelude; const std::string tag = "@BLOCK@"; pre.replace(pre.find(tag), tag.size(), std::to_string(kBlock)); os << pre; }
     os << "// patterns=" << np << " (sizes, offsets and column pointers are run-time parameters in P[])\n";
     for (int k = 0; k < np; k++) {
         const Pattern &p = m.pats[k];

@@ -98,7 +98,9 @@ struct Generated {
     ParamLayout layout;
 };
 
-constexpr int kBlock = 256;   // threads per workgroup = 4 wavefronts of 64
+// threads per workgroup (multiple of the 64-lane wavefront); 256 = 4 wavefronts measured best, EXAHIP_BLOCK overrides
+int block_threads();
+#define kBlock (::exa::block_threads())
 
 Generated generate_module(const Model &m);
 

@@ -6,6 +6,7 @@
 // IR subtree statically (constant for AD <=> contains no VAR) and replays the traversal order symbolically.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <stdexcept>
@@ -14,6 +15,15 @@
 #include "exa_traverse.hpp"
 
 namespace exa {
+
+int block_threads() {
+    static const int b = [] {
+        const char *e = getenv("EXAHIP_BLOCK");
+        const int v = e && *e ? atoi(e) : 256;
+        return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 256;
+    }();
+    return b;
+}
 
 namespace {
 
