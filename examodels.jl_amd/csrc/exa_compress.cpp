@@ -1,0 +1,145 @@
+// exa_compress.cpp — duplicate-summing ("compressed") COO for the Jacobian and the Hessian.
+//
+// Replaces CompressedNLPModel (src/utils.jl:425-579) and its device helpers (ext/ExaModelsKernelAbstractions.jl:
+// 1290-1319): at set-up the (col,row) pairs of the partially compressed COO are sorted (stable LSD radix sort on the
+// device, rocPRIM — a plain library sort, not a hot kernel), runs of equal pairs become one entry, and every
+// evaluation is the ordinary fused kernel into an internal buffer followed by ONE gather
+//     V[k] = sum_{j in ptr[k] .. ptr[k+1]-1} buffer[perm[j]]            (utils.jl:555-562)
+// Order contract: entries are sorted by (col, row) — get_compressed_sparsity builds ((j, i), k) and sorts on the first
+// component (utils.jl:476-478, 519-520) — and duplicates are added in ascending original slot order (stable sort).
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_run_length_encode.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "exa_compress.hpp"
+
+namespace exa {
+
+namespace {
+
+#define HIPCHK_C(expr)                                                                                        \
+    do {                                                                                                      \
+        hipError_t _e = (expr);                                                                               \
+        if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e));     \
+    } while (0)
+
+__global__ void __launch_bounds__(256) k_make_keys(const int64_t *__restrict__ rows, const int64_t *__restrict__ cols, int64_t nrowdim,
+                                                   uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = (uint64_t)(cols[i] - 1) * (uint64_t)nrowdim + (uint64_t)(rows[i] - 1);   // column-major order
+    idx[i] = (uint32_t)i;
+}
+
+__global__ void __launch_bounds__(256) k_decode(const uint64_t *__restrict__ ukeys, int64_t nrowdim, int64_t *__restrict__ rows,
+                                                int64_t *__restrict__ cols, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    rows[i] = (int64_t)(ukeys[i] % (uint64_t)nrowdim) + 1;
+    cols[i] = (int64_t)(ukeys[i] / (uint64_t)nrowdim) + 1;
+}
+
+// one thread per compressed entry; duplicates of an entry are few (LV Hessian: <= 5) and their slots are close
+__global__ void __launch_bounds__(256) k_compress(double *__restrict__ V, const double *__restrict__ buf, const int64_t *__restrict__ ptr,
+                                                  const uint32_t *__restrict__ perm, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    double s = 0.0;
+    for (int64_t j = ptr[k]; j < ptr[k + 1]; j++) s += buf[perm[j]];
+    V[k] = s;
+}
+
+template <class T>
+__global__ void __launch_bounds__(256) k_narrow(const int64_t *__restrict__ src, T *__restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = (T)src[i];
+}
+
+struct Tmp {
+    void *p = nullptr;
+    explicit Tmp(size_t n) { if (hipMalloc(&p, n ? n : 8) != hipSuccess) throw std::runtime_error("hipMalloc failed in exa_compress"); }
+    ~Tmp() { if (p) (void)hipFree(p); }
+    Tmp(const Tmp &) = delete;
+    Tmp &operator=(const Tmp &) = delete;
+};
+
+unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+void CompressedCOO::release() {
+    for (void **q : {&perm, &ptr, &rows, &cols}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    cnnz = nnz = 0;
+}
+
+// rows/cols: device int64[nnz] (1-based).  nrowdim: number of rows of the matrix (ncon for J, nvar for H).
+void build_compressed(CompressedCOO &c, const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t nrowdim, int64_t ncoldim,
+                      hipStream_t stream) {
+    c.release();
+    c.nnz = nnz;
+    if (nnz == 0) return;
+    if (nnz > 0xffffffffLL) throw std::runtime_error("compressed COO supports up to 2^32-1 entries per matrix");
+    Tmp keys(8 * (size_t)nnz), keys2(8 * (size_t)nnz), idx(4 * (size_t)nnz), counts(8 * (size_t)nnz), nruns(8);
+    HIPCHK_C(hipMalloc(&c.perm, 4 * (size_t)nnz));
+    hipLaunchKernelGGL(k_make_keys, dim3(grid_for(nnz)), dim3(256), 0, stream, rows, cols, nrowdim, (uint64_t *)keys.p, (uint32_t *)idx.p, nnz);
+    unsigned bits = 1;
+    while (bits < 64 && ((unsigned __int128)1 << bits) < (unsigned __int128)nrowdim * (unsigned __int128)ncoldim) bits++;
+    size_t tb = 0;
+    HIPCHK_C(rocprim::radix_sort_pairs(nullptr, tb, (uint64_t *)keys.p, (uint64_t *)keys2.p, (uint32_t *)idx.p, (uint32_t *)c.perm,
+                                       (size_t)nnz, 0, bits, stream));
+    {
+        Tmp t(tb);
+        HIPCHK_C(rocprim::radix_sort_pairs(t.p, tb, (uint64_t *)keys.p, (uint64_t *)keys2.p, (uint32_t *)idx.p, (uint32_t *)c.perm,
+                                           (size_t)nnz, 0, bits, stream));
+    }
+    // runs of equal keys -> unique keys (reuse keys.p) + run lengths
+    tb = 0;
+    HIPCHK_C(rocprim::run_length_encode(nullptr, tb, (uint64_t *)keys2.p, (size_t)nnz, (uint64_t *)keys.p, (int64_t *)counts.p,
+                                        (uint64_t *)nruns.p, stream));
+    {
+        Tmp t(tb);
+        HIPCHK_C(rocprim::run_length_encode(t.p, tb, (uint64_t *)keys2.p, (size_t)nnz, (uint64_t *)keys.p, (int64_t *)counts.p,
+                                            (uint64_t *)nruns.p, stream));
+    }
+    uint64_t nr = 0;
+    HIPCHK_C(hipMemcpyAsync(&nr, nruns.p, 8, hipMemcpyDeviceToHost, stream));
+    HIPCHK_C(hipStreamSynchronize(stream));
+    c.cnnz = (int64_t)nr;
+    HIPCHK_C(hipMalloc(&c.ptr, 8 * (size_t)(c.cnnz + 1)));
+    HIPCHK_C(hipMalloc(&c.rows, 8 * (size_t)c.cnnz));
+    HIPCHK_C(hipMalloc(&c.cols, 8 * (size_t)c.cnnz));
+    // ptr = exclusive scan of the run lengths, plus the end sentinel
+    tb = 0;
+    const int64_t *in = (const int64_t *)counts.p;
+    HIPCHK_C(rocprim::exclusive_scan(nullptr, tb, in, (int64_t *)c.ptr, (int64_t)0, (size_t)c.cnnz, rocprim::plus<int64_t>(), stream));
+    {
+        Tmp t(tb);
+        HIPCHK_C(rocprim::exclusive_scan(t.p, tb, in, (int64_t *)c.ptr, (int64_t)0, (size_t)c.cnnz, rocprim::plus<int64_t>(), stream));
+    }
+    HIPCHK_C(hipMemcpyAsync((int64_t *)c.ptr + c.cnnz, &nnz, 8, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_decode, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, (const uint64_t *)keys.p, nrowdim, (int64_t *)c.rows,
+                       (int64_t *)c.cols, c.cnnz);
+    HIPCHK_C(hipStreamSynchronize(stream));
+}
+
+void compress_values(const CompressedCOO &c, const double *buf, double *V, hipStream_t stream) {
+    if (c.cnnz == 0) return;
+    hipLaunchKernelGGL(k_compress, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, V, buf, (const int64_t *)c.ptr, (const uint32_t *)c.perm,
+                       c.cnnz);
+}
+
+void compressed_structure(const CompressedCOO &c, void *rows, void *cols, bool wide, hipStream_t stream) {
+    if (c.cnnz == 0) return;
+    if (wide) {
+        HIPCHK_C(hipMemcpyAsync(rows, c.rows, 8 * (size_t)c.cnnz, hipMemcpyDeviceToDevice, stream));
+        HIPCHK_C(hipMemcpyAsync(cols, c.cols, 8 * (size_t)c.cnnz, hipMemcpyDeviceToDevice, stream));
+    } else {
+        hipLaunchKernelGGL(k_narrow<int32_t>, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, (const int64_t *)c.rows, (int32_t *)rows, c.cnnz);
+        hipLaunchKernelGGL(k_narrow<int32_t>, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, (const int64_t *)c.cols, (int32_t *)cols, c.cnnz);
+    }
+}
+
+}  // namespace exa

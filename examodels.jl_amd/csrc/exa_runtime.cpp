@@ -11,6 +11,7 @@
 #include <sys/types.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +20,7 @@
 #include <sstream>
 #include <stdexcept>
 
+#include "exa_compress.hpp"
 #include "exa_internal.hpp"
 
 using namespace exa;
@@ -65,6 +67,9 @@ struct Handle {
     std::vector<DevBuf> dcols;              // flattened over patterns
     std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
     DevBuf sx, sy, sv, sout, srows, scols;  // scratch of the *_host variants
+    CompressedCOO cj, ch;                   // duplicate-summed COO maps (exa_compress)
+    DevBuf cbuf;                            // uncompressed values of the last compressed evaluation
+    bool compressed = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     ~Handle() {
@@ -72,6 +77,7 @@ struct Handle {
             dP.release(); dtheta.release(); dpart.release(); dobj.release();
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release();
             for (auto &b : dmap) b.release();
+            cj.release(); ch.release(); cbuf.release();
             for (auto &b : dcols) b.release();
             sx.release(); sy.release(); sv.release(); sout.release(); srows.release(); scols.release();
             if (ev0) (void)hipEventDestroy(ev0);
@@ -378,6 +384,9 @@ int guard(int id, bool need_device, F &&f) {
     try {
         f(*h);
         return 0;
+    } catch (const BadInput &e) {
+        g_err = e.what();
+        return 1;
     } catch (const std::exception &e) {
         g_err = e.what();
         return 2;
@@ -656,6 +665,56 @@ int exa_jac_structure_host(int id, int32_t *r, int32_t *c) { return struct_host(
 int exa_hess_structure_host(int id, int32_t *r, int32_t *c) { return struct_host(id, true, false, r, c); }
 int exa_jac_structure64_host(int id, int64_t *r, int64_t *c) { return struct_host(id, false, true, r, c); }
 int exa_hess_structure64_host(int id, int64_t *r, int64_t *c) { return struct_host(id, true, true, r, c); }
+
+// ---- compressed COO (CompressedNLPModel, src/utils.jl:425-579) ---------------------------------------------
+int exa_compress(int id) {
+    return guard(id, true, [&](Handle &h) {
+        if (h.world != 1) throw std::runtime_error("exa_compress needs the unsharded model (every slot must be evaluated locally)");
+        const Model &m = *h.m;
+        const int64_t mx = std::max(m.nnzj, m.nnzh);
+        DevBuf r, c;
+        r.ensure(8 * (size_t)mx); c.ensure(8 * (size_t)mx);
+        try {
+            do_struct(h, false, true, r.p, c.p);
+            build_compressed(h.cj, (const int64_t *)r.p, (const int64_t *)c.p, m.nnzj, std::max<int64_t>(m.ncon, 1), std::max<int64_t>(m.nvar, 1), h.stream);
+            do_struct(h, true, true, r.p, c.p);
+            build_compressed(h.ch, (const int64_t *)r.p, (const int64_t *)c.p, m.nnzh, std::max<int64_t>(m.nvar, 1), std::max<int64_t>(m.nvar, 1), h.stream);
+        } catch (...) { r.release(); c.release(); throw; }
+        r.release(); c.release();
+        h.cbuf.ensure(8 * (size_t)mx);
+        h.compressed = true;
+    });
+}
+int64_t exa_cnnzj64(int id) { Handle *h = get(id); return h && h->compressed ? h->cj.cnnz : -1; }
+int64_t exa_cnnzh64(int id) { Handle *h = get(id); return h && h->compressed ? h->ch.cnnz : -1; }
+static int cstruct(int id, bool hess, bool wide, void *r, void *c) {
+    return guard(id, true, [&](Handle &h) {
+        if (!h.compressed) throw BadInput("exa_compress has not been called");
+        const CompressedCOO &cc = hess ? h.ch : h.cj;
+        if (!wide && cc.cnnz > 0x7fffffffLL) throw std::runtime_error("nnz exceeds int32");
+        compressed_structure(cc, r, c, wide, h.stream);
+    });
+}
+int exa_cjac_structure(int id, int32_t *r, int32_t *c) { return cstruct(id, false, false, r, c); }
+int exa_chess_structure(int id, int32_t *r, int32_t *c) { return cstruct(id, true, false, r, c); }
+int exa_cjac_structure64(int id, int64_t *r, int64_t *c) { return cstruct(id, false, true, r, c); }
+int exa_chess_structure64(int id, int64_t *r, int64_t *c) { return cstruct(id, true, true, r, c); }
+int exa_cjac(int id, const double *x, double *vals) {
+    if (!x) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if (!h.compressed) throw BadInput("exa_compress has not been called");
+        do_jac(h, x, (double *)h.cbuf.p);
+        compress_values(h.cj, (const double *)h.cbuf.p, vals, h.stream);
+    });
+}
+int exa_chess(int id, const double *x, const double *y, double w, double *vals) {
+    if (!x) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if (!h.compressed) throw BadInput("exa_compress has not been called");
+        do_hess(h, x, y, w, (double *)h.cbuf.p);
+        compress_values(h.ch, (const double *)h.cbuf.p, vals, h.stream);
+    });
+}
 
 // ---- measurement ------------------------------------------------------------------------------------------
 int exa_time_callback(int id, int which, int reps, const double *x, const double *y, double w, double *out, float *ms_out) {

@@ -22,6 +22,8 @@ SYMBOLS = [
     "exa_hess", "exa_jprod", "exa_jtprod", "exa_hprod", "exa_jprod_host", "exa_jtprod_host", "exa_hprod_host", "exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",
     "exa_obj_host", "exa_grad_host", "exa_cons_host", "exa_jac_host", "exa_hess_host", "exa_jac_structure_host",
     "exa_hess_structure_host", "exa_jac_structure64_host", "exa_hess_structure64_host", "exa_time_callback", "exa_sync",
+    "exa_compress", "exa_cnnzj64", "exa_cnnzh64", "exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64",
+    "exa_chess_structure64", "exa_cjac", "exa_chess",
 ]
 
 
@@ -87,6 +89,13 @@ def lib():
         getattr(L, f).argtypes = [i32, vp, vp]
     L.exa_time_callback.argtypes = [i32, i32, i32, vp, vp, dbl, vp, vp]
     L.exa_sync.argtypes = [i32]
+    L.exa_compress.argtypes = [i32]
+    for f in ("exa_cnnzj64", "exa_cnnzh64"):
+        getattr(L, f).argtypes = [i32]
+        getattr(L, f).restype = i64
+    for f in ("exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64", "exa_chess_structure64", "exa_cjac"):
+        getattr(L, f).argtypes = [i32, vp, vp]
+    L.exa_chess.argtypes = [i32, vp, vp, dbl, vp]
     _LIB = L
     return L
 

@@ -229,3 +229,54 @@ class ExaModel:
                                              out.data_ptr() if out is not None else None, ctypes.addressof(ms)),
                    "exa_time_callback")
         return ms.value
+
+
+class CompressedExaModel:
+    """CompressedNLPModel(m) (src/utils.jl:425-579): same model, Jacobian/Hessian COO with duplicate (row, col) entries
+    summed.  Device tensors only (the point is to hand a solver a smaller KKT assembly on the GPU)."""
+
+    def __init__(self, m: ExaModel):
+        self.inner = m
+        self._L = m._L
+        capi.check(self._L.exa_compress(m.id), "exa_compress")
+        self.meta = SimpleNamespace(**vars(m.meta))
+        self.meta.nnzj = self._L.exa_cnnzj64(m.id)
+        self.meta.nnzh = self._L.exa_cnnzh64(m.id)
+
+    def obj(self, x):
+        return self.inner.obj(x)
+
+    def grad(self, x, out=None):
+        return self.inner.grad(x, out=out)
+
+    def cons(self, x, out=None):
+        return self.inner.cons(x, out=out)
+
+    def _structure(self, which, nnz, device):
+        import torch
+        rows = torch.empty(nnz, dtype=torch.int64, device=device)
+        cols = torch.empty(nnz, dtype=torch.int64, device=device)
+        capi.check(getattr(self._L, f"exa_c{which}_structure64")(self.inner.id, rows.data_ptr(), cols.data_ptr()), which)
+        return rows, cols
+
+    def jac_structure(self, device="cuda:0"):
+        return self._structure("jac", self.meta.nnzj, device)
+
+    def hess_structure(self, device="cuda:0"):
+        return self._structure("hess", self.meta.nnzh, device)
+
+    def jac_coord(self, x, out=None):
+        import torch
+        self.inner._use_torch_stream(x)
+        if out is None:
+            out = torch.empty(self.meta.nnzj, dtype=torch.float64, device=x.device)
+        capi.check(self._L.exa_cjac(self.inner.id, x.data_ptr(), out.data_ptr()), "exa_cjac")
+        return out
+
+    def hess_coord(self, x, y, obj_weight=1.0, out=None):
+        import torch
+        self.inner._use_torch_stream(x)
+        if out is None:
+            out = torch.empty(self.meta.nnzh, dtype=torch.float64, device=x.device)
+        capi.check(self._L.exa_chess(self.inner.id, x.data_ptr(), y.data_ptr(), float(obj_weight), out.data_ptr()), "exa_chess")
+        return out

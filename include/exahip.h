@@ -122,6 +122,19 @@ int exa_hess_structure_host (int id, int32_t *rows, int32_t *cols);
 int exa_jac_structure64_host (int id, int64_t *rows, int64_t *cols);
 int exa_hess_structure64_host(int id, int64_t *rows, int64_t *cols);
 
+/* ---- compressed COO: duplicate (row,col) entries summed (CompressedNLPModel, src/utils.jl:425-579; KA ext :1290-1319) --- */
+/* One-off set-up on the device: sorts the (col,row) pairs of both structures (stable), builds ptr/perm.  Entries come
+ * out sorted by (col, row); duplicates are added in ascending original slot order (utils.jl:476-478, 555-562). */
+int     exa_compress(int id);
+int64_t exa_cnnzj64(int id);                  /* number of distinct Jacobian entries, -1 before exa_compress */
+int64_t exa_cnnzh64(int id);
+int exa_cjac_structure   (int id, int32_t *rows, int32_t *cols);              /* DEVICE pointers */
+int exa_chess_structure  (int id, int32_t *rows, int32_t *cols);
+int exa_cjac_structure64 (int id, int64_t *rows, int64_t *cols);
+int exa_chess_structure64(int id, int64_t *rows, int64_t *cols);
+int exa_cjac (int id, const double *x, double *vals);                          /* vals [cnnzj], DEVICE pointers */
+int exa_chess(int id, const double *x, const double *y, double obj_weight, double *vals);
+
 /* ---- measurement hooks --------------------------------------------------------------------------- */
 /* Runs the named callback `reps` times on the model's stream bracketed by hipEvents recorded on THAT
  * stream and returns the average milliseconds per call in *ms_out.  which: 0 obj,1 grad,2 cons,3 jac,4 hess.

@@ -1,0 +1,69 @@
+"""-m gpu: compressed (duplicate-summed) COO — the CompressedNLPModel wrapper of the reference (src/utils.jl:425-579;
+test/UtilsTest/UtilsTest.jl uses it end to end).  Properties checked: no duplicate coordinates, (col,row)-sorted,
+same matrix as the partially compressed COO, duplicates added in original slot order (bit-exact vs numpy's ordered
+accumulation)."""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from zoo import ZOO, point
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def reference_compress(rows, cols, vals, nrowdim):
+    """utils.jl:476-478, 519-562 restated with numpy: stable sort on (col,row), runs summed in slot order."""
+    key = (cols - 1) * nrowdim + (rows - 1)
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    starts = np.concatenate([[0], np.nonzero(ks[1:] != ks[:-1])[0] + 1, [len(ks)]]) if len(ks) else np.array([0])
+    out_r, out_c, out_v = [], [], []
+    for a, b in zip(starts[:-1], starts[1:]):
+        s = 0.0
+        for j in order[a:b]:
+            s += vals[j]
+        out_v.append(s)
+        out_r.append(rows[order[a]])
+        out_c.append(cols[order[a]])
+    return np.array(out_r), np.array(out_c), np.array(out_v)
+
+
+@pytest.mark.parametrize("name", ["lv20", "lv_split_20x2", "acopf30", "mixed", "conaug2d", "rocket50"])
+def test_compressed_equals_reference_compression(libs, name):
+    import torch
+    from exahip import CompressedExaModel, ExaModel
+    m = ExaModel(ZOO[name]())
+    cm = CompressedExaModel(m)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=12)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    for which, nrowdim in (("jac", max(m.meta.ncon, 1)), ("hess", max(m.meta.nvar, 1))):
+        if which == "jac":
+            r, c = m.jac_structure()
+            v = m.jac_coord(x)
+            cr, cc = cm.jac_structure()
+            cv = cm.jac_coord(xd)
+        else:
+            r, c = m.hess_structure()
+            v = m.hess_coord(x, y, sigma)
+            cr, cc = cm.hess_structure()
+            cv = cm.hess_coord(xd, yd, sigma)
+        torch.cuda.synchronize()
+        cr, cc, cv = cr.cpu().numpy(), cc.cpu().numpy(), cv.cpu().numpy()
+        er, ec, ev = reference_compress(r, c, v, nrowdim)
+        assert np.array_equal(cr, er) and np.array_equal(cc, ec)
+        assert len(set(zip(cr.tolist(), cc.tolist()))) == len(cr), "duplicates left"
+        np.testing.assert_array_equal(cv, ev)     # same additions in the same order -> bit-exact
+    assert cm.meta.nnzh <= m.meta.nnzh and cm.meta.nnzj <= m.meta.nnzj
+
+
+def test_compressed_lv_counts(libs):
+    """LV(N): the 9N-15 partially compressed Hessian slots collapse onto the 2N-1 entries of a symmetric tridiagonal
+    lower triangle plus the (i+2,i+1)... pattern: distinct pairs are (i,i) N, (i+1,i) N-1 -> 2N-1."""
+    from exahip import CompressedExaModel, ExaModel, models
+    N = 1000
+    m = ExaModel(models.luksan_vlcek_model(N))
+    cm = CompressedExaModel(m)
+    assert m.meta.nnzh == 9 * N - 15
+    assert cm.meta.nnzh == 2 * N - 1
+    assert cm.meta.nnzj == m.meta.nnzj == 3 * (N - 2)      # the LV Jacobian has no duplicates
