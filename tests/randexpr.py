@@ -1,0 +1,102 @@
+"""Deterministic random expression patterns over the reference's function tables (src/functionlist.jl:6-81) — a
+property-style parity generator: every tree is built with the exahip front-end exactly as a user would write it
+(operators, literal Int/Float constants, parameters, data fields, symbolic variable indices with offsets)."""
+import numpy as np
+
+from exahip import ExaCore, Table, graph, rng
+
+UN_SAFE = ["sin", "cos", "tanh", "atan", "asinh", "abs2", "exp", "sqrt", "log", "inv", "cbrt", "sinh", "cosh", "tan",
+           "log1p", "expm1", "sech", "atand", "sind", "cospi", "exp2", "abs", "-", "+"]
+BIN = ["+", "-", "*", "/", "^i", "^f", "atan2", "hypot", "max", "min", "^v"]
+NVAR, NPTS = 40, 7
+
+
+class Gen:
+    def __init__(self, seed):
+        self.r = np.random.default_rng(seed)
+
+    def leaf(self, x, th, d):
+        k = self.r.integers(0, 10)
+        if k < 5:
+            return x[d.i + int(self.r.integers(0, 4))]           # symbolic index with a literal offset
+        if k == 5:
+            return x[int(self.r.integers(1, NVAR + 1))]          # constant index
+        if k == 6:
+            return th[int(self.r.integers(1, 4))]
+        if k == 7:
+            return d.w                                            # Float data field
+        if k == 8:
+            return float(np.round(self.r.uniform(0.5, 2.0), 3))
+        return int(self.r.integers(1, 4))
+
+    def tree(self, x, th, d, depth):
+        if depth == 0 or self.r.uniform() < 0.15:
+            return self.leaf(x, th, d)
+        if self.r.uniform() < 0.45:
+            f = UN_SAFE[self.r.integers(0, len(UN_SAFE))]
+            a = self.tree(x, th, d, depth - 1)
+            if not isinstance(a, graph.Node):
+                a = a + x[d.i]
+            if f in ("sqrt", "log", "cbrt", "log1p", "inv"):
+                a = 1.5 + a * a                                   # keep the argument in the domain
+            if f in ("exp", "sinh", "cosh", "exp2", "expm1", "tan"):
+                a = 0.3 * graph.tanh(a)
+            if f == "-":
+                return -a
+            if f == "+":
+                return +a
+            if f == "abs":
+                return abs(a)
+            return getattr(graph, f)(a)
+        op = BIN[self.r.integers(0, len(BIN))]
+        a = self.tree(x, th, d, depth - 1)
+        b = self.tree(x, th, d, depth - 1)
+        if not isinstance(a, graph.Node) and not isinstance(b, graph.Node):
+            a = a * x[d.j]
+        if op == "+":
+            return a + b
+        if op == "-":
+            return a - b
+        if op == "*":
+            return a * b
+        if op == "/":
+            return a / (2.0 + b * b) if isinstance(b, graph.Node) else a / b
+        if op == "^i":
+            base = a if isinstance(a, graph.Node) else b
+            return base ** int(self.r.integers(-2, 6))
+        if op == "^f":
+            base = a if isinstance(a, graph.Node) else b
+            return (1.0 + base * base) ** float(np.round(self.r.uniform(-1.5, 2.5), 2))
+        if op == "^v":
+            base = a if isinstance(a, graph.Node) else b
+            ex = b if isinstance(a, graph.Node) else a
+            return (1.0 + base * base) ** (graph.tanh(ex) if isinstance(ex, graph.Node) else ex)
+        if op == "atan2":
+            return graph.atan(a, 1.5 + b * b if isinstance(b, graph.Node) else b)
+        if op == "hypot":
+            return graph.hypot(a, 1.0 + b)
+        if op == "max":
+            return graph.maximum(a, b)
+        return graph.minimum(a, b)
+
+
+def build_model(seed, npat=12, depth=4):
+    """One model with `npat` random objective/constraint/augmentation patterns over a small table iterator."""
+    g = Gen(seed)
+    c = ExaCore()
+    x = c.add_var(NVAR + 4, start=np.linspace(0.3, 1.1, NVAR + 4))
+    th = c.add_par(3, value=[0.7, 1.3, -0.4])
+    r = np.random.default_rng(seed + 1000)
+    tab = Table(i=r.integers(1, NVAR, NPTS), j=r.integers(1, NVAR, NPTS), w=r.uniform(0.5, 1.5, NPTS),
+                t=r.integers(1, NPTS + 1, NPTS))
+    base = None
+    for k in range(npat):
+        kind = k % 4
+        fn = (lambda d, s=int(g.r.integers(0, 2**31)): Gen(s).tree(x, th, d, depth))
+        if kind == 0:
+            c.add_obj(fn, tab)
+        elif kind in (1, 2) or base is None:
+            base = c.add_con(fn, tab)
+        else:
+            c.add_con_aug(base, lambda d, fn=fn: (d.t, fn(d)), tab)      # shared target rows
+    return c

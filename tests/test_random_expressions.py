@@ -1,0 +1,59 @@
+"""Property-style parity over random expression trees (tests/randexpr.py).
+
+CPU (-m "not gpu"): the product's planner agrees with the oracle's independent implementation on the COO layout of
+every random pattern.  GPU (-m gpu): all callbacks and products agree with the oracle to 1e-10."""
+import numpy as np
+import pytest
+
+import randexpr
+from conftest import has_gpu
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_patterns_layout(libs, seed):
+    from exahip import ExaModel
+    import oracle
+    m = ExaModel(randexpr.build_model(seed), device=False)
+    o = oracle.OracleModel(m.ir)
+    assert (m.meta.nnzj, m.meta.nnzh, m.meta.nnzg) == (o.nnzj, o.nnzh, o.nnzg)
+    for k in range(m.npatterns):
+        assert m.pattern_info(k) == o.pattern_info(k)
+        assert m.pattern_comp(k, 1) == o.pattern_comp(k, 1)
+        assert m.pattern_comp(k, 2) == o.pattern_comp(k, 2)
+
+
+def relerr(a, ref):
+    a, ref = np.asarray(a), np.asarray(ref)
+    if ref.size == 0:
+        return 0.0
+    scale = np.maximum(np.abs(ref), 1e-3 * max(1.0, np.max(np.abs(ref))))
+    return float(np.max(np.abs(a - ref) / scale))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+@pytest.mark.parametrize("seed", range(10))
+def test_random_patterns_values_on_hip(libs, seed):
+    from exahip import ExaModel
+    import oracle
+    m = ExaModel(randexpr.build_model(seed))
+    o = oracle.OracleModel(m.ir)
+    x = m.meta.x0 + 0.05 * np.random.default_rng(seed).uniform(-1, 1, m.meta.nvar)
+    y = np.random.default_rng(seed + 1).standard_normal(m.meta.ncon)
+    v = np.random.default_rng(seed + 2).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(seed + 3).standard_normal(m.meta.ncon)
+    tol = 1e-10
+    assert abs(m.obj(x) - o.obj(x)) <= tol * max(1.0, abs(o.obj(x)))
+    assert relerr(m.cons(x), o.cons(x)) <= tol
+    assert relerr(m.grad(x), o.grad(x)) <= tol
+    assert relerr(m.jac_coord(x), o.jac_coord(x)) <= tol
+    assert relerr(m.hess_coord(x, y, 0.7), o.hess_coord(x, y, 0.7)) <= tol
+    jr, jc = m.jac_structure()
+    orr, oc = o.jac_structure()
+    assert np.array_equal(jr, orr) and np.array_equal(jc, oc)
+    hr, hc = m.hess_structure()
+    orr, oc = o.hess_structure()
+    assert np.array_equal(hr, orr) and np.array_equal(hc, oc)
+    assert relerr(m.jprod(x, v), o.jprod(x, v)) <= tol
+    assert relerr(m.jtprod(x, w), o.jtprod(x, w)) <= tol
+    assert relerr(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)) <= tol
