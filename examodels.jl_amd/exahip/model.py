@@ -280,3 +280,41 @@ class CompressedExaModel:
             out = torch.empty(self.meta.nnzh, dtype=torch.float64, device=x.device)
         capi.check(self._L.exa_chess(self.inner.id, x.data_ptr(), y.data_ptr(), float(obj_weight), out.data_ptr()), "exa_chess")
         return out
+
+
+class TimedExaModel:
+    """TimedNLPModel(m) (src/utils.jl:271-408): counts the calls of every callback and the seconds spent in them.
+    Unlike the reference's wrapper (which does not synchronise the device) the model's stream is drained
+    before the clock is read, so the seconds are kernel-inclusive."""
+
+    _NAMES = ("obj", "cons", "grad", "jac_coord", "hess_coord", "jprod", "jtprod", "hprod", "jac_structure", "hess_structure")
+
+    def __init__(self, m):
+        self.inner = m
+        self.meta = m.meta
+        self.stats = {n: {"calls": 0, "seconds": 0.0} for n in self._NAMES}
+
+    def __getattr__(self, name):
+        if name in TimedExaModel._NAMES:
+            import time
+            fn = getattr(self.inner, name)
+
+            def timed(*a, **kw):
+                t0 = time.perf_counter()
+                out = fn(*a, **kw)
+                if hasattr(self.inner, "sync"):
+                    self.inner.sync()
+                s = self.stats[name]
+                s["calls"] += 1
+                s["seconds"] += time.perf_counter() - t0
+                return out
+
+            return timed
+        return getattr(self.inner, name)
+
+    def report(self):
+        lines = [f"{'callback':16s} {'calls':>8s} {'seconds':>12s}"]
+        for n, s in self.stats.items():
+            if s["calls"]:
+                lines.append(f"{n:16s} {s['calls']:8d} {s['seconds']:12.6f}")
+        return "\n".join(lines)

@@ -152,3 +152,18 @@ def test_sharded_outputs_tile_the_global_coo(built):
     assert relerr(g, o.grad(x)) <= RTOL
     assert relerr(c, o.cons(x)) <= RTOL
     assert abs(f - o.obj(x)) <= RTOL * max(1.0, abs(o.obj(x)))
+
+
+def test_timed_wrapper_counts_calls(built):
+    """TimedNLPModel analogue (src/utils.jl:271-408): per-callback call counts and seconds."""
+    from exahip import TimedExaModel
+    m, o = built["lv20"]
+    t = TimedExaModel(m)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon)
+    for _ in range(3):
+        t.obj(x)
+        t.hess_coord(x, y, sigma)
+    t.cons(x)
+    assert t.stats["obj"]["calls"] == 3 and t.stats["hess_coord"]["calls"] == 3 and t.stats["cons"]["calls"] == 1
+    assert t.stats["hess_coord"]["seconds"] > 0 and "hess_coord" in t.report()
+    assert relerr(t.hess_coord(x, y, sigma), o.hess_coord(x, y, sigma)) <= RTOL
