@@ -8,7 +8,7 @@ from __future__ import annotations
 import numpy as np
 
 from .core import ExaCore, Table, product, rng
-from .graph import cos, exp, sin
+from .graph import cos, exp, sin, sqrt
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -218,3 +218,48 @@ def acopf_start(core, seed=2):
     x = ir.x0.copy()
     u = r.uniform(-0.1, 0.1, size=x.size)
     return np.where(x == 0.0, u, x + 0.0 * u)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# COPS hanging chain / electrons on a sphere — the other two models of the reference's benchmark harness
+# ---------------------------------------------------------------------------------------------------------------
+def cops_chain_model(n):
+    """benchmark/runbenchmark.jl:239-264 (`cops_chain_model`)."""
+    nh = max(2, (n - 4) // 4)
+    L, a, b = 4, 1, 3
+    tmin = 1 / 4 if b > a else 3 / 4
+    tf = 1.0
+    h = tf / nh
+    k = np.arange(1, nh + 2)
+    c = ExaCore()
+    u = c.add_var(nh + 1, start=4 * abs(b - a) * (k / nh - tmin))
+    x1 = c.add_var(nh + 1, start=4 * abs(b - a) * k / nh * (1 / 2 * k / nh - tmin) + a)
+    x2 = c.add_var(nh + 1, start=(4 * abs(b - a) * k / nh * (1 / 2 * k / nh - tmin) + a) * (4 * abs(b - a) * (k / nh - tmin)))
+    x3 = c.add_var(nh + 1, start=4 * abs(b - a) * (k / nh - tmin))
+    c.add_obj(x2[nh + 1])
+    c.add_con(lambda j: x1[j + 1] - x1[j] - 1 / 2 * h * (u[j] + u[j + 1]), rng(1, nh))
+    c.add_con(x1[1] - a)
+    c.add_con(x1[nh + 1] - b)
+    c.add_con(x2[1])
+    c.add_con(x3[1])
+    c.add_con(x3[nh + 1] - L)
+    c.add_con(lambda j: x2[j + 1] - x2[j] - 1 / 2 * h * (x1[j] * sqrt(1 + u[j] ** 2) + x1[j + 1] * sqrt(1 + u[j + 1] ** 2)), rng(1, nh))
+    c.add_con(lambda j: x3[j + 1] - x3[j] - 1 / 2 * h * (sqrt(1 + u[j] ** 2) + sqrt(1 + u[j + 1] ** 2)), rng(1, nh))
+    return c
+
+
+def cops_elec_model(npts, seed=2713):
+    """benchmark/runbenchmark.jl:267-282 (`cops_elec_model`); the start point uses numpy's generator instead of
+    Julia's Random.seed!(2713) stream (values differ, the model does not)."""
+    r = np.random.default_rng(seed)
+    theta = 2 * np.pi * r.uniform(size=npts)
+    phi = np.pi * r.uniform(size=npts)
+    ii, jj = np.triu_indices(npts, k=1)
+    itr = Table(i=ii + 1, j=jj + 1)
+    core = ExaCore()
+    x = core.add_var(rng(1, npts), start=np.cos(theta) * np.sin(phi))
+    y = core.add_var(rng(1, npts), start=np.sin(theta) * np.sin(phi))
+    z = core.add_var(rng(1, npts), start=np.cos(phi))
+    core.add_obj(lambda p: 1 / sqrt((x[p.i] - x[p.j]) ** 2 + (y[p.i] - y[p.j]) ** 2 + (z[p.i] - z[p.j]) ** 2), itr)
+    core.add_con(lambda i: x[i] ** 2 + y[i] ** 2 + z[i] ** 2 - 1, rng(1, npts))
+    return core

@@ -175,6 +175,16 @@ function ExaModels.hess_coord!(m::HM, x::AbstractVector, y::AbstractVector, v::A
     chk(ccall((:exa_hess, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
               m.ext.id, pointer(x), pointer(y), Float64(obj_weight), pointer(v)), "exa_hess"); v
 end
+function ExaModels.jprod_nln!(m::HM, x::AbstractVector, v::AbstractVector, Jv::AbstractVector)
+    chk(ccall((:exa_jprod, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, pointer(x), pointer(v), pointer(Jv)), "exa_jprod"); Jv
+end
+function ExaModels.jtprod_nln!(m::HM, x::AbstractVector, v::AbstractVector, Jtv::AbstractVector)
+    chk(ccall((:exa_jtprod, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, pointer(x), pointer(v), pointer(Jtv)), "exa_jtprod"); Jtv
+end
+function ExaModels.hprod!(m::HM, x::AbstractVector, y::AbstractVector, v::AbstractVector, Hv::AbstractVector; obj_weight = one(eltype(x)))
+    chk(ccall((:exa_hprod, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
+              m.ext.id, pointer(x), pointer(y), pointer(v), Float64(obj_weight), pointer(Hv)), "exa_hprod"); Hv
+end
 function ExaModels.jac_structure!(m::HM, rows::AbstractVector, cols::AbstractVector)
     r, c = ROCArray{Int64}(undef, length(rows)), ROCArray{Int64}(undef, length(cols))
     chk(ccall((:exa_jac_structure64, LIB), Cint, (Cint, Ptr{Int64}, Ptr{Int64}), m.ext.id, pointer(r), pointer(c)), "exa_jac_structure64")

@@ -57,4 +57,6 @@ ZOO = {
     "acopf30": small_acopf,
     "mixed": mixed_model,
     "conaug2d": conaug2d_model,
+    "cops_chain": lambda: models.cops_chain_model(200),
+    "cops_elec": lambda: models.cops_elec_model(25),
 }
