@@ -735,10 +735,11 @@ void emit_coo_prologue(std::ostringstream &os, const Body &b, const ParamLayout 
         os << "    if (I0 >= hi) return;\n    const long I = I0;\n";
     }
 }
-void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, const std::vector<std::string> &vals, bool tile) {
+void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, const std::vector<std::string> &vals, bool tile,
+                     const std::string &out = "out", const std::string &tag = "") {
     if (tile) {
         const int pp = tile_pp(S), ld = tile_ld(S);
-        os << "    double* tile = lds + (threadIdx.x >> 6) * " << tile_doubles(S) << ";\n"
+        os << "    {\n    double* tile = lds + (threadIdx.x >> 6) * " << tile_doubles(S) << ";\n"
            << "    const long obase = " << b.P(word_o) << " + " << S << "L * (I0 - lane);\n    const long npts = hi - (I0 - lane);\n";
         for (int g = 0; g < 64 / pp; g++) {
             if (pp == 64) {
@@ -748,11 +749,13 @@ void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, c
                 for (int s = 0; s < S; s++) os << "        tile[" << s * ld << " + (lane % " << pp << ")] = " << vals[s] << ";\n";
                 os << "    }\n";
             }
-            os << "    exa_flush_points<" << S << ", " << pp << ", " << ld << ">(out, obase, npts, tile, lane, " << g << ");\n";
+            os << "    exa_flush_points<" << S << ", " << pp << ", " << ld << ">(" << out << ", obase, npts, tile, lane, " << g << ");\n";
         }
+        os << "    }\n";
     } else {
-        os << "    const long o = " << b.P(word_o) << " + " << S << "L * I;\n";
-        for (int s = 0; s < S; s++) os << "    out[o + " << s << "] = " << vals[s] << ";\n";
+        os << "    if (I0 < hi) {\n    const long o" << tag << " = " << b.P(word_o) << " + " << S << "L * I;\n";
+        for (int s = 0; s < S; s++) os << "    " << out << "[o" << tag << " + " << s << "] = " << vals[s] << ";\n";
+        os << "    }\n";
     }
 }
 
@@ -901,6 +904,46 @@ void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     for (int s = 0; s < p.o2step; s++) vals.push_back(b.e.sd(a.acc[s]));
     emit_coo_stores(os, b, L.pat[pi].o2, p.o2step, vals, tile);
     os << "}\n";
+}
+
+// ---- fused sweep: value + Jacobian slots + Hessian slots from ONE second-order forward sweep --------
+// A solver iteration asks for cons!, jac_coord! and hess_coord! at the same x; the second-order forward sweep already
+// holds the value and the first partials (graph.jl:416-447), so one kernel emits c, J and H (and the objective
+// partial sums) and the transcendental work is done once instead of three times.
+void gen_fused_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
+    Body b(m, pi, L);
+    const Pattern &p = b.p;
+    b.forward(p.ad_root, 2, false);
+    Val value = b.e.tod(b.fv[p.ad_root].x);
+    if (p.ad[p.ad_root].kind == AD_CONST) value = b.e.tod(b.cval(p.root));
+    const bool isobj = p.kind == EXA_PAT_OBJ;
+    GenAlg a1(b, p.comp1, p.o1step);
+    if (!isobj && p.o1step > 0) grpass(p, p.ad_root, a1, Emitter::litf(1.0));
+    Val adj;
+    if (isobj) adj = b.e.raw("sigma", false);
+    else adj = b.e.raw("y[" + b.row0() + "]", false);
+    GenAlg a2(b, p.comp2, p.o2step);
+    if (p.o2step > 0) hrpass0(p, p.ad_root, a2, adj, Emitter::litf(0.0));
+    const std::string rowtxt = isobj ? "" : (p.kind == EXA_PAT_CONAUG ? b.P(L.pat[pi].oa) + " + I" : b.P(L.pat[pi].o0) + " + I");
+    os << "static __device__ __forceinline__ double " << fn_name(pi, "fused")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
+          "double* __restrict__ cout, double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma, "
+          "long tid, double* lds) {\n";
+    os << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n"
+       << "    const int lane = threadIdx.x & 63;\n    if (I0 - lane >= hi) return 0.0;\n    const long I = I0 < hi ? I0 : hi - 1;\n";
+    emit_lines(os, b.e);
+    if (!isobj) os << "    if (I0 < hi) " << (p.kind == EXA_PAT_CONAUG ? "augout" : "cout") << "[" << rowtxt << "] = " << b.e.sd(value) << ";\n";
+    if (!isobj && p.o1step > 0) {
+        std::vector<std::string> vals;
+        for (int s = 0; s < p.o1step; s++) vals.push_back(b.e.sd(a1.acc[s]));
+        emit_coo_stores(os, b, L.pat[pi].o1, p.o1step, vals, use_tile(p.o1step), "jout", "j");
+    }
+    if (p.o2step > 0) {
+        std::vector<std::string> vals;
+        for (int s = 0; s < p.o2step; s++) vals.push_back(b.e.sd(a2.acc[s]));
+        emit_coo_stores(os, b, L.pat[pi].o2, p.o2step, vals, use_tile(p.o2step), "hout", "h");
+    }
+    os << "    return " << (isobj ? "(I0 < hi ? " + b.e.sd(value) + " : 0.0)" : std::string("0.0")) << ";\n}\n";
 }
 
 // ---- matrix-free products: same sweeps, different leaf actions ---------------------------------
@@ -1091,6 +1134,7 @@ Generated generate_module(const Model &m) {
             if (p.o1step > 0) { L.active[CB_JAC].push_back(k); L.active[CB_JSTRUCT].push_back(k); }
         }
         if (p.o2step > 0) { L.active[CB_HESS].push_back(k); L.active[CB_HSTRUCT].push_back(k); L.active[CB_HPROD].push_back(k); }
+        L.active[CB_FUSED].push_back(k);
     }
     for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w++; L.ppt[cb] = 1; }
     // streaming value kernels keep more loads in flight per wavefront with several points per thread (measured)
@@ -1119,6 +1163,7 @@ Generated generate_module(const Model &m) {
             if (p.o1step > 0) { gen_first_fn(os, m, k, L, false); gen_struct_fn(os, m, k, L, false); gen_jtprod_fn(os, m, k, L); }
         }
         if (p.o2step > 0) { gen_hess_fn(os, m, k, L); gen_struct_fn(os, m, k, L, true); gen_hprod_fn(os, m, k, L); }
+        gen_fused_fn(os, m, k, L);
     }
     // obj: per-workgroup partial sums
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_obj(const long* __restrict__ P, const double* __restrict__ x, "
@@ -1170,6 +1215,28 @@ Generated generate_module(const Model &m) {
     lds_decl(CB_HESS, true);
     gen_dispatch(os, L, CB_HESS, "hess", "P, x, y, th, out, sigma", ", lds");
     os << "}\n";
+    // fused cons + jac + hess (+ objective partial sums)
+    {
+        int mx = 0;
+        for (int k : L.active[CB_FUSED]) {
+            const Pattern &p = m.pats[k];
+            if (p.kind != EXA_PAT_OBJ && use_tile(p.o1step)) mx = std::max(mx, tile_doubles(p.o1step));
+            if (use_tile(p.o2step)) mx = std::max(mx, tile_doubles(p.o2step));
+        }
+        os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_fused(const long* __restrict__ P, const double* __restrict__ x, "
+              "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ part, double* __restrict__ cout, "
+              "double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma) {\n";
+        if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all;\n";
+        else os << "    double* lds = nullptr;\n";
+        os << "    const long b = blockIdx.x;\n    double v = 0.0;\n"
+           << "    const long e_ = ((const long*)P[" << L.blk[CB_FUSED] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
+              "    const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
+        const auto &act = L.active[CB_FUSED];
+        for (size_t k = 0; k < act.size(); k++)
+            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") v = p" << act[k]
+               << "_fused(P, x, y, th, cout, augout, jout, hout, sigma, tid0, lds);\n";
+        os << "    const double s = exa_block_sum(v);\n    if (threadIdx.x == 0) part[b] = s;\n}\n";
+    }
     const char *prod_sig = "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, "
                            "const double* __restrict__ v, double* __restrict__ out) {\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jprod" << prod_sig;

@@ -163,6 +163,20 @@ class ExaModel:
     def hess_coord(self, x, y, obj_weight=1.0, out=None):
         return self._call("hess", x, self.meta.nnzh, out, extra=(y, obj_weight))
 
+    def eval_fused(self, x, y, obj_weight=1.0, c=None, jac=None, hess=None):
+        """obj + cons + jac_coord + hess_coord at one x in ONE sweep (exa_eval_fused).  Device tensors only.
+        Returns (obj as a 1-element device tensor, c, jac, hess)."""
+        import torch
+        self._use_torch_stream(x)
+        dev = x.device
+        f = torch.empty(1, dtype=torch.float64, device=dev)
+        c = torch.empty(self.meta.ncon, dtype=torch.float64, device=dev) if c is None else c
+        jac = torch.empty(self.meta.nnzj, dtype=torch.float64, device=dev) if jac is None else jac
+        hess = torch.empty(self.meta.nnzh, dtype=torch.float64, device=dev) if hess is None else hess
+        capi.check(self._L.exa_eval_fused(self.id, x.data_ptr(), y.data_ptr(), float(obj_weight), f.data_ptr(), c.data_ptr(),
+                                          jac.data_ptr(), hess.data_ptr()), "exa_eval_fused")
+        return f, c, jac, hess
+
     # ---- matrix-free products: jprod_nln! / jtprod_nln! / hprod! (nlp.jl:1882-1978) -----------------------------
     def _prod(self, name, x, v, nv, n_out, out, y=None, w=1.0):
         if _is_torch(x):

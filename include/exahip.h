@@ -122,6 +122,12 @@ int exa_hess_structure_host (int id, int32_t *rows, int32_t *cols);
 int exa_jac_structure64_host (int id, int64_t *rows, int64_t *cols);
 int exa_hess_structure64_host(int id, int64_t *rows, int64_t *cols);
 
+/* ---- fused sweep (new) ---------------------------------------------------------------------------- */
+/* obj, cons_nln!, jac_coord! and hess_coord! at one x from ONE second-order forward sweep (value and first partials
+ * are by-products of it, src/graph.jl:416-447): one launch instead of four, transcendental work done once.
+ * All DEVICE pointers; *obj_dev receives the objective value on the device (no synchronisation). */
+int exa_eval_fused(int id, const double *x, const double *y, double obj_weight, double *obj_dev, double *c, double *jvals, double *hvals);
+
 /* ---- compressed COO: duplicate (row,col) entries summed (CompressedNLPModel, src/utils.jl:425-579; KA ext :1290-1319) --- */
 /* One-off set-up on the device: sorts the (col,row) pairs of both structures (stable), builds ptr/perm.  Entries come
  * out sorted by (col, row); duplicates are added in ascending original slot order (utils.jl:476-478, 555-562). */

@@ -68,3 +68,28 @@ def test_products_device_pointers_and_sharding(libs):
     assert relerr(jv, o.jprod(x, v)) <= RTOL
     assert relerr(jtv, o.jtprod(x, w)) <= RTOL
     assert relerr(hv, o.hprod(x, y, v, sigma)) <= RTOL
+
+
+@pytest.mark.parametrize("name", list(ZOO))
+def test_fused_sweep_equals_separate_callbacks(libs, name):
+    """exa_eval_fused (SURVEY §8f.1): obj, cons, jac_coord, hess_coord from one sweep == the oracle's separate results;
+    outputs are poisoned first (fully overwritten)."""
+    import torch
+    from exahip import ExaModel
+    import oracle
+    m = ExaModel(ZOO[name]())
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=21)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    nan = float("nan")
+    c = torch.full((m.meta.ncon,), nan, dtype=torch.float64, device=dev)
+    j = torch.full((m.meta.nnzj,), nan, dtype=torch.float64, device=dev)
+    h = torch.full((m.meta.nnzh,), nan, dtype=torch.float64, device=dev)
+    f, c, j, h = m.eval_fused(xd, yd, sigma, c=c, jac=j, hess=h)
+    torch.cuda.synchronize()
+    fo = o.obj(x)
+    assert abs(f.item() - fo) <= RTOL * max(1.0, abs(fo))
+    assert relerr(c.cpu().numpy(), o.cons(x)) <= RTOL
+    assert relerr(j.cpu().numpy(), o.jac_coord(x)) <= RTOL
+    assert relerr(h.cpu().numpy(), o.hess_coord(x, y, sigma)) <= RTOL
