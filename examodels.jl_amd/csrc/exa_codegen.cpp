@@ -653,6 +653,13 @@ static __device__ __forceinline__ void exa_flush_points(double* __restrict__ out
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
+// Scatter to a target that is THE SAME for every data point of the pattern (a literal variable index, e.g. the shared
+// step length dt[1] of the rocket model): the wavefront adds its 64 contributions with DPP/shuffle butterflies and issues
+// ONE atomic — 64x fewer same-address FP64 atomics, which otherwise serialise at the memory side.
+static __device__ __forceinline__ void exa_wave_atomic_add(double* p, double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(p, v);
+}
 // sum over the 256-thread workgroup: 64-lane wavefront butterflies, then 4 partials through LDS
 static __device__ __forceinline__ double exa_block_sum(double v) {
     __shared__ double red[EXA_BLOCK / 64];
@@ -759,6 +766,24 @@ void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, c
     }
 }
 
+// text of one scattered `out[idx-1] += val`; a literal index is wave-reduced first (all lanes must reach it)
+std::string scatter_text(Body &b, Val vi, Val val, bool &needs_full_wave) {
+    const std::string idx = b.e.s(b.e.sub(vi, Emitter::liti(1)));
+    if (vi.is_lit() && env_int("EXAHIP_WAVE_REDUCE", 1)) {
+        needs_full_wave = true;
+        return "exa_wave_atomic_add(&out[" + idx + "], act ? " + b.e.sd(val) + " : 0.0);";
+    }
+    return "if (act) unsafeAtomicAdd(&out[" + idx + "], " + b.e.sd(val) + ");";
+}
+// prologue of a scattering pattern function (grad / jtprod / hprod)
+void emit_scatter_prologue(std::ostringstream &os, const Body &b, const ParamLayout &L, int pi, bool full_wave) {
+    os << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n";
+    if (full_wave)
+        os << "    if (I0 - (threadIdx.x & 63) >= hi) return;\n    const bool act = I0 < hi;\n    const long I = act ? I0 : hi - 1;\n";
+    else
+        os << "    if (I0 >= hi) return;\n    const bool act = true;\n    const long I = I0;\n";
+}
+
 std::string fn_name(int pi, const char *cb) { return "p" + std::to_string(pi) + "_" + cb; }
 
 // ---- per-pattern device functions -----------------------------------------------------------------
@@ -790,19 +815,20 @@ void gen_first_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     GenAlg a(b, p.comp1, p.o1step);
     grpass(p, p.ad_root, a, Emitter::litf(1.0));
     const bool tile = !grad && use_tile(p.o1step);
-    os << "static __device__ __forceinline__ void " << fn_name(pi, grad ? "grad" : "jac")
-       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ out, long tid"
-       << (grad ? "" : ", double* lds") << ") {\n";
-    emit_coo_prologue(os, b, L, pi, tile);
     // index texts are computed first so that they land in e.lines
     std::vector<std::string> stores, vals;
+    bool full_wave = false;
     for (int s = 0; s < p.o1step; s++) {
         if (grad) {
             if (a.acc[s].lit_eq(0)) continue;
-            Val vi = b.fv[p.slotvar1[s]].vidx;
-            stores.push_back("unsafeAtomicAdd(&out[" + b.e.s(b.e.sub(vi, Emitter::liti(1))) + "], " + b.e.sd(a.acc[s]) + ");");
+            stores.push_back(scatter_text(b, b.fv[p.slotvar1[s]].vidx, a.acc[s], full_wave));
         } else vals.push_back(b.e.sd(a.acc[s]));
     }
+    os << "static __device__ __forceinline__ void " << fn_name(pi, grad ? "grad" : "jac")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ out, long tid"
+       << (grad ? "" : ", double* lds") << ") {\n";
+    if (grad) emit_scatter_prologue(os, b, L, pi, full_wave);
+    else emit_coo_prologue(os, b, L, pi, tile);
     emit_lines(os, b.e);
     if (grad) { for (auto &s : stores) os << "    " << s << "\n"; }
     else emit_coo_stores(os, b, L.pat[pi].o1, p.o1step, vals, tile);
@@ -981,16 +1007,16 @@ void gen_jtprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLa
     grpass(p, p.ad_root, a, Emitter::litf(1.0));
     Val w = b.e.raw("v[" + b.row0() + "]", false);
     std::vector<std::string> stores;
+    bool full_wave = false;
     for (int s = 0; s < p.o1step; s++) {
-        Val vi = b.fv[p.slotvar1[s]].vidx;
         Val t = b.e.mul(a.acc[s], w);
         if (t.lit_eq(0)) continue;
-        stores.push_back("unsafeAtomicAdd(&out[" + b.e.s(b.e.sub(vi, Emitter::liti(1))) + "], " + b.e.sd(t) + ");");
+        stores.push_back(scatter_text(b, b.fv[p.slotvar1[s]].vidx, t, full_wave));
     }
     os << "static __device__ __forceinline__ void " << fn_name(pi, "jtprod")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, const double* __restrict__ v, "
-          "double* __restrict__ out, long tid) {\n"
-       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
+          "double* __restrict__ out, long tid) {\n";
+    emit_scatter_prologue(os, b, L, pi, full_wave);
     emit_lines(os, b.e);
     for (auto &st : stores) os << "    " << st << "\n";
     os << "}\n";
@@ -1038,15 +1064,15 @@ void gen_hprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
         }
     }
     std::vector<std::string> stores;
+    bool full_wave = false;
     for (int k = 0; k < nk; k++) {
         if (!used[k] || hv[k].lit_eq(0)) continue;
-        Val vi = b.fv[rep[k]].vidx;
-        stores.push_back("unsafeAtomicAdd(&out[" + b.e.s(b.e.sub(vi, Emitter::liti(1))) + "], " + b.e.sd(hv[k]) + ");");
+        stores.push_back(scatter_text(b, b.fv[rep[k]].vidx, hv[k], full_wave));
     }
     os << "static __device__ __forceinline__ void " << fn_name(pi, "hprod")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
-          "const double* __restrict__ v, double* __restrict__ out, double sigma, long tid) {\n"
-       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
+          "const double* __restrict__ v, double* __restrict__ out, double sigma, long tid) {\n";
+    emit_scatter_prologue(os, b, L, pi, full_wave);
     emit_lines(os, b.e);
     for (auto &st : stores) os << "    " << st << "\n";
     os << "}\n";

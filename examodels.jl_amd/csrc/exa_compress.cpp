@@ -58,6 +58,72 @@ __global__ void __launch_bounds__(256) k_narrow(const int64_t *__restrict__ src,
     if (i < n) dst[i] = (T)src[i];
 }
 
+__global__ void __launch_bounds__(256) k_keys0(const int64_t *__restrict__ keys1, uint32_t *__restrict__ k0, uint32_t *__restrict__ idx,
+                                               unsigned long long *__restrict__ cnt, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = (uint32_t)(keys1[i] - 1);
+    k0[i] = k;
+    idx[i] = (uint32_t)i;
+    atomicAdd(&cnt[k], 1ull);
+}
+
+constexpr int64_t kLongRow = 512, kChunk = 8192, kMaxLong = 1 << 20;
+
+__global__ void __launch_bounds__(256) k_find_long(const int64_t *__restrict__ ptr, int64_t n, uint32_t *__restrict__ list,
+                                                   unsigned long long *__restrict__ meta /* [0]=count [1]=maxlen */) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int64_t len = ptr[k + 1] - ptr[k];
+    if (len > kLongRow) {
+        const unsigned long long pos = atomicAdd(&meta[0], 1ull);
+        if (pos < (unsigned long long)kMaxLong) list[pos] = (uint32_t)k;
+        atomicMax(&meta[1], (unsigned long long)len);
+    }
+}
+
+// long groups: blockIdx.x = long row, blockIdx.y = chunk; workgroup-reduce the chunk, one FP64 atomic per chunk
+__global__ void __launch_bounds__(256) k_spmv_long(const uint32_t *__restrict__ list, const int64_t *__restrict__ ptr,
+                                                   const uint32_t *__restrict__ perm, const double *__restrict__ vals,
+                                                   const int64_t *__restrict__ other, const int64_t *__restrict__ rows,
+                                                   const int64_t *__restrict__ cols, int skip_diag, const double *__restrict__ v,
+                                                   double *__restrict__ out) {
+    __shared__ double red[4];
+    const int64_t k = list[blockIdx.x];
+    const int64_t beg = ptr[k] + (int64_t)blockIdx.y * kChunk;
+    const int64_t end = beg + kChunk < ptr[k + 1] ? beg + kChunk : ptr[k + 1];
+    if (beg >= ptr[k + 1]) return;
+    double s = 0.0;
+    for (int64_t j = beg + threadIdx.x; j < end; j += 256) {
+        const uint32_t e = perm[j];
+        if (skip_diag && rows[e] == cols[e]) continue;
+        s += vals[e] * v[other[e] - 1];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(&out[k], red[0] + red[1] + red[2] + red[3]);
+}
+
+// one thread per group (variable / row): contributions added in ascending slot order -> deterministic
+__global__ void __launch_bounds__(256) k_spmv_gather(const int64_t *__restrict__ ptr, const uint32_t *__restrict__ perm,
+                                                     const double *__restrict__ vals, const int64_t *__restrict__ other,
+                                                     const int64_t *__restrict__ rows, const int64_t *__restrict__ cols, int skip_diag,
+                                                     const double *__restrict__ v, double *__restrict__ out, int accumulate, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    double s = accumulate ? out[k] : 0.0;
+    const int64_t b = ptr[k], e1 = ptr[k + 1];
+    if (e1 - b <= kLongRow) {     // long groups are added by k_spmv_long
+        for (int64_t j = b; j < e1; j++) {
+            const uint32_t e = perm[j];
+            if (skip_diag && rows[e] == cols[e]) continue;
+            s += vals[e] * v[other[e] - 1];
+        }
+    }
+    out[k] = s;
+}
+
 struct Tmp {
     void *p = nullptr;
     explicit Tmp(size_t n) { if (hipMalloc(&p, n ? n : 8) != hipSuccess) throw std::runtime_error("hipMalloc failed in exa_compress"); }
@@ -123,6 +189,67 @@ void build_compressed(CompressedCOO &c, const int64_t *rows, const int64_t *cols
     hipLaunchKernelGGL(k_decode, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, (const uint64_t *)keys.p, nrowdim, (int64_t *)c.rows,
                        (int64_t *)c.cols, c.cnnz);
     HIPCHK_C(hipStreamSynchronize(stream));
+}
+
+void SortedIndex::release() {
+    for (void **q : {&perm, &ptr, &long_rows}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    nnz = ndim = nlong = maxlen = 0;
+}
+
+void build_sorted_index(SortedIndex &s, const int64_t *keys1, int64_t nnz, int64_t ndim, hipStream_t stream) {
+    s.release();
+    s.nnz = nnz; s.ndim = ndim;
+    if (nnz > 0xffffffffLL || ndim > 0xffffffffLL) throw std::runtime_error("sorted index supports up to 2^32-1 entries");
+    HIPCHK_C(hipMalloc(&s.ptr, 8 * (size_t)(ndim + 1)));
+    HIPCHK_C(hipMalloc(&s.perm, 4 * (size_t)(nnz ? nnz : 1)));
+    Tmp k0(4 * (size_t)nnz), k1(4 * (size_t)nnz), idx(4 * (size_t)nnz), cnt(8 * (size_t)(ndim + 1));
+    HIPCHK_C(hipMemsetAsync(cnt.p, 0, 8 * (size_t)(ndim + 1), stream));
+    if (nnz) {
+        hipLaunchKernelGGL(k_keys0, dim3(grid_for(nnz)), dim3(256), 0, stream, keys1, (uint32_t *)k0.p, (uint32_t *)idx.p,
+                           (unsigned long long *)cnt.p, nnz);
+        unsigned bits = 1;
+        while (bits < 32 && (1ull << bits) < (unsigned long long)ndim) bits++;
+        size_t tb = 0;
+        HIPCHK_C(rocprim::radix_sort_pairs(nullptr, tb, (uint32_t *)k0.p, (uint32_t *)k1.p, (uint32_t *)idx.p, (uint32_t *)s.perm, (size_t)nnz, 0,
+                                           bits, stream));
+        Tmp t(tb);
+        HIPCHK_C(rocprim::radix_sort_pairs(t.p, tb, (uint32_t *)k0.p, (uint32_t *)k1.p, (uint32_t *)idx.p, (uint32_t *)s.perm, (size_t)nnz, 0,
+                                           bits, stream));
+    }
+    size_t tb = 0;
+    HIPCHK_C(rocprim::exclusive_scan(nullptr, tb, (const int64_t *)cnt.p, (int64_t *)s.ptr, (int64_t)0, (size_t)(ndim + 1),
+                                     rocprim::plus<int64_t>(), stream));
+    Tmp t(tb);
+    HIPCHK_C(rocprim::exclusive_scan(t.p, tb, (const int64_t *)cnt.p, (int64_t *)s.ptr, (int64_t)0, (size_t)(ndim + 1),
+                                     rocprim::plus<int64_t>(), stream));
+    // long groups
+    Tmp meta(16);
+    HIPCHK_C(hipMemsetAsync(meta.p, 0, 16, stream));
+    Tmp list(4 * (size_t)kMaxLong);
+    if (ndim) hipLaunchKernelGGL(k_find_long, dim3(grid_for(ndim)), dim3(256), 0, stream, (const int64_t *)s.ptr, ndim, (uint32_t *)list.p,
+                                 (unsigned long long *)meta.p);
+    unsigned long long hm[2] = {0, 0};
+    HIPCHK_C(hipMemcpyAsync(hm, meta.p, 16, hipMemcpyDeviceToHost, stream));
+    HIPCHK_C(hipStreamSynchronize(stream));
+    if (hm[0] > (unsigned long long)kMaxLong) throw std::runtime_error("too many long groups for the sorted products");
+    s.nlong = (int64_t)hm[0]; s.maxlen = (int64_t)hm[1];
+    if (s.nlong) {
+        HIPCHK_C(hipMalloc(&s.long_rows, 4 * (size_t)s.nlong));
+        HIPCHK_C(hipMemcpyAsync(s.long_rows, list.p, 4 * (size_t)s.nlong, hipMemcpyDeviceToDevice, stream));
+        HIPCHK_C(hipStreamSynchronize(stream));
+    }
+}
+
+void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other, const int64_t *rows, const int64_t *cols, bool skip_diag,
+                 const double *v, double *out, bool accumulate, hipStream_t stream) {
+    if (s.ndim == 0) return;
+    hipLaunchKernelGGL(k_spmv_gather, dim3(grid_for(s.ndim)), dim3(256), 0, stream, (const int64_t *)s.ptr, (const uint32_t *)s.perm, vals,
+                       other, rows, cols, skip_diag ? 1 : 0, v, out, accumulate ? 1 : 0, s.ndim);
+    if (s.nlong) {
+        const unsigned chunks = (unsigned)((s.maxlen + kChunk - 1) / kChunk);
+        hipLaunchKernelGGL(k_spmv_long, dim3((unsigned)s.nlong, chunks), dim3(256), 0, stream, (const uint32_t *)s.long_rows,
+                           (const int64_t *)s.ptr, (const uint32_t *)s.perm, vals, other, rows, cols, skip_diag ? 1 : 0, v, out);
+    }
 }
 
 void compress_values(const CompressedCOO &c, const double *buf, double *V, hipStream_t stream) {

@@ -22,4 +22,21 @@ void build_compressed(CompressedCOO &c, const int64_t *rows, const int64_t *cols
 void compress_values(const CompressedCOO &c, const double *buf, double *V, hipStream_t stream);
 void compressed_structure(const CompressedCOO &c, void *rows, void *cols, bool wide, hipStream_t stream);
 
+// COO entries grouped by one of their coordinates: entries perm[ptr[k] .. ptr[k+1]) have key k (0-based), in ascending
+// slot order.  The reference's prod helper (`ExaModel(c; prod = true)`, KA ext :56-178) keeps the same two lists.
+struct SortedIndex {
+    int64_t nnz = 0, ndim = 0;
+    void *perm = nullptr;   // uint32[nnz]
+    void *ptr = nullptr;    // int64[ndim+1]
+    // groups longer than kLongRow entries (a variable shared by many data points, e.g. the rocket's step length) are
+    // reduced cooperatively: one workgroup per 8192-entry chunk, one atomic per chunk
+    void *long_rows = nullptr;   // uint32[nlong]
+    int64_t nlong = 0, maxlen = 0;
+    void release();
+};
+void build_sorted_index(SortedIndex &s, const int64_t *keys1, int64_t nnz, int64_t ndim, hipStream_t stream);
+// out[k] (+)= sum_{e in group k, (skip_diag ? rows[e] != cols[e] : true)} vals[e] * v[other[e] - 1]
+void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other, const int64_t *rows, const int64_t *cols, bool skip_diag,
+                 const double *v, double *out, bool accumulate, hipStream_t stream);
+
 }  // namespace exa

@@ -70,6 +70,11 @@ struct Handle {
     CompressedCOO cj, ch;                   // duplicate-summed COO maps (exa_compress)
     DevBuf cbuf;                            // uncompressed values of the last compressed evaluation
     bool compressed = false;
+    // sorted-gather products (the reference's prod helper): COO coordinates + entries grouped by column / by row
+    DevBuf pjrows, pjcols, phrows, phcols;
+    SortedIndex jbycol, hbyrow, hbycol;
+    bool prod_ready = false;
+    int jt_mode = -1, hp_mode = -1;         // -1 undecided, 0 atomics in the sweep, 1 COO + sorted gather
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     ~Handle() {
@@ -78,6 +83,8 @@ struct Handle {
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release();
             for (auto &b : dmap) b.release();
             cj.release(); ch.release(); cbuf.release();
+            pjrows.release(); pjcols.release(); phrows.release(); phcols.release();
+            jbycol.release(); hbyrow.release(); hbycol.release();
             for (auto &b : dcols) b.release();
             sx.release(); sy.release(); sv.release(); sout.release(); srows.release(); scols.release();
             if (ev0) (void)hipEventDestroy(ev0);
@@ -390,6 +397,52 @@ void do_hprod(Handle &h, const double *x, const double *y, const double *v, doub
     void *a[] = {&P, &x, &y, &th, &v, &Hv, &sigma};
     launch(h, h.f_hprod, h.grid[CB_HPROD], kBlock, a);
 }
+void do_struct(Handle &h, bool hess, bool wide, void *rows, void *cols);
+void do_jac(Handle &h, const double *x, double *v);
+void do_hess(Handle &h, const double *x, const double *y, double sigma, double *v);
+
+// Products, second implementation: evaluate the COO and gather it through build-time sorted lists — the reference's
+// own scheme (kerspmv2 / kersyspmv, KA ext :482-511).  Deterministic and contention-free; costs one extra pass over
+// the COO.  Which of the two implementations runs is decided per model by MEASURING both once (exa_jtprod/exa_hprod
+// first call): atomics win on stencil models (LV), sorted gathers win when many data points hit few targets
+// (rocket's shared step variable, ACOPF bus rows).
+void prod_setup(Handle &h) {
+    if (h.prod_ready) return;
+    const Model &m = *h.m;
+    h.pjrows.ensure(8 * (size_t)std::max<int64_t>(m.nnzj, 1)); h.pjcols.ensure(8 * (size_t)std::max<int64_t>(m.nnzj, 1));
+    h.phrows.ensure(8 * (size_t)std::max<int64_t>(m.nnzh, 1)); h.phcols.ensure(8 * (size_t)std::max<int64_t>(m.nnzh, 1));
+    do_struct(h, false, true, h.pjrows.p, h.pjcols.p);
+    do_struct(h, true, true, h.phrows.p, h.phcols.p);
+    build_sorted_index(h.jbycol, (const int64_t *)h.pjcols.p, m.nnzj, m.nvar, h.stream);
+    build_sorted_index(h.hbyrow, (const int64_t *)h.phrows.p, m.nnzh, m.nvar, h.stream);
+    build_sorted_index(h.hbycol, (const int64_t *)h.phcols.p, m.nnzh, m.nvar, h.stream);
+    h.cbuf.ensure(8 * (size_t)std::max<int64_t>(std::max(m.nnzj, m.nnzh), 1));
+    h.prod_ready = true;
+}
+void do_jtprod_sorted(Handle &h, const double *x, const double *v, double *Jtv) {
+    do_jac(h, x, (double *)h.cbuf.p);
+    spmv_gather(h.jbycol, (const double *)h.cbuf.p, (const int64_t *)h.pjrows.p, nullptr, nullptr, false, v, Jtv, false, h.stream);
+}
+void do_hprod_sorted(Handle &h, const double *x, const double *y, const double *v, double sigma, double *Hv) {
+    do_hess(h, x, y, sigma, (double *)h.cbuf.p);
+    const int64_t *r = (const int64_t *)h.phrows.p, *c = (const int64_t *)h.phcols.p;
+    spmv_gather(h.hbyrow, (const double *)h.cbuf.p, c, r, c, false, v, Hv, false, h.stream);      // lower triangle incl. diagonal
+    spmv_gather(h.hbycol, (const double *)h.cbuf.p, r, r, c, true, v, Hv, true, h.stream);        // its transpose, off-diagonal only
+}
+template <class A, class B>
+int pick_faster(Handle &h, A &&atomics, B &&sorted) {
+    float t[2] = {0.f, 0.f};
+    for (int which = 0; which < 2; which++) {
+        for (int rep = 0; rep < 4; rep++) {
+            if (rep == 1) HIPCHK(hipEventRecord(h.ev0, h.stream));
+            if (which == 0) atomics(); else sorted();
+        }
+        HIPCHK(hipEventRecord(h.ev1, h.stream));
+        HIPCHK(hipEventSynchronize(h.ev1));
+        HIPCHK(hipEventElapsedTime(&t[which], h.ev0, h.ev1));
+    }
+    return t[1] < t[0] ? 1 : 0;
+}
 void do_struct(Handle &h, bool hess, bool wide, void *rows, void *cols) {
     const void *P = h.dP.p;
     void *a[] = {&P, &rows, &cols};
@@ -520,6 +573,7 @@ int exa_set_shard(int id, int rank, int world) {
         if (h.on_device) HIPCHK(hipStreamSynchronize(h.stream));
         h.rank = rank; h.world = world;
         fill_params(h);
+        if (world != 1) { if (h.jt_mode == 1) h.jt_mode = -1; if (h.hp_mode == 1) h.hp_mode = -1; }
     });
 }
 int exa_set_value(int id, int64_t offset, const double *vals, int64_t len) {
@@ -569,13 +623,41 @@ int exa_jprod(int id, const double *x, const double *v, double *Jv) {
     if (!x || !v) return 1;
     return guard(id, true, [&](Handle &h) { if (h.m->ncon && !Jv) throw std::runtime_error("null output"); do_jprod(h, x, v, Jv); });
 }
+static void run_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
+    if (h.jt_mode < 0) {
+        if (h.world != 1 || h.m->nnzj == 0) h.jt_mode = 0;    // sorted lists describe the unsharded COO
+        else { prod_setup(h); h.jt_mode = pick_faster(h, [&] { do_jtprod(h, x, v, Jtv); }, [&] { do_jtprod_sorted(h, x, v, Jtv); }); }
+    }
+    if (h.jt_mode == 1 && h.world == 1) do_jtprod_sorted(h, x, v, Jtv); else do_jtprod(h, x, v, Jtv);
+}
+static void run_hprod(Handle &h, const double *x, const double *y, const double *v, double w, double *Hv) {
+    if (h.hp_mode < 0) {
+        if (h.world != 1 || h.m->nnzh == 0) h.hp_mode = 0;
+        else { prod_setup(h); h.hp_mode = pick_faster(h, [&] { do_hprod(h, x, y, v, w, Hv); }, [&] { do_hprod_sorted(h, x, y, v, w, Hv); }); }
+    }
+    if (h.hp_mode == 1 && h.world == 1) do_hprod_sorted(h, x, y, v, w, Hv); else do_hprod(h, x, y, v, w, Hv);
+}
 int exa_jtprod(int id, const double *x, const double *v, double *Jtv) {
     if (!x || !Jtv) return 1;
-    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !v) throw std::runtime_error("null input"); do_jtprod(h, x, v, Jtv); });
+    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !v) throw std::runtime_error("null input"); run_jtprod(h, x, v, Jtv); });
 }
 int exa_hprod(int id, const double *x, const double *y, const double *v, double w, double *Hv) {
     if (!x || !v || !Hv) return 1;
-    return guard(id, true, [&](Handle &h) { do_hprod(h, x, y, v, w, Hv); });
+    return guard(id, true, [&](Handle &h) { run_hprod(h, x, y, v, w, Hv); });
+}
+/* 0 = atomics inside the sweep, 1 = COO + sorted gather, -1 = decide by measurement at the next call (default) */
+int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode) {
+    if (jtprod_mode < -1 || jtprod_mode > 1 || hprod_mode < -1 || hprod_mode > 1) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if (jtprod_mode == 1 || hprod_mode == 1) { if (h.world != 1) throw BadInput("sorted products need the unsharded model"); prod_setup(h); }
+        h.jt_mode = jtprod_mode; h.hp_mode = hprod_mode;
+    });
+}
+int exa_get_product_mode(int id, int *jtprod_mode, int *hprod_mode) {
+    Handle *h = get(id);
+    if (!h || !jtprod_mode || !hprod_mode) return 1;
+    *jtprod_mode = h->jt_mode; *hprod_mode = h->hp_mode;
+    return 0;
 }
 int exa_jac_structure(int id, int32_t *r, int32_t *c) {
     return guard(id, true, [&](Handle &h) { if (h.m->nnzj > 0x7fffffffLL) throw std::runtime_error("nnzj exceeds int32"); do_struct(h, false, false, r, c); });
@@ -660,7 +742,7 @@ int exa_jtprod_host(int id, const double *x, const double *v, double *Jtv) {
         if (h.m->ncon) { if (!v) throw std::runtime_error("null input"); h2d(h, h.sv, v, 8 * (size_t)h.m->ncon); }
         else h.sv.ensure(8);
         h.sout.ensure(n);
-        do_jtprod(h, (const double *)h.sx.p, (const double *)h.sv.p, (double *)h.sout.p);
+        run_jtprod(h, (const double *)h.sx.p, (const double *)h.sv.p, (double *)h.sout.p);
         d2h(h, Jtv, h.sout.p, n);
     });
 }
@@ -673,7 +755,7 @@ int exa_hprod_host(int id, const double *x, const double *y, const double *v, do
         if (h.m->ncon) { if (!y) throw std::runtime_error("null multipliers"); h2d(h, h.sy, y, 8 * (size_t)h.m->ncon); }
         else h.sy.ensure(8);
         h.sout.ensure(n);
-        do_hprod(h, (const double *)h.sx.p, (const double *)h.sy.p, (const double *)h.sv.p, w, (double *)h.sout.p);
+        run_hprod(h, (const double *)h.sx.p, (const double *)h.sy.p, (const double *)h.sv.p, w, (double *)h.sout.p);
         d2h(h, Hv, h.sout.p, n);
     });
 }

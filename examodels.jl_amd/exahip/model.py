@@ -202,6 +202,15 @@ class ExaModel:
             capi.check(getattr(self._L, f"exa_{name}_host")(self.id, x.ctypes.data, v.ctypes.data if v.size else None, out.ctypes.data), name)
         return out
 
+    def set_product_mode(self, jtprod=-1, hprod=-1):
+        """0 atomics in the sweep, 1 COO + sorted gather, -1 measure both at the next call (default)."""
+        capi.check(self._L.exa_set_product_mode(self.id, int(jtprod), int(hprod)), "exa_set_product_mode")
+
+    def product_mode(self):
+        a, b = ctypes.c_int(0), ctypes.c_int(0)
+        capi.check(self._L.exa_get_product_mode(self.id, ctypes.addressof(a), ctypes.addressof(b)), "exa_get_product_mode")
+        return a.value, b.value
+
     def jprod(self, x, v, out=None):
         return self._prod("jprod", x, v, self.meta.nvar, self.meta.ncon, out)
 

@@ -103,6 +103,11 @@ int exa_hess(int id, const double *x, const double *y, double obj_weight, double
 int exa_jprod (int id, const double *x, const double *v, double *Jv);             /* Jv [ncon]  = J(x) v,   v [nvar] */
 int exa_jtprod(int id, const double *x, const double *v, double *Jtv);            /* Jtv [nvar] = J(x)' v,  v [ncon] */
 int exa_hprod (int id, const double *x, const double *y, const double *v, double obj_weight, double *Hv);  /* Hv [nvar] */
+/* exa_jtprod / exa_hprod have two implementations: FP64 atomics inside the sweep, or COO + gather through build-time
+ * sorted lists (the reference's prod helper, KA ext :56-178, :482-511).  mode: 0 atomics, 1 sorted gather, -1 (default)
+ * decide by MEASURING both at the next call on this model ("chosen by measured contention"). */
+int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode);
+int exa_get_product_mode(int id, int *jtprod_mode, int *hprod_mode);
 int exa_jac_structure  (int id, int32_t *rows, int32_t *cols);
 int exa_hess_structure (int id, int32_t *rows, int32_t *cols);
 int exa_jac_structure64 (int id, int64_t *rows, int64_t *cols);               /* Julia Vector{Int} */

@@ -93,3 +93,25 @@ def test_fused_sweep_equals_separate_callbacks(libs, name):
     assert relerr(c.cpu().numpy(), o.cons(x)) <= RTOL
     assert relerr(j.cpu().numpy(), o.jac_coord(x)) <= RTOL
     assert relerr(h.cpu().numpy(), o.hess_coord(x, y, sigma)) <= RTOL
+
+
+@pytest.mark.parametrize("name", ["lv20", "acopf30", "rocket50", "mixed", "cops_elec"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_both_product_implementations(libs, name, mode):
+    """jtprod/hprod: atomics-in-the-sweep (0) and COO + sorted gather (1, the reference's prod helper) agree with the
+    oracle; the default picks one by measurement."""
+    from exahip import ExaModel
+    import oracle
+    m = ExaModel(ZOO[name]())
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=31)
+    v = np.random.default_rng(5).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(6).standard_normal(m.meta.ncon)
+    m.set_product_mode(mode, mode)
+    assert relerr(m.jtprod(x, w), o.jtprod(x, w)) <= RTOL
+    assert relerr(m.hprod(x, y, v, sigma), o.hprod(x, y, v, sigma)) <= RTOL
+    assert m.product_mode() == (mode, mode)
+    m.set_product_mode(-1, -1)
+    assert relerr(m.jtprod(x, w), o.jtprod(x, w)) <= RTOL
+    assert relerr(m.hprod(x, y, v, sigma), o.hprod(x, y, v, sigma)) <= RTOL
+    assert all(k in (0, 1) for k in m.product_mode())

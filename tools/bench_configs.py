@@ -67,6 +67,21 @@ def run(name, core, reps=50):
     sep = sum(out["callbacks"][k]["ms"] for k in ("obj", "cons", "jac", "hess"))
     fb = 8 * (m.meta.nnzh + m.meta.nnzj + m.meta.ncon) + 8 * m.meta.nvar + 8 * m.meta.ncon + itb
     out["fused_obj_cons_jac_hess"] = {"ms": best, "separate_ms": sep, "algorithmic_bytes": fb, "GBps": fb / (best * 1e-3) / 1e9}
+    # matrix-free products (secondary)
+    v = torch.from_numpy(np.random.default_rng(2).standard_normal(m.meta.nvar)).to(dev)
+    w = torch.from_numpy(np.random.default_rng(3).standard_normal(m.meta.ncon)).to(dev)
+    prods = {}
+    for name, fn in (("jprod", lambda: m.jprod(x, v, out=bufs["cons"])), ("jtprod", lambda: m.jtprod(x, w, out=bufs["grad"])),
+                     ("hprod", lambda: m.hprod(x, y, v, 0.5, out=bufs["grad"]))):
+        for _ in range(3):
+            fn()
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        prods[name + "_ms"] = e0.elapsed_time(e1) / 20
+    out["products"] = prods
     out["hess_nnz_per_s"] = m.meta.nnzh * out["callbacks"]["hess"]["evals_per_s"]
     print(json.dumps(out), flush=True)
 
