@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--cpu-sample", type=float, default=1e7)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--all-callbacks", action="store_true", help="also time obj/cons/grad/jac (secondary)")
+    ap.add_argument("--with-collectives", action="store_true",
+                    help="N>1 only, secondary: also time sharded grad! + RCCL all_reduce (off by default so that nothing "
+                         "optional can stall the contract run)")
     args = ap.parse_args()
 
     import numpy as np
@@ -174,7 +177,7 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "exa_hess", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
     }
-    if world > 1:
+    if world > 1 and args.with_collectives:
         # secondary (never part of `value`): the callbacks that DO need a collective, completed with RCCL all_reduce
         # over xGMI through exahip.dist — sharded grad! + all_reduce(SUM) of the dense nvar vector, and obj.
         try:
