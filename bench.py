@@ -78,6 +78,9 @@ def main():
                     help="untimed: keep the GPU busy with the same call this long before the W warmup steps, so that the "
                          "clock governor has left its idle state (sclk idles at ~570 MHz and takes tens of ms to ramp)")
     ap.add_argument("--points", type=float, default=1e7, help="LV size per GPU (N)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling instead: --points is the GLOBAL LV size, split over the ranks (BASELINE.json configs[4]: "
+                         "--points 1e8 --gpus 8); value is then evals/s-proportional nnz/s of the fixed model")
     ap.add_argument("--cpu-sample", type=float, default=1e7)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--all-callbacks", action="store_true", help="also time obj/cons/grad/jac (secondary)")
@@ -113,8 +116,8 @@ def main():
             dist.init_process_group(backend)
 
     from exahip import ExaModel, models
-    per_gpu = int(args.points)
-    N = per_gpu * world
+    per_gpu = int(args.points) // world if args.strong else int(args.points)
+    N = int(args.points) if args.strong else per_gpu * world
     core = models.luksan_vlcek_model(N)
     m = ExaModel(core)
     m.set_shard(rank, world)
@@ -167,7 +170,7 @@ def main():
     out = {
         "metric": "sparse Lagrangian Hessian throughput (hess_coord!), nonzeros/s; evals/s in evals_per_s",
         "value": value, "unit": "nnz/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_ms": args.preheat_ms,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"LuksanVlcek N={per_gpu:.0e} per GPU (global N={N:.0e}), hess_coord! sharded-output",
                    "nvar": m.meta.nvar, "ncon": m.meta.ncon, "nnzh": nnzh, "obj_weight": sigma,

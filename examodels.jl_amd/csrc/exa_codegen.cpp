@@ -697,7 +697,9 @@ extern "C" __global__ void __launch_bounds__(1024) exa_reduce_partials(const dou
 int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
 // LDS budget per 256-thread workgroup for the store staging (tuning knob; changes the source and so the cache key)
 int lds_budget() { return env_int("EXAHIP_LDS_BUDGET", 40960); }
-bool use_tile(int S) { return S >= 2; }
+int tile_doubles(int S);
+// a pattern too wide to stage even 8 points per pass within the 160 KB of LDS falls back to direct per-lane stores
+bool use_tile(int S) { return S >= 2 && (long)(kBlock / 64) * tile_doubles(S) * 8 <= env_int("EXAHIP_LDS_MAX", 150000); }
 // points staged per pass: the largest of 64/32/16/8 whose tile (4 wavefronts) fits the budget
 int tile_pp(int S) {
     for (int pp = 64; pp > 8; pp >>= 1)

@@ -167,3 +167,19 @@ def test_timed_wrapper_counts_calls(built):
     assert t.stats["obj"]["calls"] == 3 and t.stats["hess_coord"]["calls"] == 3 and t.stats["cons"]["calls"] == 1
     assert t.stats["hess_coord"]["seconds"] > 0 and "hess_coord" in t.report()
     assert relerr(t.hess_coord(x, y, sigma), o.hess_coord(x, y, sigma)) <= RTOL
+
+
+def test_direct_store_fallback_path(libs, monkeypatch):
+    """Patterns too wide for LDS staging fall back to per-lane stores; force that path on ordinary models (and a
+    non-default workgroup-independent knob set) and require the same parity."""
+    from exahip import ExaModel
+    import oracle
+    from zoo import ZOO
+    monkeypatch.setenv("EXAHIP_LDS_MAX", "64")        # nothing fits: every COO store goes the direct way
+    for name in ("lv20", "rocket50", "acopf30"):
+        m = ExaModel(ZOO[name]())
+        assert "exa_flush_points<" not in m.kernel_source().split("// patterns=")[1]
+        o = oracle.OracleModel(m.ir)
+        x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=17)
+        assert relerr(m.hess_coord(x, y, sigma), o.hess_coord(x, y, sigma)) <= RTOL
+        assert relerr(m.jac_coord(x), o.jac_coord(x)) <= RTOL
