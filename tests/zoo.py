@@ -42,6 +42,20 @@ def conaug2d_model():
     return c
 
 
+def stepped_model():
+    """StepRange iterators (2:3:N), exa_sum / exa_prod nodes, Constant algebra, a parameterised power."""
+    from exahip.graph import Constant, exa_prod, exa_sum
+    N = 50
+    c = ExaCore()
+    x = c.add_var(N, start=np.linspace(0.4, 1.6, N))
+    th = c.add_par(2, value=[1.5, 0.25])
+    c.add_obj(lambda i: (x[i] - x[i + 1]) ** 2 + Constant(1) * x[i] * Constant(0) + th[1] * x[i + 1], rng(1, N - 1, 2))
+    c.add_obj(lambda i: exa_sum(x[i + k] ** 2 for k in range(3)) * 0.5, rng(2, N - 2, 3))
+    c.add_con(lambda i: exa_prod(1 + x[i + k] for k in range(3)) - x[i] ** th[2] + Constant(2) ** x[i + 1], rng(3, N - 2, 3))
+    c.add_con(lambda i: exa_sum([x[i], -x[i - 1], 2 * x[i - 2]]) / (1 + x[i] ** 2), rng(N, 3, -4))
+    return c
+
+
 def small_acopf():
     return models.ac_power_model(models.synthetic_power_data(nbus=30, nbr=41, ngen=6, seed=3))
 
@@ -57,6 +71,7 @@ ZOO = {
     "acopf30": small_acopf,
     "mixed": mixed_model,
     "conaug2d": conaug2d_model,
+    "stepped": stepped_model,
     "cops_chain": lambda: models.cops_chain_model(200),
     "cops_elec": lambda: models.cops_elec_model(25),
 }
