@@ -748,7 +748,9 @@ void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, c
                      const std::string &out = "out", const std::string &tag = "") {
     if (tile) {
         const int pp = tile_pp(S), ld = tile_ld(S);
-        os << "    {\n    double* tile = lds + (threadIdx.x >> 6) * " << tile_doubles(S) << ";\n"
+        // `lds` is this WAVEFRONT's private staging region (sized for the widest tile of the kernel): wavefronts never
+        // share LDS words, so no workgroup barrier is needed even when a function flushes two tiles of different shape
+        os << "    {\n    double* tile = lds;\n"
            << "    const long obase = " << b.P(word_o) << " + " << S << "L * (I0 - lane);\n    const long npts = hi - (I0 - lane);\n";
         for (int g = 0; g < 64 / pp; g++) {
             if (pp == 64) {
@@ -1230,7 +1232,7 @@ Generated generate_module(const Model &m) {
     auto lds_decl = [&](int cb, bool hess) {
         int mx = 0;
         for (int k : L.active[cb]) { const int S = hess ? m.pats[k].o2step : m.pats[k].o1step; if (use_tile(S)) mx = std::max(mx, tile_doubles(S)); }
-        if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all;\n";
+        if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all + (threadIdx.x >> 6) * " << mx << ";\n";
         else os << "    double* lds = nullptr;\n";
     };
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jac(const long* __restrict__ P, const double* __restrict__ x, "
@@ -1254,7 +1256,7 @@ Generated generate_module(const Model &m) {
         os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_fused(const long* __restrict__ P, const double* __restrict__ x, "
               "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ part, double* __restrict__ cout, "
               "double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma) {\n";
-        if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all;\n";
+        if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all + (threadIdx.x >> 6) * " << mx << ";\n";
         else os << "    double* lds = nullptr;\n";
         os << "    const long b = blockIdx.x;\n    double v = 0.0;\n"
            << "    const long e_ = ((const long*)P[" << L.blk[CB_FUSED] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"

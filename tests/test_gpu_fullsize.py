@@ -22,7 +22,7 @@ def maxrel(a, ref):
     return float(np.max(np.abs(a - ref) / scale))
 
 
-def full_compare(core, seed):
+def full_compare(core, seed, check_products=False):
     import torch
     from exahip import ExaModel
     import oracle
@@ -51,6 +51,39 @@ def full_compare(core, seed):
     num = (hs - (h + h2)).abs().max().item()
     den = max(1.0, hs.abs().max().item())
     assert num / den <= 1e-12
+    # fused sweep == the separate callbacks (different kernels, same arithmetic up to FMA contraction)
+    ff, cf, jf, hf = m.eval_fused(xd, yd, sigma)
+    torch.cuda.synchronize()
+    for a, b in ((cf, c), (jf, j), (hf, h)):
+        d = (a - b).abs().max().item() if a.numel() else 0.0
+        assert d <= 1e-11 * max(1.0, b.abs().max().item() if b.numel() else 1.0)
+    assert abs(ff.item() - f) <= 1e-11 * max(1.0, abs(f))
+    if not check_products:
+        return m, o, (x, y, sigma), (xd, yd)
+    # products at full size: H v and J' w against the COO of the same library, assembled on the device
+    v = torch.from_numpy(np.random.default_rng(3).standard_normal(m.meta.nvar)).to(dev)
+    w = torch.from_numpy(np.random.default_rng(4).standard_normal(m.meta.ncon)).to(dev)
+    rows = torch.empty(m.meta.nnzh, dtype=torch.int64, device=dev)
+    cols = torch.empty(m.meta.nnzh, dtype=torch.int64, device=dev)
+    m.hess_structure(rows, cols)
+    hv = m.hprod(xd, yd, v, sigma)
+    ref = torch.zeros(m.meta.nvar, dtype=torch.float64, device=dev)
+    ref.index_add_(0, rows - 1, h * v[cols - 1])
+    off = rows != cols
+    ref.index_add_(0, cols[off] - 1, h[off] * v[rows[off] - 1])
+    assert (hv - ref).abs().max().item() <= 1e-9 * max(1.0, ref.abs().max().item())
+    del rows, cols, ref
+    jr = torch.empty(m.meta.nnzj, dtype=torch.int64, device=dev)
+    jc = torch.empty(m.meta.nnzj, dtype=torch.int64, device=dev)
+    m.jac_structure(jr, jc)
+    jtv = m.jtprod(xd, w)
+    ref = torch.zeros(m.meta.nvar, dtype=torch.float64, device=dev)
+    ref.index_add_(0, jc - 1, j * w[jr - 1])
+    assert (jtv - ref).abs().max().item() <= 1e-9 * max(1.0, ref.abs().max().item())
+    jv = m.jprod(xd, v)
+    ref = torch.zeros(m.meta.ncon, dtype=torch.float64, device=dev)
+    ref.index_add_(0, jr - 1, j * v[jc - 1])
+    assert (jv - ref).abs().max().item() <= 1e-9 * max(1.0, ref.abs().max().item())
     return m, o, (x, y, sigma), (xd, yd)
 
 
@@ -87,5 +120,5 @@ def test_config4_acopf_78k_synthetic(libs):
     from exahip import models
     nbus, nbr, ngen = 78_484, 126_015, 6_800
     data = models.synthetic_power_data(nbus, nbr, ngen, seed=0)
-    m, o, _, _ = full_compare(models.ac_power_model(data), seed=2)
+    m, o, _, _ = full_compare(models.ac_power_model(data), seed=2, check_products=True)
     assert m.meta.nnzh == ngen + 44 * nbr + 2 * nbus

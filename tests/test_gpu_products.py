@@ -70,6 +70,23 @@ def test_products_device_pointers_and_sharding(libs):
     assert relerr(hv, o.hprod(x, y, v, sigma)) <= RTOL
 
 
+def test_fused_sweep_many_wavefronts(libs):
+    """Regression: the fused function flushes TWO tiles of different shape (J then H) per wavefront; their LDS regions
+    must be private to the wavefront.  Needs many concurrently resident wavefronts to show."""
+    import torch
+    from exahip import ExaModel, models
+    N = 300_000
+    m = ExaModel(models.luksan_vlcek_model(N))
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(m.meta.x0 + 0.1 * np.random.default_rng(0).uniform(-1, 1, N)).to(dev)
+    y = torch.from_numpy(np.random.default_rng(1).standard_normal(N - 2)).to(dev)
+    c, j, h = m.cons(x), m.jac_coord(x), m.hess_coord(x, y, 0.5)
+    for _ in range(3):
+        f, cf, jf, hf = m.eval_fused(x, y, 0.5)
+        torch.cuda.synchronize()
+        assert torch.equal(cf, c) and torch.equal(jf, j) and torch.equal(hf, h)
+
+
 @pytest.mark.parametrize("name", list(ZOO))
 def test_fused_sweep_equals_separate_callbacks(libs, name):
     """exa_eval_fused (SURVEY §8f.1): obj, cons, jac_coord, hess_coord from one sweep == the oracle's separate results;
