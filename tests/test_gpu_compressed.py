@@ -67,3 +67,28 @@ def test_compressed_lv_counts(libs):
     assert m.meta.nnzh == 9 * N - 15
     assert cm.meta.nnzh == 2 * N - 1
     assert cm.meta.nnzj == m.meta.nnzj == 3 * (N - 2)      # the LV Jacobian has no duplicates
+
+
+def test_compressed_mid_size_many_blocks(libs):
+    """Radix sort / run-length / scan path with millions of entries (multi-block): LV N = 200 000."""
+    import torch
+    from exahip import CompressedExaModel, ExaModel, models
+    N = 200_000
+    m = ExaModel(models.luksan_vlcek_model(N))
+    cm = CompressedExaModel(m)
+    assert cm.meta.nnzh == 2 * N - 1
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=3)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    r, c = m.hess_structure()
+    v = m.hess_coord(x, y, sigma)
+    key = (c - 1) * N + (r - 1)
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    starts = np.concatenate([[0], np.nonzero(ks[1:] != ks[:-1])[0] + 1])
+    ev = np.add.reduceat(v[order], starts)            # pairwise order may differ from sequential: compare to 1e-13
+    cr, cc = cm.hess_structure()
+    cv = cm.hess_coord(xd, yd, sigma)
+    torch.cuda.synchronize()
+    assert np.array_equal(cr.cpu().numpy(), r[order][starts]) and np.array_equal(cc.cpu().numpy(), c[order][starts])
+    np.testing.assert_allclose(cv.cpu().numpy(), ev, rtol=1e-13, atol=1e-13)
