@@ -178,7 +178,8 @@ def main():
         "evals_per_s": args.steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "exa_hess", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                     "kernel": "exa_hess", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "block_order": {0: "sequential", 1: "interleaved-128"}.get(m._L.exa_block_order(m.id, 4), "n/a")},
     }
     if world > 1 and args.with_collectives:
         # secondary (never part of `value`): the callbacks that DO need a collective, completed with RCCL all_reduce

@@ -28,6 +28,7 @@ namespace exa {
 namespace {
 
 [[noreturn]] void fail(const std::string &m) { throw BadInput(m); }
+int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
 
 // ---------------------------------------------------------------------------------------------------
 // symbolic values
@@ -258,6 +259,9 @@ Triple un_rule(Emitter &e, int fn, Val u, int order) {
         if (it == e.memo.end()) {
             sv.k = Val::SF; sv.id = e.next++;
             cv.k = Val::SF; cv.id = e.next++;
+            if (env_int("EXAHIP_WHATIF_NOTRIG", 0))   // diagnostic only (wrong numbers): how much of the kernel is FP64 transcendental issue?
+                e.lines.push_back("const double t" + std::to_string(sv.id) + " = " + e.s(u) + ", t" + std::to_string(cv.id) + " = 1.0 - " + e.s(u) + ";");
+            else
             e.lines.push_back("double t" + std::to_string(sv.id) + ", t" + std::to_string(cv.id) + "; sincos(" + e.s(u) + ", &t" +
                               std::to_string(sv.id) + ", &t" + std::to_string(cv.id) + ");");
             e.memo[key] = sv;
@@ -694,7 +698,6 @@ extern "C" __global__ void __launch_bounds__(1024) exa_reduce_partials(const dou
 }
 )HIP";
 
-int env_int(const char *name, int dflt) { const char *v = getenv(name); return v && *v ? atoi(v) : dflt; }
 // LDS budget per 256-thread workgroup for the store staging (tuning knob; changes the source and so the cache key)
 int lds_budget() { return env_int("EXAHIP_LDS_BUDGET", 40960); }
 int tile_doubles(int S);

@@ -63,7 +63,8 @@ struct Handle {
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
     DevBuf dP, dtheta, dpart, dobj, daugbuf, daugrows, daugptr, daugperm;
-    DevBuf dmap[CB_COUNT];                  // per-callback block maps
+    DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] sequential, [1] interleaved
+    int order[CB_COUNT] = {0};              // which map is active; -1 = not yet measured
     std::vector<DevBuf> dcols;              // flattened over patterns
     std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
     DevBuf sx, sy, sv, sout, srows, scols;  // scratch of the *_host variants
@@ -81,7 +82,7 @@ struct Handle {
         if (on_device) {
             dP.release(); dtheta.release(); dpart.release(); dobj.release();
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release();
-            for (auto &b : dmap) b.release();
+            for (auto &b : dmap) { b[0].release(); b[1].release(); }
             cj.release(); ch.release(); cbuf.release();
             pjrows.release(); pjcols.release(); phrows.release(); phcols.release();
             jbycol.release(); hbyrow.release(); hbycol.release();
@@ -198,40 +199,66 @@ void fill_params(Handle &h) {
             else h.P[pp.col[c]] = h.on_device ? (int64_t)(uintptr_t)h.dcols[h.colslot[k][c]].p : 0;
         }
     }
-    // Block maps: workgroup b -> (pattern slot, tile).  Default policy = patterns one after the other: every pattern
-    // streams its own contiguous COO range.  EXAHIP_INTERLEAVE=1 interleaves patterns in proportion to their tile
-    // counts in runs of 8 workgroups (tile t of every pattern on XCD t % 8 at about the same time, so shared x/y
-    // stretches hit in L2): measured on MI355X it saves the second read of x (FETCH -33 %) but is 6-13 % SLOWER on all
-    // three configs — two concurrent write streams cost more than the re-read — so it stays off.
+    // Block maps: workgroup b -> (pattern slot, tile).  Two orders are prepared per callback:
+    //   [0] sequential  — patterns one after the other, each streaming its own contiguous COO range;
+    //   [1] interleaved — patterns advance together in proportion to their tile counts, in runs of 128 workgroups: the
+    //       stretch of x / y / columns one pattern just read is still in L2/MALL when the next one needs it.
+    // Neither wins everywhere (MI355X, hess_coord!): LV N=1e7 0.143 -> 0.133 ms and rocket 0.087 -> 0.082 ms with [1],
+    // but LV N=1e8 1.75 -> 1.86 ms and the cache-resident ACOPF 0.016 -> 0.019 ms; runs of <= 16 workgroups are always
+    // slower (too many concurrent write streams).  So for callbacks that stream >= 128 MB from several patterns the
+    // order is CHOSEN BY MEASUREMENT at the first call (tune_order); everything else runs sequentially.
+    // EXAHIP_INTERLEAVE = 0 forces [0], = k forces interleaving with runs of k workgroups.
     const char *il_env = getenv("EXAHIP_INTERLEAVE");
-    const bool interleave = il_env && atoi(il_env) != 0;
+    const int64_t il_forced = il_env ? atoll(il_env) : -1;
     for (int cb = 0; cb < CB_COUNT; cb++) {
         const size_t na = L.active[cb].size();
-        std::vector<int64_t> nb(na), done(na, 0);
+        std::vector<int64_t> nb(na);
         int64_t total = 0;
+        double out_bytes = 0.0;
         for (size_t j = 0; j < na; j++) {
             const auto &pp = L.pat[L.active[cb][j]];
+            const Pattern &pt = m.pats[L.active[cb][j]];
             const int64_t tile = (int64_t)kBlock * L.ppt[cb];
-            nb[j] = (h.P[pp.hi] - h.P[pp.lo] + tile - 1) / tile;
+            const int64_t cnt = h.P[pp.hi] - h.P[pp.lo];
+            nb[j] = (cnt + tile - 1) / tile;
             total += nb[j];
+            int per = 1;
+            if (cb == CB_HESS || cb == CB_HSTRUCT) per = pt.o2step;
+            else if (cb == CB_JAC || cb == CB_JSTRUCT) per = pt.o1step;
+            else if (cb == CB_FUSED) per = 1 + pt.o1step + pt.o2step;
+            out_bytes += 8.0 * per * (double)cnt;
         }
         h.grid[cb] = total;
-        std::vector<int64_t> map;
-        map.reserve((size_t)total + 1);
-        while ((int64_t)map.size() < total) {
-            // next run goes to the pattern that is furthest behind (smallest completed fraction)
-            size_t best = na;
-            for (size_t j = 0; j < na; j++) {
-                if (done[j] >= nb[j]) continue;
-                if (best == na || (interleave && (__int128)done[j] * nb[best] < (__int128)done[best] * nb[j])) best = j;
+        auto build = [&](int64_t run_len) {
+            std::vector<int64_t> map, done(na, 0);
+            map.reserve((size_t)total + 1);
+            while ((int64_t)map.size() < total) {
+                size_t best = na;   // sequential: first unfinished pattern; interleaved: the one furthest behind
+                for (size_t j = 0; j < na; j++) {
+                    if (done[j] >= nb[j]) continue;
+                    if (best == na || (run_len > 0 && (__int128)done[j] * nb[best] < (__int128)done[best] * nb[j])) best = j;
+                }
+                const int64_t run = run_len > 0 ? run_len : nb[best];
+                for (int64_t r = 0; r < run && done[best] < nb[best]; r++) map.push_back(((int64_t)best << 40) | done[best]++);
             }
-            const int64_t run = interleave ? 8 : nb[best];
-            for (int64_t r = 0; r < run && done[best] < nb[best]; r++) map.push_back(((int64_t)best << 40) | done[best]++);
-        }
+            return map;
+        };
+        const bool tunable = cb == CB_HESS || cb == CB_JAC || cb == CB_FUSED || cb == CB_CONS;
+        const bool two = h.on_device && total > 0 && na > 1 && (il_forced > 0 || (il_forced < 0 && tunable && out_bytes >= 128e6));
+        h.order[cb] = 0;
+        h.P[L.blk[cb]] = 0;
         if (h.on_device && total > 0) {
-            h.dmap[cb].ensure(sizeof(int64_t) * map.size());
-            HIPCHK(hipMemcpy(h.dmap[cb].p, map.data(), sizeof(int64_t) * map.size(), hipMemcpyHostToDevice));
-            h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb].p;
+            std::vector<int64_t> m0 = build(0);
+            h.dmap[cb][0].ensure(sizeof(int64_t) * m0.size());
+            HIPCHK(hipMemcpy(h.dmap[cb][0].p, m0.data(), sizeof(int64_t) * m0.size(), hipMemcpyHostToDevice));
+            h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][0].p;
+            if (two) {
+                std::vector<int64_t> m1 = build(il_forced > 0 ? std::max<int64_t>(il_forced, 1) : 128);
+                h.dmap[cb][1].ensure(sizeof(int64_t) * m1.size());
+                HIPCHK(hipMemcpy(h.dmap[cb][1].p, m1.data(), sizeof(int64_t) * m1.size(), hipMemcpyHostToDevice));
+                if (il_forced > 0) { h.order[cb] = 1; h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][1].p; }
+                else h.order[cb] = -1;   // undecided: measured at the first call
+            }
         }
     }
     if (h.on_device) {
@@ -297,6 +324,50 @@ void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **arg
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, block, 1, 1, 0, h.stream, args, nullptr));
 }
 
+// Chooses the block order of callback `cb` by measurement: 1 warm-up + 3 timed launches of each order on the model's
+// stream (the outputs are simply rewritten with the same values), then the faster map is installed in P[].
+template <class F>
+void tune_order(Handle &h, int cb, F &&run) {
+    if (h.order[cb] >= 0) return;
+    const ParamLayout &L = h.gen.layout;
+    float t[2] = {1e30f, 1e30f};
+    // bring the clocks up first: the governor idles at ~570 MHz and needs tens of ms of load, and at low clocks the two
+    // orders rank differently than in steady state (measured: cold tuning picked the slower order 2 times out of 3)
+    {
+        HIPCHK(hipEventRecord(h.ev0, h.stream));
+        for (int it = 0; it < 200; it++) {
+            for (int r = 0; r < 4; r++) run();
+            HIPCHK(hipEventRecord(h.ev1, h.stream));
+            HIPCHK(hipEventSynchronize(h.ev1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h.ev0, h.ev1));
+            if (ms > 60.f) break;
+        }
+    }
+    // A/B/A/B rounds, minimum per order: the first launches run while the clock governor is still ramping, and a single
+    // sample per order is within the run-to-run noise of the difference being measured (5-7 %)
+    for (int round = 0; round < 4; round++) {
+        for (int k = 0; k < 2; k++) {
+            h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][k].p;
+            HIPCHK(hipMemcpyAsync((int64_t *)h.dP.p + L.blk[cb], &h.P[L.blk[cb]], 8, hipMemcpyHostToDevice, h.stream));
+            h.order[cb] = k;
+            run();
+            HIPCHK(hipEventRecord(h.ev0, h.stream));
+            for (int r = 0; r < 4; r++) run();
+            HIPCHK(hipEventRecord(h.ev1, h.stream));
+            HIPCHK(hipEventSynchronize(h.ev1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h.ev0, h.ev1));
+            if (round > 0 && ms < t[k]) t[k] = ms;     // round 0 only warms up
+        }
+    }
+    const int best = t[1] < t[0] ? 1 : 0;
+    h.order[cb] = best;
+    h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][best].p;
+    HIPCHK(hipMemcpyAsync((int64_t *)h.dP.p + L.blk[cb], &h.P[L.blk[cb]], 8, hipMemcpyHostToDevice, h.stream));
+    HIPCHK(hipStreamSynchronize(h.stream));
+}
+
 // ---- callbacks (device pointers, asynchronous) ------------------------------------------------------------
 void do_obj(Handle &h, const double *x, double *out_dev) {
     const void *P = h.dP.p, *th = h.dtheta.p;
@@ -326,6 +397,7 @@ void do_cons(Handle &h, const double *x, double *c) {
     if (h.world > 1) HIPCHK(hipMemsetAsync(c, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &th, &c};
+    tune_order(h, CB_CONS, [&] { launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a); });
     launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a);
     if (h.m->nconaug == 0) return;
     // augmentation: values into the buffer (coalesced), then one deterministic gather per target row
@@ -341,11 +413,13 @@ void do_cons(Handle &h, const double *x, double *c) {
 void do_jac(Handle &h, const double *x, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &th, &v};
+    tune_order(h, CB_JAC, [&] { launch(h, h.f_jac, h.grid[CB_JAC], kBlock, a); });
     launch(h, h.f_jac, h.grid[CB_JAC], kBlock, a);
 }
 void do_hess(Handle &h, const double *x, const double *y, double sigma, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &y, &th, &v, &sigma};
+    tune_order(h, CB_HESS, [&] { launch(h, h.f_hess, h.grid[CB_HESS], kBlock, a); });
     launch(h, h.f_hess, h.grid[CB_HESS], kBlock, a);
 }
 // fused obj + cons_nln! + jac_coord! + hess_coord! at one x
@@ -358,6 +432,7 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
     }
     int64_t n = h.grid[CB_FUSED];
     void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma};
+    tune_order(h, CB_FUSED, [&] { launch(h, h.f_fused, n, kBlock, a); });
     launch(h, h.f_fused, n, kBlock, a);
     if (n > 0) { void *a2[] = {&part, &n, &obj_dev}; launch(h, h.f_red, 1, 1024, a2); }
     else HIPCHK(hipMemsetAsync(obj_dev, 0, sizeof(double), h.stream));
@@ -846,6 +921,13 @@ int exa_time_callback(int id, int which, int reps, const double *x, const double
         HIPCHK(hipEventElapsedTime(&ms, h.ev0, h.ev1));
         *ms_out = ms / (float)reps;
     });
+}
+/* which: 3 jac, 4 hess (as exa_time_callback), 2 cons, 5 fused.  -1 = not measured yet, 0 sequential, 1 interleaved */
+int exa_block_order(int id, int which) {
+    Handle *h = get(id);
+    if (!h) return -2;
+    const int cb = which == 3 ? CB_JAC : which == 4 ? CB_HESS : which == 2 ? CB_CONS : which == 5 ? CB_FUSED : -1;
+    return cb < 0 ? -2 : h->order[cb];
 }
 int exa_sync(int id) { return guard(id, true, [&](Handle &h) { HIPCHK(hipStreamSynchronize(h.stream)); }); }
 

@@ -21,7 +21,7 @@ SYMBOLS = [
     "exa_set_stream", "exa_set_shard", "exa_set_value", "exa_obj", "exa_obj_async", "exa_grad", "exa_cons", "exa_jac",
     "exa_hess", "exa_jprod", "exa_jtprod", "exa_hprod", "exa_jprod_host", "exa_jtprod_host", "exa_hprod_host", "exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",
     "exa_obj_host", "exa_grad_host", "exa_cons_host", "exa_jac_host", "exa_hess_host", "exa_jac_structure_host",
-    "exa_hess_structure_host", "exa_jac_structure64_host", "exa_hess_structure64_host", "exa_time_callback", "exa_sync",
+    "exa_hess_structure_host", "exa_jac_structure64_host", "exa_hess_structure64_host", "exa_time_callback", "exa_sync", "exa_block_order",
     "exa_eval_fused", "exa_set_product_mode", "exa_get_product_mode", "exa_compress", "exa_cnnzj64", "exa_cnnzh64", "exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64",
     "exa_chess_structure64", "exa_cjac", "exa_chess",
 ]
@@ -89,6 +89,7 @@ def lib():
         getattr(L, f).argtypes = [i32, vp, vp]
     L.exa_time_callback.argtypes = [i32, i32, i32, vp, vp, dbl, vp, vp]
     L.exa_sync.argtypes = [i32]
+    L.exa_block_order.argtypes = [i32, i32]
     L.exa_eval_fused.argtypes = [i32, vp, vp, dbl, vp, vp, vp, vp]
     L.exa_set_product_mode.argtypes = [i32, i32, i32]
     L.exa_get_product_mode.argtypes = [i32, vp, vp]

@@ -153,6 +153,10 @@ int exa_chess(int id, const double *x, const double *y, double obj_weight, doubl
 int exa_time_callback(int id, int which, int reps, const double *x, const double *y, double obj_weight,
                       double *out, float *ms_out);
 int exa_sync(int id);
+/* Order of the (pattern, tile) workgroups of a multi-pattern callback, chosen by measurement at its first call:
+ * 0 patterns one after the other, 1 interleaved in runs of 128 workgroups, -1 not measured yet, -2 bad argument.
+ * which: 2 cons, 3 jac, 4 hess, 5 fused. */
+int exa_block_order(int id, int which);
 
 #ifdef __cplusplus
 }
