@@ -251,7 +251,11 @@ Triple un_rule(Emitter &e, int fn, Val u, int order) {
     u = e.tod(u);
     if (u.is_lit() && host_un_ok(fn) && order == 0) { r.x = Emitter::litf(host_un(fn, u.f)); return r; }
     if (fn == EXA_U_SIN || fn == EXA_U_COS) {
-        if (order == 0) { r.x = e.call(fn == EXA_U_SIN ? "sin($1)" : "cos($1)", {u}); return r; }
+        if (order == 0) {
+            const bool fast = env_int("EXAHIP_FAST_TRIG", 1) != 0;
+            r.x = e.call(fn == EXA_U_SIN ? (fast ? "exa_sin($1)" : "sin($1)") : (fast ? "exa_cos($1)" : "cos($1)"), {u});
+            return r;
+        }
         // one sincos per argument serves value and both derivatives (functionlist.jl:22-23)
         const std::string key = "sincos|" + e.s(u);
         Val sv, cv;
@@ -262,7 +266,8 @@ Triple un_rule(Emitter &e, int fn, Val u, int order) {
             if (env_int("EXAHIP_WHATIF_NOTRIG", 0))   // diagnostic only (wrong numbers): how much of the kernel is FP64 transcendental issue?
                 e.lines.push_back("const double t" + std::to_string(sv.id) + " = " + e.s(u) + ", t" + std::to_string(cv.id) + " = 1.0 - " + e.s(u) + ";");
             else
-            e.lines.push_back("double t" + std::to_string(sv.id) + ", t" + std::to_string(cv.id) + "; sincos(" + e.s(u) + ", &t" +
+            e.lines.push_back("double t" + std::to_string(sv.id) + ", t" + std::to_string(cv.id) + "; " +
+                              (env_int("EXAHIP_FAST_TRIG", 1) ? "exa_sincos(" : "sincos(") + e.s(u) + ", &t" +
                               std::to_string(sv.id) + ", &t" + std::to_string(cv.id) + ");");
             e.memo[key] = sv;
             e.memo[key + "|c"] = cv;
@@ -615,6 +620,38 @@ static __device__ __forceinline__ double exa_sind(double x) { return sin(EXA_D2R
 static __device__ __forceinline__ double exa_cosd(double x) { return cos(EXA_D2R * fmod(x, 360.0)); }
 static __device__ __forceinline__ double exa_tand(double x) { return tan(EXA_D2R * fmod(x, 180.0)); }
 static __device__ __forceinline__ double exa_sinc(double x) { return x == 0.0 ? 1.0 : sinpi(x) / (EXA_PI * x); }
+// sin and cos together, FP64.  FP64 transcendentals are software sequences on CDNA4 and the ocml pair costs ~50 FP64
+// instructions (it carries double-double terms for < 1 ulp); for |x| < 2^19 * pi/2 this version does a 3-term Cody-Waite
+// reduction with FMAs (the products k*PIO2_1, k*PIO2_2 are exact for |k| < 2^20: 33-bit constants) and the fdlibm
+// minimax kernels on [-pi/4, pi/4] — ~28 FP64 instructions, <= 1.5 ulp.  Larger arguments take the ocml path.
+static __device__ __forceinline__ void exa_sincos(double x, double* sp, double* cp) {
+    if (!(fabs(x) < 823549.6)) { sincos(x, sp, cp); return; }            // also routes NaN/Inf to ocml
+    const double kd = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-kd, 1.57079632673412561417e+00, x);   // pio2_1  (first 33 bits of pi/2)
+    r = __builtin_fma(-kd, 6.07710050630396597660e-11, r);     // pio2_2  (next 33 bits)
+    r = __builtin_fma(-kd, 2.02226624879595063154e-21, r);     // pio2_2t (tail): pi/2 to ~119 bits in total
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = __builtin_fma(r * z, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double cs = w + (((1.0 - w) - hz) + z * z * pc);
+    const int q = (int)kd & 3;
+    const double s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
+    *sp = (q & 2) ? -s0 : s0;
+    *cp = ((q + 1) & 2) ? -c0 : c0;
+}
+static __device__ __forceinline__ double exa_sin(double x) { double s, c; exa_sincos(x, &s, &c); return s; }
+static __device__ __forceinline__ double exa_cos(double x) { double s, c; exa_sincos(x, &s, &c); return c; }
 // x^n, run-time integer n (Base.^(::Float64, ::Integer)): by squaring; n < 0 through the reciprocal
 static __device__ double exa_powi(double x, long n) {
     if (n == 0) return 1.0;
