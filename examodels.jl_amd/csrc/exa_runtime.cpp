@@ -163,7 +163,8 @@ std::string build_code_object(const std::string &source) {
     const char *cc = getenv("EXAHIP_HIPCC");
     std::string hipcc = cc && *cc ? cc : "/opt/rocm/bin/hipcc";
     const std::string log = obj + tag + ".log";
-    const std::string cmd = hipcc + " " + flags + " -o " + obj + tag + " " + src + " > " + log + " 2>&1";
+    auto q = [](const std::string &p) { return "'" + p + "'"; };   // paths may contain spaces; they never contain quotes
+    const std::string cmd = q(hipcc) + " " + flags + " -o " + q(obj + tag) + " " + q(src) + " > " + q(log) + " 2>&1";
     const int rc = std::system(cmd.c_str());
     if (rc != 0 || !file_exists(obj + tag)) {
         std::ifstream l(log);
