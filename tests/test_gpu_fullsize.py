@@ -122,3 +122,36 @@ def test_config4_acopf_78k_synthetic(libs):
     data = models.synthetic_power_data(nbus, nbr, ngen, seed=0)
     m, o, _, _ = full_compare(models.ac_power_model(data), seed=2, check_products=True)
     assert m.meta.nnzh == ngen + 44 * nbr + 2 * nbus
+
+
+def test_config5_size_lv_1e8_on_one_gpu(libs):
+    """BASELINE.json configs[4] size on ONE GPU: LV N=1e8 (nnzh = 9e8 < 2^31, 7.2 GB of COO).  64-bit indexing, int32
+    structure, and window parity against small models (window locality of Luksan-Vlcek: the slots of points [a, a+n)
+    depend only on x[a : a+n+2], y[a : a+n])."""
+    import torch
+    import oracle
+    from exahip import ExaModel, models
+    N = 100_000_000
+    m = ExaModel(models.luksan_vlcek_model(N))
+    dev = torch.device("cuda:0")
+    x = m.meta.x0 + 0.1 * np.random.default_rng(0).uniform(-1, 1, N)
+    y = np.random.default_rng(1).standard_normal(N - 2)
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    h = torch.empty(m.meta.nnzh, dtype=torch.float64, device=dev)
+    m.hess_coord(xd, yd, 0.5, out=h)
+    torch.cuda.synchronize()
+    assert m.meta.nnzh == 9 * N - 15
+    ob = 6 * (N - 2)
+    for a in (0, 12_345_678, 49_999_000, N - 1000 - 2):
+        n = 1000
+        o = oracle.OracleModel(models.luksan_vlcek_model(n + 2).to_ir())
+        ref = o.hess_coord(x[a:a + n + 2], y[a:a + n], 0.5)
+        got = h[6 * a:6 * (a + n)].cpu().numpy()
+        assert maxrel(got, ref[:6 * n]) <= RTOL
+        got_o = h[ob + 3 * a: ob + 3 * (a + n)].cpu().numpy()     # objective block: points I = a .. a+n (i = I+2)
+        assert maxrel(got_o, ref[6 * n: 6 * n + 3 * n]) <= RTOL
+    rows = torch.empty(m.meta.nnzh, dtype=torch.int32, device=dev)
+    cols = torch.empty(m.meta.nnzh, dtype=torch.int32, device=dev)
+    m.hess_structure(rows, cols)
+    torch.cuda.synchronize()
+    assert bool(torch.all(rows >= cols)) and int(rows.max()) == N and int(cols.min()) == 1

@@ -7,8 +7,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (os.path.join(ROOT, "examodels.jl_amd"), os.path.join(ROOT, "oracle")):
-    sys.path.insert(0, p)
+sys.path.insert(0, os.path.join(ROOT, "examodels.jl_amd"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
