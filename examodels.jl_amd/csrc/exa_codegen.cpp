@@ -843,11 +843,12 @@ void gen_value_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
 void gen_cons_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
     Body b(m, pi, L);
     os << "static __device__ __forceinline__ void " << fn_name(pi, "cons")
-       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ c, long tid) {\n"
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ c, "
+          "double* __restrict__ aug, long tid) {\n"
        << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n"
        << "    const double v = " << fn_name(pi, "val") << "(P, x, th, I);\n";
     // base rows: plain store into c; augmentation terms: into the value buffer, gathered per row by exa_aug_gather
-    if (b.p.kind == EXA_PAT_CONAUG) os << "    c[" << b.P(L.pat[pi].oa) << " + I] = v;\n";
+    if (b.p.kind == EXA_PAT_CONAUG) os << "    aug[" << b.P(L.pat[pi].oa) << " + I] = v;\n";
     else os << "    c[" << b.P(L.pat[pi].o0) << " + I] = v;\n";
     os << "}\n";
 }
@@ -1033,13 +1034,13 @@ void gen_jprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
             sum = b.e.add(sum, b.e.mul(a.acc[s], vv));
         }
     }
-    const std::string dst = p.kind == EXA_PAT_CONAUG ? b.P(L.pat[pi].oa) + " + I" : b.P(L.pat[pi].o0) + " + I";
+    const std::string dst = p.kind == EXA_PAT_CONAUG ? "aug[" + b.P(L.pat[pi].oa) + " + I]" : "out[" + b.P(L.pat[pi].o0) + " + I]";
     os << "static __device__ __forceinline__ void " << fn_name(pi, "jprod")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, const double* __restrict__ v, "
-          "double* __restrict__ out, long tid) {\n"
+          "double* __restrict__ out, double* __restrict__ aug, long tid) {\n"
        << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
     emit_lines(os, b.e);
-    os << "    out[" << dst << "] = " << b.e.sd(sum) << ";\n}\n";
+    os << "    " << dst << " = " << b.e.sd(sum) << ";\n}\n";
 }
 
 // J'v: out[k_s] += acc_s * v[row] (jacobian.jl:55-68) — shared targets, FP64 hardware atomics on a zeroed vector
@@ -1198,8 +1199,8 @@ Generated generate_module(const Model &m) {
             if (pull_ok(p, sl)) L.pull.push_back(k);
             else if (p.o1step > 0) L.active[CB_GRAD].push_back(k);
         } else {
-            if (p.kind == EXA_PAT_CON) { L.active[CB_CONS].push_back(k); L.active[CB_JPROD].push_back(k); }
-            else { L.active[CB_CONSAUG].push_back(k); L.active[CB_JPRODAUG].push_back(k); }
+            L.active[CB_CONS].push_back(k);      // base rows and augmentation terms share one launch
+            L.active[CB_JPROD].push_back(k);
             if (p.o1step > 0) L.active[CB_JTPROD].push_back(k);
             if (p.o1step > 0) { L.active[CB_JAC].push_back(k); L.active[CB_JSTRUCT].push_back(k); }
         }
@@ -1262,12 +1263,8 @@ Generated generate_module(const Model &m) {
     for (int k : L.pull) os << "    g += p" << k << "_pull(P, x, th, v + 1);\n";
     os << "    out[v] = g;\n}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_cons(const long* __restrict__ P, const double* __restrict__ x, "
-          "const double* __restrict__ th, double* __restrict__ out) {\n";
-    gen_dispatch(os, L, CB_CONS, "cons", "P, x, th, out");
-    os << "}\n";
-    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_consaug(const long* __restrict__ P, const double* __restrict__ x, "
-          "const double* __restrict__ th, double* __restrict__ out) {\n";
-    gen_dispatch(os, L, CB_CONSAUG, "cons", "P, x, th, out");
+          "const double* __restrict__ th, double* __restrict__ out, double* __restrict__ aug) {\n";
+    gen_dispatch(os, L, CB_CONS, "cons", "P, x, th, out, aug");
     os << "}\n";
     auto lds_decl = [&](int cb, bool hess) {
         int mx = 0;
@@ -1309,11 +1306,9 @@ Generated generate_module(const Model &m) {
     }
     const char *prod_sig = "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, "
                            "const double* __restrict__ v, double* __restrict__ out) {\n";
-    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jprod" << prod_sig;
-    gen_dispatch(os, L, CB_JPROD, "jprod", "P, x, th, v, out");
-    os << "}\n";
-    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jprodaug" << prod_sig;
-    gen_dispatch(os, L, CB_JPRODAUG, "jprod", "P, x, th, v, out");
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jprod(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ th, const double* __restrict__ v, double* __restrict__ out, double* __restrict__ aug) {\n";
+    gen_dispatch(os, L, CB_JPROD, "jprod", "P, x, th, v, out, aug");
     os << "}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jtprod" << prod_sig;
     gen_dispatch(os, L, CB_JTPROD, "jtprod", "P, x, th, v, out");

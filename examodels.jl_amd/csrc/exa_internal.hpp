@@ -75,8 +75,8 @@ std::unique_ptr<Model> plan_model(const exa_model_desc_t *desc);   // throws std
 // ---------------------------------------------------------------------------------------------------
 // Code generator (exa_codegen.cpp)
 // ---------------------------------------------------------------------------------------------------
-enum Callback { CB_OBJ = 0, CB_GRAD, CB_CONS, CB_CONSAUG, CB_JAC, CB_HESS, CB_JSTRUCT, CB_HSTRUCT,
-                CB_JPROD, CB_JPRODAUG, CB_JTPROD, CB_HPROD, CB_FUSED, CB_COUNT };
+enum Callback { CB_OBJ = 0, CB_GRAD, CB_CONS, CB_JAC, CB_HESS, CB_JSTRUCT, CB_HSTRUCT,
+                CB_JPROD, CB_JTPROD, CB_HPROD, CB_FUSED, CB_COUNT };
 
 struct ParamLayout {
     // word indices into the int64 parameter table P that every kernel receives

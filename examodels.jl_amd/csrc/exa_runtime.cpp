@@ -58,7 +58,7 @@ struct Handle {
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jprodaug = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_consaug = nullptr, f_jac = nullptr,
+    hipFunction_t f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
                   f_hess = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
@@ -281,9 +281,9 @@ void to_device(Handle &h) {
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
     h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
-    h.f_consaug = fn("exa_consaug"); h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull");
+    h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull");
     h.f_fused = fn("exa_fused");
-    h.f_jprod = fn("exa_jprod"); h.f_jprodaug = fn("exa_jprodaug"); h.f_jtprod = fn("exa_jtprod"); h.f_hprod = fn("exa_hprod"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
+    h.f_jprod = fn("exa_jprod"); h.f_jtprod = fn("exa_jtprod"); h.f_hprod = fn("exa_hprod"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
     h.colslot.resize(m.pats.size());
     for (size_t k = 0; k < m.pats.size(); k++) {
@@ -395,17 +395,18 @@ void do_grad(Handle &h, const double *x, double *g) {
 }
 void do_cons(Handle &h, const double *x, double *c) {
     if (h.m->ncon == 0) return;
-    if (h.world > 1) HIPCHK(hipMemsetAsync(c, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
+    void *buf = h.daugbuf.p;
+    if (h.world > 1) {
+        HIPCHK(hipMemsetAsync(c, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
+        if (h.m->nconaug) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
+    }
     const void *P = h.dP.p, *th = h.dtheta.p;
-    void *a[] = {&P, &x, &th, &c};
+    // one launch: base rows (plain stores into c) and augmentation terms (into the value buffer, coalesced)
+    void *a[] = {&P, &x, &th, &c, &buf};
     tune_order(h, CB_CONS, [&] { launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a); });
     launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a);
     if (h.m->nconaug == 0) return;
-    // augmentation: values into the buffer (coalesced), then one deterministic gather per target row
-    void *buf = h.daugbuf.p;
-    if (h.world > 1) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
-    void *a2[] = {&P, &x, &th, &buf};
-    launch(h, h.f_consaug, h.grid[CB_CONSAUG], kBlock, a2);
+    // then one deterministic gather per target row
     const void *rows = h.daugrows.p, *ptr = h.daugptr.p, *perm = h.daugperm.p;
     int64_t nrows = (int64_t)h.m->aug_rows.size();
     void *a3[] = {&rows, &ptr, &perm, &buf, &c, &nrows};
@@ -447,15 +448,15 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
 // matrix-free products (jprod_nln! / jtprod_nln! / hprod!, nlp.jl:1882-1978)
 void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
     if (h.m->ncon == 0) return;
-    if (h.world > 1) HIPCHK(hipMemsetAsync(Jv, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
+    void *buf = h.daugbuf.p;
+    if (h.world > 1) {
+        HIPCHK(hipMemsetAsync(Jv, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
+        if (h.m->nconaug) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
+    }
     const void *P = h.dP.p, *th = h.dtheta.p;
-    void *a[] = {&P, &x, &th, &v, &Jv};
+    void *a[] = {&P, &x, &th, &v, &Jv, &buf};
     launch(h, h.f_jprod, h.grid[CB_JPROD], kBlock, a);
     if (h.m->nconaug == 0) return;
-    void *buf = h.daugbuf.p;
-    if (h.world > 1) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
-    void *a2[] = {&P, &x, &th, &v, &buf};
-    launch(h, h.f_jprodaug, h.grid[CB_JPRODAUG], kBlock, a2);
     const void *rows = h.daugrows.p, *ptr = h.daugptr.p, *perm = h.daugperm.p;
     int64_t nrows = (int64_t)h.m->aug_rows.size();
     void *a3[] = {&rows, &ptr, &perm, &buf, &Jv, &nrows};
