@@ -144,3 +144,18 @@ def test_module_source_is_size_independent(libs):
     a = ExaModel(models.luksan_vlcek_model(10), device=False).kernel_source()
     b = ExaModel(models.luksan_vlcek_model(12345), device=False).kernel_source()
     assert a == b
+
+
+def test_kernel_build_failure_is_status_2_with_message(libs, tmp_path, monkeypatch):
+    """A failing hipcc (internal error) must come back as status 2 with the compiler's text, never as a crash or a
+    silent fallback."""
+    from exahip import ExaModel, models
+    from exahip.capi import ExaHipError
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))       # empty cache -> must invoke the compiler
+    monkeypatch.setenv("EXAHIP_HIPCC", "/bin/false")
+    m = ExaModel(models.luksan_vlcek_model(10), device=False)
+    with pytest.raises(ExaHipError, match="status 2.*hipcc failed"):
+        m.compile()
+    monkeypatch.setenv("EXAHIP_HIPCC", "/opt/rocm/bin/hipcc")
+    path = m.compile()
+    assert path.startswith(str(tmp_path)) and os.path.getsize(path) > 1000
