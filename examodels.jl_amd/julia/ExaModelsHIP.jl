@@ -185,6 +185,15 @@ function ExaModels.hprod!(m::HM, x::AbstractVector, y::AbstractVector, v::Abstra
     chk(ccall((:exa_hprod, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
               m.ext.id, pointer(x), pointer(y), pointer(v), Float64(obj_weight), pointer(Hv)), "exa_hprod"); Hv
 end
+# set_value!(model, param, values) (nlp.jl:1279-1287) writes model.θ; the library keeps its own device copy of θ, so the
+# update is forwarded (host values) — no rebuild, exactly as in the reference.
+function ExaModels.set_value!(m::ExaModels.ExaModel{T,VT,E}, param::ExaModels.Parameter, values) where {T,VT,E<:HIPExtension}
+    length(values) == param.length || throw(DimensionMismatch("expected $(param.length) elements, got $(length(values))"))
+    copyto!(view(m.θ, param.offset+1:param.offset+param.length), values)
+    v = Array{Float64}(values)
+    chk(ccall((:exa_set_value, LIB), Cint, (Cint, Int64, Ptr{Cdouble}, Int64), m.ext.id, param.offset, v, length(v)), "exa_set_value")
+    return nothing
+end
 function ExaModels.jac_structure!(m::HM, rows::AbstractVector, cols::AbstractVector)
     r, c = ROCArray{Int64}(undef, length(rows)), ROCArray{Int64}(undef, length(cols))
     chk(ccall((:exa_jac_structure64, LIB), Cint, (Cint, Ptr{Int64}, Ptr{Int64}), m.ext.id, pointer(r), pointer(c)), "exa_jac_structure64")
