@@ -810,20 +810,132 @@ void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, c
     }
 }
 
-// text of one scattered `out[idx-1] += val`; a literal index is wave-reduced first (all lanes must reach it)
-std::string scatter_text(Body &b, Val vi, Val val, bool &needs_full_wave) {
-    const std::string idx = b.e.s(b.e.sub(vi, Emitter::liti(1)));
-    if (vi.is_lit() && env_int("EXAHIP_WAVE_REDUCE", 1)) {
-        needs_full_wave = true;
-        return "exa_wave_atomic_add(&out[" + idx + "], act ? " + b.e.sd(val) + " : 0.0);";
+// ---- gather ("pull") formulation of the objective gradient ------------------------------------------------
+// index expression == a * (RANGE column) + c ?
+struct Affine { bool ok = false; int col = -1; int64_t a = 0, c = 0; };
+Affine affine(const Pattern &p, int k) {
+    const exa_node_t &nd = p.nodes[k];
+    Affine r;
+    if (nd.op == EXA_OP_CONST_I) { r.ok = true; r.c = nd.ival; return r; }
+    if (nd.op == EXA_OP_DATA) {
+        if (p.cols[nd.a].type != EXA_COL_RANGE) return r;
+        r.ok = true; r.col = nd.a; r.a = 1; return r;
     }
-    return "if (act) unsafeAtomicAdd(&out[" + idx + "], " + b.e.sd(val) + ");";
+    if (nd.op == EXA_OP_UN && (nd.fn == EXA_U_PLUS || nd.fn == EXA_U_MINUS)) {
+        Affine x = affine(p, nd.a);
+        if (!x.ok) return r;
+        if (nd.fn == EXA_U_MINUS) { x.a = -x.a; x.c = -x.c; }
+        return x;
+    }
+    if (nd.op == EXA_OP_BIN && (nd.fn == EXA_B_ADD || nd.fn == EXA_B_SUB || nd.fn == EXA_B_MUL)) {
+        Affine x = affine(p, nd.a), y = affine(p, nd.b);
+        if (!x.ok || !y.ok) return r;
+        if (nd.fn == EXA_B_MUL) {
+            if (x.col >= 0 && y.col >= 0) return r;
+            if (y.col >= 0) std::swap(x, y);
+            r.ok = true; r.col = x.col; r.a = x.a * y.c; r.c = x.c * y.c; return r;
+        }
+        const int64_t sg = nd.fn == EXA_B_ADD ? 1 : -1;
+        if (x.col >= 0 && y.col >= 0 && x.col != y.col) return r;
+        r.ok = true; r.col = x.col >= 0 ? x.col : y.col; r.a = x.a + sg * y.a; r.c = x.c + sg * y.c;
+        if (r.a == 0) r.col = -1;
+        return r;
+    }
+    return r;
 }
+
+// ---- scattered `out[idx-1] += val` (grad of data-indexed patterns, J'v, Hv) ------------------------------------
+// Three mechanisms, picked per target at generation time:
+//   * literal index (same target for every data point)      -> wavefront butterfly + ONE atomic (exa_wave_atomic_add);
+//   * index = (unit-step range value) + c for >= 2 targets   -> the wavefront's contributions fall into a window of
+//     64 + span consecutive variables: accumulate them in LDS (ds_add_f64), then 64 + span global atomics instead of
+//     64 per target (LV J'v: 192 -> 66 per wavefront);
+//   * anything else                                           -> one FP64 hardware atomic per lane.
+int g_lds_need[CB_COUNT];   // doubles of LDS per wavefront needed by the scatter windows of each callback (per module)
+// literal scatter targets of every (callback, pattern): 0-based variable indices, in the order of the pattern's `lit[]`
+std::map<std::pair<int, int>, std::vector<std::string>> g_lit_idx;
+
+struct Scatter {
+    struct Item { int ir; Val vidx, val; };
+    Body &b;
+    std::vector<Item> items;
+    std::vector<std::string> lit_idx;
+    explicit Scatter(Body &bb) : b(bb) {}
+    void add(int ad_leaf, Val val) {
+        if (val.lit_eq(0)) return;
+        items.push_back({b.p.ad[ad_leaf].ir, b.fv[ad_leaf].vidx, val});
+    }
+    // returns the LDS doubles needed per wavefront; fills `lines`; sets full_wave
+    int emit(std::vector<std::string> &lines, bool &full_wave) {
+        // candidates: index = (unit-step range value) + c, all on the same range column; clustered into windows of
+        // offsets that lie within 64 of each other (one window per variable block the pattern touches)
+        struct Cand { int item; int64_t c; };
+        std::vector<Cand> cand;
+        int col = -1;
+        if (env_int("EXAHIP_LDS_SCATTER", 1)) {
+            for (size_t k = 0; k < items.size(); k++) {
+                Affine a = affine(b.p, items[k].ir);
+                if (!a.ok || a.col < 0 || a.a != 1 || b.p.cols[a.col].step != 1) continue;
+                if (col >= 0 && a.col != col) continue;
+                col = a.col;
+                cand.push_back({(int)k, a.c});
+            }
+            std::stable_sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.c < y.c; });
+        }
+        std::vector<char> inwin(items.size(), 0);
+        int total = 0;
+        bool first = true;
+        for (size_t g0 = 0; g0 < cand.size();) {
+            size_t g1 = g0 + 1;
+            while (g1 < cand.size() && cand[g1].c - cand[g0].c <= 64) g1++;
+            if (g1 - g0 >= 2) {
+                const int64_t cmin = cand[g0].c, cmax = cand[g1 - 1].c;
+                const int W = 64 + (int)(cmax - cmin);
+                const std::string reg = "(lds + " + std::to_string(total) + ")";
+                full_wave = true;
+                if (first) lines.push_back("// scatter windows in LDS (one per variable block)");
+                first = false;
+                lines.push_back("for (int j = lane; j < " + std::to_string(W) + "; j += 64) " + reg + "[j] = 0.0;");
+                lines.push_back("__builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); "
+                                "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
+                std::string body = "if (act) {";
+                for (size_t q = g0; q < g1; q++) {
+                    body += " unsafeAtomicAdd(&" + reg + "[lane + " + std::to_string(cand[q].c - cmin) + "], " + b.e.sd(items[cand[q].item].val) + ");";
+                    inwin[cand[q].item] = 1;
+                }
+                lines.push_back(body + " }");
+                lines.push_back("__builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); "
+                                "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
+                // variable (0-based) held by the window's first word: range value of the wavefront's first point + cmin - 1
+                lines.push_back("{ const long wb = " + b.P(b.L.pat[b.pi].col[col]) + " + (I0 - lane) + (" + std::to_string(cmin) + "L) - 1L;");
+                lines.push_back("  for (int j = lane; j < " + std::to_string(W) + "; j += 64) { const double t_ = " + reg +
+                                "[j]; if (t_ != 0.0) unsafeAtomicAdd(&out[wb + j], t_); } }");
+                total += W;
+            }
+            g0 = g1;
+        }
+        const int W = total;
+        for (size_t k = 0; k < items.size(); k++) {
+            if (inwin[k]) continue;
+            const std::string idx = b.e.s(b.e.sub(items[k].vidx, Emitter::liti(1)));
+            if (items[k].vidx.is_lit() && env_int("EXAHIP_WAVE_REDUCE", 1)) {
+                // same target for every data point: accumulate in a register across this thread's tiles; the kernel
+                // adds it to memory ONCE per wavefront after the tile loop (pK_*_fin)
+                full_wave = true;
+                lines.push_back("lit[" + std::to_string(lit_idx.size()) + "] += act ? " + b.e.sd(items[k].val) + " : 0.0;");
+                lit_idx.push_back(idx);
+            } else {
+                lines.push_back("if (act) unsafeAtomicAdd(&out[" + idx + "], " + b.e.sd(items[k].val) + ");");
+            }
+        }
+        return W;
+    }
+};
 // prologue of a scattering pattern function (grad / jtprod / hprod)
 void emit_scatter_prologue(std::ostringstream &os, const Body &b, const ParamLayout &L, int pi, bool full_wave) {
     os << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n";
     if (full_wave)
-        os << "    if (I0 - (threadIdx.x & 63) >= hi) return;\n    const bool act = I0 < hi;\n    const long I = act ? I0 : hi - 1;\n";
+        os << "    const int lane = threadIdx.x & 63;\n    if (I0 - lane >= hi) return;\n    const bool act = I0 < hi;\n    const long I = act ? I0 : hi - 1;\n";
     else
         os << "    if (I0 >= hi) return;\n    const bool act = true;\n    const long I = I0;\n";
 }
@@ -863,15 +975,15 @@ void gen_first_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     // index texts are computed first so that they land in e.lines
     std::vector<std::string> stores, vals;
     bool full_wave = false;
+    Scatter sc(b);
     for (int s = 0; s < p.o1step; s++) {
-        if (grad) {
-            if (a.acc[s].lit_eq(0)) continue;
-            stores.push_back(scatter_text(b, b.fv[p.slotvar1[s]].vidx, a.acc[s], full_wave));
-        } else vals.push_back(b.e.sd(a.acc[s]));
+        if (grad) sc.add(p.slotvar1[s], a.acc[s]);
+        else vals.push_back(b.e.sd(a.acc[s]));
     }
+    if (grad) { g_lds_need[CB_GRAD] = std::max(g_lds_need[CB_GRAD], sc.emit(stores, full_wave)); g_lit_idx[{CB_GRAD, pi}] = sc.lit_idx; }
     os << "static __device__ __forceinline__ void " << fn_name(pi, grad ? "grad" : "jac")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ out, long tid"
-       << (grad ? "" : ", double* lds") << ") {\n";
+       << ", double* lds" << (grad ? ", double* lit" : "") << ") {\n";
     if (grad) emit_scatter_prologue(os, b, L, pi, full_wave);
     else emit_coo_prologue(os, b, L, pi, tile);
     emit_lines(os, b.e);
@@ -881,39 +993,6 @@ void gen_first_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
 }
 
 // ---- gather ("pull") formulation of the objective gradient ------------------------------------------------
-// index expression == a * (RANGE column) + c ?
-struct Affine { bool ok = false; int col = -1; int64_t a = 0, c = 0; };
-Affine affine(const Pattern &p, int k) {
-    const exa_node_t &nd = p.nodes[k];
-    Affine r;
-    if (nd.op == EXA_OP_CONST_I) { r.ok = true; r.c = nd.ival; return r; }
-    if (nd.op == EXA_OP_DATA) {
-        if (p.cols[nd.a].type != EXA_COL_RANGE) return r;
-        r.ok = true; r.col = nd.a; r.a = 1; return r;
-    }
-    if (nd.op == EXA_OP_UN && (nd.fn == EXA_U_PLUS || nd.fn == EXA_U_MINUS)) {
-        Affine x = affine(p, nd.a);
-        if (!x.ok) return r;
-        if (nd.fn == EXA_U_MINUS) { x.a = -x.a; x.c = -x.c; }
-        return x;
-    }
-    if (nd.op == EXA_OP_BIN && (nd.fn == EXA_B_ADD || nd.fn == EXA_B_SUB || nd.fn == EXA_B_MUL)) {
-        Affine x = affine(p, nd.a), y = affine(p, nd.b);
-        if (!x.ok || !y.ok) return r;
-        if (nd.fn == EXA_B_MUL) {
-            if (x.col >= 0 && y.col >= 0) return r;
-            if (y.col >= 0) std::swap(x, y);
-            r.ok = true; r.col = x.col; r.a = x.a * y.c; r.c = x.c * y.c; return r;
-        }
-        const int64_t sg = nd.fn == EXA_B_ADD ? 1 : -1;
-        if (x.col >= 0 && y.col >= 0 && x.col != y.col) return r;
-        r.ok = true; r.col = x.col >= 0 ? x.col : y.col; r.a = x.a + sg * y.a; r.c = x.c + sg * y.c;
-        if (r.a == 0) r.col = -1;
-        return r;
-    }
-    return r;
-}
-
 // An objective pattern can be gathered when every first-order slot's variable index is (range value) + c: variable
 // v then receives slot s from exactly one data point, I = (v - c_s - start) / step.  One thread per VARIABLE
 // re-evaluates the (cheap) pattern at those points: coalesced store, no zero-fill, no atomics, deterministic.
@@ -1053,14 +1132,13 @@ void gen_jtprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLa
     Val w = b.e.raw("v[" + b.row0() + "]", false);
     std::vector<std::string> stores;
     bool full_wave = false;
-    for (int s = 0; s < p.o1step; s++) {
-        Val t = b.e.mul(a.acc[s], w);
-        if (t.lit_eq(0)) continue;
-        stores.push_back(scatter_text(b, b.fv[p.slotvar1[s]].vidx, t, full_wave));
-    }
+    Scatter sc(b);
+    for (int s = 0; s < p.o1step; s++) sc.add(p.slotvar1[s], b.e.mul(a.acc[s], w));
+    g_lds_need[CB_JTPROD] = std::max(g_lds_need[CB_JTPROD], sc.emit(stores, full_wave));
+    g_lit_idx[{CB_JTPROD, pi}] = sc.lit_idx;
     os << "static __device__ __forceinline__ void " << fn_name(pi, "jtprod")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, const double* __restrict__ v, "
-          "double* __restrict__ out, long tid) {\n";
+          "double* __restrict__ out, long tid, double* lds, double* lit) {\n";
     emit_scatter_prologue(os, b, L, pi, full_wave);
     emit_lines(os, b.e);
     for (auto &st : stores) os << "    " << st << "\n";
@@ -1110,13 +1188,14 @@ void gen_hprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     }
     std::vector<std::string> stores;
     bool full_wave = false;
-    for (int k = 0; k < nk; k++) {
-        if (!used[k] || hv[k].lit_eq(0)) continue;
-        stores.push_back(scatter_text(b, b.fv[rep[k]].vidx, hv[k], full_wave));
-    }
+    Scatter sc(b);
+    for (int k = 0; k < nk; k++)
+        if (used[k]) sc.add(rep[k], hv[k]);
+    g_lds_need[CB_HPROD] = std::max(g_lds_need[CB_HPROD], sc.emit(stores, full_wave));
+    g_lit_idx[{CB_HPROD, pi}] = sc.lit_idx;
     os << "static __device__ __forceinline__ void " << fn_name(pi, "hprod")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
-          "const double* __restrict__ v, double* __restrict__ out, double sigma, long tid) {\n";
+          "const double* __restrict__ v, double* __restrict__ out, double sigma, long tid, double* lds, double* lit) {\n";
     emit_scatter_prologue(os, b, L, pi, full_wave);
     emit_lines(os, b.e);
     for (auto &st : stores) os << "    " << st << "\n";
@@ -1168,12 +1247,22 @@ void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const st
     // reading the same x ranges run on the same XCD at about the same time)
     os << "    const long e_ = ((const long*)P[" << L.blk[cb] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
           "    const long tid0 = (e_ & ((1L << 40) - 1)) * (EXA_BLOCK * " << ppt << ") + threadIdx.x;\n";
+    const bool scatter = cb == CB_GRAD || cb == CB_JTPROD || cb == CB_HPROD;
+    size_t maxlit = 0;
+    if (scatter) for (int pk : act) maxlit = std::max(maxlit, g_lit_idx[{cb, pk}].size());
+    if (scatter) os << "    double lit[" << std::max<size_t>(maxlit, 1) << "] = {0.0};\n";
     for (size_t k = 0; k < act.size(); k++) {
         os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n";
-        if (ppt > 1) os << "#pragma unroll\n        for (int u = 0; u < " << ppt << "; u++) ";
+        if (ppt > 1) os << "#pragma unroll 2\n        for (int u = 0; u < " << ppt << "; u++) ";
         else os << "        { const int u = 0; ";
-        os << "p" << act[k] << "_" << call_prefix << "(" << call_args << ", tid0 + u * EXA_BLOCK" << tail_args << ");" << (ppt > 1 ? "" : " }")
-           << "\n    }\n";
+        os << "p" << act[k] << "_" << call_prefix << "(" << call_args << ", tid0 + u * EXA_BLOCK" << tail_args << (scatter ? ", lit" : "") << ");"
+           << (ppt > 1 ? "" : " }") << "\n";
+        if (scatter) {
+            // targets shared by all data points: one wavefront reduction + one atomic per wavefront AFTER the tile loop
+            const auto &li = g_lit_idx[{cb, act[k]}];
+            for (size_t q = 0; q < li.size(); q++) os << "        exa_wave_atomic_add(&out[" << li[q] << "], lit[" << q << "]);\n";
+        }
+        os << "    }\n";
     }
 }
 
@@ -1216,6 +1305,8 @@ Generated generate_module(const Model &m) {
     L.ppt[CB_HESS] = env_int("EXAHIP_PPT_HESS", 1);
     L.nwords = w;
 
+    for (int &v : g_lds_need) v = 0;
+    g_lit_idx.clear();
     std::ostringstream os;
     { std::string pre = kPrelude; const std::string tag = "@BLOCK@"; pre.replace(pre.find(tag), tag.size(), std::to_string(kBlock)); os << pre; }
     os << "// patterns=" << np << " (sizes, offsets and column pointers are run-time parameters in P[])\n";
@@ -1236,6 +1327,14 @@ Generated generate_module(const Model &m) {
         if (p.o2step > 0) { gen_hess_fn(os, m, k, L); gen_struct_fn(os, m, k, L, true); gen_hprod_fn(os, m, k, L); }
         gen_fused_fn(os, m, k, L);
     }
+    // scatter kernels whose patterns have targets shared by ALL data points process 16 tiles per workgroup: the shared
+    // target then receives one atomic per wavefront per 16 tiles (same-address atomics serialise chip-wide at ~10 ns:
+    // the rocket's step variable took 47 000 of them per J'v, 0.47 ms)
+    for (int cb : {CB_GRAD, CB_JTPROD, CB_HPROD}) {
+        bool any = false;
+        for (int pk : L.active[cb]) any = any || !g_lit_idx[{cb, pk}].empty();
+        if (any) L.ppt[cb] = env_int("EXAHIP_PPT_LITERAL", 16);
+    }
     // obj: per-workgroup partial sums
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_obj(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ part) {\n    const long b = blockIdx.x;\n    double v = 0.0;\n";
@@ -1254,7 +1353,13 @@ Generated generate_module(const Model &m) {
     os << "    const double s = exa_block_sum(v);\n    if (threadIdx.x == 0) part[b] = s;\n}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_grad(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out) {\n";
-    gen_dispatch(os, L, CB_GRAD, "grad", "P, x, th, out");
+    auto scatter_lds = [&](int cb) {
+        if (g_lds_need[cb]) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << g_lds_need[cb] << "];\n    double* lds = lds_all + (threadIdx.x >> 6) * "
+                               << g_lds_need[cb] << ";\n";
+        else os << "    double* lds = nullptr;\n";
+    };
+    scatter_lds(CB_GRAD);
+    gen_dispatch(os, L, CB_GRAD, "grad", "P, x, th, out", ", lds");
     os << "}\n";
     // grad!, gather part: one thread per variable; also provides the zero of untouched variables (no memset)
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_grad_pull(const long* __restrict__ P, const double* __restrict__ x, "
@@ -1311,11 +1416,13 @@ Generated generate_module(const Model &m) {
     gen_dispatch(os, L, CB_JPROD, "jprod", "P, x, th, v, out, aug");
     os << "}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jtprod" << prod_sig;
-    gen_dispatch(os, L, CB_JTPROD, "jtprod", "P, x, th, v, out");
+    scatter_lds(CB_JTPROD);
+    gen_dispatch(os, L, CB_JTPROD, "jtprod", "P, x, th, v, out", ", lds");
     os << "}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hprod(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ y, const double* __restrict__ th, const double* __restrict__ v, double* __restrict__ out, double sigma) {\n";
-    gen_dispatch(os, L, CB_HPROD, "hprod", "P, x, y, th, v, out, sigma");
+    scatter_lds(CB_HPROD);
+    gen_dispatch(os, L, CB_HPROD, "hprod", "P, x, y, th, v, out, sigma", ", lds");
     os << "}\n";
     for (int wide = 0; wide < 2; wide++) {
         const char *it = wide ? "long" : "int";
