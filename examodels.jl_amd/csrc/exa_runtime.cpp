@@ -74,7 +74,7 @@ struct Handle {
     // sorted-gather products (the reference's prod helper): COO coordinates + entries grouped by column / by row
     DevBuf pjrows, pjcols, phrows, phcols;
     SortedIndex jbycol, hbyrow, hbycol;
-    bool prod_ready = false;
+    bool prod_ready_j = false, prod_ready_h = false;
     int jt_mode = -1, hp_mode = -1;         // -1 undecided, 0 atomics in the sweep, 1 COO + sorted gather
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
@@ -483,18 +483,22 @@ void do_hess(Handle &h, const double *x, const double *y, double sigma, double *
 // the COO.  Which of the two implementations runs is decided per model by MEASURING both once (exa_jtprod/exa_hprod
 // first call): atomics win on stencil models (LV), sorted gathers win when many data points hit few targets
 // (rocket's shared step variable, ACOPF bus rows).
-void prod_setup(Handle &h) {
-    if (h.prod_ready) return;
+void prod_setup(Handle &h, bool hess) {
     const Model &m = *h.m;
-    h.pjrows.ensure(8 * (size_t)std::max<int64_t>(m.nnzj, 1)); h.pjcols.ensure(8 * (size_t)std::max<int64_t>(m.nnzj, 1));
-    h.phrows.ensure(8 * (size_t)std::max<int64_t>(m.nnzh, 1)); h.phcols.ensure(8 * (size_t)std::max<int64_t>(m.nnzh, 1));
-    do_struct(h, false, true, h.pjrows.p, h.pjcols.p);
-    do_struct(h, true, true, h.phrows.p, h.phcols.p);
-    build_sorted_index(h.jbycol, (const int64_t *)h.pjcols.p, m.nnzj, m.nvar, h.stream);
-    build_sorted_index(h.hbyrow, (const int64_t *)h.phrows.p, m.nnzh, m.nvar, h.stream);
-    build_sorted_index(h.hbycol, (const int64_t *)h.phcols.p, m.nnzh, m.nvar, h.stream);
     h.cbuf.ensure(8 * (size_t)std::max<int64_t>(std::max(m.nnzj, m.nnzh), 1));
-    h.prod_ready = true;
+    if (!hess && !h.prod_ready_j) {
+        h.pjrows.ensure(8 * (size_t)std::max<int64_t>(m.nnzj, 1)); h.pjcols.ensure(8 * (size_t)std::max<int64_t>(m.nnzj, 1));
+        do_struct(h, false, true, h.pjrows.p, h.pjcols.p);
+        build_sorted_index(h.jbycol, (const int64_t *)h.pjcols.p, m.nnzj, m.nvar, h.stream);
+        h.prod_ready_j = true;
+    }
+    if (hess && !h.prod_ready_h) {
+        h.phrows.ensure(8 * (size_t)std::max<int64_t>(m.nnzh, 1)); h.phcols.ensure(8 * (size_t)std::max<int64_t>(m.nnzh, 1));
+        do_struct(h, true, true, h.phrows.p, h.phcols.p);
+        build_sorted_index(h.hbyrow, (const int64_t *)h.phrows.p, m.nnzh, m.nvar, h.stream);
+        build_sorted_index(h.hbycol, (const int64_t *)h.phcols.p, m.nnzh, m.nvar, h.stream);
+        h.prod_ready_h = true;
+    }
 }
 void do_jtprod_sorted(Handle &h, const double *x, const double *v, double *Jtv) {
     do_jac(h, x, (double *)h.cbuf.p);
@@ -702,15 +706,24 @@ int exa_jprod(int id, const double *x, const double *v, double *Jv) {
 }
 static void run_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
     if (h.jt_mode < 0) {
-        if (h.world != 1 || h.m->nnzj == 0) h.jt_mode = 0;    // sorted lists describe the unsharded COO
-        else { prod_setup(h); h.jt_mode = pick_faster(h, [&] { do_jtprod(h, x, v, Jtv); }, [&] { do_jtprod_sorted(h, x, v, Jtv); }); }
+        // sorted lists describe the unsharded COO; beyond 3e8 entries the trial's transient memory is not worth it
+        if (h.world != 1 || h.m->nnzj == 0 || h.m->nnzj > 300000000LL) h.jt_mode = 0;
+        else {
+            prod_setup(h, false);
+            h.jt_mode = pick_faster(h, [&] { do_jtprod(h, x, v, Jtv); }, [&] { do_jtprod_sorted(h, x, v, Jtv); });
+            if (h.jt_mode == 0) { h.jbycol.release(); h.pjrows.release(); h.pjcols.release(); h.prod_ready_j = false; }
+        }
     }
     if (h.jt_mode == 1 && h.world == 1) do_jtprod_sorted(h, x, v, Jtv); else do_jtprod(h, x, v, Jtv);
 }
 static void run_hprod(Handle &h, const double *x, const double *y, const double *v, double w, double *Hv) {
     if (h.hp_mode < 0) {
-        if (h.world != 1 || h.m->nnzh == 0) h.hp_mode = 0;
-        else { prod_setup(h); h.hp_mode = pick_faster(h, [&] { do_hprod(h, x, y, v, w, Hv); }, [&] { do_hprod_sorted(h, x, y, v, w, Hv); }); }
+        if (h.world != 1 || h.m->nnzh == 0 || h.m->nnzh > 300000000LL) h.hp_mode = 0;
+        else {
+            prod_setup(h, true);
+            h.hp_mode = pick_faster(h, [&] { do_hprod(h, x, y, v, w, Hv); }, [&] { do_hprod_sorted(h, x, y, v, w, Hv); });
+            if (h.hp_mode == 0) { h.hbyrow.release(); h.hbycol.release(); h.phrows.release(); h.phcols.release(); h.prod_ready_h = false; }
+        }
     }
     if (h.hp_mode == 1 && h.world == 1) do_hprod_sorted(h, x, y, v, w, Hv); else do_hprod(h, x, y, v, w, Hv);
 }
@@ -726,7 +739,11 @@ int exa_hprod(int id, const double *x, const double *y, const double *v, double 
 int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode) {
     if (jtprod_mode < -1 || jtprod_mode > 1 || hprod_mode < -1 || hprod_mode > 1) return 1;
     return guard(id, true, [&](Handle &h) {
-        if (jtprod_mode == 1 || hprod_mode == 1) { if (h.world != 1) throw BadInput("sorted products need the unsharded model"); prod_setup(h); }
+        if (jtprod_mode == 1 || hprod_mode == 1) {
+            if (h.world != 1) throw BadInput("sorted products need the unsharded model");
+            if (jtprod_mode == 1) prod_setup(h, false);
+            if (hprod_mode == 1) prod_setup(h, true);
+        }
         h.jt_mode = jtprod_mode; h.hp_mode = hprod_mode;
     });
 }
