@@ -315,10 +315,12 @@ class Expression:
 
     def __init__(self, fn, size):
         self.fn, self.size = fn, size
+        self.length = 1
+        for s in size:
+            self.length *= _length(s)
 
     def __getitem__(self, i):
-        if isinstance(i, tuple):
-            return self.fn(*i)
+        # the body sees its index exactly as an iterator element would arrive: a scalar for 1-D, a tuple otherwise
         return self.fn(i)
 
 
@@ -454,7 +456,11 @@ class ExaCore:
     # -- subexpressions ------------------------------------------------------------------------------------
     def add_expr(self, fn, itr):
         it = _Iter(itr)
-        return Expression(fn, it.dims)
+        if it.kind == "product":        # size = the axes themselves when they are ranges (subexpr_test.jl:81)
+            size = tuple(_as_urange(a) if isinstance(a, (URange, range)) else len(a) for a in it.axes)
+        else:
+            size = it.dims
+        return Expression(fn, size)
 
     # -- objective ------------------------------------------------------------------------------------------
     def add_obj(self, fn, itr=None):

@@ -60,6 +60,15 @@ def small_acopf():
     return models.ac_power_model(models.synthetic_power_data(nbus=30, nbr=41, ngen=6, seed=3))
 
 
+def trivialmax_model(n=6):
+    """test/NLPTest/trivialmax.jl:3-10: a maximisation with scalar (iterator-free) objective and constraint."""
+    c = ExaCore(minimize=False)
+    x = c.add_var(n, start=0.3)
+    c.add_con(x[1], lcon=0.0, ucon=1.0)
+    c.add_obj(x[1] ** 2)
+    return c
+
+
 ZOO = {
     "lv3": lambda: models.luksan_vlcek_model(3),
     "lv20": lambda: models.luksan_vlcek_model(20),
@@ -74,4 +83,5 @@ ZOO = {
     "stepped": stepped_model,
     "cops_chain": lambda: models.cops_chain_model(200),
     "cops_elec": lambda: models.cops_elec_model(25),
+    "trivialmax": trivialmax_model,
 }
