@@ -104,4 +104,17 @@ int block_threads();
 
 Generated generate_module(const Model &m);
 
+// ---------------------------------------------------------------------------------------------------
+// Runtime services used by the recipe layer (exa_recipe.cpp)
+// ---------------------------------------------------------------------------------------------------
+struct BlockInfo {          // one named variable / constraint / parameter block of an instance (cnlp P_block)
+    std::string name;
+    int kind = 0;           // 0 variable, 1 constraint, 2 parameter
+    int64_t offset = 0, length = 0;
+    std::vector<int64_t> dims;
+};
+int create_model(const exa_model_desc_t *desc, int *id_out, bool device);   // C-ABI status; sets the last-error text
+int attach_blocks(int id, std::vector<BlockInfo> blocks);
+void set_last_error(const std::string &text);
+
 }  // namespace exa

@@ -22,6 +22,7 @@
 
 #include "exa_compress.hpp"
 #include "exa_internal.hpp"
+#include "../../include/exahip_recipe.h"
 
 using namespace exa;
 
@@ -71,6 +72,9 @@ struct Handle {
     CompressedCOO cj, ch;                   // duplicate-summed COO maps (exa_compress)
     DevBuf cbuf;                            // uncompressed values of the last compressed evaluation
     bool compressed = false;
+    std::vector<BlockInfo> blocks;          // named blocks (recipes; empty for plain pattern tables)
+    std::vector<exa_pattern_t> view_pats;   // exa_describe: pattern-table view of the host copy
+    std::vector<std::vector<exa_column_t>> view_cols;
     // sorted-gather products (the reference's prod helper): COO coordinates + entries grouped by column / by row
     DevBuf pjrows, pjcols, phrows, phcols;
     SortedIndex jbycol, hbyrow, hbycol;
@@ -584,6 +588,17 @@ int create(const exa_model_desc_t *desc, int *id_out, bool device) {
 
 }  // namespace
 
+namespace exa {
+int create_model(const exa_model_desc_t *desc, int *id_out, bool device) { return create(desc, id_out, device); }
+int attach_blocks(int id, std::vector<BlockInfo> blocks) {
+    Handle *h = get(id);
+    if (!h) return 1;
+    h->blocks = std::move(blocks);
+    return 0;
+}
+void set_last_error(const std::string &text) { g_err = text; }
+}  // namespace exa
+
 extern "C" {
 
 int exa_abi_version(void) { return EXAHIP_ABI_VERSION; }
@@ -667,6 +682,72 @@ int exa_set_value(int id, int64_t offset, const double *vals, int64_t len) {
             HIPCHK(hipStreamSynchronize(h.stream));
         }
     });
+}
+
+int exa_get_value(int id, int64_t offset, double *vals, int64_t len) {
+    Handle *hh = get(id);
+    if (!hh || !vals || offset < 0 || len < 0 || offset + len > hh->m->npar) return 1;
+    std::memcpy(vals, hh->m->theta.data() + offset, 8 * (size_t)len);   // the host copy is authoritative (exa_set_value)
+    return 0;
+}
+
+// ---- named blocks (cnlp P_nblocks / P_block_name / P_block / P_get_value / P_set_value, Compiler :1476-1535) ----
+int exa_nblocks(int id) { Handle *h = get(id); return h ? (int)h->blocks.size() : -1; }
+int exa_block_name(int id, int k, char *buf, int cap) {
+    Handle *h = get(id);
+    if (!h || k < 0 || k >= (int)h->blocks.size()) return -1;
+    const std::string &s = h->blocks[k].name;
+    const int n = (int)s.size(), c = std::min(cap, n);
+    if (c > 0 && buf) std::memcpy(buf, s.data(), (size_t)c);
+    return n;
+}
+int exa_block(int id, int k, int *out) {
+    Handle *h = get(id);
+    if (!h || !out || k < 0 || k >= (int)h->blocks.size()) return 1;
+    const BlockInfo &b = h->blocks[k];
+    out[0] = b.kind; out[1] = (int)b.offset; out[2] = (int)b.length; out[3] = (int)b.dims.size();
+    for (size_t j = 0; j < b.dims.size(); j++) out[4 + j] = (int)b.dims[j];
+    return 0;
+}
+static int value_block(int id, int k, double *get_to, const double *set_from, int len) {
+    Handle *h = get(id);
+    if (!h || k < 0 || k >= (int)h->blocks.size() || h->blocks[k].kind != 2 || (!get_to && !set_from)) return 1;
+    const BlockInfo &b = h->blocks[k];
+    if ((int64_t)len != b.length) return 3;
+    return get_to ? exa_get_value(id, b.offset, get_to, len) : exa_set_value(id, b.offset, set_from, len);
+}
+int exa_get_value_block(int id, int k, double *vals, int len) { return value_block(id, k, vals, nullptr, len); }
+int exa_set_value_block(int id, int k, const double *vals, int len) { return value_block(id, k, nullptr, vals, len); }
+
+// pattern-table view of a planned model that still holds its host columns
+int exa_describe(int id, exa_model_desc_t *out) {
+    Handle *hh = get(id);
+    if (!hh || !out) return 1;
+    if (hh->on_device) { set_last_error("exa_describe: the host columns were released when the model went to the device"); return 1; }
+    Handle &h = *hh;
+    Model &m = *h.m;
+    h.view_pats.assign(m.pats.size(), exa_pattern_t{});
+    h.view_cols.assign(m.pats.size(), {});
+    for (size_t k = 0; k < m.pats.size(); k++) {
+        Pattern &p = m.pats[k];
+        for (Column &c : p.cols) {
+            exa_column_t v{};
+            v.type = c.type;
+            v.data = c.type == EXA_COL_I64 ? (const void *)c.idata.data() : c.type == EXA_COL_F64 ? (const void *)c.fdata.data() : nullptr;
+            v.start = c.start; v.step = c.step;
+            h.view_cols[k].push_back(v);
+        }
+        exa_pattern_t &v = h.view_pats[k];
+        v.kind = p.kind; v.n_nodes = (int)p.nodes.size(); v.nodes = p.nodes.data();
+        v.root = p.root; v.target = p.target; v.base = p.base;
+        v.n_cols = (int)p.cols.size(); v.cols = h.view_cols[k].data(); v.n = p.n;
+    }
+    *out = exa_model_desc_t{};
+    out->nvar = m.nvar; out->npar = m.npar;
+    out->x0 = m.x0.data(); out->lvar = m.lvar.data(); out->uvar = m.uvar.data(); out->theta0 = m.theta.data();
+    out->n_patterns = (int)m.pats.size(); out->minimize = m.minimize; out->patterns = h.view_pats.data();
+    out->y0 = m.y0.data(); out->lcon = m.lcon.data(); out->ucon = m.ucon.data();
+    return 0;
 }
 
 int exa_obj_async(int id, const double *x, double *out_dev) {

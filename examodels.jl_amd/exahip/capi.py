@@ -25,12 +25,19 @@ SYMBOLS = [
     "exa_eval_fused", "exa_set_product_mode", "exa_get_product_mode", "exa_compress", "exa_cnnzj64", "exa_cnnzh64", "exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64",
     "exa_chess_structure64", "exa_cjac", "exa_chess",
 ]
+# ... and include/exahip_recipe.h
+RECIPE_SYMBOLS = [
+    "exa_recipe_load", "exa_recipe_free", "exa_recipe_nargs", "exa_recipe_argtype", "exa_recipe_schema", "exa_recipe_new",
+    "exa_recipe_plan", "exa_data_begin", "exa_data_free", "exa_set_scalar_i64", "exa_set_scalar_f64", "exa_set_array_i64",
+    "exa_set_array_f64", "exa_set_col_i64", "exa_set_col_f64", "exa_data_ready", "exa_new_from_data", "exa_plan_from_data",
+    "exa_nblocks", "exa_block_name", "exa_block", "exa_get_value_block", "exa_set_value_block", "exa_get_value", "exa_describe",
+]
 
 
 def build(force=False):
     """Compile libexahip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hpp"))]
-    srcs += [os.path.join(CSRC, "..", "..", "include", f) for f in ("exahip.h", "exahip_ir.h")]
+    srcs += [os.path.join(CSRC, "..", "..", "include", f) for f in ("exahip.h", "exahip_ir.h", "exahip_recipe.h")]
     newest = max(os.path.getmtime(s) for s in srcs)
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
         subprocess.check_call(["make", "-C", CSRC, "-s", "-B"])
@@ -100,6 +107,28 @@ def lib():
     for f in ("exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64", "exa_chess_structure64", "exa_cjac"):
         getattr(L, f).argtypes = [i32, vp, vp]
     L.exa_chess.argtypes = [i32, vp, vp, dbl, vp]
+    # include/exahip_recipe.h
+    cp, sz = ctypes.c_char_p, ctypes.c_size_t
+    L.exa_recipe_load.argtypes = [vp, sz]
+    for f in ("exa_recipe_free", "exa_recipe_nargs", "exa_data_begin", "exa_data_free", "exa_data_ready", "exa_new_from_data",
+              "exa_plan_from_data", "exa_nblocks"):
+        getattr(L, f).argtypes = [i32]
+    for f in ("exa_recipe_argtype", "exa_recipe_schema"):
+        getattr(L, f).argtypes = [i32, vp, i32]
+    L.exa_recipe_new.argtypes = [i32, i32]
+    L.exa_recipe_plan.argtypes = [i32, i32]
+    L.exa_set_scalar_i64.argtypes = [i32, cp, i64]
+    L.exa_set_scalar_f64.argtypes = [i32, cp, dbl]
+    L.exa_set_array_i64.argtypes = [i32, cp, vp, i32]
+    L.exa_set_array_f64.argtypes = [i32, cp, vp, i32]
+    L.exa_set_col_i64.argtypes = [i32, cp, cp, vp, i32]
+    L.exa_set_col_f64.argtypes = [i32, cp, cp, vp, i32]
+    L.exa_block_name.argtypes = [i32, i32, vp, i32]
+    L.exa_block.argtypes = [i32, i32, vp]
+    L.exa_get_value_block.argtypes = [i32, i32, vp, i32]
+    L.exa_set_value_block.argtypes = [i32, i32, vp, i32]
+    L.exa_get_value.argtypes = [i32, i64, vp, i64]
+    L.exa_describe.argtypes = [i32, vp]
     _LIB = L
     return L
 

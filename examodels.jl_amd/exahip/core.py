@@ -17,6 +17,8 @@ import itertools
 import numpy as np
 
 from . import graph as G
+from . import recipe as R
+from .recipe import ArgTable, TArray, TInt, keep_int, max0
 from .graph import (BIN_ID, UN_ID, Constant, DataIndexed, DataSource, Node, Node1, Node2, Null,
                     ParameterNode, Var, _is_real, _norm_real)
 
@@ -60,15 +62,20 @@ class URange:
     """Julia-style inclusive range a:b or a:s:b."""
 
     def __init__(self, start, stop, step=1):
-        self.start, self.stop, self.step = int(start), int(stop), int(step)
+        self.start, self.stop, self.step = keep_int(start), keep_int(stop), keep_int(step)
+
+    @property
+    def length(self):
+        """len(self) that keeps a recipe's size expression (Python's len() must return a plain int)."""
+        if self.step > 0:
+            return max0((self.stop - self.start) // self.step + 1)
+        return max0((self.start - self.stop) // (-self.step) + 1)
 
     def __len__(self):
-        if self.step > 0:
-            return max(0, (self.stop - self.start) // self.step + 1)
-        return max(0, (self.start - self.stop) // (-self.step) + 1)
+        return int(self.length)
 
     def __iter__(self):
-        return iter(range(self.start, self.start + self.step * len(self), self.step))
+        return iter(range(int(self.start), int(self.start) + int(self.step) * len(self), int(self.step)))
 
     def __repr__(self):
         return f"{self.start}:{self.stop}" if self.step == 1 else f"{self.start}:{self.step}:{self.stop}"
@@ -119,7 +126,7 @@ class Product:
     """Iterators.product(r1, r2, ...) / multi-`for` generator: first index fastest (column-major)."""
 
     def __init__(self, *axes):
-        self.axes = [a if isinstance(a, (URange, range)) else np.asarray(a) for a in axes]
+        self.axes = [a if isinstance(a, (URange, range, TArray)) else np.asarray(a) for a in axes]
 
     def __len__(self):
         n = 1
@@ -141,10 +148,24 @@ class _Iter:
         if isinstance(itr, (URange, range)):
             r = _as_urange(itr)
             self.kind = "range"
-            self.n = len(r)
+            self.n = r.length
             self.r = r
             self.template = 0
             self.dims = (r,)
+        elif isinstance(itr, ArgTable):            # recipe placeholder: a table whose rows arrive at instantiation
+            self.kind = "table"
+            self.src = Table(**itr.cols)
+            self.arg = itr
+            self.n = itr.nrows
+            self.template = {k: (0 if v.dtype.kind == "i" else 0.0) for k, v in itr.cols.items()}
+            self.dims = (self.n,)
+        elif isinstance(itr, TArray) and itr.src is not None:   # recipe placeholder array iterated directly
+            self.kind = "list"
+            self.lst = np.asarray(itr)
+            self.arg = itr
+            self.n = itr.n
+            self.dims = (self.n,)
+            self.template = _template_of(self.lst[0]) if len(self.lst) else 0
         elif isinstance(itr, Table):
             self.kind = "table"
             self.n = itr.n
@@ -152,10 +173,12 @@ class _Iter:
             self.dims = (self.n,)
         elif isinstance(itr, Product):
             self.kind = "product"
-            self.n = len(itr)
-            self.template = tuple(0 for _ in itr.axes)
-            self.dims = tuple(len(a) for a in itr.axes)
             self.axes = itr.axes
+            self.dims = tuple(_axis_len(a) for a in itr.axes)
+            self.n = 1
+            for d in self.dims:
+                self.n = self.n * d
+            self.template = tuple(0 for _ in itr.axes)
         elif isinstance(itr, np.ndarray) and itr.dtype.names:
             self.kind = "table"
             t = Table(**{k: itr[k] for k in itr.dtype.names})
@@ -191,7 +214,7 @@ class _Iter:
             inner = 1
             for a in self.axes[:k]:
                 inner *= len(a)
-            outer = self.n // (inner * len(self.axes[k])) if self.n else 0
+            outer = int(self.n) // (inner * len(self.axes[k])) if int(self.n) else 0
             ax = self.axes[k]
             vals = np.fromiter(iter(ax), dtype=np.int64, count=len(ax)) if isinstance(ax, (URange, range)) \
                 else np.asarray(ax)
@@ -215,6 +238,50 @@ class _Iter:
                 out = (COL_F64, a, 0, 0)
         self._cache[path] = out
         return out
+
+
+def _axis_len(a):
+    if isinstance(a, (URange, range)):
+        return _as_urange(a).length
+    if isinstance(a, TArray) and a.src is not None:
+        return a.n
+    return len(a)
+
+
+def _rcolumn(it, path):
+    """Recipe form of the column `path` of iterator `it` (include/exahip_recipe.h, column kinds)."""
+    if it.kind == "range":
+        return (R.RCOL_RANGE, it.r.start, it.r.step)
+    arg = getattr(it, "arg", None)
+    if it.kind == "table" and arg is not None:
+        return (R.RCOL_COL, arg.field, list(arg.cols).index(path[0]))
+    if it.kind == "list" and arg is not None:
+        assert path == (), "a placeholder array element has no fields"
+        return (R.RCOL_FIELD, arg.src[1]) if arg.src[0] == R.SRC_FIELD else (R.RCOL_COL, arg.src[1], arg.src[2])
+    if it.kind == "product":
+        k = path[0]
+        inner = 1
+        for a in it.axes[:k]:
+            inner = inner * _axis_len(a)
+        ax = it.axes[k]
+        tagged = any(isinstance(v, TInt) for v in it.dims)
+        if isinstance(ax, (URange, range)):
+            r = _as_urange(ax)
+            if tagged or isinstance(r.start, TInt) or isinstance(r.step, TInt):
+                return (R.RCOL_AXIS_RANGE, r.start, r.step, r.length, inner)
+        elif isinstance(ax, TArray) and ax.src is not None:
+            col = -1 if ax.src[0] == R.SRC_FIELD else ax.src[2]
+            return (R.RCOL_AXIS_FIELD, ax.src[1], col, ax.n, inner)
+        elif tagged:
+            a = np.asarray(ax)
+            kind = R.RCOL_AXIS_INLINE_I64 if a.dtype.kind in "iu" else R.RCOL_AXIS_INLINE_F64
+            return (kind, a, len(a), inner)
+    ct, arr, st, sp = it.column(path)          # size-independent data: inline
+    if ct == COL_RANGE:
+        return (R.RCOL_RANGE, st, sp)
+    if isinstance(it.n, TInt):
+        raise R.RecipeError("an iterator of placeholder length needs placeholder data (a table / array field)")
+    return (R.RCOL_INLINE_I64 if ct == COL_I64 else R.RCOL_INLINE_F64, arr)
 
 
 def _template_of(e):
@@ -248,7 +315,7 @@ def _start(s):
 
 
 def _length(s):
-    return len(s) if isinstance(s, URange) else int(s)
+    return s.length if isinstance(s, URange) else keep_int(s)
 
 
 def _idxx(coord, sizes):
@@ -409,8 +476,17 @@ class ExaCore:
     """Mutable accumulator (the reference's ExaCore is immutable and returned anew, nlp.jl:328-366; the
     counters and their order are the same)."""
 
-    def __init__(self, minimize=True):
+    def __init__(self, minimize=True, examples=None):
+        """`examples` makes the core a RECIPE (the reference's `ExaCore(nargs = Val(N))`, nlp.jl:507-523): one
+        placeholder per example value is available as `core.args` — see exahip/recipe.py."""
         self.minimize = bool(minimize)
+        self.schema = None
+        self.args = ()
+        if examples is not None:
+            self.schema = R.Schema()
+            self.args = tuple(R.make_placeholders(self.schema, tuple(examples)))
+        self.blocks = []          # named blocks (name, kind 0 var / 1 con / 2 par, offset, length, dims): cnlp P_block
+        self._segs = {k: [] for k in ("x0", "lvar", "uvar", "theta", "y0", "lcon", "ucon")}
         self.nvar = 0
         self.npar = 0
         self.ncon = 0
@@ -422,36 +498,58 @@ class ExaCore:
         self.patterns: list[_Pattern] = []
 
     # -- variables / parameters ---------------------------------------------------------------------------
-    def add_var(self, *ns, start=0.0, lvar=-np.inf, uvar=np.inf):
+    def add_var(self, *ns, start=0.0, lvar=-np.inf, uvar=np.inf, name=None):
         size = tuple(_as_size(n) for n in ns)
         length = 1
         for s in size:
-            length *= _length(s)
+            length = length * _length(s)
         o = self.nvar
-        self.nvar += length
-        self.x0.append(_fill(start, length))
-        self.lvar.append(_fill(lvar, length))
-        self.uvar.append(_fill(uvar, length))
+        self.nvar = self.nvar + length
+        self._vec("x0", self.x0, start, length)
+        self._vec("lvar", self.lvar, lvar, length)
+        self._vec("uvar", self.uvar, uvar, length)
+        self._block(name, 0, o, length, size)
         return Variable(size, length, o)
 
-    def add_par(self, *ns, value=0.0):
+    def _vec(self, which, parts, value, n):
+        """append one block of a start/bound vector, remembering where it came from (recipe segments)"""
+        parts.append(_fill(value, int(n)))
+        if isinstance(value, TArray) and value.src is not None:
+            src = value.src
+        elif isinstance(value, TArray) or np.ndim(value) > 0 or callable(value):
+            if isinstance(n, TInt):
+                raise R.RecipeError(f"{which}: a block of placeholder length needs a scalar or a placeholder array")
+            src = (R.SRC_INLINE, parts[-1])
+        else:
+            src = (R.SRC_CONST, float(value))
+        self._segs[which].append((n, src))
+
+    def _block(self, name, kind, offset, length, size):
+        if name is not None:
+            self.blocks.append((str(name), kind, offset, length, tuple(_length(s) for s in size)))
+
+    def add_par(self, *ns, value=0.0, name=None):
         if len(ns) == 1 and not isinstance(ns[0], (int, np.integer, URange, range)):
             value = ns[0]
-            ns = (len(value),)
+            ns = (R.length(value),)
         size = tuple(_as_size(n) for n in ns)
         length = 1
         for s in size:
-            length *= _length(s)
+            length = length * _length(s)
         o = self.npar
-        self.npar += length
-        self.theta.append(_fill(value, length))
+        self.npar = self.npar + length
+        self._vec("theta", self.theta, value, length)
+        self._block(name, 2, o, length, size)
         return Parameter(size, length, o)
 
     def set_value(self, par: Parameter, values):
         """set_value!(core, θ, vals) before the model is built (nlp.jl:1279-1287)."""
+        if any(isinstance(n, TInt) or src[0] in (R.SRC_FIELD, R.SRC_COL) for n, src in self._segs["theta"]):
+            raise R.RecipeError("set_value on a recipe core: set the instance's values after instantiation")
         flat = np.concatenate(self.theta) if self.theta else np.zeros(0)
         flat[par.offset:par.offset + par.length] = _fill(values, par.length)
         self.theta = [flat]
+        self._segs["theta"] = [(len(flat), (R.SRC_INLINE, flat))]
 
     # -- subexpressions ------------------------------------------------------------------------------------
     def add_expr(self, fn, itr):
@@ -468,12 +566,12 @@ class ExaCore:
         (then itr defaults to 1:1, nlp.jl:1468)."""
         it = _Iter(URange(1, 1) if itr is None else itr)
         expr = fn(DataSource(it.template)) if callable(fn) else fn
-        self.nobj += it.n
+        self.nobj = self.nobj + it.n
         self.patterns.append(_Pattern(PAT_OBJ, expr, it))
         return Objective(len(self.patterns) - 1)
 
     # -- constraints -----------------------------------------------------------------------------------------
-    def add_con(self, *args, start=0.0, lcon=0.0, ucon=0.0):
+    def add_con(self, *args, start=0.0, lcon=0.0, ucon=0.0, name=None):
         """add_con(core, f, itr; ...) or add_con(core, dims...; ...) (empty rows, nlp.jl:1570-1581)."""
         if args and (callable(args[0]) or isinstance(args[0], Node)):
             fn = args[0]
@@ -491,12 +589,13 @@ class ExaCore:
             expr = Null(expr)
         o = self.ncon
         n = it.n
-        self.ncon += n
-        self.y0.append(_fill(start, n))
-        self.lcon.append(_fill(lcon, n))
-        self.ucon.append(_fill(ucon, n))
+        self.ncon = self.ncon + n
+        self._vec("y0", self.y0, start, n)
+        self._vec("lcon", self.lcon, lcon, n)
+        self._vec("ucon", self.ucon, ucon, n)
         self.patterns.append(_Pattern(PAT_CON, expr, it))
         dims = tuple(_length(s) for s in size)
+        self._block(name, 1, o, n, size)
         return Constraint(len(self.patterns) - 1, o, n, size, dims)
 
     def add_con_aug(self, c1, fn, itr):
@@ -517,7 +616,7 @@ class ExaCore:
             target = _idxx(tuple(idx), base.dims)     # offset0(...) = o0 + idxx(coord, dims) (nlp.jl:2000-2001)
         else:
             target = idx                               # o0 + idx(p)                         (nlp.jl:1996-1997)
-        self.nconaug += it.n
+        self.nconaug = self.nconaug + it.n
         self.patterns.append(_Pattern(PAT_CONAUG, expr, it, target=target, base=base.pat_index))
         return ConstraintAugmentation(base, len(self.patterns) - 1)
 
@@ -525,11 +624,16 @@ class ExaCore:
     def to_ir(self):
         return ModelIR(self)
 
+    def to_recipe(self) -> bytes:
+        """Wire form (include/exahip_recipe.h): sizes/data deferred to the schema fields for a recipe core, fully
+        inline for an ordinary one."""
+        return R.dumps(self)
+
 
 def _as_size(n):
     if isinstance(n, (URange, range)):
         return _as_urange(n)
-    return int(n)
+    return keep_int(n)
 
 
 def _infer_dims(it: _Iter):
@@ -550,6 +654,56 @@ def _fill(v, n):
     a = a.reshape(-1, order="F")
     assert a.size == n, f"expected {n} values, got {a.size}"
     return np.ascontiguousarray(a)
+
+
+def lower_pattern(p: _Pattern, symbolic=False):
+    """Post-order node list + column list of one pattern -> (nodes, cols, root, target).
+    nodes: (op, fn, a, b, fval, ival); with `symbolic` the ival of an Int leaf may be a tagged TInt and the
+    columns are in recipe form (exahip/recipe.py), otherwise (coltype, array, start, step)."""
+    nodes = []
+    cols = []
+    colid = {}
+
+    def col_of(path):
+        if path not in colid:
+            colid[path] = len(cols)
+            cols.append(_rcolumn(p.itr, path) if symbolic else p.itr.column(path))
+        return colid[path]
+
+    def emit(e):
+        e = _norm_real(e)
+        if isinstance(e, bool):
+            raise TypeError("bool in expression")
+        if isinstance(e, int):
+            nodes.append((OP_CONST_I, 0, -1, -1, 0.0, e if symbolic else int(e)))
+        elif isinstance(e, float):
+            nodes.append((OP_CONST_F, 0, -1, -1, e, 0))
+        elif isinstance(e, Constant):
+            return emit(e.v)
+        elif isinstance(e, Null):
+            nodes.append((OP_NULLV, 0, -1, -1, 0.0 if e.v is None else e.v, 0))
+        elif isinstance(e, (DataSource, DataIndexed)):
+            nodes.append((OP_DATA, 0, col_of(e.path()), -1, 0.0, 0))
+        elif isinstance(e, Var):
+            a = emit(e.i)
+            nodes.append((OP_VAR, 0, a, -1, 0.0, 0))
+        elif isinstance(e, ParameterNode):
+            a = emit(e.i)
+            nodes.append((OP_PAR, 0, a, -1, 0.0, 0))
+        elif isinstance(e, Node1):
+            a = emit(e.inner)
+            nodes.append((OP_UN, UN_ID[e.fn], a, -1, 0.0, 0))
+        elif isinstance(e, Node2):
+            a = emit(e.a)
+            b = emit(e.b)
+            nodes.append((OP_BIN, BIN_ID[e.fn], a, b, 0.0, 0))
+        else:
+            raise TypeError(f"cannot lower {type(e).__name__} into the pattern IR")
+        return len(nodes) - 1
+
+    root = emit(p.expr)
+    target = emit(p.target) if p.kind == PAT_CONAUG else -1
+    return nodes, cols, root, target
 
 
 class ModelIR:
@@ -580,49 +734,7 @@ class ModelIR:
         self.desc = d
 
     def _emit_pattern(self, p: _Pattern, out: CPattern):
-        nodes = []
-        cols = []       # list of (coltype, array, start, step)
-        colid = {}
-
-        def col_of(path):
-            if path not in colid:
-                colid[path] = len(cols)
-                cols.append(p.itr.column(path))
-            return colid[path]
-
-        def emit(e):
-            e = _norm_real(e)
-            if isinstance(e, bool):
-                raise TypeError("bool in expression")
-            if isinstance(e, int):
-                nodes.append((OP_CONST_I, 0, -1, -1, 0.0, e))
-            elif isinstance(e, float):
-                nodes.append((OP_CONST_F, 0, -1, -1, e, 0))
-            elif isinstance(e, Constant):
-                return emit(e.v)
-            elif isinstance(e, Null):
-                nodes.append((OP_NULLV, 0, -1, -1, 0.0 if e.v is None else e.v, 0))
-            elif isinstance(e, (DataSource, DataIndexed)):
-                nodes.append((OP_DATA, 0, col_of(e.path()), -1, 0.0, 0))
-            elif isinstance(e, Var):
-                a = emit(e.i)
-                nodes.append((OP_VAR, 0, a, -1, 0.0, 0))
-            elif isinstance(e, ParameterNode):
-                a = emit(e.i)
-                nodes.append((OP_PAR, 0, a, -1, 0.0, 0))
-            elif isinstance(e, Node1):
-                a = emit(e.inner)
-                nodes.append((OP_UN, UN_ID[e.fn], a, -1, 0.0, 0))
-            elif isinstance(e, Node2):
-                a = emit(e.a)
-                b = emit(e.b)
-                nodes.append((OP_BIN, BIN_ID[e.fn], a, b, 0.0, 0))
-            else:
-                raise TypeError(f"cannot lower {type(e).__name__} into the pattern IR")
-            return len(nodes) - 1
-
-        root = emit(p.expr)
-        target = emit(p.target) if p.kind == PAT_CONAUG else -1
+        nodes, cols, root, target = lower_pattern(p)
         cn = (CNode * len(nodes))()
         for i, t in enumerate(nodes):
             cn[i].op, cn[i].fn, cn[i].a, cn[i].b, cn[i].fval, cn[i].ival = t

@@ -325,6 +325,8 @@ def _pow(x, p):
     if isinstance(p, Node):
         return _bin("^", x, p)
     if isinstance(p, int):
+        if hasattr(p, "sym"):
+            raise TypeError("a size placeholder as a literal exponent has no recipe form; use powi(x, n)")
         # Base.literal_pow -> _pow_val (specialization.jl:193-202)
         if p == 1:
             return x

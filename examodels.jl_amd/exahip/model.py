@@ -20,21 +20,177 @@ from .core import ExaCore, ModelIR
 _WHICH = {"obj": 0, "grad": 1, "cons": 2, "jac": 3, "hess": 4}
 
 
+class Recipe:
+    """A model whose sizes and data arrive at instantiation (exahip/recipe.py; include/exahip_recipe.h).
+    Built from a recipe core (`ExaCore(examples=...)`), from an ordinary core (a fixed model: the same bytes are the
+    model file format) or from serialized bytes."""
+
+    def __init__(self, src):
+        import json
+        self._L = capi.lib()
+        self.bytes = bytes(src) if isinstance(src, (bytes, bytearray)) else src.to_recipe()
+        self.id = self._L.exa_recipe_load(self.bytes, len(self.bytes))
+        if self.id <= 0:
+            raise capi.ExaHipError("exa_recipe_load: " + self._L.exa_last_error().decode(errors="replace"))
+        self.minimize = bool(int.from_bytes(self.bytes[8:12], "little"))
+        self.nargs = self._L.exa_recipe_nargs(self.id)
+        self.argtype = self._text(self._L.exa_recipe_argtype)
+        self.schema_json = self._text(self._L.exa_recipe_schema)
+        self.fields = json.loads(self.schema_json)["fields"]
+
+    def __del__(self):
+        try:
+            if self.id > 0:
+                self._L.exa_recipe_free(self.id)
+                self.id = 0
+        except Exception:
+            pass
+
+    def _text(self, fn):
+        n = fn(self.id, None, 0)
+        buf = ctypes.create_string_buffer(max(1, n))
+        fn(self.id, buf, n)
+        return buf.raw[:n].decode()
+
+    def save(self, path):
+        with open(path, "wb") as fh:
+            fh.write(self.bytes)
+
+    @classmethod
+    def load(cls, path):
+        with open(path, "rb") as fh:
+            return cls(fh.read())
+
+    def _flatten(self, values):
+        """`ExaModel(core, n, (v0 = .., lo = ..), tab)` or the consumers' flat spelling `CModel(lib, n, v0, lo, tab)`:
+        a dict whose keys are the next schema fields is spread over them."""
+        flat = []
+        for v in values:
+            k = len(flat)
+            if isinstance(v, dict) and k < len(self.fields) and self.fields[k]["kind"] != "table" and \
+                    list(v) == [f["name"] for f in self.fields[k:k + len(v)]]:
+                flat.extend(v.values())
+            else:
+                flat.append(v)
+        if len(flat) != len(self.fields):
+            raise TypeError(f"this recipe instantiates from {len(self.fields)} values ({self.argtype}), got {len(flat)}")
+        return flat
+
+    def _instantiate(self, values, device=True):
+        from .recipe import _table_columns
+        L = self._L
+        if not self.fields:
+            if values:
+                raise TypeError("a fixed model takes no instantiation values")
+            mid = (L.exa_recipe_new if device else L.exa_recipe_plan)(self.id, 0)
+        else:
+            b = L.exa_data_begin(self.id)
+            if b <= 0:
+                raise capi.ExaHipError("exa_data_begin failed")
+            try:
+                for f, v in zip(self.fields, self._flatten(values)):
+                    name = f["name"].encode()
+                    if f["kind"] == "scalar":
+                        st = L.exa_set_scalar_i64(b, name, int(v)) if f["type"] == "i64" else L.exa_set_scalar_f64(b, name, float(v))
+                    elif f["kind"] == "array":
+                        a = np.ascontiguousarray(v, dtype=np.int64 if f["type"] == "i64" else np.float64)
+                        fn = L.exa_set_array_i64 if f["type"] == "i64" else L.exa_set_array_f64
+                        st = fn(b, name, a.ctypes.data, a.size)
+                    else:
+                        cols = v if isinstance(v, dict) else _table_columns(v)
+                        st = 0
+                        for c in f["columns"]:
+                            a = np.ascontiguousarray(cols[c["name"]], dtype=np.int64 if c["type"] == "i64" else np.float64)
+                            fn = L.exa_set_col_i64 if c["type"] == "i64" else L.exa_set_col_f64
+                            st = st or fn(b, name, c["name"].encode(), a.ctypes.data, a.size)
+                    if st:
+                        raise capi.ExaHipError(f"builder: field {f['name']!r} rejected (status {st})")
+                if L.exa_data_ready(b) != 1:
+                    raise capi.ExaHipError("builder: data not ready (a table's columns differ in length?)")
+                mid = (L.exa_new_from_data if device else L.exa_plan_from_data)(b)
+            finally:
+                L.exa_data_free(b)
+        if mid <= 0:
+            raise capi.ExaHipError("recipe instantiation failed: " + L.exa_last_error().decode(errors="replace"))
+        return mid
+
+    def instantiate(self, *values, device=True):
+        return ExaModel(self, *values, device=device)
+
+    def matches(self, core, *values):
+        """True iff this recipe instantiated at `values` is, entry for entry, the pattern table of `core` (the same
+        model built directly at those values).  The reference checks a recipe by instantiating its example before
+        compiling (ExaModelsCompiler.jl:153-156); here a SECOND, different set of values is the meaningful check:
+        Python cannot stop `1.0 / N` or `2.5 * N` from silently baking the example's N into a real constant (float
+        arithmetic accepts the tagged int as a plain one), and this is what catches it.  No device needed."""
+        a = ExaModel(self, *values, device=False)
+        b = ExaModel(core, device=False)
+        return tables_equal(a, b)
+
+
+def _view(ptr, n, ctype):
+    if not ptr or n <= 0:
+        return np.zeros(0, dtype=ctype)
+    return np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(np.ctypeslib.as_ctypes_type(ctype))), shape=(int(n),))
+
+
+def tables_equal(a, b):
+    """Entry-for-entry comparison of the pattern tables of two models planned without a device."""
+    from .core import CNode, COL_RANGE, PAT_CON
+    da, db = a.describe().desc, b.describe().desc
+    if (da.nvar, da.npar, da.n_patterns, da.minimize) != (db.nvar, db.npar, db.n_patterns, db.minimize):
+        return False
+    ncon = 0
+    for k in range(da.n_patterns):
+        pa, pb = da.patterns[k], db.patterns[k]
+        if (pa.kind, pa.n_nodes, pa.root, pa.target, pa.base, pa.n_cols, pa.n) != \
+                (pb.kind, pb.n_nodes, pb.root, pb.target, pb.base, pb.n_cols, pb.n):
+            return False
+        if ctypes.string_at(pa.nodes, pa.n_nodes * ctypes.sizeof(CNode)) != ctypes.string_at(pb.nodes, pb.n_nodes * ctypes.sizeof(CNode)):
+            return False
+        for c in range(pa.n_cols):
+            ca, cb = pa.cols[c], pb.cols[c]
+            if ca.type != cb.type:
+                return False
+            if ca.type == COL_RANGE:
+                if (ca.start, ca.step) != (cb.start, cb.step):
+                    return False
+            elif ctypes.string_at(ca.data, 8 * pa.n) != ctypes.string_at(cb.data, 8 * pb.n):
+                return False
+        if pa.kind == PAT_CON:
+            ncon += pa.n
+    for name, n in (("x0", da.nvar), ("lvar", da.nvar), ("uvar", da.nvar), ("theta0", da.npar), ("y0", ncon), ("lcon", ncon), ("ucon", ncon)):
+        va, vb = _view(getattr(da, name), n, np.float64), _view(getattr(db, name), n, np.float64)
+        if not np.array_equal(va, vb):
+            return False
+    return True
+
+
 def _is_torch(a):
     return type(a).__module__.startswith("torch")
 
 
 class ExaModel:
-    def __init__(self, core, device=True):
+    def __init__(self, core, *args, device=True):
         """device=True: exa_new_from_table (needs an MI355X; raises otherwise — no CPU fallback).
-        device=False: exa_plan_only — layout + generated source only, callbacks raise."""
+        device=False: exa_plan_only — layout + generated source only, callbacks raise.
+        `ExaModel(recipe_core, args...)` instantiates a recipe (nlp.jl:809-863) through the builder ABI."""
         self._L = capi.lib()
-        self.ir = core if isinstance(core, ModelIR) else core.to_ir()
         self.id = 0
-        idc = ctypes.c_int(0)
-        fn = self._L.exa_new_from_table if device else self._L.exa_plan_only
-        capi.check(fn(ctypes.addressof(self.ir.desc), ctypes.byref(idc)), "exa_new_from_table" if device else "exa_plan_only")
-        self.id = idc.value
+        if isinstance(core, Recipe) or getattr(core, "schema", None) is not None:
+            rec = core if isinstance(core, Recipe) else Recipe(core)
+            self.ir = None
+            self.id = rec._instantiate(args, device)
+            self._minimize = rec.minimize
+        else:
+            if args:
+                raise TypeError("instantiation arguments given, but the core is not a recipe")
+            self.ir = core if isinstance(core, ModelIR) else core.to_ir()
+            idc = ctypes.c_int(0)
+            fn = self._L.exa_new_from_table if device else self._L.exa_plan_only
+            capi.check(fn(ctypes.addressof(self.ir.desc), ctypes.byref(idc)), "exa_new_from_table" if device else "exa_plan_only")
+            self.id = idc.value
+            self._minimize = bool(self.ir.desc.minimize)
         self.device = device
         L = self._L
         nvar, ncon = L.exa_nvar64(self.id), L.exa_ncon64(self.id)
@@ -43,8 +199,38 @@ class ExaModel:
         capi.check(L.exa_meta(self.id, x0.ctypes.data, lv.ctypes.data, uv.ctypes.data, lc.ctypes.data, uc.ctypes.data), "exa_meta")
         self.meta = SimpleNamespace(nvar=nvar, ncon=ncon, nnzj=L.exa_nnzj64(self.id), nnzh=L.exa_nnzh64(self.id),
                                     nnzg=L.exa_nnzg64(self.id), x0=x0, lvar=lv, uvar=uv, lcon=lc[:ncon], ucon=uc[:ncon],
-                                    minimize=bool(self.ir.desc.minimize))
+                                    minimize=self._minimize)
         self._stream = None
+
+    def describe(self):
+        """Pattern-table view (exa_model_desc_t) of a model planned without a device — what a recipe became."""
+        from .core import CModelDesc
+        d = CModelDesc()
+        capi.check(self._L.exa_describe(self.id, ctypes.addressof(d)), "exa_describe")
+        return SimpleNamespace(desc=d, owner=self)
+
+    # ---- named blocks (cnlp P_nblocks / P_block_name / P_block, ExaModelsCompiler.jl:1476-1510) -----------------
+    def blocks(self):
+        out = []
+        for k in range(max(0, self._L.exa_nblocks(self.id))):
+            n = self._L.exa_block_name(self.id, k, None, 0)
+            buf = ctypes.create_string_buffer(max(1, n))
+            self._L.exa_block_name(self.id, k, buf, n)
+            rec = (ctypes.c_int * 72)()
+            capi.check(self._L.exa_block(self.id, k, rec), "exa_block")
+            out.append(SimpleNamespace(name=buf.raw[:n].decode(), kind=rec[0], offset=rec[1], length=rec[2],
+                                       dims=[rec[4 + j] for j in range(rec[3])]))
+        return out
+
+    def get_value_block(self, k):
+        b = self.blocks()[k]
+        v = np.empty(b.length)
+        capi.check(self._L.exa_get_value_block(self.id, k, v.ctypes.data, v.size), "exa_get_value_block")
+        return v
+
+    def set_value_block(self, k, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        capi.check(self._L.exa_set_value_block(self.id, k, v.ctypes.data, v.size), "exa_set_value_block")
 
     def __del__(self):
         try:

@@ -26,8 +26,8 @@ from conftest import has_gpu  # noqa: E402
 from zoo import ZOO  # noqa: E402
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "exahip.h")).read()
+def header_symbols(name="exahip.h"):
+    txt = open(os.path.join(ROOT, "include", name)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(exa_[a-z0-9_]+)\s*\(", txt)))
 
@@ -40,6 +40,11 @@ def test_library_exports_every_declared_symbol(libs):
     for s in declared:
         assert hasattr(L, s), f"libexahip.so does not export {s}"
     assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS and include/exahip.h disagree"
+    recipe = header_symbols("exahip_recipe.h")
+    assert len(recipe) >= 25
+    for s in recipe:
+        assert hasattr(L, s), f"libexahip.so does not export {s}"
+    assert sorted(capi.RECIPE_SYMBOLS) == recipe, "capi.RECIPE_SYMBOLS and include/exahip_recipe.h disagree"
     assert L.exa_abi_version() == 1
 
 
