@@ -138,7 +138,7 @@ void describe(Recipe &r) {
                  tname(f.type) + "\"}";
             // signature form of P_argtype (Compiler test :655-657): `int|arg1,Vector{f64}|v0,...`
             if (f.kind == F_SCALAR) a += std::string(f.type == T_I64 ? "int" : "f64") + "|" + f.name;
-            else a += std::string("Vector{") + tname(f.type) + "}|" + f.name;
+            else a += std::string("Vector{") + (f.type == T_I64 ? "int" : "f64") + "}|" + f.name;   // _jtype, Compiler :936-943
         }
     }
     j += "]}";

@@ -67,8 +67,7 @@ class Recipe:
         flat = []
         for v in values:
             k = len(flat)
-            if isinstance(v, dict) and k < len(self.fields) and self.fields[k]["kind"] != "table" and \
-                    list(v) == [f["name"] for f in self.fields[k:k + len(v)]]:
+            if isinstance(v, dict) and list(v) == [f["name"] for f in self.fields[k:k + len(v)]]:
                 flat.extend(v.values())
             else:
                 flat.append(v)

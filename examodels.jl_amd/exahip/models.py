@@ -160,23 +160,25 @@ def synthetic_power_data(nbus, nbr, ngen, seed=0):
         vmax=np.full(nbus, 1.1), vmin=np.full(nbus, 0.9),
         pmax=r.uniform(1.0, 5.0, ngen), pmin=np.zeros(ngen),
         qmax=r.uniform(1.0, 3.0, ngen), qmin=-r.uniform(1.0, 3.0, ngen),
-        rate_a=np.concatenate([rate_a, rate_a]),
+        rate_a=np.concatenate([rate_a, rate_a]), rate_a_lo=-np.concatenate([rate_a, rate_a]),
         angmax=np.full(nbr, np.pi / 6), angmin=np.full(nbr, -np.pi / 6),
     )
 
 
-def ac_power_model(data):
+def ac_power_model(data, core=None):
     """test/NLPTest/power.jl:112-213 (`__exa_ac_power_model`): variable order va, vm, pg, qg, p, q;
-    15 blocks (1 objective, 10 constraints, 4 augmentations)."""
-    w = ExaCore()
-    nbus, ngen, narc = len(data["bus"]), len(data["gen"]), len(data["arc"])
-    nbr = len(data["branch"])
-    va = w.add_var(nbus)
-    vm = w.add_var(nbus, start=np.ones(nbus), lvar=data["vmin"], uvar=data["vmax"])
-    pg = w.add_var(ngen, lvar=data["pmin"], uvar=data["pmax"])
-    qg = w.add_var(ngen, lvar=data["qmin"], uvar=data["qmax"])
-    p = w.add_var(narc, lvar=-data["rate_a"], uvar=data["rate_a"])
-    q = w.add_var(narc, lvar=-data["rate_a"], uvar=data["rate_a"])
+    15 blocks (1 objective, 10 constraints, 4 augmentations).
+    With `core` = a recipe core (`ExaCore(examples=(data,))`) and `data` = its placeholder the same statements give
+    the DATA-DEFINED recipe: every size is a table length, every bound a data field."""
+    from .recipe import length
+    w = ExaCore() if core is None else core
+    nbus, ngen, narc = length(data["bus"]), length(data["gen"]), length(data["arc"])
+    va = w.add_var(nbus, name="va")
+    vm = w.add_var(nbus, start=1.0, lvar=data["vmin"], uvar=data["vmax"], name="vm")
+    pg = w.add_var(ngen, lvar=data["pmin"], uvar=data["pmax"], name="pg")
+    qg = w.add_var(ngen, lvar=data["qmin"], uvar=data["qmax"], name="qg")
+    p = w.add_var(narc, lvar=data["rate_a_lo"], uvar=data["rate_a"], name="p")
+    q = w.add_var(narc, lvar=data["rate_a_lo"], uvar=data["rate_a"], name="q")
 
     w.add_obj(lambda g: g.cost1 * pg[g.i] ** 2 + g.cost2 * pg[g.i] + g.cost3, data["gen"])
 
@@ -199,9 +201,9 @@ def ac_power_model(data):
         - b.c1 * (vm[b.t_bus] * vm[b.f_bus] * sin(va[b.t_bus] - va[b.f_bus])), data["branch"])
     w.add_con(lambda b: va[b.f_bus] - va[b.t_bus], data["branch"], lcon=data["angmin"], ucon=data["angmax"])
     w.add_con(lambda b: p[b.f_idx] ** 2 + q[b.f_idx] ** 2 - b.rate_a_sq, data["branch"],
-              lcon=np.full(nbr, -np.inf))
+              lcon=-np.inf)
     w.add_con(lambda b: p[b.t_idx] ** 2 + q[b.t_idx] ** 2 - b.rate_a_sq, data["branch"],
-              lcon=np.full(nbr, -np.inf))
+              lcon=-np.inf)
     c9 = w.add_con(lambda b: b.pd + b.gs * vm[b.i] ** 2, data["bus"])
     c10 = w.add_con(lambda b: b.qd - b.bs * vm[b.i] ** 2, data["bus"])
     w.add_con_aug(c9, lambda a: (a.bus, p[a.i]), data["arc"])

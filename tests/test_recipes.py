@@ -119,6 +119,32 @@ def test_headline_model_from_one_recipe(libs):
         assert np.array_equal(o.jac_coord(x), ref.jac_coord(x)) and o.obj(x) == ref.obj(x)
 
 
+def _acopf_recipe():
+    from exahip import ExaCore, Recipe, models
+    ex = models.synthetic_power_data(nbus=5, nbr=6, ngen=2, seed=1)
+    c = ExaCore(examples=(ex,))
+    models.ac_power_model(c.args[0], core=c)
+    return Recipe(c)
+
+
+def test_data_defined_acopf_recipe(libs):
+    """The shape the builder ABI exists for (ExaModelsCompiler.jl:58-66, test/NLPTest/power.jl:112-213): every size a
+    table length, every bound a data field; traced on a 5-bus example, instantiated on a 30-bus network."""
+    from exahip import ExaModel, models
+    rec = _acopf_recipe()
+    assert rec.nargs == 15 and rec.argtype.startswith("Table{i::int pd::f64 gs::f64 qd::f64 bs::f64}|bus,")
+    assert "Vector{int}|ref_buses" in rec.argtype
+    d = models.synthetic_power_data(nbus=30, nbr=41, ngen=6, seed=3)
+    assert rec.matches(models.ac_power_model(d), d)
+    m = ExaModel(rec, d, device=False)
+    assert [(b.name, b.offset, b.length) for b in m.blocks()] == \
+        [("va", 0, 30), ("vm", 30, 30), ("pg", 60, 6), ("qg", 66, 6), ("p", 72, 82), ("q", 154, 82)]
+    direct = ExaModel(models.ac_power_model(d), device=False)
+    assert m.kernel_source() == direct.kernel_source()
+    for k in range(m.npatterns):
+        assert m.pattern_info(k) == direct.pattern_info(k)
+
+
 def test_builder_error_paths(libs):
     from exahip import Recipe, capi
     L = capi.lib()
@@ -205,13 +231,35 @@ def test_hip_structured_recipe_instance(libs):
     ref = oracle.OracleModel(make(build_struct, S_ARGS, False).to_ir())
     x, y = np.linspace(0.5, 3.0, S_N), np.linspace(-1.0, 1.0, S_N - 1)
     assert (m.meta.nvar, m.meta.ncon) == (S_N, S_N - 1)
-    np.testing.assert_allclose(m.obj(x), ref.obj(x), rtol=1e-13)
-    np.testing.assert_allclose(m.grad(x), ref.grad(x), rtol=1e-13)
-    np.testing.assert_allclose(m.cons(x), ref.cons(x), rtol=1e-13)
-    np.testing.assert_allclose(m.jac_coord(x), ref.jac_coord(x), rtol=1e-13)
-    np.testing.assert_allclose(m.hess_coord(x, y, 0.5), ref.hess_coord(x, y, 0.5), rtol=1e-13)
+    np.testing.assert_allclose(m.obj(x), ref.obj(x), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(m.grad(x), ref.grad(x), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(m.cons(x), ref.cons(x), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(m.jac_coord(x), ref.jac_coord(x), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(m.hess_coord(x, y, 0.5), ref.hess_coord(x, y, 0.5), rtol=1e-10, atol=1e-12)
     for a, b in zip(m.jac_structure() + m.hess_structure(), ref.jac_structure() + ref.hess_structure()):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+def test_hip_acopf_recipe_at_config4_scale(libs):
+    """BASELINE configs[3] instantiated through the builder ABI from the 5-bus recipe: same module, same numbers."""
+    import torch
+    from exahip import ExaModel, models
+    rec = _acopf_recipe()
+    d = models.synthetic_power_data(nbus=78484, nbr=126015, ngen=6800, seed=0)
+    m = ExaModel(rec, d)
+    core = models.ac_power_model(d)
+    direct = ExaModel(core)
+    assert m._L.exa_code_object_path(m.id) == direct._L.exa_code_object_path(direct.id)
+    assert (m.meta.nvar, m.meta.ncon, m.meta.nnzj, m.meta.nnzh) == (direct.meta.nvar, direct.meta.ncon, direct.meta.nnzj, direct.meta.nnzh)
+    x = torch.from_numpy(models.acopf_start(core)).cuda()
+    y = torch.from_numpy(np.random.default_rng(1).standard_normal(m.meta.ncon)).cuda()
+    assert torch.equal(m.hess_coord(x, y, 0.5), direct.hess_coord(x, y, 0.5))
+    assert torch.equal(m.jac_coord(x), direct.jac_coord(x)) and torch.equal(m.cons(x), direct.cons(x))
+    hr, hc = m.hess_structure()
+    dr, dc = direct.hess_structure()
+    assert np.array_equal(hr, dr) and np.array_equal(hc, dc)
 
 
 @pytest.mark.gpu
