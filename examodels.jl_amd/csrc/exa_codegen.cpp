@@ -614,6 +614,7 @@ const char *kPrelude = R"HIP(// Generated by libexahip (examodels.jl_amd/csrc/ex
 #define EXA_D2R (EXA_PI / 180.0)
 #define EXA_R2D (180.0 / EXA_PI)
 #define EXA_BLOCK @BLOCK@
+#define EXA_PULL_PPT @PULLPPT@
 static __device__ __forceinline__ double exa_sq(double x) { return x * x; }
 static __device__ __forceinline__ double exa_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : x); }
 static __device__ __forceinline__ double exa_sind(double x) { return sin(EXA_D2R * fmod(x, 360.0)); }
@@ -954,12 +955,17 @@ void gen_value_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
 
 void gen_cons_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
     Body b(m, pi, L);
-    os << "static __device__ __forceinline__ void " << fn_name(pi, "cons")
-       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ c, "
-          "double* __restrict__ aug, long tid) {\n"
-       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n"
-       << "    const double v = " << fn_name(pi, "val") << "(P, x, th, I);\n";
-    // base rows: plain store into c; augmentation terms: into the value buffer, gathered per row by exa_aug_gather
+    // Two pieces so that a thread handling several points evaluates ALL of them before storing any: the value at an
+    // index clamped into the shard (no branch -> one basic block -> the loads of all points are in flight together),
+    // then the guarded store.  Base rows: plain store into c; augmentation terms: into the value buffer, gathered per
+    // row by exa_aug_gather.
+    os << "static __device__ __forceinline__ double " << fn_name(pi, "consv")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, long tid) {\n"
+       << "    const long I_ = " << b.P(L.pat[pi].lo) << " + tid, h_ = " << b.P(L.pat[pi].hi) << " - 1;\n"
+       << "    return " << fn_name(pi, "val") << "(P, x, th, I_ < h_ ? I_ : h_);\n}\n";
+    os << "static __device__ __forceinline__ void " << fn_name(pi, "conss")
+       << "(const long* __restrict__ P, double* __restrict__ c, double* __restrict__ aug, long tid, double v) {\n"
+       << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
     if (b.p.kind == EXA_PAT_CONAUG) os << "    aug[" << b.P(L.pat[pi].oa) << " + I] = v;\n";
     else os << "    c[" << b.P(L.pat[pi].o0) << " + I] = v;\n";
     os << "}\n";
@@ -1019,6 +1025,10 @@ void gen_pull_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     pull_ok(p, slots);
     os << "static __device__ __forceinline__ double " << fn_name(pi, "pull")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, long v) {\n    double g = 0.0;\n";
+    // every slot is evaluated unconditionally at an index clamped into the shard and its contribution selected
+    // afterwards: no data-dependent branch, so a thread handling several variables has all its loads in flight at once
+    os << "    const long lo_ = " << Body(m, pi, L).P(L.pat[pi].lo) << ", hi_ = " << Body(m, pi, L).P(L.pat[pi].hi) << ";\n"
+       << "    if (lo_ >= hi_) return 0.0;\n";
     for (int s = 0; s < p.o1step; s++) {
         Body b(m, pi, L);
         b.forward(p.ad_root, 1, false);
@@ -1027,10 +1037,11 @@ void gen_pull_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
         const int64_t step = p.cols[slots[s].col].step;
         os << "    {   // slot " << s << ": x[range" << (slots[s].c >= 0 ? " + " : " - ") << std::llabs(slots[s].c) << "]\n"
            << "        const long r = v - (" << slots[s].c << "L) - " << b.P(L.pat[pi].col[slots[s].col]) << ";\n"
-           << "        const long I = r / " << step << "L;\n"
-           << "        if (r >= 0 && I * " << step << "L == r && I >= " << b.P(L.pat[pi].lo) << " && I < " << b.P(L.pat[pi].hi) << ") {\n";
-        emit_lines(os, b.e, "            ");
-        os << "            g += " << b.e.sd(a.acc[s]) << ";\n        }\n    }\n";
+           << "        const long J = r / " << step << "L;\n"
+           << "        const bool ok = r >= 0 && J * " << step << "L == r && J >= lo_ && J < hi_;\n"
+           << "        const long I = J < lo_ ? lo_ : (J >= hi_ ? hi_ - 1 : J);\n";
+        emit_lines(os, b.e, "        ");
+        os << "        g += ok ? " << b.e.sd(a.acc[s]) << " : 0.0;\n    }\n";
     }
     os << "    return g;\n}\n";
 }
@@ -1298,7 +1309,7 @@ Generated generate_module(const Model &m) {
     }
     for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w++; L.ppt[cb] = 1; }
     // streaming value kernels keep more loads in flight per wavefront with several points per thread (measured)
-    L.ppt[CB_OBJ] = env_int("EXAHIP_PPT_OBJ", 4);
+    L.ppt[CB_OBJ] = env_int("EXAHIP_PPT_OBJ", 8);
     L.ppt[CB_CONS] = env_int("EXAHIP_PPT_CONS", 1);
     L.ppt[CB_GRAD] = env_int("EXAHIP_PPT_GRAD", 1);
     L.ppt[CB_JAC] = env_int("EXAHIP_PPT_JAC", 1);
@@ -1308,7 +1319,14 @@ Generated generate_module(const Model &m) {
     for (int &v : g_lds_need) v = 0;
     g_lit_idx.clear();
     std::ostringstream os;
-    { std::string pre = kPrelude; const std::string tag = "@BLOCK@"; pre.replace(pre.find(tag), tag.size(), std::to_string(kBlock)); os << pre; }
+    L.pull_ppt = std::max(1, env_int("EXAHIP_PPT_PULL", 2));
+    {
+        std::string pre = kPrelude;
+        const std::string tag = "@BLOCK@", tag2 = "@PULLPPT@";
+        pre.replace(pre.find(tag), tag.size(), std::to_string(kBlock));
+        pre.replace(pre.find(tag2), tag2.size(), std::to_string(L.pull_ppt));
+        os << pre;
+    }
     os << "// patterns=" << np << " (sizes, offsets and column pointers are run-time parameters in P[])\n";
     for (int k = 0; k < np; k++) {
         const Pattern &p = m.pats[k];
@@ -1346,8 +1364,8 @@ Generated generate_module(const Model &m) {
         for (size_t k = 0; k < act.size(); k++) {
             const auto &pp = L.pat[act[k]];
             os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n        const long I0 = P[" << pp.lo << "] + t0_;\n#pragma unroll\n"
-               << "        for (int u = 0; u < " << ppt << "; u++) { const long I = I0 + u * EXA_BLOCK; if (I < P[" << pp.hi << "]) v += p"
-               << act[k] << "_val(P, x, th, I); }\n    }\n";
+               << "        for (int u = 0; u < " << ppt << "; u++) { const long I = I0 + u * EXA_BLOCK, h_ = P[" << pp.hi << "] - 1; "
+               << "const double t_ = p" << act[k] << "_val(P, x, th, I < h_ ? I : h_); v += I <= h_ ? t_ : 0.0; }\n    }\n";
         }
     }
     os << "    const double s = exa_block_sum(v);\n    if (threadIdx.x == 0) part[b] = s;\n}\n";
@@ -1364,12 +1382,23 @@ Generated generate_module(const Model &m) {
     // grad!, gather part: one thread per variable; also provides the zero of untouched variables (no memset)
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_grad_pull(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out, long nvar) {\n"
-          "    const long v = (long)blockIdx.x * EXA_BLOCK + threadIdx.x;\n    if (v >= nvar) return;\n    double g = 0.0;\n";
-    for (int k : L.pull) os << "    g += p" << k << "_pull(P, x, th, v + 1);\n";
-    os << "    out[v] = g;\n}\n";
+          "    const long v0 = (long)blockIdx.x * (EXA_BLOCK * EXA_PULL_PPT) + threadIdx.x;\n    double g[EXA_PULL_PPT];\n"
+          "#pragma unroll\n    for (int u = 0; u < EXA_PULL_PPT; u++) {\n        const long v_ = v0 + u * EXA_BLOCK, v = v_ < nvar ? v_ : nvar - 1;\n        g[u] = 0.0;\n";
+    for (int k : L.pull) os << "        g[u] += p" << k << "_pull(P, x, th, v + 1);\n";
+    os << "    }\n#pragma unroll\n    for (int u = 0; u < EXA_PULL_PPT; u++) { const long v = v0 + u * EXA_BLOCK; if (v < nvar) out[v] = g[u]; }\n}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_cons(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out, double* __restrict__ aug) {\n";
-    gen_dispatch(os, L, CB_CONS, "cons", "P, x, th, out, aug");
+    {
+        const auto &act = L.active[CB_CONS];
+        const int ppt = L.ppt[CB_CONS];
+        os << "    const long e_ = ((const long*)P[" << L.blk[CB_CONS] << "])[blockIdx.x];\n    const int ps_ = (int)(e_ >> 40);\n"
+              "    const long tid0 = (e_ & ((1L << 40) - 1)) * (EXA_BLOCK * " << ppt << ") + threadIdx.x;\n    double v_[" << ppt << "];\n";
+        for (size_t k = 0; k < act.size(); k++) {
+            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n#pragma unroll\n        for (int u = 0; u < " << ppt
+               << "; u++) v_[u] = p" << act[k] << "_consv(P, x, th, tid0 + u * EXA_BLOCK);\n#pragma unroll\n        for (int u = 0; u < " << ppt
+               << "; u++) p" << act[k] << "_conss(P, out, aug, tid0 + u * EXA_BLOCK, v_[u]);\n    }\n";
+        }
+    }
     os << "}\n";
     auto lds_decl = [&](int cb, bool hess) {
         int mx = 0;

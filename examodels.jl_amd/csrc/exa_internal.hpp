@@ -91,6 +91,7 @@ struct ParamLayout {
     int ppt[CB_COUNT];                   // data points per thread (a workgroup covers kBlock * ppt points)
     int nwords = 0;
     std::vector<int> pull;               // objective patterns whose gradient is GATHERED per variable (exa_grad_pull)
+    int pull_ppt = 1;                    // variables per thread of exa_grad_pull
 };
 
 struct Generated {

@@ -390,7 +390,8 @@ void do_grad(Handle &h, const double *x, double *g) {
     if (!h.gen.layout.pull.empty()) {
         // gathered patterns: plain coalesced store of every g[v] (zero where nothing contributes)
         void *a0[] = {&P, &x, &th, &g, &nvar};
-        launch(h, h.f_gradpull, (nvar + kBlock - 1) / kBlock, kBlock, a0);
+        const int64_t per = (int64_t)kBlock * h.gen.layout.pull_ppt;
+        launch(h, h.f_gradpull, (nvar + per - 1) / per, kBlock, a0);
     } else {
         HIPCHK(hipMemsetAsync(g, 0, sizeof(double) * (size_t)nvar, h.stream));
     }
