@@ -334,6 +334,12 @@ void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **arg
 template <class F>
 void tune_order(Handle &h, int cb, F &&run) {
     if (h.order[cb] >= 0) return;
+    // a stream that is being captured into a hipGraph cannot be synchronised: keep the default order for the captured
+    // launches and measure at the first call outside a capture
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return;
+    }
     const ParamLayout &L = h.gen.layout;
     float t[2] = {1e30f, 1e30f};
     // bring the clocks up first: the governor idles at ~570 MHz and needs tens of ms of load, and at low clocks the two
@@ -786,7 +792,12 @@ int exa_jprod(int id, const double *x, const double *v, double *Jv) {
     if (!x || !v) return 1;
     return guard(id, true, [&](Handle &h) { if (h.m->ncon && !Jv) throw std::runtime_error("null output"); do_jprod(h, x, v, Jv); });
 }
+static bool capturing(Handle &h) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(h.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 static void run_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
+    if (h.jt_mode < 0 && capturing(h)) { do_jtprod(h, x, v, Jtv); return; }   // measuring needs a synchronisation
     if (h.jt_mode < 0) {
         // sorted lists describe the unsharded COO; beyond 3e8 entries the trial's transient memory is not worth it
         if (h.world != 1 || h.m->nnzj == 0 || h.m->nnzj > 300000000LL) h.jt_mode = 0;
@@ -799,6 +810,7 @@ static void run_jtprod(Handle &h, const double *x, const double *v, double *Jtv)
     if (h.jt_mode == 1 && h.world == 1) do_jtprod_sorted(h, x, v, Jtv); else do_jtprod(h, x, v, Jtv);
 }
 static void run_hprod(Handle &h, const double *x, const double *y, const double *v, double w, double *Hv) {
+    if (h.hp_mode < 0 && capturing(h)) { do_hprod(h, x, y, v, w, Hv); return; }
     if (h.hp_mode < 0) {
         if (h.world != 1 || h.m->nnzh == 0 || h.m->nnzh > 300000000LL) h.hp_mode = 0;
         else {

@@ -348,13 +348,14 @@ class ExaModel:
     def hess_coord(self, x, y, obj_weight=1.0, out=None):
         return self._call("hess", x, self.meta.nnzh, out, extra=(y, obj_weight))
 
-    def eval_fused(self, x, y, obj_weight=1.0, c=None, jac=None, hess=None):
+    def eval_fused(self, x, y, obj_weight=1.0, c=None, jac=None, hess=None, obj_out=None):
         """obj + cons + jac_coord + hess_coord at one x in ONE sweep (exa_eval_fused).  Device tensors only.
-        Returns (obj as a 1-element device tensor, c, jac, hess)."""
+        Returns (obj as a 1-element device tensor, c, jac, hess).  Nothing here synchronises, so the call can be
+        captured into a hipGraph (torch.cuda.graph) once the model has been evaluated once outside the capture."""
         import torch
         self._use_torch_stream(x)
         dev = x.device
-        f = torch.empty(1, dtype=torch.float64, device=dev)
+        f = torch.empty(1, dtype=torch.float64, device=dev) if obj_out is None else obj_out
         c = torch.empty(self.meta.ncon, dtype=torch.float64, device=dev) if c is None else c
         jac = torch.empty(self.meta.nnzj, dtype=torch.float64, device=dev) if jac is None else jac
         hess = torch.empty(self.meta.nnzh, dtype=torch.float64, device=dev) if hess is None else hess
