@@ -186,6 +186,41 @@ def test_builder_error_paths(libs):
         assert L.exa_recipe_load(good[:cut], cut) == 0
 
 
+def test_mutated_recipes_never_crash_the_library(libs):
+    """Recipe bytes are external input: random byte mutations must end in a refusal (0) or in a valid model, never in
+    a crash.  (A recipe that still parses is instantiated on the planner only.)"""
+    from exahip import Recipe, capi
+    L = capi.lib()
+    good = Recipe(make(build_struct, S_EX, True)).bytes
+    n, dat, tab = S_ARGS
+    bound = [(b"v0", np.ascontiguousarray(dat["v0"])), (b"lo", np.ascontiguousarray(dat["lo"]))]
+    cols = [(k.encode(), np.ascontiguousarray(v)) for k, v in tab.cols.items()]
+    r = np.random.default_rng(0)
+    loaded = built = 0
+    for _ in range(600):
+        b = bytearray(good)
+        for _ in range(int(r.integers(1, 4))):
+            b[int(r.integers(8, len(b)))] = int(r.integers(0, 256))
+        rid = L.exa_recipe_load(bytes(b), len(b))
+        if rid <= 0:
+            continue
+        loaded += 1
+        bid = L.exa_data_begin(rid)
+        L.exa_set_scalar_i64(bid, b"arg1", n)
+        for name, a in bound:
+            L.exa_set_array_f64(bid, name, a.ctypes.data, a.size)
+        for name, a in cols:
+            (L.exa_set_col_i64 if a.dtype.kind == "i" else L.exa_set_col_f64)(bid, b"arg3", name, a.ctypes.data, a.size)
+        mid = L.exa_plan_from_data(bid)
+        if mid > 0:
+            built += 1
+            assert L.exa_nvar(mid) >= 0
+            L.exa_free(mid)
+        L.exa_data_free(bid)
+        L.exa_recipe_free(rid)
+    assert loaded > 100 and built > 50          # the mutations do reach the planner, they are not all refused up front
+
+
 def test_recipe_refuses_what_it_cannot_defer(libs):
     from exahip import ExaCore
     from exahip.recipe import RecipeError
