@@ -213,6 +213,68 @@ int64_t eval_int(const Pattern &p, int k, int64_t I) {
     fail("non-integer node inside an index expression");
 }
 
+// ---- index bounds -----------------------------------------------------------------------------------------
+// Every x[...] / theta[...] a kernel will read is checked against 1..nvar / 1..npar when the model is built: the
+// reference checks concrete indices at build time (nlp.jl:990-995) and leaves symbolic ones unchecked; here an index
+// comes from an external table and an out-of-range one would be an out-of-bounds device read.  Index expressions over
+// ranges only (+, -, * by a constant) are monotone in the data point and are checked at both ends; anything reading a
+// stored column is scanned point by point (budget: 4e8 node visits per model, beyond that the rest is left unchecked).
+bool range_affine(const Pattern &p, int k, bool &has_point) {
+    const exa_node_t &nd = p.nodes[k];
+    switch (nd.op) {
+    case EXA_OP_CONST_I: return true;
+    case EXA_OP_DATA:
+        if (p.cols[nd.a].type != EXA_COL_RANGE) return false;
+        has_point = true;
+        return true;
+    case EXA_OP_UN:
+        return (nd.fn == EXA_U_PLUS || nd.fn == EXA_U_MINUS) && range_affine(p, nd.a, has_point);
+    case EXA_OP_BIN: {
+        bool la = false, lb = false;
+        if (!range_affine(p, nd.a, la) || !range_affine(p, nd.b, lb)) return false;
+        if (nd.fn == EXA_B_MUL && la && lb) return false;      // point * point: not monotone in general
+        if (nd.fn != EXA_B_ADD && nd.fn != EXA_B_SUB && nd.fn != EXA_B_MUL) return false;
+        has_point = has_point || la || lb;
+        return true;
+    }
+    default: return false;
+    }
+}
+int tree_size(const Pattern &p, int k) {
+    const exa_node_t &nd = p.nodes[k];
+    if (nd.op == EXA_OP_UN) return 1 + tree_size(p, nd.a);
+    if (nd.op == EXA_OP_BIN) return 1 + tree_size(p, nd.a) + tree_size(p, nd.b);
+    return 1;
+}
+void check_index_bounds(const Model &m) {
+    double budget = 4e8;
+    for (size_t pk = 0; pk < m.pats.size(); pk++) {
+        const Pattern &p = m.pats[pk];
+        if (p.n == 0) continue;
+        std::vector<std::pair<int, bool>> roots;    // (index expression root, is a parameter index)
+        for (const exa_node_t &nd : p.nodes)
+            if (nd.op == EXA_OP_VAR || nd.op == EXA_OP_PAR) {
+                const std::pair<int, bool> r(nd.a, nd.op == EXA_OP_PAR);
+                if (std::find(roots.begin(), roots.end(), r) == roots.end()) roots.push_back(r);
+            }
+        for (const auto &r : roots) {
+            const int64_t limit = r.second ? m.npar : m.nvar;
+            auto check = [&](int64_t I) {
+                const int64_t v = eval_int(p, r.first, I);
+                if (v < 1 || v > limit)
+                    fail("pattern " + std::to_string(pk) + ": " + (r.second ? "parameter" : "variable") + " index " + std::to_string(v) +
+                         " at data point " + std::to_string(I + 1) + " is outside 1.." + std::to_string(limit));
+            };
+            bool has_point = false;
+            if (range_affine(p, r.first, has_point)) { check(0); check(p.n - 1); continue; }
+            const double cost = (double)p.n * tree_size(p, r.first);
+            if (cost > budget) continue;
+            budget -= cost;
+            for (int64_t I = 0; I < p.n; I++) check(I);
+        }
+    }
+}
+
 // sorted (target row -> contributing buffer entries) lists for the constraint augmentations
 void build_aug_lists(Model &m) {
     if (m.nconaug == 0) return;
@@ -295,6 +357,7 @@ std::unique_ptr<Model> plan_model(const exa_model_desc_t *d) {
         }
     }
     build_aug_lists(*m);
+    check_index_bounds(*m);
     m->y0 = copy_or<double>(d->y0, m->ncon, 0.0);
     m->lcon = copy_or<double>(d->lcon, m->ncon, 0.0);
     m->ucon = copy_or<double>(d->ucon, m->ncon, 0.0);

@@ -164,3 +164,34 @@ def test_kernel_build_failure_is_status_2_with_message(libs, tmp_path, monkeypat
     monkeypatch.setenv("EXAHIP_HIPCC", "/opt/rocm/bin/hipcc")
     path = m.compile()
     assert path.startswith(str(tmp_path)) and os.path.getsize(path) > 1000
+
+
+def test_out_of_range_indices_are_refused_at_build(libs):
+    """An index that would be an out-of-bounds device read is the caller's error (status 1) when the model is built:
+    range-affine expressions are checked at both ends, table-indexed ones point by point."""
+    import numpy as np
+    from exahip import ExaCore, ExaModel, Table, capi, rng
+
+    def build(kind):
+        c = ExaCore()
+        x = c.add_var(10)
+        th = c.add_par(3, value=1.0)
+        if kind == "range_hi":
+            c.add_obj(lambda i: x[i + 1] ** 2, rng(1, 10))              # x[11]
+        elif kind == "range_lo":
+            c.add_con(lambda i: x[i - 2] * x[i], rng(2, 10))            # x[0]
+        elif kind == "table":
+            c.add_obj(lambda t: t.w * x[t.i], Table(i=np.array([1, 5, 12]), w=np.ones(3)))
+        elif kind == "param":
+            c.add_obj(lambda i: th[i] * x[i], rng(1, 4))                # theta[4]
+        elif kind == "ok":
+            c.add_obj(lambda t: t.w * x[t.i] * th[3], Table(i=np.array([1, 5, 10]), w=np.ones(3)))
+        return c
+
+    assert ExaModel(build("ok"), device=False).meta.nvar == 10
+    for kind, needle in (("range_hi", "variable index 11"), ("range_lo", "variable index 0"), ("table", "variable index 12"),
+                         ("param", "parameter index 4")):
+        with pytest.raises(capi.ExaHipError) as e:
+            ExaModel(build(kind), device=False)
+        assert "status 1" in str(e.value)
+        assert needle in capi.lib().exa_last_error().decode()
