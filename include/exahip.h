@@ -51,7 +51,9 @@ const char *exa_last_error(void);                       /* thread-local text of 
 /* ---- build / destroy -------------------------------------------------------------------------- */
 /* Plans the COO layout (slot maps comp1/comp2, o1step/o2step, running offsets in insertion order),
  * generates + compiles one HIP module for the model (cached on disk by source hash), uploads the SoA
- * iterator columns.  Returns id > 0 in *id_out. */
+ * iterator columns.  Returns id > 0 in *id_out.  The table is validated (node links, column references, integer-typed
+ * index expressions, augmentation targets inside their base block, every x[...] / theta[...] index inside 1..nvar /
+ * 1..npar for every data point): a malformed table is status 1, never a crash or an out-of-bounds device access. */
 int exa_new_from_table(const exa_model_desc_t *desc, int *id_out);
 /* Same, but only plan + generate source (no device needed): used by the CPU-side build check and tests. */
 int exa_plan_only(const exa_model_desc_t *desc, int *id_out);
