@@ -5,6 +5,10 @@
 //   v2: direct + nontemporal
 //   v3: LDS transpose — stage the wavefront's 64*S doubles in LDS, then store them lane-interleaved (coalesced)
 //   v4: v3 + nontemporal
+//   v5-v11: what the write path itself prefers (no generated kernel uses these shapes — see DESIGN.md §5):
+//     v8  K stores of 8 or 16 B per lane per wavefront: 1 KB per wavefront (4 KB per workgroup) 6.9 TB/s, >= 1.5 KB 5.5-5.9
+//     v9  a workgroup writing 3 CONSECUTIVE 4 KB units 5.6-5.9;  v10 the same three units 8 apart (= blockIdx mod 8) 6.5
+//     v11 v10 with loads + LDS staging (whole 4 KB-aligned units per workgroup, 16-B nt stores) 6.3-7.0 at 720 MB
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -52,6 +56,115 @@ __global__ void __launch_bounds__(256) k_lds(double* __restrict__ out, const dou
         if (base + j < lim) { if (NT) __builtin_nontemporal_store(val, out + base + j); else out[base + j] = val; }
     }
 }
+// v5/v6: no loads, no LDS — only the store shape.  CHUNK: a wavefront writes its own 64*S contiguous doubles with S
+// 512-B bursts (the shape of the generated flush).  !CHUNK: burst k of every wavefront lands in region k (all wavefronts
+// advance one contiguous front per step).
+template <bool NT, bool CHUNK>
+__global__ void __launch_bounds__(256) k_shape(double* __restrict__ out, long n) {
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const long nw = (n + 63) / 64;
+    if (wave >= nw) return;
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const long j = CHUNK ? (wave * S + k) * 64 + lane : ((long)k * nw + wave) * 64 + lane;
+        if (j < n * S) { if (NT) __builtin_nontemporal_store((double)j, out + j); else out[j] = (double)j; }
+    }
+}
+// v8: K stores of W doubles per lane per wavefront, to its own contiguous chunk (K * 64 * W doubles)
+template <int W, int K>
+__global__ void __launch_bounds__(256) k_multi(double* __restrict__ out, long total) {
+    const long wave = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const long j = ((wave * K + k) * 64 + lane) * W;
+        if (j + W <= total) {
+            if (W == 2) reinterpret_cast<double2*>(out)[j / 2] = make_double2((double)j, 1.0);
+            else out[j] = (double)j;
+        }
+    }
+}
+// v9: a workgroup owns 256*S contiguous doubles and writes them in steps of 4 KB: at step k wavefront w writes the
+// 1 KB piece k*4 + w with one 16-B-per-lane store (no loads, no LDS)
+__global__ void __launch_bounds__(256) k_wg1k(double* __restrict__ out, long total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long base = (long)blockIdx.x * 256 * S;
+#pragma unroll
+    for (int k = 0; k < S / 2; k++) {
+        const long j = base + ((k * 4 + w) * 64 + lane) * 2;
+        if (j + 2 <= total) reinterpret_cast<double2*>(out)[j / 2] = make_double2((double)j, 1.0);
+    }
+}
+// v10: as v9, but the three 4 KB units of workgroup b are 8 units apart and congruent to b mod 8: if the hardware
+// places workgroup b on XCD b % 8 and interleaves 4 KB units over the HBM stacks, every XCD then writes to "its" stack
+template <int UNIT_DOUBLES>
+__global__ void __launch_bounds__(256) k_wg_affine(double* __restrict__ out, long total, int shift) {
+    const int t = threadIdx.x;
+    const long b = blockIdx.x, grp = b >> 3, r = (b + shift) & 7;
+    constexpr int PER_WG = 256 * S / UNIT_DOUBLES;          // units per workgroup
+#pragma unroll
+    for (int k = 0; k < PER_WG; k++) {
+        const long unit = (grp * PER_WG + k) * 8 + r;
+#pragma unroll
+        for (int q = 0; q < UNIT_DOUBLES / 512; q++) {
+            const long j = unit * UNIT_DOUBLES + (q * 256 + t) * 2;
+            if (j + 2 <= total) reinterpret_cast<double2*>(out)[j / 2] = make_double2((double)j, 1.0);
+        }
+    }
+}
+// v11: the full shape of a unit-affine flush: loads + LDS staging + whole 4 KB units.  A workgroup of 448 threads
+// owns 5 units (= blockIdx mod 8, 8 units apart); thread t computes point q = t % 87 of unit t / 87 (a unit touches
+// 86-87 points of S = 6 doubles; points straddling a unit boundary are computed by both neighbours), stages its S values
+// at their final positions inside the unit, then the unit is streamed out with one 16-B-per-lane store per wavefront.
+template <bool NT, int G = 5, int T = 87, int BLK = 448>
+__global__ void __launch_bounds__(BLK) k_unit(double* __restrict__ out, const double* __restrict__ x, long n) {
+    __shared__ double tile[G][512];
+    const int t = threadIdx.x, k = t / T, q = t - k * T;
+    const long grp = blockIdx.x >> 3, r = blockIdx.x & 7;
+    if (k < G) {
+        const long u = (grp * G + k) * 8 + r;
+        const long p = (512 * u) / S + q;
+        const double a = p < n ? x[p] : 0.0;
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            const long e = p * S + s - 512 * u;
+            if (e >= 0 && e < 512) tile[k][e] = a * (s + 1);
+        }
+    }
+    __syncthreads();
+    const long lim = n * S;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    for (int f = t; f < G * 256; f += BLK) {
+        const int kk = f >> 8, e = (f & 255) * 2;
+        const long j = 512 * ((grp * G + kk) * 8 + r) + e;
+        if (j + 2 <= lim) {
+            const v2d v = *(const v2d*)&tile[kk][e];
+            if (NT) __builtin_nontemporal_store(v, (v2d*)(out + j)); else *(v2d*)(out + j) = v;
+        }
+    }
+}
+// v7: the LDS-transposed flush, but the 4 wavefronts of a workgroup share one 12 KB tile and store it interleaved:
+// at step k wavefront w writes burst 4k + w, so the workgroup's concurrent stores are 2 KB contiguous
+template <bool NT>
+__global__ void __launch_bounds__(256) k_lds_wg(double* __restrict__ out, const double* __restrict__ x, long n) {
+    __shared__ double tile[S * 257];
+    const long I = (long)blockIdx.x * 256 + threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const double a = I < n ? x[I] : 0.0;
+#pragma unroll
+    for (int s = 0; s < S; s++) tile[s * 257 + t] = a * (s + 1);
+    __syncthreads();
+    const long base = (long)blockIdx.x * 256 * S;
+    const long lim = n * S;
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const int j = (k * 4 + w) * 64 + lane;
+        const int l2 = j / S, s2 = j - l2 * S;
+        const double val = tile[s2 * 257 + l2];
+        if (base + j < lim) { if (NT) __builtin_nontemporal_store(val, out + base + j); else out[base + j] = val; }
+    }
+}
 // read-side calibration for the FETCH_SIZE counter: the access pattern of exa_hess on Luksan-Vlcek
 // (three overlapping 8-B/lane loads of x, one of y), nothing written but one double per workgroup
 __global__ void __launch_bounds__(256) k_read8(const double* __restrict__ x, const double* __restrict__ y, double* __restrict__ part, long n) {
@@ -84,6 +197,46 @@ int main(int argc, char** argv) {
     timeit("v2 direct nt", [&] { k_direct<true><<<grid, 256>>>(out, x, n); });
     timeit("v3 lds transpose", [&] { k_lds<false><<<grid, 256>>>(out, x, n); });
     timeit("v4 lds transpose nt", [&] { k_lds<true><<<grid, 256>>>(out, x, n); });
+    timeit("v5 shape: chunk/wave", [&] { k_shape<false, true><<<grid, 256>>>(out, n); });
+    timeit("v5 shape: chunk/wave nt", [&] { k_shape<true, true><<<grid, 256>>>(out, n); });
+    timeit("v6 shape: front", [&] { k_shape<false, false><<<grid, 256>>>(out, n); });
+    timeit("v6 shape: front nt", [&] { k_shape<true, false><<<grid, 256>>>(out, n); });
+    {
+        const long total = n * S;
+        auto g = [&](int w, int k) { return (unsigned)((total / ((long)w * k) + 255) / 256 + 1); };
+        timeit("v8 8B/lane x1 store/wave", [&] { k_multi<1, 1><<<g(1, 1), 256>>>(out, total); });
+        timeit("v8 8B/lane x2", [&] { k_multi<1, 2><<<g(1, 2), 256>>>(out, total); });
+        timeit("v8 8B/lane x3", [&] { k_multi<1, 3><<<g(1, 3), 256>>>(out, total); });
+        timeit("v8 8B/lane x6", [&] { k_multi<1, 6><<<g(1, 6), 256>>>(out, total); });
+        timeit("v8 8B/lane x12", [&] { k_multi<1, 12><<<g(1, 12), 256>>>(out, total); });
+        timeit("v8 8B/lane x4", [&] { k_multi<1, 4><<<g(1, 4), 256>>>(out, total); });
+        timeit("v8 8B/lane x8", [&] { k_multi<1, 8><<<g(1, 8), 256>>>(out, total); });
+        timeit("v8 16B/lane x2", [&] { k_multi<2, 2><<<g(2, 2), 256>>>(out, total); });
+        timeit("v8 16B/lane x4", [&] { k_multi<2, 4><<<g(2, 4), 256>>>(out, total); });
+        timeit("v9 wg 12KB in 3 x 4KB steps", [&] { k_wg1k<<<grid, 256>>>(out, total); });
+        for (int c = 0; c < 8; c++) {
+            char nm[64]; snprintf(nm, sizeof nm, "v10 3 x 4KB units = b+%d mod 8", c);
+            timeit(nm, [&] { k_wg_affine<512><<<grid, 256>>>(out, total, c); });
+        }
+        timeit("v10 3 x 4KB units, +512B misaligned", [&] { k_wg_affine<512><<<grid, 256>>>(out + 64, total - 64, 0); });
+        timeit("v10 6 x 4KB... (1024-double units)", [&] { k_wg_affine<1024><<<grid, 256>>>(out, total, 0); });
+        {
+            const unsigned gu = (unsigned)(((total + 511) / 512 + 4) / 5 + 8);
+            timeit("v11 unit-affine flush (loads+LDS)", [&] { k_unit<false><<<gu, 448>>>(out, x, n); });
+            timeit("v11 unit-affine flush nt", [&] { k_unit<true><<<gu, 448>>>(out, x, n); });
+            const unsigned g2 = (unsigned)(((total + 511) / 512 + 1) / 2 + 8);
+            timeit("v11 nt, 192 threads / 2 units", [&] { k_unit<true, 2, 96, 192><<<g2, 192>>>(out, x, n); });
+            const unsigned g4 = (unsigned)(((total + 511) / 512 + 3) / 4 + 8);
+            timeit("v11 nt, 384 threads / 4 units", [&] { k_unit<true, 4, 96, 384><<<g4, 384>>>(out, x, n); });
+            const unsigned g1 = (unsigned)((total + 511) / 512 + 8);
+            timeit("v11 nt, 128 threads / 1 unit", [&] { k_unit<true, 1, 128, 128><<<g1, 128>>>(out, x, n); });
+        }
+        timeit("v8 16B/lane x1", [&] { k_multi<2, 1><<<g(2, 1), 256>>>(out, total); });
+        timeit("v8 16B/lane x3", [&] { k_multi<2, 3><<<g(2, 3), 256>>>(out, total); });
+        timeit("v8 16B/lane x6", [&] { k_multi<2, 6><<<g(2, 6), 256>>>(out, total); });
+    }
+    timeit("v7 lds, workgroup-interleaved", [&] { k_lds_wg<false><<<grid, 256>>>(out, x, n); });
+    timeit("v7 lds, wg-interleaved nt", [&] { k_lds_wg<true><<<grid, 256>>>(out, x, n); });
     {
         const long nr = 10000000;
         double *xr, *yr, *pr;
