@@ -564,6 +564,16 @@ struct Body {
     }
 };
 
+// Second-order adjoint at the root.  The reference seeds it with a RUN-TIME zero (shessian!, hessian.jl:714-717:
+// `adj2 = zero(T)`) and its generic node rule computes adj2 * y^2 + adj * h (hessian.jl:346-360) — so wherever a first
+// partial is Inf or NaN (log'(0), exp overflow, ...) the reference's Hessian entry is NaN (0 * Inf), not +-Inf.  A
+// literal zero would be folded away here and give +-Inf instead; the seed is therefore an SSA value the compiler
+// must multiply with (no fast-math), which costs one multiply-add per first generic node under the root.
+Val zero_seed(Body &b) {
+    if (env_int("EXAHIP_FOLD_ZERO_SEED", 0)) return Emitter::litf(0.0);     // experiment knob: the folded form
+    return b.e.raw("0.0", false);
+}
+
 // symbolic algebra for the reverse sweeps
 struct GenAlg {
     using T = Val;
@@ -1054,7 +1064,7 @@ void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     if (p.kind == EXA_PAT_OBJ) adj = b.e.raw("sigma", false);
     else adj = b.e.raw("y[" + b.row0() + "]", false);
     GenAlg a(b, p.comp2, p.o2step);
-    hrpass0(p, p.ad_root, a, adj, Emitter::litf(0.0));
+    hrpass0(p, p.ad_root, a, adj, zero_seed(b));
     const bool tile = use_tile(p.o2step);
     os << "static __device__ __forceinline__ void " << fn_name(pi, "hess")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
@@ -1084,7 +1094,7 @@ void gen_fused_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     if (isobj) adj = b.e.raw("sigma", false);
     else adj = b.e.raw("y[" + b.row0() + "]", false);
     GenAlg a2(b, p.comp2, p.o2step);
-    if (p.o2step > 0) hrpass0(p, p.ad_root, a2, adj, Emitter::litf(0.0));
+    if (p.o2step > 0) hrpass0(p, p.ad_root, a2, adj, zero_seed(b));
     const std::string rowtxt = isobj ? "" : (p.kind == EXA_PAT_CONAUG ? b.P(L.pat[pi].oa) + " + I" : b.P(L.pat[pi].o0) + " + I");
     os << "static __device__ __forceinline__ double " << fn_name(pi, "fused")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "

@@ -77,8 +77,22 @@ static inline double tand_(double x) { return tan(d2r(fmod(x, 180.0))); }
 static inline double cscd_(double x) { return 1.0 / sind_(x); }
 static inline double secd_(double x) { return 1.0 / cosd_(x); }
 static inline double cotd_(double x) { return 1.0 / tand_(x); }
-static inline double sinpi_(double x) { return sin(M_PI * fmod(x, 2.0)); }
-static inline double cospi_(double x) { return cos(M_PI * fmod(x, 2.0)); }
+/* Base.sinpi / Base.cospi semantics: exact at integers and half-integers (the argument is reduced BEFORE it is multiplied
+ * by pi): n = nearest integer, r = x - n is exact and |r| <= 1/2; sin(pi x) = (-1)^n sin(pi r). */
+static inline double sinpi_(double x) {
+    if (!isfinite(x)) return NAN;
+    const double n = nearbyint(x), r = x - n, a = fabs(r);
+    double s = a <= 0.25 ? sin(M_PI * r) : copysign(cos(M_PI * (0.5 - a)), r);
+    if (fmod(n, 2.0) != 0.0) s = -s;
+    return s;
+}
+static inline double cospi_(double x) {
+    if (!isfinite(x)) return NAN;
+    const double n = nearbyint(x), r = x - n, a = fabs(r);
+    double c = a <= 0.25 ? cos(M_PI * r) : sin(M_PI * (0.5 - a));
+    if (fmod(n, 2.0) != 0.0) c = -c;
+    return c;
+}
 static inline double sinc_(double x) { return x == 0.0 ? 1.0 : sinpi_(x) / (M_PI * x); }
 static inline double sign_(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
 
