@@ -1,0 +1,60 @@
+"""-m gpu: distinct model ids are independent (ExaModelsCompiler/test/runtests.jl:299-307; SURVEY §8b threading):
+two host threads drive two models on two HIP streams at the same time (ctypes releases the GIL during the calls, so
+the library really is entered concurrently) while a third keeps creating and freeing models (registry churn)."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from zoo import ZOO, point
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def test_two_threads_two_models_two_streams(libs):
+    import torch
+    from exahip import ExaModel
+    dev = torch.device("cuda:0")
+    jobs = {}
+    for name in ("lv1000", "rocket50"):
+        m = ExaModel(ZOO[name]())
+        x0, y0, s = point(m.meta.x0, m.meta.ncon, seed=21)
+        x, y = torch.from_numpy(x0).to(dev), torch.from_numpy(y0).to(dev)
+        ref = (m.obj(x), m.cons(x).clone(), m.jac_coord(x).clone(), m.hess_coord(x, y, s).clone())
+        jobs[name] = (m, x, y, s, ref)
+    torch.cuda.synchronize()
+    errors = []
+    stop = threading.Event()
+
+    def worker(name):
+        m, x, y, s, ref = jobs[name]
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                xs, ys = x.clone(), y.clone()
+                for _ in range(150):
+                    f = m.obj(xs)
+                    c, j, h = m.cons(xs), m.jac_coord(xs), m.hess_coord(xs, ys, s)
+                    stream.synchronize()
+                    assert f == ref[0] and torch.equal(c, ref[1]) and torch.equal(j, ref[2]) and torch.equal(h, ref[3])
+        except Exception as e:          # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    def churn():
+        try:
+            while not stop.is_set():
+                t = ExaModel(ZOO["lv20"]())
+                assert t.meta.nvar == 20 and t.obj(np.full(20, 2.0)) == 100.0 * 4 * 19 + 19
+                del t
+        except Exception as e:          # noqa: BLE001
+            errors.append(("churn", repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(n,)) for n in jobs] + [threading.Thread(target=churn)]
+    for t in threads:
+        t.start()
+    for t in threads[:2]:
+        t.join()
+    stop.set()
+    threads[2].join()
+    assert not errors, errors
