@@ -1274,7 +1274,9 @@ void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const st
     if (scatter) os << "    double lit[" << std::max<size_t>(maxlit, 1) << "] = {0.0};\n";
     for (size_t k = 0; k < act.size(); k++) {
         os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n";
-        if (ppt > 1) os << "#pragma unroll 2\n        for (int u = 0; u < " << ppt << "; u++) ";
+        // no unrolling for the scatter kernels: two inlined copies of a large Hessian body exhaust the register file
+        // (512 VGPRs + scratch spills were observed, and a spilling exa_hprod produced wrong sums on gfx950)
+        if (ppt > 1) os << "#pragma unroll " << (scatter ? 1 : 2) << "\n        for (int u = 0; u < " << ppt << "; u++) ";
         else os << "        { const int u = 0; ";
         os << "p" << act[k] << "_" << call_prefix << "(" << call_args << ", tid0 + u * EXA_BLOCK" << tail_args << (scatter ? ", lit" : "") << ");"
            << (ppt > 1 ? "" : " }") << "\n";

@@ -57,3 +57,30 @@ def test_random_patterns_values_on_hip(libs, seed):
     assert relerr(m.jprod(x, v), o.jprod(x, v)) <= tol
     assert relerr(m.jtprod(x, w), o.jtprod(x, w)) <= tol
     assert relerr(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)) <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+@pytest.mark.parametrize("seed", [523, 541])
+def test_deep_random_patterns_on_hip(libs, seed, monkeypatch):
+    """Depth-6 trees over 300 data points: Hessian bodies of several hundred SSA values per pattern, kernels at the
+    512-VGPR limit with scratch spills.  Seed 523 is the regression case of a wrong H*v (and an occasional memory fault)
+    when the 16-tile loop of the scatter kernels was unrolled twice; found by a one-off sweep over 260 such models."""
+    from exahip import ExaModel
+    import oracle
+    monkeypatch.setattr(randexpr, "NPTS", 300)
+    m = ExaModel(randexpr.build_model(seed, 12, 6))
+    o = oracle.OracleModel(m.ir)
+    m.set_product_mode(0, 0)
+    x = m.meta.x0 + 0.05 * np.random.default_rng(seed).uniform(-1, 1, m.meta.nvar)
+    y = np.random.default_rng(seed + 1).standard_normal(m.meta.ncon)
+    v = np.random.default_rng(seed + 2).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(seed + 3).standard_normal(m.meta.ncon)
+    tol = 1e-10
+    for _ in range(3):                                   # the failure was intermittent
+        assert relerr(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)) <= tol
+        assert relerr(m.jtprod(x, w), o.jtprod(x, w)) <= tol
+    assert relerr(m.grad(x), o.grad(x)) <= tol
+    assert relerr(m.hess_coord(x, y, 0.7), o.hess_coord(x, y, 0.7)) <= tol
+    assert relerr(m.jac_coord(x), o.jac_coord(x)) <= tol
+    assert relerr(m.cons(x), o.cons(x)) <= tol
