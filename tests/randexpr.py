@@ -100,3 +100,43 @@ def build_model(seed, npat=12, depth=4):
         else:
             c.add_con_aug(base, lambda d, fn=fn: (d.t, fn(d)), tab)      # shared target rows
     return c
+
+
+class _RangePoint:
+    """Adapter: a range iterator's data point `i` presented with the fields the tree generator reads."""
+
+    def __init__(self, i, step):
+        self.i, self.j, self.w, self.t = i, i + 1, 0.75, i if step == 1 else (i - 1) * 0 + 1
+
+
+def build_range_model(seed, npts=1000, npat=8, depth=4):
+    """As build_model, but every pattern iterates a RANGE (unit or stepped), so indices are `range + c`: the
+    gathered gradient, the LDS-window scatter of J'v / Hv, the multi-tile flush and partial wavefronts are exercised."""
+    g = Gen(seed)
+    c = ExaCore()
+    nvar = 3 * npts + 8
+    x = c.add_var(nvar, start=np.linspace(0.3, 1.1, nvar))
+    th = c.add_par(3, value=[0.7, 1.3, -0.4])
+    base = None
+    global NVAR
+    saved = NVAR
+    NVAR = 40                      # constant-index leaves stay inside the variable block
+    try:
+        for k in range(npat):
+            step = 1 + int(g.r.integers(0, 3)) * (k % 3 == 2)
+            lo = 1 + int(g.r.integers(0, 3))
+            n = npts - int(g.r.integers(0, 70))
+            itr = rng(lo, lo + step * (n - 1), step)
+            fn = (lambda i, s=int(g.r.integers(0, 2**31)), st=step: Gen(s).tree(x, th, _RangePoint(i, st), depth))
+            kind = k % 4
+            if kind == 0:
+                c.add_obj(fn, itr)
+            elif kind in (1, 2) or base is None:
+                base = c.add_con(fn, itr)
+                base_n = n
+            else:
+                m = min(n, base_n)
+                c.add_con_aug(base, lambda i, fn=fn: (i, fn(i)), rng(1, m))
+    finally:
+        NVAR = saved
+    return c

@@ -84,3 +84,43 @@ def test_deep_random_patterns_on_hip(libs, seed, monkeypatch):
     assert relerr(m.hess_coord(x, y, 0.7), o.hess_coord(x, y, 0.7)) <= tol
     assert relerr(m.jac_coord(x), o.jac_coord(x)) <= tol
     assert relerr(m.cons(x), o.cons(x)) <= tol
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+@pytest.mark.parametrize("seed", range(6))
+def test_random_range_patterns_on_hip(libs, seed):
+    """Random trees over RANGE iterators (unit and stepped, ~1000 points, `range + c` indices): the gathered gradient,
+    the LDS-window scatter of J'v / Hv, multi-tile flushes, partial wavefronts, the fused sweep and a 3-way shard."""
+    import torch
+    from exahip import ExaModel
+    import oracle
+    m = ExaModel(randexpr.build_range_model(seed))
+    o = oracle.OracleModel(m.ir)
+    x = m.meta.x0 + 0.05 * np.random.default_rng(seed).uniform(-1, 1, m.meta.nvar)
+    y = np.random.default_rng(seed + 1).standard_normal(m.meta.ncon)
+    v = np.random.default_rng(seed + 2).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(seed + 3).standard_normal(m.meta.ncon)
+    tol = 1e-10
+    H = o.hess_coord(x, y, 0.7)
+    assert abs(m.obj(x) - o.obj(x)) <= tol * max(1.0, abs(o.obj(x)))
+    assert relerr(m.cons(x), o.cons(x)) <= tol and relerr(m.grad(x), o.grad(x)) <= tol
+    assert relerr(m.jac_coord(x), o.jac_coord(x)) <= tol and relerr(m.hess_coord(x, y, 0.7), H) <= tol
+    assert relerr(m.jprod(x, v), o.jprod(x, v)) <= tol and relerr(m.jtprod(x, w), o.jtprod(x, w)) <= tol
+    assert relerr(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)) <= tol
+    for a, b in zip(m.jac_structure() + m.hess_structure(), o.jac_structure() + o.hess_structure()):
+        assert np.array_equal(a, b)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    f, c, j, h = m.eval_fused(xd, yd, 0.7)
+    assert relerr(h.cpu().numpy(), H) <= tol and relerr(j.cpu().numpy(), o.jac_coord(x)) <= tol
+    acc = torch.zeros(m.meta.nnzh, dtype=torch.float64, device="cuda")
+    g = np.zeros(m.meta.nvar)
+    try:
+        for r in range(3):
+            m.set_shard(r, 3)
+            part = torch.zeros_like(acc)
+            acc += m.hess_coord(xd, yd, 0.7, out=part)
+            g += m.grad(xd).cpu().numpy()
+    finally:
+        m.set_shard(0, 1)
+    assert relerr(acc.cpu().numpy(), H) <= tol and relerr(g, o.grad(x)) <= tol
