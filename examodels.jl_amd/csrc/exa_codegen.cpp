@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <sstream>
 #include <stdexcept>
 
@@ -1292,6 +1293,10 @@ void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const st
 }  // namespace
 
 Generated generate_module(const Model &m) {
+    // the scatter bookkeeping above (g_lds_need, g_lit_idx) is module-level state of one generation: serialise
+    // concurrent model builds here (planning and hipcc still run in parallel)
+    static std::mutex gen_mu;
+    std::lock_guard<std::mutex> gen_lock(gen_mu);
     Generated g;
     ParamLayout &L = g.layout;
     const int np = (int)m.pats.size();

@@ -58,3 +58,30 @@ def test_two_threads_two_models_two_streams(libs):
     stop.set()
     threads[2].join()
     assert not errors, errors
+
+
+def test_concurrent_model_builds(libs):
+    """several threads build (plan + generate + load) different models at once; each result is then checked"""
+    from exahip import ExaModel
+    import oracle
+    names = ["lv20", "mixed", "rocket50", "acopf30", "stepped", "conaug2d", "cops_chain", "lv_split_20x2"]
+    built, errors = {}, []
+
+    def build(name):
+        try:
+            for _ in range(3):
+                built[name] = ExaModel(ZOO[name]())
+        except Exception as e:          # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    ts = [threading.Thread(target=build, args=(n,)) for n in names]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for name, m in built.items():
+        o = oracle.OracleModel(m.ir)
+        x, y, s = point(m.meta.x0, m.meta.ncon, seed=2)
+        np.testing.assert_allclose(m.hess_coord(x, y, s), o.hess_coord(x, y, s), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(m.jtprod(x, y), o.jtprod(x, y), rtol=1e-10, atol=1e-12)
