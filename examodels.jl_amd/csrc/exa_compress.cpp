@@ -112,6 +112,50 @@ __global__ void __launch_bounds__(256) k_spmv_long(const uint32_t *__restrict__ 
     if (threadIdx.x == 0) unsafeAtomicAdd(&out[k], red[0] + red[1] + red[2] + red[3]);
 }
 
+__global__ void __launch_bounds__(256) k_other(const uint32_t *__restrict__ perm, const int64_t *__restrict__ other,
+                                               const int64_t *__restrict__ rows, const int64_t *__restrict__ cols, int skip_diag,
+                                               uint32_t *__restrict__ oth, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t e = perm[j];
+    oth[j] = (skip_diag && rows[e] == cols[e]) ? 0xffffffffu : (uint32_t)(other[e] - 1);
+}
+// same sums as below with the "other" index pre-gathered in sorted order: per entry one sequential 8-byte read
+// (perm, oth) and two gathers (value, v) instead of up to four random 8-byte loads
+__global__ void __launch_bounds__(256) k_spmv_gather2(const int64_t *__restrict__ ptr, const uint32_t *__restrict__ perm,
+                                                      const uint32_t *__restrict__ oth, const double *__restrict__ vals,
+                                                      const double *__restrict__ v, double *__restrict__ out, int accumulate, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    double s = accumulate ? out[k] : 0.0;
+    const int64_t b = ptr[k], e1 = ptr[k + 1];
+    if (e1 - b <= kLongRow) {
+        for (int64_t j = b; j < e1; j++) {
+            const uint32_t o = oth[j];
+            if (o != 0xffffffffu) s += vals[perm[j]] * v[o];
+        }
+    }
+    out[k] = s;
+}
+__global__ void __launch_bounds__(256) k_spmv_long2(const uint32_t *__restrict__ list, const int64_t *__restrict__ ptr,
+                                                    const uint32_t *__restrict__ perm, const uint32_t *__restrict__ oth,
+                                                    const double *__restrict__ vals, const double *__restrict__ v, double *__restrict__ out) {
+    __shared__ double red[4];
+    const int64_t k = list[blockIdx.x];
+    const int64_t beg = ptr[k] + (int64_t)blockIdx.y * kChunk;
+    const int64_t end = beg + kChunk < ptr[k + 1] ? beg + kChunk : ptr[k + 1];
+    if (beg >= ptr[k + 1]) return;
+    double s = 0.0;
+    for (int64_t j = beg + threadIdx.x; j < end; j += 256) {
+        const uint32_t o = oth[j];
+        if (o != 0xffffffffu) s += vals[perm[j]] * v[o];
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(&out[k], red[0] + red[1] + red[2] + red[3]);
+}
+
 // one thread per group (variable / row): contributions added in ascending slot order -> deterministic
 __global__ void __launch_bounds__(256) k_spmv_gather(const int64_t *__restrict__ ptr, const uint32_t *__restrict__ perm,
                                                      const double *__restrict__ vals, const int64_t *__restrict__ other,
@@ -199,7 +243,7 @@ void build_compressed(CompressedCOO &c, const int64_t *rows, const int64_t *cols
 }
 
 void SortedIndex::release() {
-    for (void **q : {&perm, &ptr, &long_rows}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    for (void **q : {&perm, &ptr, &long_rows, &oth}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     nnz = ndim = nlong = maxlen = 0;
 }
 
@@ -244,6 +288,16 @@ void build_sorted_index(SortedIndex &s, const int64_t *keys1, int64_t nnz, int64
 void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other, const int64_t *rows, const int64_t *cols, bool skip_diag,
                  const double *v, double *out, bool accumulate, hipStream_t stream) {
     if (s.ndim == 0) return;
+    if (s.oth) {
+        hipLaunchKernelGGL(k_spmv_gather2, dim3(grid_for(s.ndim)), dim3(256), 0, stream, (const int64_t *)s.ptr, (const uint32_t *)s.perm,
+                           (const uint32_t *)s.oth, vals, v, out, accumulate ? 1 : 0, s.ndim);
+        if (s.nlong) {
+            const unsigned chunks = (unsigned)((s.maxlen + kChunk - 1) / kChunk);
+            hipLaunchKernelGGL(k_spmv_long2, dim3((unsigned)s.nlong, chunks), dim3(256), 0, stream, (const uint32_t *)s.long_rows,
+                               (const int64_t *)s.ptr, (const uint32_t *)s.perm, (const uint32_t *)s.oth, vals, v, out);
+        }
+        return;
+    }
     hipLaunchKernelGGL(k_spmv_gather, dim3(grid_for(s.ndim)), dim3(256), 0, stream, (const int64_t *)s.ptr, (const uint32_t *)s.perm, vals,
                        other, rows, cols, skip_diag ? 1 : 0, v, out, accumulate ? 1 : 0, s.ndim);
     if (s.nlong) {
@@ -251,6 +305,14 @@ void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other,
         hipLaunchKernelGGL(k_spmv_long, dim3((unsigned)s.nlong, chunks), dim3(256), 0, stream, (const uint32_t *)s.long_rows,
                            (const int64_t *)s.ptr, (const uint32_t *)s.perm, vals, other, rows, cols, skip_diag ? 1 : 0, v, out);
     }
+}
+
+void attach_other(SortedIndex &s, const int64_t *other, const int64_t *rows, const int64_t *cols, bool skip_diag, int64_t other_dim,
+                  hipStream_t stream) {
+    if (s.nnz == 0 || other_dim >= 0xffffffffLL) return;
+    if (!s.oth) HIPCHK_C(hipMalloc(&s.oth, 4 * (size_t)s.nnz));
+    hipLaunchKernelGGL(k_other, dim3(grid_for(s.nnz)), dim3(256), 0, stream, (const uint32_t *)s.perm, other, rows, cols, skip_diag ? 1 : 0,
+                       (uint32_t *)s.oth, s.nnz);
 }
 
 void compress_values(const CompressedCOO &c, const double *buf, double *V, hipStream_t stream) {

@@ -32,8 +32,15 @@ struct SortedIndex {
     // reduced cooperatively: one workgroup per 8192-entry chunk, one atomic per chunk
     void *long_rows = nullptr;   // uint32[nlong]
     int64_t nlong = 0, maxlen = 0;
+    // per sorted position: 0-based index of the OTHER coordinate of that entry (what v is gathered with), or
+    // 0xffffffff for an entry this product skips — read sequentially instead of three random int64 loads per entry
+    void *oth = nullptr;         // uint32[nnz], optional (attach_other)
     void release();
 };
+// fills s.oth from the structure arrays (1-based int64, device); entries with rows[e] == cols[e] are marked skipped when
+// skip_diag.  No-op (oth stays null) when an index does not fit 32 bits.
+void attach_other(SortedIndex &s, const int64_t *other, const int64_t *rows, const int64_t *cols, bool skip_diag, int64_t other_dim,
+                  hipStream_t stream);
 void build_sorted_index(SortedIndex &s, const int64_t *keys1, int64_t nnz, int64_t ndim, hipStream_t stream);
 // out[k] (+)= sum_{e in group k, (skip_diag ? rows[e] != cols[e] : true)} vals[e] * v[other[e] - 1]
 void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other, const int64_t *rows, const int64_t *cols, bool skip_diag,

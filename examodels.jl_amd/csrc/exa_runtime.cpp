@@ -501,6 +501,7 @@ void prod_setup(Handle &h, bool hess) {
         h.pjrows.ensure(8 * (size_t)std::max<int64_t>(m.nnzj, 1)); h.pjcols.ensure(8 * (size_t)std::max<int64_t>(m.nnzj, 1));
         do_struct(h, false, true, h.pjrows.p, h.pjcols.p);
         build_sorted_index(h.jbycol, (const int64_t *)h.pjcols.p, m.nnzj, m.nvar, h.stream);
+        attach_other(h.jbycol, (const int64_t *)h.pjrows.p, nullptr, nullptr, false, m.ncon, h.stream);
         h.prod_ready_j = true;
     }
     if (hess && !h.prod_ready_h) {
@@ -508,6 +509,9 @@ void prod_setup(Handle &h, bool hess) {
         do_struct(h, true, true, h.phrows.p, h.phcols.p);
         build_sorted_index(h.hbyrow, (const int64_t *)h.phrows.p, m.nnzh, m.nvar, h.stream);
         build_sorted_index(h.hbycol, (const int64_t *)h.phcols.p, m.nnzh, m.nvar, h.stream);
+        const int64_t *r = (const int64_t *)h.phrows.p, *c = (const int64_t *)h.phcols.p;
+        attach_other(h.hbyrow, c, r, c, false, m.nvar, h.stream);     // lower triangle incl. diagonal: gathers v[col]
+        attach_other(h.hbycol, r, r, c, true, m.nvar, h.stream);      // its transpose, off-diagonal only: gathers v[row]
         h.prod_ready_h = true;
     }
 }
