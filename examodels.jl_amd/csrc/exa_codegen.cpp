@@ -1178,7 +1178,7 @@ void gen_hprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     if (p.kind == EXA_PAT_OBJ) adj = b.e.raw("sigma", false);
     else adj = b.e.raw("y[" + b.row0() + "]", false);
     GenAlg a(b, p.comp2, p.o2step);
-    hrpass0(p, p.ad_root, a, adj, Emitter::litf(0.0));
+    hrpass0(p, p.ad_root, a, adj, zero_seed(b));
     const int nk = (int)p.keys.size();
     std::vector<int> rep(nk, -1);
     for (size_t n = 0; n < p.ad.size(); n++)

@@ -50,6 +50,11 @@ def test_every_univariate_at_special_arguments(libs):
                 _agree(m.jac_coord(SPECIAL), o.jac_coord(SPECIAL), f"{fn}: first derivative")
                 _agree(m.hess_coord(SPECIAL, y, 1.0), o.hess_coord(SPECIAL, y, 1.0), f"{fn}: second derivative")
                 _agree(m.grad(SPECIAL), o.grad(SPECIAL), f"{fn}: gradient")
+                v = np.linspace(0.5, 1.5, len(SPECIAL))
+                m.set_product_mode(0, 0)               # the matrix-free sweeps, not the COO-based alternative
+                _agree(m.hprod(SPECIAL, y, v, 1.0), o.hprod(SPECIAL, y, v, 1.0), f"{fn}: H*v")
+                _agree(m.jtprod(SPECIAL, y), o.jtprod(SPECIAL, y), f"{fn}: J'*v")
+                _agree(m.jprod(SPECIAL, v), o.jprod(SPECIAL, v), f"{fn}: J*v")
             except AssertionError as e:
                 bad.append(str(e)[:600])
     assert not bad, "\n\n".join(bad)
