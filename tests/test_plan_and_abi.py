@@ -195,3 +195,11 @@ def test_out_of_range_indices_are_refused_at_build(libs):
             ExaModel(build(kind), device=False)
         assert "status 1" in str(e.value)
         assert needle in capi.lib().exa_last_error().decode()
+
+
+def test_julia_shim_binds_only_declared_symbols():
+    """The ccall shim cannot be executed here (no julia); at least every symbol it names must exist in the C ABI."""
+    shim = open(os.path.join(ROOT, "examodels.jl_amd", "julia", "ExaModelsHIP.jl")).read()
+    used = sorted(set(re.findall(r":(exa_[a-z0-9_]+)", shim)))
+    declared = set(header_symbols()) | set(header_symbols("exahip_recipe.h"))
+    assert len(used) >= 10 and not [u for u in used if u not in declared]
