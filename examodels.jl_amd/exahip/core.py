@@ -513,7 +513,10 @@ class ExaCore:
 
     def _vec(self, which, parts, value, n):
         """append one block of a start/bound vector, remembering where it came from (recipe segments)"""
-        parts.append(_fill(value, int(n)))
+        if _is_real(value) and not isinstance(value, TArray):
+            parts.append(_ConstVec(float(value), int(n)))      # materialised only if somebody asks for the array
+        else:
+            parts.append(_fill(value, int(n)))
         if isinstance(value, TArray) and value.src is not None:
             src = value.src
         elif isinstance(value, TArray) or np.ndim(value) > 0 or callable(value):
@@ -645,6 +648,21 @@ def _infer_dims(it: _Iter):
     return (it.n,)
 
 
+class _ConstVec:
+    """n copies of one value.  A model at N = 1e8 has six such vectors of 0.8 GB each; the library fills in its own
+    defaults (0, -Inf, +Inf) when it is handed no array at all (include/exahip_ir.h), so they are never built."""
+    __slots__ = ("value", "n")
+
+    def __init__(self, value, n):
+        self.value, self.n = value, n
+
+    def __array__(self, dtype=None, copy=None):
+        return np.full(self.n, self.value, dtype=dtype or np.float64)
+
+    def __len__(self):
+        return self.n
+
+
 def _fill(v, n):
     if callable(v):
         return np.array([float(v(i)) for i in range(1, n + 1)], dtype=np.float64)
@@ -718,20 +736,29 @@ class ModelIR:
         self.patterns = pats
         d = CModelDesc()
         d.nvar, d.npar = core.nvar, core.npar
-        self.x0 = _cat(core.x0)
-        self.lvar = _cat(core.lvar)
-        self.uvar = _cat(core.uvar)
-        self.theta0 = _cat(core.theta)
-        self.y0 = _cat(core.y0)
-        self.lcon = _cat(core.lcon)
-        self.ucon = _cat(core.ucon)
-        d.x0, d.lvar, d.uvar = _ptr(self.x0), _ptr(self.lvar), _ptr(self.uvar)
-        d.theta0 = _ptr(self.theta0)
+        # None = "all default": the descriptor then carries a NULL pointer and the library fills the constant in
+        self._vecs = {"x0": _cat(core.x0, 0.0), "lvar": _cat(core.lvar, -np.inf), "uvar": _cat(core.uvar, np.inf),
+                      "theta0": _cat(core.theta), "y0": _cat(core.y0, 0.0), "lcon": _cat(core.lcon, 0.0), "ucon": _cat(core.ucon, 0.0)}
+        self._defaults = {"x0": (0.0, core.nvar), "lvar": (-np.inf, core.nvar), "uvar": (np.inf, core.nvar),
+                          "y0": (0.0, core.ncon), "lcon": (0.0, core.ncon), "ucon": (0.0, core.ncon)}
+        v = self._vecs
+        d.x0, d.lvar, d.uvar = _ptr(v["x0"]), _ptr(v["lvar"]), _ptr(v["uvar"])
+        d.theta0 = _ptr(v["theta0"])
         d.n_patterns = len(core.patterns)
         d.minimize = 1 if core.minimize else 0
         d.patterns = ctypes.cast(pats, ctypes.POINTER(CPattern))
-        d.y0, d.lcon, d.ucon = _ptr(self.y0), _ptr(self.lcon), _ptr(self.ucon)
+        d.y0, d.lcon, d.ucon = _ptr(v["y0"]), _ptr(v["lcon"]), _ptr(v["ucon"])
         self.desc = d
+
+    def __getattr__(self, name):
+        # x0 / lvar / uvar / theta0 / y0 / lcon / ucon as arrays (an all-default vector is built on first use)
+        vecs = self.__dict__.get("_vecs")
+        if vecs is not None and name in vecs:
+            if vecs[name] is None:
+                value, n = self._defaults[name]
+                vecs[name] = np.full(int(n), value)      # the descriptor keeps its NULL: same contents by definition
+            return vecs[name]
+        raise AttributeError(name)
 
     def _emit_pattern(self, p: _Pattern, out: CPattern):
         nodes, cols, root, target = lower_pattern(p)
@@ -757,11 +784,16 @@ class ModelIR:
         out.n = p.itr.n
 
 
-def _cat(parts):
+def _cat(parts, default=None):
+    """one contiguous array, or None when every block is the library's default constant for this vector"""
     if not parts:
         return np.zeros(0, dtype=np.float64)
+    if default is not None and all(isinstance(a, _ConstVec) and a.value == default for a in parts):
+        return None
+    if len(parts) == 1:            # a single block (the benchmark models at N = 1e8): no second copy
+        return np.ascontiguousarray(np.asarray(parts[0], dtype=np.float64))
     return np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float64) for a in parts]))
 
 
 def _ptr(a):
-    return a.ctypes.data if a.size else None
+    return a.ctypes.data if a is not None and a.size else None

@@ -169,6 +169,27 @@ def _is_torch(a):
     return type(a).__module__.startswith("torch")
 
 
+class Meta:
+    """Sizes as plain attributes; x0 / lvar / uvar / lcon / ucon are fetched on first use (five vectors of nvar or ncon
+    doubles — 4 GB at N = 1e8 — that an evaluation loop never needs)."""
+    _VECTORS = ("x0", "lvar", "uvar", "lcon", "ucon")
+
+    def __init__(self, loader, **scalars):
+        self.__dict__.update(scalars)
+        self.__dict__["_loader"] = loader
+
+    def __getattr__(self, name):
+        if name in Meta._VECTORS:
+            self.__dict__.update(self._loader(name))
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def copy(self):
+        m = Meta(self._loader)
+        m.__dict__.update(self.__dict__)
+        return m
+
+
 class ExaModel:
     def __init__(self, core, *args, device=True):
         """device=True: exa_new_from_table (needs an MI355X; raises otherwise — no CPU fallback).
@@ -193,12 +214,17 @@ class ExaModel:
         self.device = device
         L = self._L
         nvar, ncon = L.exa_nvar64(self.id), L.exa_ncon64(self.id)
-        x0, lv, uv = np.empty(nvar), np.empty(nvar), np.empty(nvar)
-        lc, uc = np.empty(max(1, ncon)), np.empty(max(1, ncon))
-        capi.check(L.exa_meta(self.id, x0.ctypes.data, lv.ctypes.data, uv.ctypes.data, lc.ctypes.data, uc.ctypes.data), "exa_meta")
-        self.meta = SimpleNamespace(nvar=nvar, ncon=ncon, nnzj=L.exa_nnzj64(self.id), nnzh=L.exa_nnzh64(self.id),
-                                    nnzg=L.exa_nnzg64(self.id), x0=x0, lvar=lv, uvar=uv, lcon=lc[:ncon], ucon=uc[:ncon],
-                                    minimize=self._minimize)
+
+        def load_vectors(name):
+            if self.ir is not None and hasattr(self.ir, "_vecs"):
+                return {name: getattr(self.ir, name)}        # the array the table was built from (the library holds a copy)
+            x0, lv, uv = np.empty(nvar), np.empty(nvar), np.empty(nvar)
+            lc, uc = np.empty(max(1, ncon)), np.empty(max(1, ncon))
+            capi.check(L.exa_meta(self.id, x0.ctypes.data, lv.ctypes.data, uv.ctypes.data, lc.ctypes.data, uc.ctypes.data), "exa_meta")
+            return {"x0": x0, "lvar": lv, "uvar": uv, "lcon": lc[:ncon], "ucon": uc[:ncon]}
+
+        self.meta = Meta(load_vectors, nvar=nvar, ncon=ncon, nnzj=L.exa_nnzj64(self.id), nnzh=L.exa_nnzh64(self.id),
+                         nnzg=L.exa_nnzg64(self.id), minimize=self._minimize)
         self._stream = None
 
     def describe(self):
@@ -448,7 +474,7 @@ class CompressedExaModel:
         self.inner = m
         self._L = m._L
         capi.check(self._L.exa_compress(m.id), "exa_compress")
-        self.meta = SimpleNamespace(**vars(m.meta))
+        self.meta = m.meta.copy()
         self.meta.nnzj = self._L.exa_cnnzj64(m.id)
         self.meta.nnzh = self._L.exa_cnnzh64(m.id)
 
