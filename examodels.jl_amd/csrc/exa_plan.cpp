@@ -312,9 +312,12 @@ std::unique_ptr<Model> plan_model(const exa_model_desc_t *d) {
     if (d->nvar < 0 || d->npar < 0 || d->n_patterns < 0) fail("negative size in model description");
     auto m = std::make_unique<Model>();
     m->nvar = d->nvar; m->npar = d->npar; m->minimize = d->minimize;
-    m->x0 = copy_or<double>(d->x0, d->nvar, 0.0);
-    m->lvar = copy_or<double>(d->lvar, d->nvar, -INFINITY);
-    m->uvar = copy_or<double>(d->uvar, d->nvar, INFINITY);
+    // a NULL start / bound vector means "the default constant" (exahip_ir.h) and stays unmaterialised (empty): at
+    // N = 1e8 these six vectors would be 4.8 GB of host memory nobody reads
+    auto keep = [](const double *src, int64_t n) { return src ? std::vector<double>(src, src + n) : std::vector<double>(); };
+    m->x0 = keep(d->x0, d->nvar);
+    m->lvar = keep(d->lvar, d->nvar);
+    m->uvar = keep(d->uvar, d->nvar);
     m->theta = copy_or<double>(d->theta0, d->npar, 0.0);
     m->pats.resize(d->n_patterns);
     for (int k = 0; k < d->n_patterns; k++) {
@@ -358,9 +361,9 @@ std::unique_ptr<Model> plan_model(const exa_model_desc_t *d) {
     }
     build_aug_lists(*m);
     check_index_bounds(*m);
-    m->y0 = copy_or<double>(d->y0, m->ncon, 0.0);
-    m->lcon = copy_or<double>(d->lcon, m->ncon, 0.0);
-    m->ucon = copy_or<double>(d->ucon, m->ncon, 0.0);
+    m->y0 = keep(d->y0, m->ncon);
+    m->lcon = keep(d->lcon, m->ncon);
+    m->ucon = keep(d->ucon, m->ncon);
     return m;
 }
 

@@ -664,11 +664,17 @@ int exa_meta(int id, double *x0, double *lvar, double *uvar, double *lcon, doubl
     Handle *h = get(id);
     if (!h) return 1;
     const Model &m = *h->m;
-    if (x0) std::memcpy(x0, m.x0.data(), 8 * (size_t)m.nvar);
-    if (lvar) std::memcpy(lvar, m.lvar.data(), 8 * (size_t)m.nvar);
-    if (uvar) std::memcpy(uvar, m.uvar.data(), 8 * (size_t)m.nvar);
-    if (lcon) std::memcpy(lcon, m.lcon.data(), 8 * (size_t)m.ncon);
-    if (ucon) std::memcpy(ucon, m.ucon.data(), 8 * (size_t)m.ncon);
+    // an empty vector is the unmaterialised default constant (plan_model)
+    auto put = [](double *dst, const std::vector<double> &v, int64_t n, double dflt) {
+        if (!dst) return;
+        if (v.empty()) std::fill(dst, dst + n, dflt);
+        else std::memcpy(dst, v.data(), 8 * (size_t)n);
+    };
+    put(x0, m.x0, m.nvar, 0.0);
+    put(lvar, m.lvar, m.nvar, -INFINITY);
+    put(uvar, m.uvar, m.nvar, INFINITY);
+    put(lcon, m.lcon, m.ncon, 0.0);
+    put(ucon, m.ucon, m.ncon, 0.0);
     return 0;
 }
 const char *exa_kernel_source(int id) { Handle *h = get(id); return h ? h->gen.source.c_str() : nullptr; }
@@ -755,9 +761,10 @@ int exa_describe(int id, exa_model_desc_t *out) {
     }
     *out = exa_model_desc_t{};
     out->nvar = m.nvar; out->npar = m.npar;
-    out->x0 = m.x0.data(); out->lvar = m.lvar.data(); out->uvar = m.uvar.data(); out->theta0 = m.theta.data();
+    auto ptr = [](const std::vector<double> &v) { return v.empty() ? nullptr : v.data(); };     // NULL = default constant
+    out->x0 = ptr(m.x0); out->lvar = ptr(m.lvar); out->uvar = ptr(m.uvar); out->theta0 = ptr(m.theta);
     out->n_patterns = (int)m.pats.size(); out->minimize = m.minimize; out->patterns = h.view_pats.data();
-    out->y0 = m.y0.data(); out->lcon = m.lcon.data(); out->ucon = m.ucon.data();
+    out->y0 = ptr(m.y0); out->lcon = ptr(m.lcon); out->ucon = ptr(m.ucon);
     return 0;
 }
 

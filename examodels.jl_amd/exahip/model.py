@@ -158,8 +158,11 @@ def tables_equal(a, b):
                 return False
         if pa.kind == PAT_CON:
             ncon += pa.n
-    for name, n in (("x0", da.nvar), ("lvar", da.nvar), ("uvar", da.nvar), ("theta0", da.npar), ("y0", ncon), ("lcon", ncon), ("ucon", ncon)):
-        va, vb = _view(getattr(da, name), n, np.float64), _view(getattr(db, name), n, np.float64)
+    # a NULL vector stands for its default constant (include/exahip_ir.h)
+    for name, n, dflt in (("x0", da.nvar, 0.0), ("lvar", da.nvar, -np.inf), ("uvar", da.nvar, np.inf), ("theta0", da.npar, 0.0),
+                          ("y0", ncon, 0.0), ("lcon", ncon, 0.0), ("ucon", ncon, 0.0)):
+        va = _view(getattr(da, name), n, np.float64) if getattr(da, name) else np.full(int(n), dflt)
+        vb = _view(getattr(db, name), n, np.float64) if getattr(db, name) else np.full(int(n), dflt)
         if not np.array_equal(va, vb):
             return False
     return True
