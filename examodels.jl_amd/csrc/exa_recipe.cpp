@@ -17,7 +17,10 @@
 namespace exa {
 namespace {
 
-enum { SYM_CONST = 0, SYM_SCALAR, SYM_LEN, SYM_ADD, SYM_SUB, SYM_MUL, SYM_FLOORDIV, SYM_MAX0, SYM_NEG };
+enum { SYM_CONST = 0, SYM_SCALAR, SYM_LEN, SYM_ADD, SYM_SUB, SYM_MUL, SYM_FLOORDIV, SYM_MAX0, SYM_NEG,
+       // real-valued expressions of the sizes (a deferred coefficient such as 1 / (N + 1), ArgumentTest.jl:231-280)
+       SYM_FCONST, SYM_ITOF, SYM_FADD, SYM_FSUB, SYM_FMUL, SYM_FDIV, SYM_FNEG };
+inline bool sym_is_real(int op) { return op >= SYM_FCONST; }
 enum { F_SCALAR = 0, F_ARRAY = 1, F_TABLE = 2 };
 enum { T_I64 = 0, T_F64 = 1 };
 enum { SRC_CONST = 0, SRC_INLINE, SRC_FIELD, SRC_COL };
@@ -91,6 +94,7 @@ std::vector<std::unique_ptr<Builder>> g_builders;
 // ---- reader ---------------------------------------------------------------------------------------------
 struct Reader {
     const unsigned char *p, *end;
+    const std::vector<char> *real = nullptr;     // per size expression: is it real-valued? (set once the table is read)
     void need(size_t n) const { if ((size_t)(end - p) < n) throw BadInput("recipe: truncated"); }
     int32_t i32() { need(4); int32_t v; std::memcpy(&v, p, 4); p += 4; return v; }
     int64_t i64() { need(8); int64_t v; std::memcpy(&v, p, 8); p += 8; return v; }
@@ -109,7 +113,7 @@ struct Reader {
         IVal v;
         const int is = i32();
         const int64_t x = i64();
-        if (is) { if (x < 0 || (uint64_t)x >= nsyms) throw BadInput("recipe: size expression out of range"); v.sym = (int)x; }
+        if (is) { if (x < 0 || (uint64_t)x >= nsyms || (real && (*real)[(size_t)x])) throw BadInput("recipe: size expression out of range or not an integer"); v.sym = (int)x; }
         else v.v = x;
         return v;
     }
@@ -171,16 +175,26 @@ std::unique_ptr<Recipe> parse(const void *bytes, size_t len) {
     for (int k = 0; k < ns; k++) {
         RSym s;
         s.op = rd.i32(); s.a = rd.i64(); s.b = rd.i64();
-        const bool leaf = s.op == SYM_CONST, fld = s.op == SYM_SCALAR || s.op == SYM_LEN, un = s.op == SYM_MAX0 || s.op == SYM_NEG;
-        if (s.op < SYM_CONST || s.op > SYM_NEG) throw BadInput("recipe: bad size opcode");
+        const bool leaf = s.op == SYM_CONST || s.op == SYM_FCONST, fld = s.op == SYM_SCALAR || s.op == SYM_LEN,
+                   un = s.op == SYM_MAX0 || s.op == SYM_NEG || s.op == SYM_ITOF || s.op == SYM_FNEG;
+        if (s.op < SYM_CONST || s.op > SYM_FNEG) throw BadInput("recipe: bad size opcode");
         if (fld && (s.a < 0 || s.a >= nf)) throw BadInput("recipe: size expression names an unknown field");
         if (fld && s.op == SYM_SCALAR && (r->fields[s.a].kind != F_SCALAR || r->fields[s.a].type != T_I64))
             throw BadInput("recipe: SCALAR size must be an i64 scalar field");
         if (fld && s.op == SYM_LEN && r->fields[s.a].kind == F_SCALAR) throw BadInput("recipe: LEN of a scalar field");
         if (!leaf && !fld && (s.a < 0 || s.a >= k || (!un && (s.b < 0 || s.b >= k)))) throw BadInput("recipe: size expression not in SSA order");
+        if (!leaf && !fld) {
+            // integer operators take integer operands; ITOF takes an integer; the real operators take reals
+            const bool want_real = sym_is_real(s.op) && s.op != SYM_ITOF;
+            if (sym_is_real(r->syms[s.a].op) != want_real || (!un && sym_is_real(r->syms[s.b].op) != want_real))
+                throw BadInput("recipe: size expression mixes integer and real operands");
+        }
         r->syms.push_back(s);
     }
     const size_t nsy = r->syms.size();
+    std::vector<char> is_real(nsy);
+    for (size_t k = 0; k < nsy; k++) is_real[k] = sym_is_real(r->syms[k].op);
+    rd.real = &is_real;
     auto field_ok = [&](int f, int kind) { return f >= 0 && f < nf && r->fields[f].kind == kind; };
     r->nvar = rd.ival(nsy);
     r->npar = rd.ival(nsy);
@@ -222,7 +236,8 @@ std::unique_ptr<Recipe> parse(const void *bytes, size_t len) {
             exa_node_t nd{};
             nd.op = rd.i32(); nd.fn = rd.i32(); nd.a = rd.i32(); nd.b = rd.i32(); nd.fval = rd.f64(); nd.ival = rd.i64();
             const int sy = rd.i32();
-            if (sy >= (int)nsy || (sy >= 0 && nd.op != EXA_OP_CONST_I)) throw BadInput("recipe: bad node size reference");
+            if (sy >= (int)nsy || (sy >= 0 && nd.op != (is_real[(size_t)sy] ? EXA_OP_CONST_F : EXA_OP_CONST_I)))
+                throw BadInput("recipe: bad node size reference");
             p.nodes.push_back(nd);
             p.nodesym.push_back(sy);
         }
@@ -281,9 +296,17 @@ int64_t floordiv(int64_t a, int64_t b) {
 void instantiate(const Recipe &r, const Builder &B, Instance &I) {
     // 1. size expressions
     std::vector<int64_t> sv(r.syms.size());
+    std::vector<double> sf(r.syms.size(), 0.0);       // values of the real-valued expressions
     for (size_t k = 0; k < r.syms.size(); k++) {
         const RSym &s = r.syms[k];
         switch (s.op) {
+        case SYM_FCONST: std::memcpy(&sf[k], &s.a, 8); break;
+        case SYM_ITOF: sf[k] = (double)sv[s.a]; break;
+        case SYM_FADD: sf[k] = sf[s.a] + sf[s.b]; break;
+        case SYM_FSUB: sf[k] = sf[s.a] - sf[s.b]; break;
+        case SYM_FMUL: sf[k] = sf[s.a] * sf[s.b]; break;
+        case SYM_FDIV: sf[k] = sf[s.a] / sf[s.b]; break;
+        case SYM_FNEG: sf[k] = -sf[s.a]; break;
         case SYM_CONST: sv[k] = s.a; break;
         case SYM_SCALAR: sv[k] = B.slots[s.a].iscalar; break;
         case SYM_LEN: {
@@ -337,7 +360,10 @@ void instantiate(const Recipe &r, const Builder &B, Instance &I) {
         if (n < 0) throw BadInput("recipe: negative iterator length");
         I.nodes[k] = p.nodes;
         for (size_t i = 0; i < p.nodes.size(); i++)
-            if (p.nodesym[i] >= 0) I.nodes[k][i].ival = sv[p.nodesym[i]];
+            if (p.nodesym[i] >= 0) {
+                if (p.nodes[i].op == EXA_OP_CONST_F) I.nodes[k][i].fval = sf[p.nodesym[i]];
+                else I.nodes[k][i].ival = sv[p.nodesym[i]];
+            }
         I.icol[k].resize(p.cols.size());
         I.fcol[k].resize(p.cols.size());
         for (size_t c = 0; c < p.cols.size(); c++) {

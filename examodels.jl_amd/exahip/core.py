@@ -695,7 +695,7 @@ def lower_pattern(p: _Pattern, symbolic=False):
         if isinstance(e, int):
             nodes.append((OP_CONST_I, 0, -1, -1, 0.0, e if symbolic else int(e)))
         elif isinstance(e, float):
-            nodes.append((OP_CONST_F, 0, -1, -1, e, 0))
+            nodes.append((OP_CONST_F, 0, -1, -1, e if symbolic else float(e), 0))     # a deferred real keeps its tag
         elif isinstance(e, Constant):
             return emit(e.v)
         elif isinstance(e, Null):

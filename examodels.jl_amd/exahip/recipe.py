@@ -22,6 +22,8 @@ import numpy as np
 
 # symbolic integer expression opcodes (include/exahip_recipe.h)
 SYM_CONST, SYM_SCALAR, SYM_LEN, SYM_ADD, SYM_SUB, SYM_MUL, SYM_FLOORDIV, SYM_MAX0, SYM_NEG = range(9)
+# ... and REAL-valued expressions of the sizes (a coefficient such as h = 1 / (N + 1), ArgumentTest.jl:231-280)
+SYM_FCONST, SYM_ITOF, SYM_FADD, SYM_FSUB, SYM_FMUL, SYM_FDIV, SYM_FNEG = range(9, 16)
 FIELD_SCALAR, FIELD_ARRAY, FIELD_TABLE = range(3)
 TYPE_I64, TYPE_F64 = range(2)
 SRC_CONST, SRC_INLINE, SRC_FIELD, SRC_COL = range(4)
@@ -54,9 +56,12 @@ class TInt(int):
     def _bin(self, o, op, f, swap=False):
         so = TInt._s(o)
         if so is None:
-            if isinstance(o, (float, np.floating)):
-                raise RecipeError("a size-dependent REAL constant cannot be expressed in a recipe: pass it as a "
-                                  "parameter (add_par) or as data")
+            if isinstance(o, (float, np.floating)):          # mixed with a real: the result is a deferred real
+                fop = {SYM_ADD: "__add__", SYM_SUB: "__sub__", SYM_MUL: "__mul__"}.get(op)
+                if fop is None:
+                    raise RecipeError("floor division of a size placeholder by a real has no recipe form")
+                me, other = TFloat.of(self), TFloat.of(o)
+                return getattr(other, fop)(me) if swap else getattr(me, fop)(other)
             return NotImplemented
         a, b = (so, self.sym) if swap else (self.sym, so)
         va, vb = (int(o), int(self)) if swap else (int(self), int(o))
@@ -74,13 +79,62 @@ class TInt(int):
     def __pos__(self): return self
 
     def _no(self, *_):
-        raise RecipeError("this operation on a size placeholder has no recipe form (only + - * // are deferred)")
+        raise RecipeError("this operation on a size placeholder has no recipe form (deferred: + - * // and / )")
 
-    __truediv__ = __rtruediv__ = __mod__ = __rmod__ = __pow__ = __rpow__ = _no
+    # true division leaves the integers: the result is a deferred REAL (h = 1 / (N + 1))
+    def __truediv__(self, o): return TFloat.of(self) / o
+    def __rtruediv__(self, o): return o / TFloat.of(self)
+
+    __mod__ = __rmod__ = __pow__ = __rpow__ = _no
     __lshift__ = __rshift__ = __and__ = __or__ = __xor__ = _no
 
     def __repr__(self):
         return f"TInt({int(self)})"
+
+
+class TFloat(float):
+    """An example real that remembers the expression over the sizes it stands for (a deferred coefficient)."""
+
+    def __new__(cls, value, sym):
+        o = float.__new__(cls, float(value))
+        o.sym = sym
+        return o
+
+    @staticmethod
+    def of(v):
+        if isinstance(v, TFloat):
+            return v
+        if isinstance(v, TInt):
+            return TFloat(int(v), (SYM_ITOF, v.sym, None))
+        if isinstance(v, (bool,)) or not isinstance(v, (int, float, np.integer, np.floating)):
+            return None
+        return TFloat(v, (SYM_FCONST, float(v), None))
+
+    def _bin(self, o, op, f, swap=False):
+        b = TFloat.of(o)
+        if b is None:
+            return NotImplemented
+        x, y = (b, self) if swap else (self, b)
+        return TFloat(f(float(x), float(y)), (op, x.sym, y.sym))
+
+    def __add__(self, o): return self._bin(o, SYM_FADD, lambda a, b: a + b)
+    def __radd__(self, o): return self._bin(o, SYM_FADD, lambda a, b: a + b, True)
+    def __sub__(self, o): return self._bin(o, SYM_FSUB, lambda a, b: a - b)
+    def __rsub__(self, o): return self._bin(o, SYM_FSUB, lambda a, b: a - b, True)
+    def __mul__(self, o): return self._bin(o, SYM_FMUL, lambda a, b: a * b)
+    def __rmul__(self, o): return self._bin(o, SYM_FMUL, lambda a, b: a * b, True)
+    def __truediv__(self, o): return self._bin(o, SYM_FDIV, lambda a, b: a / b)
+    def __rtruediv__(self, o): return self._bin(o, SYM_FDIV, lambda a, b: a / b, True)
+    def __neg__(self): return TFloat(-float(self), (SYM_FNEG, self.sym, None))
+    def __pos__(self): return self
+
+    def _no(self, *_):
+        raise RecipeError("this operation on a deferred real has no recipe form (deferred: + - * /)")
+
+    __pow__ = __rpow__ = __mod__ = __rmod__ = __floordiv__ = __rfloordiv__ = _no
+
+    def __repr__(self):
+        return f"TFloat({float(self)})"
 
 
 def keep_int(v):
@@ -285,7 +339,9 @@ class _W:
         op = t[0]
         if op in (SYM_CONST, SYM_SCALAR, SYM_LEN):
             rec = (op, t[1], 0)
-        elif op in (SYM_MAX0, SYM_NEG):
+        elif op == SYM_FCONST:
+            rec = (op, struct.unpack("<q", struct.pack("<d", t[1]))[0], 0)      # the double's bit pattern
+        elif op in (SYM_MAX0, SYM_NEG, SYM_ITOF, SYM_FNEG):
             rec = (op, self.sym(t[1]), 0)
         else:
             rec = (op, self.sym(t[1]), self.sym(t[2]))
@@ -349,7 +405,8 @@ def dumps(core) -> bytes:
             body.i32(b)
             body.f64(fval)
             body.i64(int(ival))
-            body.i32(body.sym(ival.sym) if isinstance(ival, TInt) else -1)
+            tagged = ival if isinstance(ival, TInt) else (fval if isinstance(fval, TFloat) else None)
+            body.i32(body.sym(tagged.sym) if tagged is not None else -1)
         body.i32(len(cols))
         for c in cols:
             kind = c[0]

@@ -27,6 +27,8 @@
  *   i32 nsyms     { i32 op; i64 a; i64 b }                                   -- size expressions, SSA, post-order:
  *                   0 CONST a | 1 SCALAR field a | 2 LEN field a | 3 ADD | 4 SUB | 5 MUL | 6 FLOORDIV (a,b = earlier
  *                   syms) | 7 MAX0 a | 8 NEG a
+ *                   real-valued (a deferred coefficient such as 1/(N+1)): 9 FCONST (a = bits of the double) | 10 ITOF a |
+ *                   11 FADD | 12 FSUB | 13 FMUL | 14 FDIV | 15 FNEG a   (operands real, ITOF's operand integer)
  *   ival          = i32 is_sym; i64 (sym id | literal)                       -- every size-like integer below
  *   ival nvar; ival npar
  *   7 vectors (x0, lvar, uvar, theta, y0, lcon, ucon), each:
@@ -35,8 +37,8 @@
  *   i32 nblocks   { str name; i32 kind (0 var, 1 con, 2 par); ival offset; ival length; i32 ndims; ival dims[] }
  *   i32 npatterns {
  *       i32 kind; i32 root; i32 target; i32 base; ival n                     -- exa_pattern_t (exahip_ir.h)
- *       i32 nnodes { i32 op; i32 fn; i32 a; i32 b; f64 fval; i64 ival; i32 sym }   -- sym >= 0: CONST_I leaf whose
- *                                                                                value is that size expression
+ *       i32 nnodes { i32 op; i32 fn; i32 a; i32 b; f64 fval; i64 ival; i32 sym }   -- sym >= 0: CONST_I (CONST_F) leaf
+ *                                                                                whose value is that integer (real) expression
  *       i32 ncols  { i32 kind; payload }
  *           0 RANGE        ival start; ival step
  *           1 INLINE_I64   arr<i64>             2 INLINE_F64  arr<f64>

@@ -119,6 +119,84 @@ def test_headline_model_from_one_recipe(libs):
         assert np.array_equal(o.jac_coord(x), ref.jac_coord(x)) and o.obj(x) == ref.obj(x)
 
 
+def test_argument_test_models(libs):
+    """test/ArgumentTest/ArgumentTest.jl:185-229 — sizes, starts and bounds supplied at instantiation; one core
+    instantiated twice without being consumed."""
+    from exahip import ExaCore, ExaModel, Recipe, rng
+
+    # "a model built against two argument objects" (:185-200)
+    c = ExaCore(examples=(dict(N=2), dict(lo=np.zeros(2), v=np.ones(2))))
+    sz, dat = c.args
+    y = c.add_var(sz.N, lvar=dat.lo, start=dat.v)
+    c.add_obj(lambda i: y[i] ** 2, rng(1, sz.N))
+    rec = Recipe(c)
+    m = ExaModel(rec, dict(N=3), dict(lo=[-1.0, -2.0, -3.0], v=[4.0, 5.0, 6.0]), device=False)
+    assert m.meta.nvar == 3 and list(m.meta.lvar) == [-1.0, -2.0, -3.0] and list(m.meta.x0) == [4.0, 5.0, 6.0]
+    assert _oracle_of(m).obj(m.meta.x0) == 77.0
+    m2 = ExaModel(rec, dict(N=2), dict(lo=[0.0, 0.0], v=[1.0, 2.0]), device=False)
+    assert m2.meta.nvar == 2 and list(m2.meta.x0) == [1.0, 2.0]
+
+    # "building a model against arg" (:202-229)
+    c = ExaCore(examples=(dict(N=2, v=np.ones(2)),))
+    (arg,) = c.args
+    y = c.add_var(arg.N, start=arg.v)
+    c.add_obj(lambda i: y[i] ** 2, rng(1, arg.N))
+    c.add_con(lambda i: y[i] - 2.0, rng(1, arg.N), lcon=0.0, ucon=0.0)
+    rec = Recipe(c)
+    m = ExaModel(rec, dict(N=3, v=[1.0, 2.0, 3.0]), device=False)
+    assert (m.meta.nvar, m.meta.ncon) == (3, 3) and _oracle_of(m).obj(m.meta.x0) == 14.0
+    m2 = ExaModel(rec, dict(N=2, v=[4.0, 5.0]), device=False)
+    assert m2.meta.nvar == 2 and _oracle_of(m2).obj(m2.meta.x0) == 41.0 and list(m.meta.x0) == [1.0, 2.0, 3.0]
+    cb = ExaCore(examples=(dict(N=3, lo=np.zeros(3)),))
+    (arg,) = cb.args
+    cb.add_var(arg.N, lvar=arg.lo, uvar=0.0)
+    mb = ExaModel(cb, dict(N=2, lo=[-1.0, -2.0]), device=False)
+    assert list(mb.meta.lvar) == [-1.0, -2.0] and list(mb.meta.uvar) == [0.0, 0.0]
+
+
+def test_deferred_real_coefficient_and_second_block_offset(libs):
+    """ArgumentTest.jl:231-307 — h = 1 / (N + 1) is a loop-invariant REAL computed from the size and used as a
+    coefficient; the offset of a block behind a block of deferred length is deferred too."""
+    from exahip import ExaCore, ExaModel, Recipe, rng
+
+    def build_h(c, N):
+        h = 1 / (N + 1)
+        x = c.add_var(N, start=1.0)
+        c.add_obj(lambda i: h * (x[i] - 2.0) ** 2, rng(1, N))
+        c.add_con(lambda i: h * x[i] + x[i], rng(1, N), lcon=0.0, ucon=1.0)
+        return c
+
+    c = ExaCore(examples=(4,))
+    rec = Recipe(build_h(c, c.args[0]))
+    for n, pt in ((6, np.arange(0.1, 0.65, 0.1)), (9, np.arange(0.1, 0.95, 0.1))):
+        ref = _oracle_of(ExaModel(build_h(ExaCore(), n), device=False))
+        o = _oracle_of(ExaModel(rec, n, device=False))
+        mult = pt[::-1].copy()
+        assert (o.nvar, o.nnzj, o.nnzh) == (ref.nvar, ref.nnzj, ref.nnzh)
+        assert o.obj(pt) == ref.obj(pt) and np.array_equal(o.grad(pt), ref.grad(pt)) and np.array_equal(o.cons(pt), ref.cons(pt))
+        assert np.array_equal(o.jac_coord(pt), ref.jac_coord(pt)) and np.array_equal(o.hess_coord(pt, mult, 1.0), ref.hess_coord(pt, mult, 1.0))
+        assert rec.matches(build_h(ExaCore(), n), n)
+    # the coefficient really is deferred: a baked-in h would make the two sizes agree on a common point
+    o6, o9 = _oracle_of(ExaModel(rec, 6, device=False)), _oracle_of(ExaModel(rec, 9, device=False))
+    assert o6.obj(np.full(6, 0.5)) / 6 != o9.obj(np.full(9, 0.5)) / 9
+
+    def build_z(c, N):
+        x = c.add_var(N, start=1.0)
+        z = c.add_var(3, start=2.0)
+        c.add_obj(lambda j: z[j] ** 2, rng(1, 3))
+        c.add_con(lambda i: x[i] + z[1], rng(1, N), lcon=0.0, ucon=np.inf)
+        return c
+
+    c = ExaCore(examples=(5,))
+    rec = Recipe(build_z(c, c.args[0]))
+    for n in (4, 7):
+        assert rec.matches(build_z(ExaCore(), n), n)
+        o, ref = _oracle_of(ExaModel(rec, n, device=False)), _oracle_of(ExaModel(build_z(ExaCore(), n), device=False))
+        pt = np.arange(1.0, n + 4) / 10
+        assert o.nvar == n + 3 and o.obj(pt) == ref.obj(pt) and np.array_equal(o.cons(pt), ref.cons(pt))
+        assert all(np.array_equal(a, b) for a, b in zip(o.jac_structure(), ref.jac_structure()))
+
+
 def _acopf_recipe():
     from exahip import ExaCore, Recipe, models
     ex = models.synthetic_power_data(nbus=5, nbr=6, ngen=2, seed=1)
@@ -228,7 +306,7 @@ def test_recipe_refuses_what_it_cannot_defer(libs):
     (N,) = c.args
     x = c.add_var(N)
     with pytest.raises(RecipeError):
-        c.add_obj(lambda i: (N / 2) * x[i], range(1, 6))         # a size-dependent real constant
+        c.add_obj(lambda i: (N % 2) * x[i], range(1, 6))         # an operation with no deferred form
     with pytest.raises(TypeError):
         c.add_obj(lambda i: x[i] ** N, range(1, 6))               # a size as a literal exponent
     with pytest.raises(RecipeError):
