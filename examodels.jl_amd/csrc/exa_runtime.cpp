@@ -782,15 +782,19 @@ int exa_grad(int id, const double *x, double *g) {
 }
 int exa_cons(int id, const double *x, double *c) {
     if (!x) return 1;
-    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !c) throw std::runtime_error("null output"); do_cons(h, x, c); });
+    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !c) throw BadInput("null output"); do_cons(h, x, c); });
 }
 int exa_jac(int id, const double *x, double *v) {
     if (!x) return 1;
-    return guard(id, true, [&](Handle &h) { if (h.m->nnzj && !v) throw std::runtime_error("null output"); do_jac(h, x, v); });
+    return guard(id, true, [&](Handle &h) { if (h.m->nnzj && !v) throw BadInput("null output"); do_jac(h, x, v); });
 }
 int exa_hess(int id, const double *x, const double *y, double w, double *v) {
     if (!x) return 1;
-    return guard(id, true, [&](Handle &h) { if (h.m->nnzh && !v) throw std::runtime_error("null output"); do_hess(h, x, y, w, v); });
+    return guard(id, true, [&](Handle &h) {
+        if (h.m->nnzh && !v) throw BadInput("null output");
+        if (h.m->ncon && !y) throw BadInput("null multipliers for a model with constraints");   // would be a device fault
+        do_hess(h, x, y, w, v);
+    });
 }
 int exa_eval_fused(int id, const double *x, const double *y, double w, double *obj_dev, double *c, double *jvals, double *hvals) {
     if (!x || !obj_dev) return 1;
@@ -801,7 +805,7 @@ int exa_eval_fused(int id, const double *x, const double *y, double w, double *o
 }
 int exa_jprod(int id, const double *x, const double *v, double *Jv) {
     if (!x || !v) return 1;
-    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !Jv) throw std::runtime_error("null output"); do_jprod(h, x, v, Jv); });
+    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !Jv) throw BadInput("null output"); do_jprod(h, x, v, Jv); });
 }
 static bool capturing(Handle &h) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -834,11 +838,14 @@ static void run_hprod(Handle &h, const double *x, const double *y, const double 
 }
 int exa_jtprod(int id, const double *x, const double *v, double *Jtv) {
     if (!x || !Jtv) return 1;
-    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !v) throw std::runtime_error("null input"); run_jtprod(h, x, v, Jtv); });
+    return guard(id, true, [&](Handle &h) { if (h.m->ncon && !v) throw BadInput("null input"); run_jtprod(h, x, v, Jtv); });
 }
 int exa_hprod(int id, const double *x, const double *y, const double *v, double w, double *Hv) {
     if (!x || !v || !Hv) return 1;
-    return guard(id, true, [&](Handle &h) { run_hprod(h, x, y, v, w, Hv); });
+    return guard(id, true, [&](Handle &h) {
+        if (h.m->ncon && !y) throw BadInput("null multipliers for a model with constraints");
+        run_hprod(h, x, y, v, w, Hv);
+    });
 }
 /* 0 = atomics inside the sweep, 1 = COO + sorted gather, -1 = decide by measurement at the next call (default) */
 int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode) {
@@ -1027,8 +1034,12 @@ int exa_chess(int id, const double *x, const double *y, double w, double *vals) 
 
 // ---- measurement ------------------------------------------------------------------------------------------
 int exa_time_callback(int id, int which, int reps, const double *x, const double *y, double w, double *out, float *ms_out) {
-    if (reps < 1 || !ms_out || which < 0 || which > 4) return 1;   /* 0 obj 1 grad 2 cons 3 jac 4 hess */
+    if (reps < 1 || !ms_out || which < 0 || which > 4 || !x) return 1;   /* 0 obj 1 grad 2 cons 3 jac 4 hess */
     return guard(id, true, [&](Handle &h) {
+        const Model &m = *h.m;
+        if ((which == 1 && !out) || (which == 2 && m.ncon && !out) || (which == 3 && m.nnzj && !out) ||
+            (which == 4 && ((m.nnzh && !out) || (m.ncon && !y))))
+            throw BadInput("null pointer for a buffer the callback reads or writes");
         HIPCHK(hipEventRecord(h.ev0, h.stream));
         for (int r = 0; r < reps; r++) {
             switch (which) {

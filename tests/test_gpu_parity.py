@@ -183,3 +183,23 @@ def test_direct_store_fallback_path(libs, monkeypatch):
         x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=17)
         assert relerr(m.hess_coord(x, y, sigma), o.hess_coord(x, y, sigma)) <= RTOL
         assert relerr(m.jac_coord(x), o.jac_coord(x)) <= RTOL
+
+
+def test_null_pointers_are_status_1_not_device_faults(built):
+    """A NULL for a buffer a kernel would dereference is the caller's error, caught on the host."""
+    import ctypes
+    import torch
+    m, _ = built["lv20"]
+    L = m._L
+    x = torch.zeros(m.meta.nvar, dtype=torch.float64, device="cuda")
+    h = torch.zeros(m.meta.nnzh, dtype=torch.float64, device="cuda")
+    xp, hp = ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(h.data_ptr())
+    assert L.exa_hess(m.id, xp, None, 1.0, hp) == 1                      # multipliers missing, ncon > 0
+    assert L.exa_hess(m.id, None, xp, 1.0, hp) == 1 and L.exa_hess(m.id, xp, xp, 1.0, None) == 1
+    assert L.exa_hprod(m.id, xp, None, xp, 1.0, xp) == 1
+    assert L.exa_cons(m.id, xp, None) == 1 and L.exa_jac(m.id, xp, None) == 1 and L.exa_grad(m.id, xp, None) == 1
+    ms = ctypes.c_float(0)
+    assert L.exa_time_callback(m.id, 4, 1, xp, None, 1.0, hp, ctypes.addressof(ms)) == 1
+    assert L.exa_eval_fused(m.id, xp, None, 1.0, hp, hp, hp, hp) == 1
+    torch.cuda.synchronize()                                              # the device is still healthy
+    assert m.obj(x) == m.obj(x)
