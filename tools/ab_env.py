@@ -18,7 +18,9 @@ if "--" in args:
     args = args[:args.index("--")]
 knob, values = args[0], args[1:]
 N = int(float(os.environ.get("SWEEP_N", "1e7")))
-core = models.luksan_vlcek_model(N)
+which = os.environ.get("SWEEP_MODEL", "lv")
+core = {"lv": lambda: models.luksan_vlcek_model(N), "rocket": lambda: models.rocket_model(1_000_000),
+        "acopf": lambda: models.ac_power_model(models.synthetic_power_data(78_484, 126_015, 6_800, seed=0))}[which]()
 runs = {}
 for v in values:
     os.environ[knob] = v
@@ -34,4 +36,4 @@ for rnd in range(6):
     for v in values:
         m, x, y, out, acc = runs[v]
         acc.append(m.time_callback(cb, 200, x, y, 0.5, out=out))
-print(knob, cb, N, {v: (round(min(r[4]), 5), round(float(np.median(r[4])), 5)) for v, r in runs.items()})
+print(which, knob, cb, N, {v: (round(min(r[4]), 5), round(float(np.median(r[4])), 5)) for v, r in runs.items()})
