@@ -155,7 +155,7 @@ struct Emitter {
 // ---------------------------------------------------------------------------------------------------
 struct UnSpec { const char *f, *df, *ddf; };
 // A leading '=' marks an exact literal (lets the reverse sweep fold it).
-const double kLog2 = 0.69314718055994530942, kLog10 = 2.30258509299404568402, kPi = 3.14159265358979323846;
+const double kPi = 3.14159265358979323846;
 const double kD2R = kPi / 180.0, kR2D = 180.0 / kPi;
 
 const UnSpec *un_spec(int fn) {
