@@ -136,6 +136,13 @@ std::string cache_dir() {
     const char *env = getenv("EXAHIP_CACHE_DIR");
     std::string d = env && *env ? std::string(env) : lib_dir() + "/../kernel_cache";
     mkdir(d.c_str(), 0755);
+    if (access(d.c_str(), W_OK) != 0) {
+        // read-only installation: modules that are already cached there are still found by build_code_object;
+        // new ones go to a per-user directory under /tmp
+        const std::string alt = "/tmp/exahip_kernel_cache_" + std::to_string((long)getuid());
+        mkdir(alt.c_str(), 0700);
+        if (access(alt.c_str(), W_OK) == 0) return alt;
+    }
     return d;
 }
 
@@ -157,6 +164,11 @@ std::string build_code_object(const std::string &source) {
     const std::string dir = cache_dir();
     const std::string src = dir + "/" + name + ".hip", obj = dir + "/" + name + ".hsaco";
     if (file_exists(obj)) return obj;
+    {   // a read-only primary cache (cache_dir fell back to /tmp) may still hold the module
+        const char *env = getenv("EXAHIP_CACHE_DIR");
+        const std::string primary = (env && *env ? std::string(env) : lib_dir() + "/../kernel_cache") + "/" + name + ".hsaco";
+        if (primary != obj && file_exists(primary)) return primary;
+    }
     const std::string tag = "." + std::to_string((long)getpid());
     {
         std::ofstream o(src + tag);
