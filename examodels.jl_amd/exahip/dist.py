@@ -33,7 +33,13 @@ class ShardedEvaluator:
 
     def _allreduce(self, t):
         if self.world > 1:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+            if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
+                # gloo is the CPU test backend: stage device tensors through the host (RCCL reduces them in place)
+                h = t.cpu()
+                self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+                t.copy_(h)
+            else:
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
         return t
 
     def obj(self, x):
