@@ -47,9 +47,34 @@ __global__ void __launch_bounds__(256) k_compress(double *__restrict__ V, const 
                                                   const uint32_t *__restrict__ perm, int64_t n) {
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (k >= n) return;
+    const int64_t b = ptr[k], e = ptr[k + 1];
+    if (e - b > 512) return;                      // kLongRow: summed by k_compress_long / k_compress_fold
     double s = 0.0;
-    for (int64_t j = ptr[k]; j < ptr[k + 1]; j++) s += buf[perm[j]];
+    for (int64_t j = b; j < e; j++) s += buf[perm[j]];
     V[k] = s;
+}
+// entries with very many duplicates: blockIdx.x = long entry, blockIdx.y = chunk of 8192 sorted positions -> partial sum
+__global__ void __launch_bounds__(256) k_compress_long(const uint32_t *__restrict__ list, const int64_t *__restrict__ ptr,
+                                                       const uint32_t *__restrict__ perm, const double *__restrict__ buf,
+                                                       double *__restrict__ partial, int chunks) {
+    __shared__ double red[4];
+    const int64_t k = list[blockIdx.x];
+    const int64_t beg = ptr[k] + (int64_t)blockIdx.y * 8192;
+    const int64_t end = beg + 8192 < ptr[k + 1] ? beg + 8192 : ptr[k + 1];
+    double s = 0.0;
+    for (int64_t j = beg + threadIdx.x; j < end; j += 256) s += buf[perm[j]];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * chunks + blockIdx.y] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void __launch_bounds__(256) k_compress_fold(const uint32_t *__restrict__ list, const double *__restrict__ partial, int chunks,
+                                                       double *__restrict__ V, int64_t nlong) {
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= nlong) return;
+    double s = 0.0;
+    for (int c = 0; c < chunks; c++) s += partial[l * chunks + c];     // chunks past the entry's end hold 0
+    V[list[l]] = s;
 }
 
 template <class T>
@@ -188,8 +213,8 @@ unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 void CompressedCOO::release() {
-    for (void **q : {&perm, &ptr, &rows, &cols}) { if (*q) (void)hipFree(*q); *q = nullptr; }
-    cnnz = nnz = 0;
+    for (void **q : {&perm, &ptr, &rows, &cols, &long_list, &partial}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    cnnz = nnz = nlong = maxlen = 0;
 }
 
 // rows/cols: device int64[nnz] (1-based).  nrowdim: number of rows of the matrix (ncon for J, nvar for H).
@@ -239,6 +264,24 @@ void build_compressed(CompressedCOO &c, const int64_t *rows, const int64_t *cols
     HIPCHK_C(hipMemcpyAsync((int64_t *)c.ptr + c.cnnz, &nnz, 8, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_decode, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, (const uint64_t *)keys.p, nrowdim, (int64_t *)c.rows,
                        (int64_t *)c.cols, c.cnnz);
+    {   // entries with very many duplicates
+        Tmp meta(16), list(4 * (size_t)kMaxLong);
+        HIPCHK_C(hipMemsetAsync(meta.p, 0, 16, stream));
+        if (c.cnnz) hipLaunchKernelGGL(k_find_long, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, (const int64_t *)c.ptr, c.cnnz,
+                                       (uint32_t *)list.p, (unsigned long long *)meta.p);
+        unsigned long long hm[2] = {0, 0};
+        HIPCHK_C(hipMemcpyAsync(hm, meta.p, 16, hipMemcpyDeviceToHost, stream));
+        HIPCHK_C(hipStreamSynchronize(stream));
+        if (hm[0] > (unsigned long long)kMaxLong) throw std::runtime_error("too many long groups for the compressed COO");
+        c.nlong = (int64_t)hm[0]; c.maxlen = (int64_t)hm[1];
+        if (c.nlong) {
+            const int64_t chunks = (c.maxlen + kChunk - 1) / kChunk;
+            HIPCHK_C(hipMalloc(&c.long_list, 4 * (size_t)c.nlong));
+            HIPCHK_C(hipMalloc(&c.partial, 8 * (size_t)(c.nlong * chunks)));
+            HIPCHK_C(hipMemcpyAsync(c.long_list, list.p, 4 * (size_t)c.nlong, hipMemcpyDeviceToDevice, stream));
+            HIPCHK_C(hipStreamSynchronize(stream));
+        }
+    }
     HIPCHK_C(hipStreamSynchronize(stream));
 }
 
@@ -319,6 +362,13 @@ void compress_values(const CompressedCOO &c, const double *buf, double *V, hipSt
     if (c.cnnz == 0) return;
     hipLaunchKernelGGL(k_compress, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, V, buf, (const int64_t *)c.ptr, (const uint32_t *)c.perm,
                        c.cnnz);
+    if (c.nlong) {
+        const int chunks = (int)((c.maxlen + kChunk - 1) / kChunk);
+        hipLaunchKernelGGL(k_compress_long, dim3((unsigned)c.nlong, (unsigned)chunks), dim3(256), 0, stream, (const uint32_t *)c.long_list,
+                           (const int64_t *)c.ptr, (const uint32_t *)c.perm, buf, (double *)c.partial, chunks);
+        hipLaunchKernelGGL(k_compress_fold, dim3(grid_for(c.nlong)), dim3(256), 0, stream, (const uint32_t *)c.long_list,
+                           (const double *)c.partial, chunks, V, c.nlong);
+    }
 }
 
 void compressed_structure(const CompressedCOO &c, void *rows, void *cols, bool wide, hipStream_t stream) {

@@ -14,6 +14,11 @@ struct CompressedCOO {
     void *ptr = nullptr;    // int64[cnnz+1] first sorted position of every distinct (row,col)
     void *rows = nullptr;   // int64[cnnz]
     void *cols = nullptr;   // int64[cnnz]
+    // entries with more than 512 duplicates (a variable shared by every data point: the rocket's step length puts 1e6
+    // contributions into ONE Hessian entry) are summed cooperatively, in a fixed order: per-chunk partial sums, then a fold
+    void *long_list = nullptr;   // uint32[nlong]
+    void *partial = nullptr;     // double[nlong * chunks]
+    int64_t nlong = 0, maxlen = 0;
     void release();
 };
 

@@ -92,3 +92,39 @@ def test_compressed_mid_size_many_blocks(libs):
     torch.cuda.synchronize()
     assert np.array_equal(cr.cpu().numpy(), r[order][starts]) and np.array_equal(cc.cpu().numpy(), c[order][starts])
     np.testing.assert_allclose(cv.cpu().numpy(), ev, rtol=1e-13, atol=1e-13)
+
+
+def test_heavily_duplicated_entry(libs):
+    """The rocket's step length is shared by every data point: ONE compressed Hessian entry collects thousands of
+    contributions (was summed by a single thread: 0.9 s at nh = 1e6; now per-chunk partial sums + an ordered fold).
+    Those entries are summed as a tree, so they match the slot-ordered sum to rounding, the rest bit for bit."""
+    import time
+    import torch
+    from exahip import CompressedExaModel, ExaModel, models
+    m = ExaModel(models.rocket_model(20000))
+    cm = CompressedExaModel(m)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=4)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    r, c = m.hess_structure()
+    v = m.hess_coord(x, y, sigma)
+    cr, cc = (t.cpu().numpy() for t in cm.hess_structure())
+    cv = cm.hess_coord(xd, yd, sigma).cpu().numpy()
+    key = (c - 1) * m.meta.nvar + (r - 1)
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    starts = np.concatenate([[0], np.nonzero(ks[1:] != ks[:-1])[0] + 1, [len(ks)]])
+    counts = np.diff(starts)
+    assert counts.max() > 10000 and len(counts) == len(cv)
+    want = np.add.reduceat(v[order], starts[:-1])
+    assert np.array_equal(cr, r[order][starts[:-1]]) and np.array_equal(cc, c[order][starts[:-1]])
+    # numpy's reduceat sums pairwise, the library sequentially (or as a tree for the long entries): compare relative to
+    # the magnitude of what was added, entry by entry (bit-exactness of the sequential sums is test 1's business)
+    mag = np.add.reduceat(np.abs(v[order]), starts[:-1])
+    assert np.all(np.abs(cv - want) <= 1e-13 * np.maximum(mag, 1e-300) * np.sqrt(counts))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        cm.hess_coord(xd, yd, sigma)
+    torch.cuda.synchronize()
+    assert (time.perf_counter() - t0) / 5 < 0.05          # seconds; the single-thread sum took 18 ms per 20000 points
