@@ -59,11 +59,12 @@ struct Handle {
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
+    hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
                   f_hess = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
-    DevBuf dP, dtheta, dpart, dobj, daugbuf, daugrows, daugptr, daugperm;
+    DevBuf dP, dtheta, dpart, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
+    int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation
     DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] sequential, [1] interleaved
     int order[CB_COUNT] = {0};              // which map is active; -1 = not yet measured
     std::vector<DevBuf> dcols;              // flattened over patterns
@@ -85,7 +86,7 @@ struct Handle {
     ~Handle() {
         if (on_device) {
             dP.release(); dtheta.release(); dpart.release(); dobj.release();
-            daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release();
+            daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
             cj.release(); ch.release(); cbuf.release();
             pjrows.release(); pjcols.release(); phrows.release(); phcols.release();
@@ -298,6 +299,7 @@ void to_device(Handle &h) {
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
     h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
     h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull");
+    h.f_auglong = fn("exa_aug_long"); h.f_augfold = fn("exa_aug_fold");
     h.f_fused = fn("exa_fused");
     h.f_jprod = fn("exa_jprod"); h.f_jtprod = fn("exa_jtprod"); h.f_hprod = fn("exa_hprod"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
@@ -329,6 +331,15 @@ void to_device(Handle &h) {
         };
         up(h.daugrows, m.aug_rows); up(h.daugptr, m.aug_ptr); up(h.daugperm, m.aug_perm);
         h.daugbuf.ensure(8 * (size_t)m.nconaug);
+        std::vector<int64_t> longs;
+        int64_t maxlen = 0;
+        for (size_t t = 0; t + 1 < m.aug_ptr.size(); t++) {
+            const int64_t len = m.aug_ptr[t + 1] - m.aug_ptr[t];
+            if (len > 512) { longs.push_back((int64_t)t); maxlen = std::max(maxlen, len); }     // EXA_AUG_LONG
+        }
+        h.aug_nlong = (int64_t)longs.size();
+        h.aug_chunks = (maxlen + 8191) / 8192;                                                    // EXA_AUG_CHUNK
+        if (h.aug_nlong) { up(h.dauglong, longs); h.daugpartial.ensure(8 * (size_t)(h.aug_nlong * h.aug_chunks)); }
     }
     HIPCHK(hipEventCreate(&h.ev0));
     HIPCHK(hipEventCreate(&h.ev1));
@@ -391,6 +402,23 @@ void tune_order(Handle &h, int cb, F &&run) {
     HIPCHK(hipStreamSynchronize(h.stream));
 }
 
+// second stage of cons_nln! / jprod_nln! / the fused sweep: add the buffered augmentation terms to their rows
+void aug_gather(Handle &h, void *buf, double *c) {
+    const void *rows = h.daugrows.p, *ptr = h.daugptr.p, *perm = h.daugperm.p;
+    int64_t nrows = (int64_t)h.m->aug_rows.size();
+    void *a3[] = {&rows, &ptr, &perm, &buf, &c, &nrows};
+    launch(h, h.f_auggather, (nrows + kBlock - 1) / kBlock, kBlock, a3);
+    if (h.aug_nlong == 0) return;
+    const void *list = h.dauglong.p;
+    void *partial = h.daugpartial.p;
+    int chunks = (int)h.aug_chunks;
+    void *a4[] = {&list, &ptr, &perm, &buf, &partial, &chunks};
+    HIPCHK(hipModuleLaunchKernel(h.f_auglong, (unsigned)h.aug_nlong, (unsigned)chunks, 1, kBlock, 1, 1, 0, h.stream, a4, nullptr));
+    int64_t nlong = h.aug_nlong;
+    void *a5[] = {&list, &rows, &partial, &chunks, &c, &nlong};
+    launch(h, h.f_augfold, (nlong + kBlock - 1) / kBlock, kBlock, a5);
+}
+
 // ---- callbacks (device pointers, asynchronous) ------------------------------------------------------------
 void do_obj(Handle &h, const double *x, double *out_dev) {
     const void *P = h.dP.p, *th = h.dtheta.p;
@@ -429,11 +457,7 @@ void do_cons(Handle &h, const double *x, double *c) {
     tune_order(h, CB_CONS, [&] { launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a); });
     launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a);
     if (h.m->nconaug == 0) return;
-    // then one deterministic gather per target row
-    const void *rows = h.daugrows.p, *ptr = h.daugptr.p, *perm = h.daugperm.p;
-    int64_t nrows = (int64_t)h.m->aug_rows.size();
-    void *a3[] = {&rows, &ptr, &perm, &buf, &c, &nrows};
-    launch(h, h.f_auggather, (nrows + kBlock - 1) / kBlock, kBlock, a3);
+    aug_gather(h, buf, c);       // then one deterministic gather per target row
 }
 void do_jac(Handle &h, const double *x, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
@@ -461,12 +485,7 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
     launch(h, h.f_fused, n, kBlock, a);
     if (n > 0) { void *a2[] = {&part, &n, &obj_dev}; launch(h, h.f_red, 1, 1024, a2); }
     else HIPCHK(hipMemsetAsync(obj_dev, 0, sizeof(double), h.stream));
-    if (h.m->nconaug) {
-        const void *rows = h.daugrows.p, *ptr = h.daugptr.p, *perm = h.daugperm.p;
-        int64_t nrows = (int64_t)h.m->aug_rows.size();
-        void *a3[] = {&rows, &ptr, &perm, &buf, &c, &nrows};
-        launch(h, h.f_auggather, (nrows + kBlock - 1) / kBlock, kBlock, a3);
-    }
+    if (h.m->nconaug) aug_gather(h, buf, c);
 }
 // matrix-free products (jprod_nln! / jtprod_nln! / hprod!, nlp.jl:1882-1978)
 void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
@@ -480,10 +499,7 @@ void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
     void *a[] = {&P, &x, &th, &v, &Jv, &buf};
     launch(h, h.f_jprod, h.grid[CB_JPROD], kBlock, a);
     if (h.m->nconaug == 0) return;
-    const void *rows = h.daugrows.p, *ptr = h.daugptr.p, *perm = h.daugperm.p;
-    int64_t nrows = (int64_t)h.m->aug_rows.size();
-    void *a3[] = {&rows, &ptr, &perm, &buf, &Jv, &nrows};
-    launch(h, h.f_auggather, (nrows + kBlock - 1) / kBlock, kBlock, a3);
+    aug_gather(h, buf, Jv);
 }
 void do_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
     HIPCHK(hipMemsetAsync(Jtv, 0, sizeof(double) * (size_t)h.m->nvar, h.stream));
