@@ -715,6 +715,22 @@ static __device__ __forceinline__ void exa_wave_atomic_add(double* p, double v) 
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(p, v);
 }
+// Scatter through a DATA index: the target may be one variable shared by every data point (a step length, a slack, a
+// reference bus reached through a table column) — 64 same-address atomics per wavefront that serialise chip-wide at
+// ~12 ns each (1e7 points: 120 ms).  If all active lanes of the wavefront name the same variable, add the 64 values with
+// a butterfly and issue ONE atomic; otherwise one atomic per lane.  Must be reached by the whole wavefront.
+static __device__ __forceinline__ void exa_scatter_add(double* __restrict__ out, long idx, double v, bool act) {
+    const unsigned long long m = __ballot(act);
+    if (m == 0) return;
+    const long first = __shfl(idx, __ffsll((long long)m) - 1, 64);
+    if (__ballot(act && idx != first) == 0) {
+        double s = act ? v : 0.0;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&out[first], s);
+    } else if (act) {
+        unsafeAtomicAdd(&out[idx], v);
+    }
+}
 // sum over the 256-thread workgroup: 64-lane wavefront butterflies, then 4 partials through LDS
 static __device__ __forceinline__ double exa_block_sum(double v) {
     __shared__ double red[EXA_BLOCK / 64];
@@ -962,6 +978,10 @@ struct Scatter {
                 full_wave = true;
                 lines.push_back("lit[" + std::to_string(lit_idx.size()) + "] += act ? " + b.e.sd(items[k].val) + " : 0.0;");
                 lit_idx.push_back(idx);
+            } else if (!affine(b.p, items[k].ir).ok && env_int("EXAHIP_WAVE_REDUCE", 1)) {
+                // reached through a data column: possibly the same variable for the whole wavefront (exa_scatter_add)
+                full_wave = true;
+                lines.push_back("exa_scatter_add(out, " + idx + ", " + b.e.sd(items[k].val) + ", act);");
             } else {
                 lines.push_back("if (act) unsafeAtomicAdd(&out[" + idx + "], " + b.e.sd(items[k].val) + ");");
             }
