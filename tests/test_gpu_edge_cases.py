@@ -154,3 +154,40 @@ def test_shared_variable_reached_through_a_data_index(libs):
         m.grad(xd)
     torch.cuda.synchronize()
     assert (time.perf_counter() - t0) / 10 < 1.5e-3                    # was 3.6 ms at this size
+
+
+def test_steady_state_calls_allocate_nothing(libs):
+    """test/NLPTest/alloc_test.jl: the callbacks do not allocate.  Here: after one warm call of each entry point the
+    device's free memory does not move over hundreds of further calls with caller-provided outputs (scratch, block maps
+    and product set-up are sized once)."""
+    import torch
+    from exahip import ExaModel
+    from zoo import ZOO
+    m = ExaModel(ZOO["acopf30"]())
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(np.asarray(m.meta.x0) + 0.01).to(dev)
+    y = torch.ones(m.meta.ncon, dtype=torch.float64, device=dev)
+    v = torch.ones(m.meta.nvar, dtype=torch.float64, device=dev)
+    outs = {k: torch.empty(n, dtype=torch.float64, device=dev) for k, n in
+            (("c", m.meta.ncon), ("g", m.meta.nvar), ("j", m.meta.nnzj), ("h", m.meta.nnzh), ("jv", m.meta.ncon), ("hv", m.meta.nvar), ("f", 1))}
+
+    def sweep():
+        m.obj(x)
+        m.cons(x, out=outs["c"])
+        m.grad(x, out=outs["g"])
+        m.jac_coord(x, out=outs["j"])
+        m.hess_coord(x, y, 0.5, out=outs["h"])
+        m.jprod(x, v, out=outs["jv"])
+        m.jtprod(x, y, out=outs["g"])
+        m.hprod(x, y, v, 0.5, out=outs["hv"])
+        m.eval_fused(x, y, 0.5, c=outs["c"], jac=outs["j"], hess=outs["h"], obj_out=outs["f"])
+
+    for _ in range(3):
+        sweep()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(200):
+        sweep()
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free1 == free0
