@@ -297,9 +297,19 @@ class ExaModel:
         capi.check(self._L.exa_set_shard(self.id, int(rank), int(world)), "exa_set_shard")
 
     def set_value(self, par, values):
-        """set_value!(m, θ, vals): update a Parameter block without rebuilding (nlp.jl:1279-1287)."""
-        v = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.float64), (par.length,)))
+        """set_value!(m, θ, vals): update a Parameter block without rebuilding (nlp.jl:1279-1287).  A vector of the
+        wrong length is a DimensionMismatch in the reference (GetterSetterTest.jl:33-34); a scalar fills the block."""
+        a = np.asarray(values, dtype=np.float64)
+        if a.ndim > 0 and a.size != par.length:
+            raise ValueError(f"dimension mismatch: parameter block has {par.length} entries, got {a.size}")
+        v = np.ascontiguousarray(np.broadcast_to(a.reshape(-1) if a.ndim else a, (par.length,)))
         capi.check(self._L.exa_set_value(self.id, par.offset, v.ctypes.data, v.size), "exa_set_value")
+
+    def get_value(self, par):
+        """get_value(m, θ): the model's current values of a Parameter block (a copy: the storage is the library's)."""
+        v = np.empty(par.length)
+        capi.check(self._L.exa_get_value(self.id, par.offset, v.ctypes.data, v.size), "exa_get_value")
+        return v
 
     def _use_torch_stream(self, t):
         import torch

@@ -126,3 +126,25 @@ def test_hip_modify_after_build(libs):
     cn, _ = lv_parametric(3, 2, False, AFTER_BUILD)
     _same_evaluations(mp, _hip(cn))
     assert list(np.concatenate(cp.theta)) == DEFAULT_THETA      # the core keeps what it was built with
+
+
+def test_get_set_value_api(libs):
+    """test/GetterSetterTest/GetterSetterTest.jl:20-36 (parameters; the start/bound getters are host metadata)."""
+    from exahip import ExaCore, ExaModel, rng
+    c = ExaCore()
+    x = c.add_var(3, start=1.0, lvar=-2.0, uvar=5.0)
+    y = c.add_var(2, start=0.5, lvar=0.0, uvar=1.0)
+    t1 = c.add_par([10.0, 20.0, 30.0])
+    t2 = c.add_par(2, value=7.0)
+    c.add_con(lambda i: x[i] + x[i + 1] + t1[i] * t2[1], rng(1, 2), lcon=-1.0, ucon=1.0, start=0.1)
+    c.add_con(y[1] - y[2], lcon=0.0, ucon=0.0, start=0.5)
+    m = ExaModel(c, device=False)
+    assert list(m.get_value(t1)) == [10.0, 20.0, 30.0] and list(m.get_value(t2)) == [7.0, 7.0]
+    m.set_value(t1, [1.0, 2.0, 3.0])
+    m.set_value(t2, [9.0, 8.0])
+    assert list(m.get_value(t1)) == [1.0, 2.0, 3.0] and list(m.get_value(t2)) == [9.0, 8.0]
+    for par, bad in ((t1, [1.0, 2.0]), (t2, [1.0])):
+        with pytest.raises(ValueError):
+            m.set_value(par, bad)
+    assert list(m.meta.x0) == [1.0, 1.0, 1.0, 0.5, 0.5] and list(m.meta.lvar) == [-2.0] * 3 + [0.0] * 2
+    assert list(m.meta.uvar) == [5.0] * 3 + [1.0] * 2 and list(m.meta.lcon) == [-1.0, -1.0, 0.0] and list(m.meta.ucon) == [1.0, 1.0, 0.0]
