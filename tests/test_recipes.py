@@ -390,3 +390,43 @@ def test_hip_recipe_instances_share_one_kernel_module(libs):
         x, y = np.linspace(0.5, 1.5, n), np.linspace(-1.0, 1.0, n - 2)
         np.testing.assert_allclose(m.hess_coord(x, y, 0.5), ref.hess_coord(x, y, 0.5), rtol=1e-10, atol=1e-9)
     assert len(paths) == 1
+
+
+def test_two_dimensional_recipe_with_products_and_tuple_targets(libs):
+    """The split Luksan-Vlcek model (test/NLPTest/luksan.jl:17-26) as a recipe in TWO sizes: 2-D variable strides,
+    product iterators and the column-major row of an augmentation target are all deferred."""
+    from exahip import ExaCore, Recipe, product, rng
+    from exahip.graph import exp, sin
+
+    def build(c, N, M):
+        x = c.add_var(N, M, start=0.7, name="x")
+
+        def con1(p):
+            i, j = p
+            return 3 * x[i + 1, j] ** 3 + 2 * x[i + 2, j] - 5
+
+        def con2(p):
+            i, j = p
+            return ((i, j), sin(x[i + 1, j] - x[i + 2, j]) * sin(x[i + 1, j] + x[i + 2, j]) + 4 * x[i + 1, j]
+                    - x[i, j] * exp(x[i, j] - x[i + 1, j]) - 3)
+
+        def obj(p):
+            i, j = p
+            return 100 * (x[i - 1, j] ** 2 - x[i, j]) ** 2 + (x[i - 1, j] - 1) ** 2
+
+        s = c.add_con(con1, product(rng(1, N - 2), rng(1, M)), name="s")
+        c.add_con_aug(s, con2, product(rng(1, N - 2), rng(1, M)))
+        c.add_obj(obj, product(rng(2, N), rng(1, M)))
+        e = c.add_con(N, M, lcon=-1.0, ucon=1.0)                                   # an empty 2-D constraint block ...
+        c.add_con_aug(e, lambda p: ((p[0], p[1]), x[p[0], p[1]] ** 2), product(rng(1, N, 2), rng(M, 1, -1)))   # stepped / reversed axes
+        return c
+
+    c = ExaCore(examples=(5, 2))
+    rec = Recipe(build(c, *c.args))
+    assert rec.argtype == "int|arg1,int|arg2"
+    for n, mm in ((5, 2), (9, 1), (4, 7), (20, 3)):
+        assert rec.matches(build(ExaCore(), n, mm), n, mm), (n, mm)
+    from exahip import ExaModel
+    m = ExaModel(rec, 6, 4, device=False)
+    b = {blk.name: blk for blk in m.blocks()}
+    assert b["x"].dims == [6, 4] and b["s"].dims == [4, 4] and b["s"].length == 16
