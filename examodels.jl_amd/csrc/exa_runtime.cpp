@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <map>
 #include <mutex>
 #include <sstream>
 #include <stdexcept>
@@ -157,6 +158,17 @@ std::string compile_flags() {
 
 bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && st.st_size > 0; }
 
+// Code objects handed over in memory (exa_cache_add): a packed library carries the module it was built with, so its
+// consumer needs neither hipcc nor a writable cache (the ahead-of-time half of ExaModelsCompiler's compile_library).
+std::mutex g_pre_mu;
+std::map<std::string, std::vector<char>> g_preloaded;      // "exa_<hash>" -> code object
+
+std::string module_name(const std::string &source) {
+    char name[64];
+    snprintf(name, sizeof name, "exa_%016llx", (unsigned long long)fnv1a(source + "|" + compile_flags()));
+    return name;
+}
+
 // Compiles `source` for gfx950 into the on-disk cache; returns the path of the code object.
 std::string build_code_object(const std::string &source) {
     const std::string flags = compile_flags();
@@ -292,8 +304,17 @@ void to_device(Handle &h) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
         throw HipError("no HIP device available (libexahip has no CPU fallback): " + std::string(hipGetErrorString(e)));
-    h.hsaco_path = build_code_object(h.gen.source);
-    std::vector<char> image = read_file(h.hsaco_path);
+    std::vector<char> image;
+    {
+        const std::string name = module_name(h.gen.source);
+        std::lock_guard<std::mutex> lk(g_pre_mu);
+        auto it = g_preloaded.find(name);
+        if (it != g_preloaded.end()) { image = it->second; h.hsaco_path = "(preloaded) " + name; }
+    }
+    if (image.empty()) {
+        h.hsaco_path = build_code_object(h.gen.source);
+        image = read_file(h.hsaco_path);
+    }
     h.on_device = true;   // from here on the destructor releases whatever was acquired
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
@@ -646,6 +667,19 @@ const char *exa_last_error(void) { return g_err.c_str(); }
 int exa_new_from_table(const exa_model_desc_t *desc, int *id_out) { return create(desc, id_out, true); }
 int exa_plan_only(const exa_model_desc_t *desc, int *id_out) { return create(desc, id_out, false); }
 
+int exa_cache_add(const char *name, const void *code_object, size_t len) {
+    if (!name || !code_object || len == 0 || std::strncmp(name, "exa_", 4) != 0) return 1;
+    std::lock_guard<std::mutex> lk(g_pre_mu);
+    g_preloaded[name] = std::vector<char>((const char *)code_object, (const char *)code_object + len);
+    return 0;
+}
+const char *exa_module_name(int id) {
+    Handle *h = get(id);
+    if (!h) return nullptr;
+    static thread_local std::string name;
+    name = module_name(h->gen.source);
+    return name.c_str();
+}
 int exa_compile(int id) {
     return guard(id, false, [&](Handle &h) { h.hsaco_path = build_code_object(h.gen.source); });
 }

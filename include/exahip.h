@@ -36,6 +36,7 @@
  */
 #ifndef EXAHIP_H
 #define EXAHIP_H
+#include <stddef.h>
 #include <stdint.h>
 #include "exahip_ir.h"
 
@@ -61,6 +62,12 @@ int exa_plan_only(const exa_model_desc_t *desc, int *id_out);
  * the build check).  exa_code_object_path() then names the .hsaco. */
 int exa_compile(int id);
 const char *exa_code_object_path(int id);
+/* Cache key of the model's module ("exa_<16 hex digits>": hash of the generated source and the compile flags). */
+const char *exa_module_name(int id);
+/* Hand a compiled code object to the library in memory under that key: models whose module has this key load it instead
+ * of looking on disk or invoking hipcc.  A packed library (exahip.pack) ships its module this way — ahead-of-time, like
+ * a compile_library product of ExaModelsCompiler (ExaModelsCompiler.jl:108-222). */
+int exa_cache_add(const char *name, const void *code_object, size_t len);
 int exa_free(int id);
 
 /* ---- sizes (cnlp: P_nvar/P_ncon/P_nnzj/P_nnzh, Compiler :1564-1582) ---------------------------- */

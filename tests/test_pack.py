@@ -187,3 +187,19 @@ def test_layout_and_live_parameters_through_cnlp_names(packed):
     got = (c_dbl * 3)()
     assert lib.lay_get_value(lid, 1, got, 3) == 0 and list(got) == [2.0, 1.0, 1.0]
     np.testing.assert_allclose(m.call("obj", 1, x)[0], 2.0 * f1, rtol=1e-13)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+def test_packed_library_is_ahead_of_time(libs, tmp_path, monkeypatch):
+    """The packed library carries its gfx950 code object: with an EMPTY kernel cache and NO usable hipcc the consumer
+    still instantiates and evaluates (compile_library's ahead-of-time promise, ExaModelsCompiler.jl:108-222)."""
+    from exahip.pack import pack_library
+    path = pack_library(str(tmp_path / "aot"), ("knob2", make(build_knob, (4,), True)))
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path / "empty_cache"))
+    monkeypatch.setenv("EXAHIP_HIPCC", "/nonexistent/hipcc")
+    lib = ctypes.CDLL(path)
+    m = Consumer(lib, "knob2", lib.knob2_new(9))
+    assert m.nvar == 9 and m.call("obj", 1, np.ones(9))[0] == 9.0
+    _against_oracle(m, make(build_knob, (9,), False))
+    assert not list((tmp_path / "empty_cache").glob("*.hsaco"))          # nothing was compiled or cached at run time
