@@ -69,6 +69,18 @@ def test_no_device_no_model(packed):
     assert packed.knob_new(5) == 0 and packed.lv7_new(0) == 0
 
 
+def test_bundle_is_relocatable(libs, tmp_path):
+    """bundle=True: the directory carries libexahip.so and finds it through $ORIGIN after being moved."""
+    import shutil
+    import subprocess
+    from exahip.pack import pack_library
+    pack_library(str(tmp_path / "a" / "rosen"), make(build_knob, (4,), True), bundle=True)
+    shutil.move(str(tmp_path / "a"), str(tmp_path / "moved"))
+    out = subprocess.check_output(["ldd", str(tmp_path / "moved" / "librosen.so")]).decode()
+    line = [ln for ln in out.splitlines() if "libexahip.so" in ln][0]
+    assert str(tmp_path / "moved" / "libexahip.so") in line
+
+
 def test_prefix_must_be_a_c_identifier(libs, tmp_path):
     from exahip.pack import pack_library
     for bad in ("lib-a", "2fast"):                                           # runtests.jl:88-89
