@@ -1358,7 +1358,7 @@ Generated generate_module(const Model &m) {
     L.pat.resize(np);
     for (int k = 0; k < np; k++) {
         auto &pp = L.pat[k];
-        pp.lo = w++; pp.hi = w++; pp.o0 = w++; pp.o1 = w++; pp.o2 = w++; pp.oa = w++;
+        pp.lo = w++; pp.hi = w++; pp.o0 = w++; pp.o1 = w++; pp.o2 = w++; pp.oa = w++; pp.ob = w++;
         for (size_t c = 0; c < m.pats[k].cols.size(); c++) pp.col.push_back(w++);
     }
     for (int k = 0; k < np; k++) {
@@ -1500,14 +1500,21 @@ Generated generate_module(const Model &m) {
               "double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma) {\n";
         if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all + (threadIdx.x >> 6) * " << mx << ";\n";
         else os << "    double* lds = nullptr;\n";
-        os << "    const long b = blockIdx.x;\n    double v = 0.0;\n"
+        // only the workgroups of OBJECTIVE patterns have something to add to obj: they write one partial sum each, at a
+        // compact index (pattern's first slot + tile), so the reduction reads 1/3 of the workgroup count on LV
+        os << "    const long b = blockIdx.x;\n"
            << "    const long e_ = ((const long*)P[" << L.blk[CB_FUSED] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
-              "    const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
+              "    const long tile_ = e_ & ((1L << 40) - 1);\n    const long tid0 = tile_ * EXA_BLOCK + threadIdx.x;\n";
         const auto &act = L.active[CB_FUSED];
-        for (size_t k = 0; k < act.size(); k++)
-            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") v = p" << act[k]
-               << "_fused(P, x, y, th, cout, augout, jout, hout, sigma, tid0, lds);\n";
-        os << "    const double s = exa_block_sum(v);\n    if (threadIdx.x == 0) part[b] = s;\n}\n";
+        for (size_t k = 0; k < act.size(); k++) {
+            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") { const double v = p" << act[k]
+               << "_fused(P, x, y, th, cout, augout, jout, hout, sigma, tid0, lds);";
+            if (m.pats[act[k]].kind == EXA_PAT_OBJ)
+                os << " const double s = exa_block_sum(v); if (threadIdx.x == 0) part[P[" << L.pat[act[k]].ob << "] + tile_] = s;";
+            else os << " (void)v;";
+            os << " }\n";
+        }
+        os << "}\n";
     }
     const char *prod_sig = "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, "
                            "const double* __restrict__ v, double* __restrict__ out) {\n";

@@ -82,6 +82,7 @@ struct ParamLayout {
     // word indices into the int64 parameter table P that every kernel receives
     struct Pat {
         int lo = -1, hi = -1, o0 = -1, o1 = -1, o2 = -1, oa = -1;
+        int ob = -1;            // OBJ patterns: first slot of this pattern's workgroups among the fused sweep's objective partials
         std::vector<int> col;   // per column: device pointer (I64/F64) or range start (RANGE)
     };
     std::vector<Pat> pat;

@@ -68,6 +68,7 @@ struct Handle {
     int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation
     DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] sequential, [1] interleaved
     int order[CB_COUNT] = {0};              // which map is active; -1 = not yet measured
+    int64_t fused_nobj = 0;                 // objective partial sums written by exa_fused
     std::vector<DevBuf> dcols;              // flattened over patterns
     std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
     DevBuf sx, sy, sv, sout, srows, scols;  // scratch of the *_host variants
@@ -259,6 +260,15 @@ void fill_params(Handle &h) {
             out_bytes += 8.0 * per * (double)cnt;
         }
         h.grid[cb] = total;
+        if (cb == CB_FUSED) {
+            // objective partial sums of the fused sweep: one per workgroup of an OBJECTIVE pattern, at a compact index
+            int64_t nobj = 0;
+            for (size_t j = 0; j < na; j++) {
+                const int k = L.active[cb][j];
+                if (m.pats[k].kind == EXA_PAT_OBJ) { h.P[L.pat[k].ob] = nobj; nobj += nb[j]; }
+            }
+            h.fused_nobj = nobj;
+        }
         auto build = [&](int64_t run_len) {
             std::vector<int64_t> map, done(na, 0);
             map.reserve((size_t)total + 1);
@@ -504,7 +514,8 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
     void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma};
     tune_order(h, CB_FUSED, [&] { launch(h, h.f_fused, n, kBlock, a); });
     launch(h, h.f_fused, n, kBlock, a);
-    if (n > 0) { void *a2[] = {&part, &n, &obj_dev}; launch(h, h.f_red, 1, 1024, a2); }
+    int64_t nobj = h.fused_nobj;
+    if (n > 0 && nobj > 0) { void *a2[] = {&part, &nobj, &obj_dev}; launch(h, h.f_red, 1, 1024, a2); }
     else HIPCHK(hipMemsetAsync(obj_dev, 0, sizeof(double), h.stream));
     if (h.m->nconaug) aug_gather(h, buf, c);
 }
