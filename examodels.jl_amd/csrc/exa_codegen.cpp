@@ -1547,4 +1547,208 @@ Generated generate_module(const Model &m) {
     return g;
 }
 
+// ---- windowed compressed COO ------------------------------------------------------------------
+// exa_chess / exa_cjac without the uncompressed round trip.  For a pattern whose data point I puts slot s on compressed
+// entry a_s + b*I (checked against the sorted structure at exa_compress time), a workgroup OWNS a window of W
+// consecutive compressed entries: it evaluates, for every pattern, exactly the points that touch the window (the few
+// points straddling two windows are evaluated by both, each keeping its own entries), adds the values into an LDS copy
+// of the window — slot groups in a fixed order, a barrier between groups that could meet in one word, so the sum order
+// is fixed and the result bit-reproducible — and streams the window out with plain coalesced stores: no zero-fill, no
+// atomics, 8 B of HBM traffic per COMPRESSED entry instead of 16 B + 12 B per uncompressed one.
+// The handful of points at a pattern's ends where the structure is irregular (first columns holding fewer rows) are
+// left out of the windows and added afterwards by exa_c*x, sequentially.
+static void gen_window_value_fn(std::ostringstream &os, const Model &m, const ParamLayout &L, int k, bool hess) {
+    Body b(m, k, L);
+    const Pattern &p = b.p;
+    const int S = hess ? p.o2step : p.o1step;
+    std::vector<Val> acc;
+    if (hess) {
+        b.forward(p.ad_root, 2, false);
+        Val adj;
+        if (p.kind == EXA_PAT_OBJ) adj = b.e.raw("sigma", false);
+        else adj = b.e.raw("y[" + b.row0() + "]", false);
+        GenAlg a(b, p.comp2, p.o2step);
+        hrpass0(p, p.ad_root, a, adj, zero_seed(b));
+        acc = a.acc;
+    } else {
+        b.forward(p.ad_root, 1, false);
+        GenAlg a(b, p.comp1, p.o1step);
+        grpass(p, p.ad_root, a, Emitter::litf(1.0));
+        acc = a.acc;
+    }
+    std::vector<std::string> vals;
+    for (int s = 0; s < S; s++) vals.push_back(b.e.sd(acc[s]));
+    const char *tag = hess ? "hessv" : "jacv";
+    // values of one data point, in slot order
+    os << "static __device__ __forceinline__ void " << fn_name(k, tag)
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
+          "double sigma, long I, double* v) {\n";
+    emit_lines(os, b.e);
+    for (int s = 0; s < S; s++) os << "    v[" << s << "] = " << vals[s] << ";\n";
+    os << "}\n";
+}
+
+// adds one chunk's values of pass j into the window: groups of a phase never meet in one word, a barrier between phases
+static void gen_window_fn(std::ostringstream &os, const WindowPat &wp, int j, bool hess, int S) {
+    const int ngroups = (int)wp.phase.size();
+    int nphase = 0;
+    for (int ph : wp.phase) nphase = std::max(nphase, ph + 1);
+    os << "static __device__ __forceinline__ void w" << j << (hess ? "_hessa" : "_jaca")
+       << "(const long* __restrict__ Q, long I, bool act, long c0, int W, double* win, const double* v) {\n"
+       << "    const long cb_ = Q[" << wp.qbase << "] * I - c0;\n";
+    for (int ph = 0; ph < nphase; ph++) {
+        if (ph) os << "    __syncthreads();\n";
+        for (int g = 0; g < ngroups; g++) {
+            if (wp.phase[g] != ph) continue;
+            std::string sum;
+            for (int s = 0; s < S; s++)
+                if (wp.group[s] == g) sum += (sum.empty() ? "" : " + ") + ("v[" + std::to_string(s) + "]");
+            os << "    { const long c = Q[" << wp.qbase + 5 + g << "] + cb_; if (act && (unsigned long)c < (unsigned long)W) win[c] += " << sum << "; }\n";
+        }
+    }
+    os << "}\n";
+}
+
+static void gen_window_kernels(std::ostringstream &os, const Model &m, const std::vector<WindowPat> &pats, bool hess) {
+    const char *nm = hess ? "chess" : "cjac";
+    const char *fa = hess ? "hessa" : "jaca";
+    const char *fv = hess ? "hessv" : "jacv";
+    const int np = (int)pats.size();
+    // R[window][pattern] = first and one-past-last data point touching the window (host-computed: no 64-bit divisions
+    // at the head of every workgroup's dependency chain)
+    // occupancy hint: the kernel is latency-bound between barriers (LV 1e7: 0.141 ms unhinted at 124 VGPRs, 0.122 ms at 8
+    // waves per SIMD); only for small bodies, which fit 64 / 80 registers without spilling
+    int waves = env_int("EXAHIP_CW_WAVES", -1);
+    if (waves < 0) {
+        int slots = 0;
+        for (const auto &wp : pats) slots += hess ? m.pats[wp.k].o2step : m.pats[wp.k].o1step;
+        waves = slots <= 16 ? 8 : (slots <= 40 ? 6 : 0);
+    }
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) ";
+    if (waves > 0) os << "__attribute__((amdgpu_waves_per_eu(" << waves << "))) ";
+    os << "exa_" << nm << "w(const long* __restrict__ P, const long* __restrict__ Q, "
+          "const int* __restrict__ R, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
+          "double* __restrict__ cout, double sigma, long ncomp, int W) {\n"
+          "    extern __shared__ double win[];\n    const long c0 = (long)blockIdx.x * W;\n"
+          "    const int* r_ = R + (long)blockIdx.x * " << 2 * np << ";\n"
+          "    for (int w = threadIdx.x; w < W; w += EXA_BLOCK) win[w] = 0.0;\n";
+    std::string single;
+    for (int j = 0; j < np; j++) {
+        os << "    const long lo" << j << " = r_[" << 2 * j << "], hi" << j << " = r_[" << 2 * j + 1 << "];\n";
+        single += (j ? " && " : "") + ("hi" + std::to_string(j) + " - lo" + std::to_string(j) + " <= EXA_BLOCK");
+    }
+    // common case: every pattern's range fits one chunk — all values first (their loads overlap), then the additions
+    os << "    if (" << single << ") {\n";
+    for (int j = 0; j < np; j++) {
+        const int S = hess ? m.pats[pats[j].k].o2step : m.pats[pats[j].k].o1step;
+        os << "        const bool act" << j << " = lo" << j << " + threadIdx.x < hi" << j << ";\n        const long I" << j << " = act" << j << " ? lo" << j
+           << " + threadIdx.x : 0;\n        double v" << j << "[" << S << "];\n        " << fn_name(pats[j].k, fv) << "(P, x, y, th, sigma, I" << j << ", v" << j << ");\n";
+    }
+    for (int j = 0; j < np; j++)
+        os << "        __syncthreads();\n        w" << j << "_" << fa << "(Q, I" << j << ", act" << j << ", c0, W, win, v" << j << ");\n";
+    os << "    } else {\n";
+    for (int j = 0; j < np; j++) {
+        const int S = hess ? m.pats[pats[j].k].o2step : m.pats[pats[j].k].o1step;
+        os << "        for (long base = lo" << j << "; base < hi" << j << "; base += EXA_BLOCK) {\n            const bool act = base + threadIdx.x < hi" << j
+           << ";\n            const long I = act ? base + threadIdx.x : 0;\n            double v[" << S << "];\n            " << fn_name(pats[j].k, fv)
+           << "(P, x, y, th, sigma, I, v);\n            __syncthreads();\n            w" << j << "_" << fa << "(Q, I, act, c0, W, win, v);\n        }\n";
+    }
+    os << "    }\n    __syncthreads();\n"
+          "    for (int w = threadIdx.x; w < W; w += EXA_BLOCK) if (c0 + w < ncomp) __builtin_nontemporal_store(win[w], &cout[c0 + w]);\n}\n";
+}
+
+// irregular end points: X = [pattern, I] per point (up to EXA_BLOCK of them); values go through xbuf; then one thread
+// per DISTINCT compressed target adds that target's values in (point, slot) order: T = [ntargets, then per target:
+// compressed entry, first, one-past-last position in E], E = positions in xbuf
+static void gen_window_x(std::ostringstream &os, const Model &m, const std::vector<int> &pk, bool hess) {
+    const char *nm = hess ? "chess" : "cjac";
+    const char *fv = hess ? "hessv" : "jacv";
+    int smax = 1;
+    for (int k : pk) smax = std::max(smax, hess ? m.pats[k].o2step : m.pats[k].o1step);
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_" << nm << "x(const long* __restrict__ P, const long* __restrict__ X, "
+          "const int* __restrict__ T, const int* __restrict__ E, const double* __restrict__ x, const double* __restrict__ y, "
+          "const double* __restrict__ th, double* __restrict__ xbuf, double* __restrict__ cout, double sigma, int nx) {\n"
+          "    const int t = threadIdx.x;\n    if (t < nx) {\n        const long pk_ = X[2 * t], I = X[2 * t + 1];\n        double v[" << smax << "];\n"
+          "        for (int s = 0; s < " << smax << "; s++) v[s] = 0.0;\n";
+    for (size_t j = 0; j < pk.size(); j++)
+        os << "        " << (j ? "else " : "") << "if (pk_ == " << pk[j] << ") " << fn_name(pk[j], fv) << "(P, x, y, th, sigma, I, v);\n";
+    os << "        for (int s = 0; s < " << smax << "; s++) xbuf[t * " << smax << " + s] = v[s];\n    }\n    __syncthreads();\n"
+          "    for (int q = t; q < T[0]; q += EXA_BLOCK) {\n        const int c = T[1 + 3 * q];\n        double s = cout[c];\n"
+          "        for (int e = T[2 + 3 * q]; e < T[3 + 3 * q]; e++) s += xbuf[E[e]];\n        cout[c] = s;\n    }\n}\n";
+}
+
+// entries every data point adds to: per-workgroup sums of the regular points (S = [per pattern j: e_lo, e_hi, first
+// workgroup, first partial] + sentinel), folded by exa_cfold
+static void gen_window_shared(std::ostringstream &os, const Model &m, const std::vector<WindowShared> &sh, bool hess) {
+    const char *nm = hess ? "chess" : "cjac";
+    const char *fv = hess ? "hessv" : "jacv";
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_" << nm << "s(const long* __restrict__ P, const long* __restrict__ S, "
+          "const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ part, double sigma) {\n"
+          "    const long b = blockIdx.x;\n";
+    for (size_t j = 0; j < sh.size(); j++) {
+        const int St = hess ? m.pats[sh[j].k].o2step : m.pats[sh[j].k].o1step;
+        os << "    " << (j ? "else " : "") << "if (b < S[" << 4 * (j + 1) + 2 << "]) {\n        const long tile = b - S[" << 4 * j + 2 << "], nt = S["
+           << 4 * (j + 1) + 2 << "] - S[" << 4 * j + 2 << "];\n        const long I0 = S[" << 4 * j << "] + tile * EXA_BLOCK + threadIdx.x;\n"
+           << "        const bool act = I0 < S[" << 4 * j + 1 << "];\n        const long I = act ? I0 : 0;\n        double v[" << St << "];\n        "
+           << fn_name(sh[j].k, fv) << "(P, x, y, th, sigma, I, v);\n";
+        for (size_t g = 0; g < sh[j].groups.size(); g++) {
+            std::string sum;
+            for (int s : sh[j].groups[g]) sum += (sum.empty() ? "" : " + ") + ("v[" + std::to_string(s) + "]");
+            os << "        { const double s = exa_block_sum(act ? " << sum << " : 0.0); if (threadIdx.x == 0) part[S[" << 4 * j + 3 << "] + " << g
+               << " * nt + tile] = s; __syncthreads(); }\n";
+        }
+        os << "    }\n";
+    }
+    os << "}\n";
+}
+
+std::string generate_window_module(const Model &m, const ParamLayout &L, const WindowSpec &spec) {
+    static std::mutex gen_mu;
+    std::lock_guard<std::mutex> gen_lock(gen_mu);
+    std::ostringstream os;
+    {
+        std::string pre = kPrelude;
+        const std::string tag = "@BLOCK@", tag2 = "@PULLPPT@";
+        pre.replace(pre.find(tag), tag.size(), std::to_string(kBlock));
+        pre.replace(pre.find(tag2), tag2.size(), std::to_string(L.pull_ppt));
+        os << pre;
+    }
+    os << "// windowed compressed-COO kernels\n"
+          ;
+    os << R"HIP(// F = [ngroups, then per group: first partial, count, compressed entry]; groups in order (several may share an entry)
+extern "C" __global__ void __launch_bounds__(1024) exa_cfold(const double* __restrict__ part, const long* __restrict__ F, double* __restrict__ cout) {
+    __shared__ double red[16];
+    for (long g = 0; g < F[0]; g++) {
+        const long off = F[1 + 3 * g], n = F[2 + 3 * g];
+        double a = 0.0;
+        for (long i = threadIdx.x; i < n; i += 1024) a += part[off + i];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) { double s = 0.0; for (int w = 0; w < 16; w++) s += red[w]; cout[F[3 + 3 * g]] += s; }
+        __syncthreads();
+    }
+}
+)HIP";
+    for (int hess = 1; hess >= 0; hess--) {
+        const auto &pats = hess ? spec.hess : spec.jac;
+        const auto &sh = hess ? spec.hess_shared : spec.jac_shared;
+        if (pats.empty()) continue;
+        // value function once per pattern, accumulate function per (pattern, stride class) pass
+        std::vector<int> pk;
+        for (const auto &wp : pats) if (std::find(pk.begin(), pk.end(), wp.k) == pk.end()) pk.push_back(wp.k);
+        for (const auto &q : sh) if (std::find(pk.begin(), pk.end(), q.k) == pk.end()) pk.push_back(q.k);
+        for (int k : pk) gen_window_value_fn(os, m, L, k, hess != 0);
+        for (size_t j = 0; j < pats.size(); j++) gen_window_fn(os, pats[j], (int)j, hess != 0, hess ? m.pats[pats[j].k].o2step : m.pats[pats[j].k].o1step);
+        gen_window_kernels(os, m, pats, hess != 0);
+        // every active pattern may own irregular end points
+        std::vector<int> all;
+        for (int k : L.active[hess ? CB_HESS : CB_JAC]) all.push_back(k);
+        for (int k : all) if (std::find(pk.begin(), pk.end(), k) == pk.end()) { gen_window_value_fn(os, m, L, k, hess != 0); pk.push_back(k); }
+        gen_window_x(os, m, all, hess != 0);
+        if (!sh.empty()) gen_window_shared(os, m, sh, hess != 0);
+    }
+    return os.str();
+}
+
 }  // namespace exa

@@ -77,6 +77,27 @@ __global__ void __launch_bounds__(256) k_compress_fold(const uint32_t *__restric
     V[list[l]] = s;
 }
 
+// ---- windowed fast path support (exa_runtime.cpp: window_setup) ----------------------------------------------------
+// cmap[e] = compressed entry of original slot e
+__global__ void __launch_bounds__(256) k_slot_map(const int64_t *__restrict__ ptr, const uint32_t *__restrict__ perm, int32_t *__restrict__ cmap,
+                                                  int64_t cnnz) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= cnnz) return;
+    for (int64_t j = ptr[g]; j < ptr[g + 1]; j++) cmap[perm[j]] = (int32_t)g;
+}
+// points of a pattern whose slots are NOT at a[s] + b*I: count, smallest index >= mid and largest index < mid
+__global__ void __launch_bounds__(256) k_affine_check(const int32_t *__restrict__ cmap, int64_t o, int S, int64_t n, const int64_t *__restrict__ a,
+                                                      const int64_t *__restrict__ b, int64_t mid, unsigned long long *__restrict__ res) {
+    const int64_t I = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (I >= n) return;
+    bool bad = false;
+    for (int s = 0; s < S; s++) bad = bad || (int64_t)cmap[o + (int64_t)S * I + s] != a[s] + b[s] * I;
+    if (!bad) return;
+    atomicAdd(&res[0], 1ull);
+    if (I < mid) atomicMax(&res[1], (unsigned long long)(I + 1));      // e_lo candidate: one past the last bad point of the head
+    else atomicMin(&res[2], (unsigned long long)I);                    // e_hi candidate: first bad point of the tail
+}
+
 template <class T>
 __global__ void __launch_bounds__(256) k_narrow(const int64_t *__restrict__ src, T *__restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -380,6 +401,29 @@ void compressed_structure(const CompressedCOO &c, void *rows, void *cols, bool w
         hipLaunchKernelGGL(k_narrow<int32_t>, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, (const int64_t *)c.rows, (int32_t *)rows, c.cnnz);
         hipLaunchKernelGGL(k_narrow<int32_t>, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, (const int64_t *)c.cols, (int32_t *)cols, c.cnnz);
     }
+}
+
+void build_slot_map(const CompressedCOO &c, int32_t *cmap, hipStream_t stream) {
+    if (c.cnnz == 0) return;
+    hipLaunchKernelGGL(k_slot_map, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, (const int64_t *)c.ptr, (const uint32_t *)c.perm, cmap, c.cnnz);
+}
+
+void affine_exceptions(const int32_t *cmap, int64_t o, int S, int64_t n, const int64_t *a_host, const int64_t *b_host, int64_t mid, int64_t *count,
+                       int64_t *e_lo, int64_t *e_hi, hipStream_t stream) {
+    void *da = nullptr, *dres = nullptr;
+    HIPCHK_C(hipMalloc(&da, 16 * (size_t)S));
+    HIPCHK_C(hipMalloc(&dres, 24));
+    unsigned long long init[3] = {0ull, 0ull, (unsigned long long)n};
+    HIPCHK_C(hipMemcpyAsync(da, a_host, 8 * (size_t)S, hipMemcpyHostToDevice, stream));
+    HIPCHK_C(hipMemcpyAsync((int64_t *)da + S, b_host, 8 * (size_t)S, hipMemcpyHostToDevice, stream));
+    HIPCHK_C(hipMemcpyAsync(dres, init, 24, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_affine_check, dim3(grid_for(n)), dim3(256), 0, stream, cmap, o, S, n, (const int64_t *)da, (const int64_t *)da + S, mid,
+                       (unsigned long long *)dres);
+    unsigned long long res[3];
+    HIPCHK_C(hipMemcpyAsync(res, dres, 24, hipMemcpyDeviceToHost, stream));
+    HIPCHK_C(hipStreamSynchronize(stream));
+    (void)hipFree(da); (void)hipFree(dres);
+    *count = (int64_t)res[0]; *e_lo = (int64_t)res[1]; *e_hi = (int64_t)res[2];
 }
 
 }  // namespace exa

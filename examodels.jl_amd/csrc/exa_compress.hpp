@@ -25,6 +25,12 @@ struct CompressedCOO {
 void build_compressed(CompressedCOO &c, const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t nrowdim, int64_t ncoldim,
                       hipStream_t stream);
 void compress_values(const CompressedCOO &c, const double *buf, double *V, hipStream_t stream);
+// windowed fast path (exa_runtime.cpp): cmap[e] = compressed entry of original slot e (int32, device)
+void build_slot_map(const CompressedCOO &c, int32_t *cmap, hipStream_t stream);
+// how many points I of [0, n) have a slot s with cmap[o + S*I + s] != a[s] + b[s]*I; e_lo = one past the last such point
+// below mid (0 if none), e_hi = the first such point at or above mid (n if none).  Synchronises the stream.
+void affine_exceptions(const int32_t *cmap, int64_t o, int S, int64_t n, const int64_t *a_host, const int64_t *b_host, int64_t mid, int64_t *count,
+                       int64_t *e_lo, int64_t *e_hi, hipStream_t stream);
 void compressed_structure(const CompressedCOO &c, void *rows, void *cols, bool wide, hipStream_t stream);
 
 // COO entries grouped by one of their coordinates: entries perm[ptr[k] .. ptr[k+1]) have key k (0-based), in ascending

@@ -106,6 +106,26 @@ int block_threads();
 
 Generated generate_module(const Model &m);
 
+// Windowed compressed-COO kernels (exa_cjac / exa_chess fast path).  One pattern of such a kernel: every
+// slot s of data point I lands on compressed entry a_s + b * I; slots with the same a_s are added in registers (group),
+// and the groups are split into phases such that the lanes of a workgroup never touch one LDS word within a phase.
+struct WindowPat {             // one (pattern, stride class) pass
+    int k = 0;                  // pattern index
+    std::vector<int> group;     // slot -> group (-1: the slot advances with another stride; another pass adds it)
+    std::vector<int> phase;     // group -> phase
+    int qbase = 0;              // first word of this pass's table in Q: b, e_lo, e_hi, amin, amax, a[group]...
+};
+struct WindowShared {          // slots of a pattern that land on ONE compressed entry for every data point (b = 0):
+    int k = 0;                  // summed per workgroup (exa_c*s), folded in a fixed order (exa_cfold)
+    std::vector<std::vector<int>> groups;   // slots of each such entry
+};
+struct WindowSpec {
+    std::vector<WindowPat> hess, jac;
+    std::vector<WindowShared> hess_shared, jac_shared;
+};
+// Source of the second module of a compressed model: exa_chessw / exa_chessx (and exa_cjacw / exa_cjacx).
+std::string generate_window_module(const Model &m, const ParamLayout &L, const WindowSpec &spec);
+
 // ---------------------------------------------------------------------------------------------------
 // Runtime services used by the recipe layer (exa_recipe.cpp)
 // ---------------------------------------------------------------------------------------------------

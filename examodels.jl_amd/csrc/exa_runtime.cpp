@@ -75,6 +75,18 @@ struct Handle {
     CompressedCOO cj, ch;                   // duplicate-summed COO maps (exa_compress)
     DevBuf cbuf;                            // uncompressed values of the last compressed evaluation
     bool compressed = false;
+    // windowed fast path of exa_cjac / exa_chess (window_setup): second module, per-matrix tables
+    struct Window {
+        bool ok = false;
+        int W = 0, nx = 0, smax = 1;
+        int64_t nwin = 0;
+        hipFunction_t fw = nullptr, fx = nullptr, fs = nullptr;
+        int64_t ns_blocks = 0;             // workgroups of the shared-entry pass (exa_c*s)
+        DevBuf Q, R, X, T, E, xbuf, S, F, part;
+        std::string why;                   // why the fast path was not taken (exa_window_info)
+    } wj, wh;
+    hipModule_t wmodule = nullptr;
+    hipFunction_t f_cfold = nullptr;
     std::vector<BlockInfo> blocks;          // named blocks (recipes; empty for plain pattern tables)
     std::vector<exa_pattern_t> view_pats;   // exa_describe: pattern-table view of the host copy
     std::vector<std::vector<exa_column_t>> view_cols;
@@ -91,6 +103,8 @@ struct Handle {
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
             cj.release(); ch.release(); cbuf.release();
+            for (Window *w : {&wj, &wh}) { w->Q.release(); w->R.release(); w->X.release(); w->T.release(); w->E.release(); w->xbuf.release(); w->S.release(); w->F.release(); w->part.release(); }
+            if (wmodule) (void)hipModuleUnload(wmodule);
             pjrows.release(); pjcols.release(); phrows.release(); phcols.release();
             jbycol.release(); hbyrow.release(); hbycol.release();
             for (auto &b : dcols) b.release();
@@ -1055,6 +1069,275 @@ int exa_hess_structure_host(int id, int32_t *r, int32_t *c) { return struct_host
 int exa_jac_structure64_host(int id, int64_t *r, int64_t *c) { return struct_host(id, false, true, r, c); }
 int exa_hess_structure64_host(int id, int64_t *r, int64_t *c) { return struct_host(id, true, true, r, c); }
 
+// ---- windowed compressed evaluation (kernels: exa_codegen.cpp generate_window_module) -----------------
+// Decides, per matrix, whether the sorted structure is regular enough for the fast path, and prepares its tables:
+//   * every slot s of every active pattern sits at compressed entry a_s + b*I for all points but a few at the ends
+//     (fit at the middle point, checked for every point on the device);
+//   * one stride b per pattern, and the slots of a point at most 64 points apart (a workgroup re-evaluates the points
+//     straddling its window);
+//   * at most 256 irregular end points in total (added sequentially by exa_c*x).
+// Anything else (data-indexed targets, a variable shared by all points) keeps the gather path.
+bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPat> &pats, std::vector<WindowShared> &shared) {
+    const Model &m = *h.m;
+    const ParamLayout &L = h.gen.layout;
+    Handle::Window &w = hess ? h.wh : h.wj;
+    const CompressedCOO &cc = hess ? h.ch : h.cj;
+    const auto &act = L.active[hess ? CB_HESS : CB_JAC];
+    auto no = [&](const std::string &why) { w.why = why; return false; };
+    if (act.empty() || cc.cnnz == 0) return no("empty");
+    std::vector<int64_t> Q;
+    int64_t bmax = 0, spread_max = 0, npts = 0, passes_pts = 0;
+    int smax = 1;
+    for (int k : act) smax = std::max(smax, hess ? m.pats[k].o2step : m.pats[k].o1step);
+    struct Exc { int k; int64_t I; };
+    std::vector<Exc> exc;
+    struct Sh { int k; int64_t e_lo, e_hi; std::vector<int64_t> target; };
+    std::vector<Sh> shs;
+    for (size_t j = 0; j < act.size(); j++) {
+        const int k = act[j];
+        const Pattern &p = m.pats[k];
+        const int S = hess ? p.o2step : p.o1step;
+        const int64_t n = p.n, o = hess ? p.o2 : p.o1;
+        const int64_t mid = n >= 2 ? std::min(n / 2, n - 2) : 0;
+        std::vector<int32_t> two((size_t)2 * S);
+        HIPCHK(hipMemcpy(two.data(), cmap + o + (int64_t)S * mid, 4 * (size_t)S * (n >= 2 ? 2 : 1), hipMemcpyDeviceToHost));
+        std::vector<int64_t> a((size_t)S), bs((size_t)S);
+        for (int s = 0; s < S; s++) {
+            bs[s] = n >= 2 ? (int64_t)two[S + s] - two[s] : 1;
+            a[s] = (int64_t)two[s] - bs[s] * mid;
+        }
+        int64_t cnt = 0, e_lo = 0, e_hi = n;
+        affine_exceptions(cmap, o, S, n, a.data(), bs.data(), mid, &cnt, &e_lo, &e_hi, h.stream);
+        if (e_lo + (n - e_hi) > 256) return no("pattern " + std::to_string(k) + ": " + std::to_string(cnt) + " points off the regular structure");
+        for (int64_t I = 0; I < e_lo; I++) exc.push_back({k, I});
+        for (int64_t I = e_hi; I < n; I++) exc.push_back({k, I});
+        if (e_hi <= e_lo) continue;     // every point of the pattern is irregular (tiny pattern): exa_c*x does it all
+        npts += e_hi - e_lo;
+        // stride classes
+        std::vector<int64_t> strides;
+        for (int s = 0; s < S; s++) if (std::find(strides.begin(), strides.end(), bs[s]) == strides.end()) strides.push_back(bs[s]);
+        if (strides.size() > 8) return no("pattern " + std::to_string(k) + ": slots advance with " + std::to_string(strides.size()) + " different strides");
+        for (int64_t b : strides) {
+            if (b == 0) {
+                // entries every point adds to: per-workgroup sums + fold
+                WindowShared q;
+                Sh sh{k, e_lo, e_hi, {}};
+                q.k = k;
+                for (int s = 0; s < S; s++) {
+                    if (bs[s] != 0) continue;
+                    size_t g = 0;
+                    for (; g < sh.target.size(); g++) if (sh.target[g] == a[s]) break;
+                    if (g == sh.target.size()) { sh.target.push_back(a[s]); q.groups.emplace_back(); }
+                    q.groups[g].push_back(s);
+                }
+                shared.push_back(std::move(q));
+                shs.push_back(std::move(sh));
+                passes_pts += e_hi - e_lo;
+                continue;
+            }
+            // distinct targets of this stride, ascending; targets more than 64 points apart (another block of
+            // variables: x[i] and u[i] of a discretised ODE) form separate passes, each re-evaluating the points for
+            // its own slots only (the compiler drops what those slots do not need)
+            std::vector<int64_t> av;
+            for (int s = 0; s < S; s++) if (bs[s] == b && std::find(av.begin(), av.end(), a[s]) == av.end()) av.push_back(a[s]);
+            std::sort(av.begin(), av.end());
+            const int64_t ab = b < 0 ? -b : b;
+            for (size_t c0 = 0; c0 < av.size();) {
+                size_t c1 = c0 + 1;
+                while (c1 < av.size() && (av[c1] - av[c0]) / ab <= 48) c1++;
+                WindowPat wp;
+                wp.k = k;
+                wp.qbase = (int)Q.size();
+                wp.group.assign(S, -1);
+                std::vector<int64_t> ga;      // groups in slot order (the order the values are added in)
+                for (int s = 0; s < S; s++) {
+                    if (bs[s] != b || a[s] < av[c0] || a[s] > av[c1 - 1]) continue;
+                    int g = -1;
+                    for (size_t q = 0; q < ga.size(); q++) if (ga[q] == a[s]) g = (int)q;
+                    if (g < 0) { g = (int)ga.size(); ga.push_back(a[s]); }
+                    wp.group[s] = g;
+                }
+                wp.phase.assign(ga.size(), 0);
+                for (size_t g = 0; g < ga.size(); g++) {
+                    int ph = 0;
+                    for (bool again = true; again;) {
+                        again = false;
+                        for (size_t q = 0; q < g; q++)
+                            if (wp.phase[q] == ph && (ga[g] - ga[q]) % ab == 0) { ph++; again = true; break; }
+                    }
+                    wp.phase[g] = ph;
+                }
+                const int64_t amin = av[c0], amax = av[c1 - 1];
+                spread_max = std::max(spread_max, (amax - amin) / ab + 1);
+                bmax = std::max(bmax, ab);
+                passes_pts += e_hi - e_lo;
+                Q.push_back(b); Q.push_back(e_lo); Q.push_back(e_hi); Q.push_back(amin); Q.push_back(amax);
+                for (int64_t v : ga) Q.push_back(v);
+                pats.push_back(std::move(wp));
+                c0 = c1;
+            }
+        }
+    }
+    if (exc.size() > 256) return no(std::to_string(exc.size()) + " irregular end points");
+    if (pats.empty()) return no("no regular pattern");
+    if (pats.size() > 24 || (double)passes_pts > 6.0 * (double)npts)
+        return no(std::to_string(pats.size()) + " passes over " + std::to_string((double)passes_pts / std::max<double>(1.0, (double)npts)) + "x the points");
+    // window: the compressed entries that kBlock points of the WIDEST-striding pass produce (less the straddling points);
+    // passes with a smaller stride take several chunks of kBlock points per window
+    int64_t W = (kBlock - spread_max - 1) * bmax;
+    W = std::min<int64_t>(W, 4096) / 16 * 16;
+    if (W < 16) return no("window too small");
+    const int64_t nwin = (cc.cnnz + W - 1) / W;
+    // work amplification: points evaluated (whole chunks of kBlock) over points present
+    double work = 0.0;
+    for (const auto &wp : pats) {
+        const int64_t ab = std::llabs(Q[wp.qbase]);
+        const int64_t n = Q[wp.qbase + 2] - Q[wp.qbase + 1];
+        const double per = (double)W / (double)ab + (double)spread_max;
+        const double wins = std::min<double>((double)nwin, (double)n * (double)ab / (double)W + 1.0);
+        work += wins * std::ceil(per / kBlock) * kBlock;
+    }
+    if (work > 1.5 * (double)passes_pts + 4096.0 * pats.size())
+        return no("windows would evaluate " + std::to_string(work / std::max<double>(1.0, (double)passes_pts)) + "x the points");
+    // irregular points: targets straight from the slot map, grouped by distinct target
+    w.nx = (int)exc.size();
+    w.smax = smax;
+    if (w.nx) {
+        std::vector<int64_t> X;
+        std::vector<int32_t> tgt((size_t)w.nx * smax, -1);
+        for (int t = 0; t < w.nx; t++) {
+            const Pattern &p = m.pats[exc[t].k];
+            const int S = hess ? p.o2step : p.o1step;
+            const int64_t o = hess ? p.o2 : p.o1;
+            X.push_back(exc[t].k); X.push_back(exc[t].I);
+            HIPCHK(hipMemcpy(tgt.data() + (size_t)t * smax, cmap + o + (int64_t)S * exc[t].I, 4 * (size_t)S, hipMemcpyDeviceToHost));
+        }
+        std::map<int32_t, std::vector<int32_t>> by;
+        for (size_t e = 0; e < tgt.size(); e++) if (tgt[e] >= 0) by[tgt[e]].push_back((int32_t)e);
+        std::vector<int32_t> T{(int32_t)by.size()}, E;
+        for (auto &kv : by) {
+            T.push_back(kv.first); T.push_back((int32_t)E.size());
+            E.insert(E.end(), kv.second.begin(), kv.second.end());
+            T.push_back((int32_t)E.size());
+        }
+        w.X.ensure(8 * X.size()); w.T.ensure(4 * T.size()); w.E.ensure(4 * std::max<size_t>(E.size(), 1)); w.xbuf.ensure(8 * tgt.size());
+        HIPCHK(hipMemcpy(w.X.p, X.data(), 8 * X.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(w.T.p, T.data(), 4 * T.size(), hipMemcpyHostToDevice));
+        if (!E.empty()) HIPCHK(hipMemcpy(w.E.p, E.data(), 4 * E.size(), hipMemcpyHostToDevice));
+    }
+    // shared entries: workgroup map, partial-sum layout, fold list
+    w.ns_blocks = 0;
+    if (!shs.empty()) {
+        std::vector<int64_t> St, F{0};
+        int64_t blocks = 0, parts = 0;
+        for (const auto &sh : shs) {
+            const int64_t nt = (sh.e_hi - sh.e_lo + kBlock - 1) / kBlock;
+            St.push_back(sh.e_lo); St.push_back(sh.e_hi); St.push_back(blocks); St.push_back(parts);
+            for (size_t g = 0; g < sh.target.size(); g++) { F.push_back(parts + (int64_t)g * nt); F.push_back(nt); F.push_back(sh.target[g]); F[0]++; }
+            blocks += nt;
+            parts += nt * (int64_t)sh.target.size();
+        }
+        St.push_back(0); St.push_back(0); St.push_back(blocks); St.push_back(parts);     // sentinel
+        w.ns_blocks = blocks;
+        w.S.ensure(8 * St.size()); w.F.ensure(8 * F.size()); w.part.ensure(8 * (size_t)std::max<int64_t>(parts, 1));
+        HIPCHK(hipMemcpy(w.S.p, St.data(), 8 * St.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(w.F.p, F.data(), 8 * F.size(), hipMemcpyHostToDevice));
+    }
+    w.Q.ensure(8 * Q.size());
+    HIPCHK(hipMemcpy(w.Q.p, Q.data(), 8 * Q.size(), hipMemcpyHostToDevice));
+    // R[window][pass] = [lo, hi): the regular points with a slot of that pass inside the window
+    {
+        auto fdiv = [](int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; };   // b > 0
+        auto cdiv = [&](int64_t a, int64_t b) { return -fdiv(-a, b); };
+        const size_t np = pats.size();
+        std::vector<int32_t> R((size_t)nwin * np * 2);
+        for (int64_t j = 0; j < nwin; j++) {
+            const int64_t c0 = j * W, c1 = c0 + W - 1;
+            for (size_t q = 0; q < np; q++) {
+                const int64_t *t = &Q[pats[q].qbase];
+                const int64_t b = t[0], amin = t[3], amax = t[4];
+                int64_t lo, hi;
+                if (b > 0) { lo = cdiv(c0 - amax, b); hi = fdiv(c1 - amin, b) + 1; }
+                else { lo = cdiv(amin - c1, -b); hi = fdiv(amax - c0, -b) + 1; }
+                lo = std::max(lo, t[1]); hi = std::min(hi, t[2]);
+                if (hi < lo) hi = lo;
+                R[(j * np + q) * 2] = (int32_t)lo; R[(j * np + q) * 2 + 1] = (int32_t)hi;
+            }
+        }
+        w.R.ensure(4 * R.size());
+        HIPCHK(hipMemcpy(w.R.p, R.data(), 4 * R.size(), hipMemcpyHostToDevice));
+    }
+    w.W = (int)W;
+    w.nwin = nwin;
+    return true;
+}
+
+void window_setup(Handle &h) {
+    const char *env = getenv("EXAHIP_CWINDOW");
+    if (env && atoi(env) == 0) { h.wj.why = h.wh.why = "disabled (EXAHIP_CWINDOW=0)"; return; }
+    const Model &m = *h.m;
+    if (std::max(m.nnzj, m.nnzh) > 0x7fffffffLL) { h.wj.why = h.wh.why = "nnz exceeds int32"; return; }
+    WindowSpec spec;
+    DevBuf cmap;
+    cmap.ensure(4 * (size_t)std::max<int64_t>(std::max(m.nnzj, m.nnzh), 1));
+    bool okj = false, okh = false;
+    try {
+        build_slot_map(h.cj, (int32_t *)cmap.p, h.stream);
+        HIPCHK(hipStreamSynchronize(h.stream));
+        okj = window_plan(h, false, (const int32_t *)cmap.p, spec.jac, spec.jac_shared);
+        if (!okj) { spec.jac.clear(); spec.jac_shared.clear(); }
+        build_slot_map(h.ch, (int32_t *)cmap.p, h.stream);
+        HIPCHK(hipStreamSynchronize(h.stream));
+        okh = window_plan(h, true, (const int32_t *)cmap.p, spec.hess, spec.hess_shared);
+        if (!okh) { spec.hess.clear(); spec.hess_shared.clear(); }
+    } catch (...) { cmap.release(); throw; }
+    cmap.release();
+    if (!okj && !okh) return;
+    const std::string src = generate_window_module(m, h.gen.layout, spec);
+    if (const char *dump = getenv("EXAHIP_DUMP_WINDOW")) { FILE *f = fopen(dump, "w"); if (f) { fwrite(src.data(), 1, src.size(), f); fclose(f); } }
+    std::vector<char> image;
+    {
+        const std::string name = module_name(src);
+        std::lock_guard<std::mutex> lk(g_pre_mu);
+        auto it = g_preloaded.find(name);
+        if (it != g_preloaded.end()) image = it->second;
+    }
+    if (image.empty()) image = read_file(build_code_object(src));
+    HIPCHK(hipModuleLoadData(&h.wmodule, image.data()));
+    auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
+    h.f_cfold = fn("exa_cfold");
+    if (okj) { h.wj.fw = fn("exa_cjacw"); h.wj.fx = fn("exa_cjacx"); if (h.wj.ns_blocks) h.wj.fs = fn("exa_cjacs"); h.wj.ok = true; }
+    if (okh) { h.wh.fw = fn("exa_chessw"); h.wh.fx = fn("exa_chessx"); if (h.wh.ns_blocks) h.wh.fs = fn("exa_chesss"); h.wh.ok = true; }
+}
+
+void do_window(Handle &h, bool hess, const double *x, const double *y, double sigma, double *vals) {
+    Handle::Window &w = hess ? h.wh : h.wj;
+    const void *P = h.dP.p, *Q = w.Q.p, *R = w.R.p, *th = h.dtheta.p;
+    int64_t ncomp = hess ? h.ch.cnnz : h.cj.cnnz;
+    int W = w.W;
+    void *part = w.part.p;
+    if (w.ns_blocks) {
+        // independent of the windows: runs first so that its (small) grid overlaps the head of the window kernel
+        const void *S = w.S.p;
+        void *a1[] = {&P, &S, &x, &y, &th, &part, &sigma};
+        HIPCHK(hipModuleLaunchKernel(w.fs, (unsigned)w.ns_blocks, 1, 1, kBlock, 1, 1, 0, h.stream, a1, nullptr));
+    }
+    void *a[] = {&P, &Q, &R, &x, &y, &th, &vals, &sigma, &ncomp, &W};
+    HIPCHK(hipModuleLaunchKernel(w.fw, (unsigned)w.nwin, 1, 1, kBlock, 1, 1, (unsigned)(8 * W), h.stream, a, nullptr));
+    if (w.ns_blocks) {
+        const void *F = w.F.p;
+        void *a3[] = {&part, &F, &vals};
+        HIPCHK(hipModuleLaunchKernel(h.f_cfold, 1, 1, 1, 1024, 1, 1, 0, h.stream, a3, nullptr));
+    }
+    if (w.nx) {
+        const void *X = w.X.p, *T = w.T.p, *E = w.E.p;
+        void *xbuf = w.xbuf.p;
+        int nx = w.nx;
+        void *a2[] = {&P, &X, &T, &E, &x, &y, &th, &xbuf, &vals, &sigma, &nx};
+        HIPCHK(hipModuleLaunchKernel(w.fx, 1, 1, 1, kBlock, 1, 1, 0, h.stream, a2, nullptr));
+    }
+}
+
 // ---- compressed COO (CompressedNLPModel, src/utils.jl:425-579) ---------------------------------------------
 int exa_compress(int id) {
     return guard(id, true, [&](Handle &h) {
@@ -1070,7 +1353,8 @@ int exa_compress(int id) {
             build_compressed(h.ch, (const int64_t *)r.p, (const int64_t *)c.p, m.nnzh, std::max<int64_t>(m.nvar, 1), std::max<int64_t>(m.nvar, 1), h.stream);
         } catch (...) { r.release(); c.release(); throw; }
         r.release(); c.release();
-        h.cbuf.ensure(8 * (size_t)mx);
+        window_setup(h);
+        if (!(h.wj.ok || m.nnzj == 0) || !(h.wh.ok || m.nnzh == 0)) h.cbuf.ensure(8 * (size_t)mx);
         h.compressed = true;
     });
 }
@@ -1088,10 +1372,24 @@ int exa_cjac_structure(int id, int32_t *r, int32_t *c) { return cstruct(id, fals
 int exa_chess_structure(int id, int32_t *r, int32_t *c) { return cstruct(id, true, false, r, c); }
 int exa_cjac_structure64(int id, int64_t *r, int64_t *c) { return cstruct(id, false, true, r, c); }
 int exa_chess_structure64(int id, int64_t *r, int64_t *c) { return cstruct(id, true, true, r, c); }
+int exa_compress_info(int id, int hess, char *buf, int cap, int *len_out) {
+    Handle *h = get(id);
+    if (!h || !h->compressed) return -1;
+    const Handle::Window &w = hess ? h->wh : h->wj;
+    const std::string &why = w.why;
+    if (len_out) *len_out = (int)why.size();
+    if (buf && cap > 0) {
+        const int c = std::min<int>(cap - 1, (int)why.size());
+        memcpy(buf, why.data(), (size_t)c);
+        buf[c] = 0;
+    }
+    return w.ok ? 1 : 0;
+}
 int exa_cjac(int id, const double *x, double *vals) {
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) {
         if (!h.compressed) throw BadInput("exa_compress has not been called");
+        if (h.wj.ok) { do_window(h, false, x, nullptr, 0.0, vals); return; }
         do_jac(h, x, (double *)h.cbuf.p);
         compress_values(h.cj, (const double *)h.cbuf.p, vals, h.stream);
     });
@@ -1100,6 +1398,7 @@ int exa_chess(int id, const double *x, const double *y, double w, double *vals) 
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) {
         if (!h.compressed) throw BadInput("exa_compress has not been called");
+        if (h.wh.ok) { do_window(h, true, x, y, w, vals); return; }
         do_hess(h, x, y, w, (double *)h.cbuf.p);
         compress_values(h.ch, (const double *)h.cbuf.p, vals, h.stream);
     });

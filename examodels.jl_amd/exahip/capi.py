@@ -22,7 +22,7 @@ SYMBOLS = [
     "exa_hess", "exa_jprod", "exa_jtprod", "exa_hprod", "exa_jprod_host", "exa_jtprod_host", "exa_hprod_host", "exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",
     "exa_obj_host", "exa_grad_host", "exa_cons_host", "exa_jac_host", "exa_hess_host", "exa_jac_structure_host",
     "exa_hess_structure_host", "exa_jac_structure64_host", "exa_hess_structure64_host", "exa_time_callback", "exa_sync", "exa_block_order",
-    "exa_eval_fused", "exa_set_product_mode", "exa_get_product_mode", "exa_compress", "exa_cnnzj64", "exa_cnnzh64", "exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64",
+    "exa_eval_fused", "exa_set_product_mode", "exa_get_product_mode", "exa_compress", "exa_compress_info", "exa_cnnzj64", "exa_cnnzh64", "exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64",
     "exa_chess_structure64", "exa_cjac", "exa_chess",
 ]
 # ... and include/exahip_recipe.h
@@ -110,6 +110,7 @@ def lib():
     for f in ("exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64", "exa_chess_structure64", "exa_cjac"):
         getattr(L, f).argtypes = [i32, vp, vp]
     L.exa_chess.argtypes = [i32, vp, vp, dbl, vp]
+    L.exa_compress_info.argtypes = [i32, i32, ctypes.c_char_p, i32, vp]
     # include/exahip_recipe.h
     cp, sz = ctypes.c_char_p, ctypes.c_size_t
     L.exa_recipe_load.argtypes = [vp, sz]

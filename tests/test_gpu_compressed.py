@@ -28,10 +28,15 @@ def reference_compress(rows, cols, vals, nrowdim):
     return np.array(out_r), np.array(out_c), np.array(out_v)
 
 
+@pytest.mark.parametrize("window", [0, 1])
 @pytest.mark.parametrize("name", ["lv20", "lv_split_20x2", "acopf30", "mixed", "conaug2d", "rocket50"])
-def test_compressed_equals_reference_compression(libs, name):
+def test_compressed_equals_reference_compression(libs, name, window, monkeypatch):
+    """window = 0: the reference's scheme (uncompressed evaluation + sorted gather), bit-exact against its summation
+    order.  window = 1: whatever exa_compress picks — for stencil models the windowed sweep, which adds the same terms
+    in a different (fixed) order: equal within rounding of the terms' magnitudes, and bit-identical run to run."""
     import torch
     from exahip import CompressedExaModel, ExaModel
+    monkeypatch.setenv("EXAHIP_CWINDOW", str(window))
     m = ExaModel(ZOO[name]())
     cm = CompressedExaModel(m)
     x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=12)
@@ -53,7 +58,16 @@ def test_compressed_equals_reference_compression(libs, name):
         er, ec, ev = reference_compress(r, c, v, nrowdim)
         assert np.array_equal(cr, er) and np.array_equal(cc, ec)
         assert len(set(zip(cr.tolist(), cc.tolist()))) == len(cr), "duplicates left"
-        np.testing.assert_array_equal(cv, ev)     # same additions in the same order -> bit-exact
+        kind, why = cm.path(which)
+        if window == 0:
+            assert kind == "gather" and "disabled" in why
+        if kind == "gather":
+            np.testing.assert_array_equal(cv, ev)     # same additions in the same order -> bit-exact
+        else:
+            _, _, mag = reference_compress(r, c, np.abs(v), nrowdim)
+            assert np.all(np.abs(cv - ev) <= 2e-14 * mag), (np.abs(cv - ev) / np.maximum(mag, 1e-300)).max()
+            again = (cm.jac_coord(xd) if which == "jac" else cm.hess_coord(xd, yd, sigma)).cpu().numpy()
+            np.testing.assert_array_equal(again, cv)
     assert cm.meta.nnzh <= m.meta.nnzh and cm.meta.nnzj <= m.meta.nnzj
 
 
@@ -67,6 +81,8 @@ def test_compressed_lv_counts(libs):
     assert m.meta.nnzh == 9 * N - 15
     assert cm.meta.nnzh == 2 * N - 1
     assert cm.meta.nnzj == m.meta.nnzj == 3 * (N - 2)      # the LV Jacobian has no duplicates
+    # a stencil model: both matrices take the windowed sweep
+    assert cm.path("hess")[0] == "windowed" and cm.path("jac")[0] == "windowed", (cm.path("hess"), cm.path("jac"))
 
 
 def test_compressed_mid_size_many_blocks(libs):
