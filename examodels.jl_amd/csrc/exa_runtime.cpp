@@ -1273,6 +1273,9 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
 }
 
 void window_setup(Handle &h) {
+    // exa_compress may be called again (e.g. with another EXAHIP_CWINDOW): start from scratch
+    for (Handle::Window *w : {&h.wj, &h.wh}) { w->ok = false; w->why.clear(); w->nx = 0; w->ns_blocks = 0; w->nwin = 0; }
+    if (h.wmodule) { (void)hipModuleUnload(h.wmodule); h.wmodule = nullptr; }
     const char *env = getenv("EXAHIP_CWINDOW");
     if (env && atoi(env) == 0) { h.wj.why = h.wh.why = "disabled (EXAHIP_CWINDOW=0)"; return; }
     const Model &m = *h.m;

@@ -109,7 +109,7 @@ class _RangePoint:
         self.i, self.j, self.w, self.t = i, i + 1, 0.75, i if step == 1 else (i - 1) * 0 + 1
 
 
-def build_range_model(seed, npts=1000, npat=8, depth=4):
+def build_range_model(seed, npts=1000, npat=8, depth=4, unit=False):
     """As build_model, but every pattern iterates a RANGE (unit or stepped), so indices are `range + c`: the
     gathered gradient, the LDS-window scatter of J'v / Hv, the multi-tile flush and partial wavefronts are exercised."""
     g = Gen(seed)
@@ -126,6 +126,8 @@ def build_range_model(seed, npts=1000, npat=8, depth=4):
             step = 1 + int(g.r.integers(0, 3)) * (k % 3 == 2)
             lo = 1 + int(g.r.integers(0, 3))
             n = npts - int(g.r.integers(0, 70))
+            if unit:                   # stencil-like: unit ranges of (almost) equal length — regular sorted structure
+                step, n = 1, npts - (k % 2)
             itr = rng(lo, lo + step * (n - 1), step)
             fn = (lambda i, s=int(g.r.integers(0, 2**31)), st=step: Gen(s).tree(x, th, _RangePoint(i, st), depth))
             kind = k % 4

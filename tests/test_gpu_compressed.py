@@ -144,3 +144,91 @@ def test_heavily_duplicated_entry(libs):
         cm.hess_coord(xd, yd, sigma)
     torch.cuda.synchronize()
     assert (time.perf_counter() - t0) / 5 < 0.05          # seconds; the single-thread sum took 18 ms per 20000 points
+
+
+def _check_against_uncompressed(m, cm, seed):
+    """compressed values == duplicate-summed uncompressed values, within rounding of the summed magnitudes; the path
+    taken is returned"""
+    import torch
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=seed)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    kinds = []
+    for which, nrowdim in (("jac", max(m.meta.ncon, 1)), ("hess", max(m.meta.nvar, 1))):
+        if which == "jac":
+            r, c = m.jac_structure(); v = m.jac_coord(x); cv = cm.jac_coord(xd); cr, cc = cm.jac_structure()
+        else:
+            r, c = m.hess_structure(); v = m.hess_coord(x, y, sigma); cv = cm.hess_coord(xd, yd, sigma); cr, cc = cm.hess_structure()
+        if len(v) == 0:
+            continue
+        key = (c - 1) * nrowdim + (r - 1)
+        order = np.argsort(key, kind="stable")
+        ks = key[order]
+        starts = np.concatenate([[0], np.nonzero(ks[1:] != ks[:-1])[0] + 1])
+        ev = np.add.reduceat(v[order], starts)
+        mag = np.add.reduceat(np.abs(v[order]), starts)
+        cnt = np.diff(np.concatenate([starts, [len(ks)]]))
+        cv = cv.cpu().numpy()
+        assert np.array_equal(cr.cpu().numpy(), r[order][starts]) and np.array_equal(cc.cpu().numpy(), c[order][starts])
+        fin = np.isfinite(ev)
+        assert np.array_equal(np.isfinite(cv), fin)
+        bound = (2e-15 * np.sqrt(cnt) + 1e-14) * mag
+        err = np.abs(cv[fin] - ev[fin])
+        assert np.all(err <= bound[fin]), (which, (err / np.maximum(bound[fin], 1e-300)).max())
+        kinds.append(cm.path(which)[0])
+    return kinds
+
+
+@pytest.mark.parametrize("unit", [False, True])
+@pytest.mark.parametrize("seed", range(8))
+def test_windowed_random_range_models(libs, seed, unit):
+    """Random range-iterated models (tests/randexpr.build_range_model): stepped ranges, index offsets, constant-index
+    leaves (entries shared by every point), several patterns meeting in the same compressed entries — the shapes the
+    windowed sweep classifies into passes.  Whatever path exa_compress picks must reproduce the uncompressed sums."""
+    import randexpr
+    from exahip import CompressedExaModel, ExaModel
+    m = ExaModel(randexpr.build_range_model(seed, npts=1500, npat=6, depth=3, unit=unit).to_ir())
+    cm = CompressedExaModel(m)
+    kinds = _check_against_uncompressed(m, cm, seed)
+    print(seed, unit, kinds, cm.path("jac"), cm.path("hess"))
+
+
+def test_windowed_reversed_and_tiny_patterns(libs):
+    """Index decreasing with the data point (negative stride in the compressed array), one- and two-point patterns,
+    and a pattern whose every point is 'irregular' (all of it goes through exa_c*x)."""
+    from exahip import CompressedExaModel, ExaCore, ExaModel
+    from exahip.core import rng
+    N = 700
+    c = ExaCore()
+    x = c.add_var(N + 2, start=np.linspace(0.5, 1.5, N + 2))
+    c.add_obj(lambda i: (x[N + 1 - i] - x[N - i] ** 2) ** 2 * x[N + 2 - i], rng(1, N - 1))
+    c.add_obj(lambda i: x[i] ** 3, rng(5, 5))
+    c.add_obj(lambda i: x[i] * x[i + 1], rng(9, 10))
+    g = c.add_con(lambda i: x[N + 1 - i] ** 2 - 1.0, rng(1, N))
+    c.add_con_aug(g, lambda i: (i, x[N + 2 - i] ** 3), rng(1, N))
+    m = ExaModel(c.to_ir())
+    cm = CompressedExaModel(m)
+    kinds = _check_against_uncompressed(m, cm, 5)
+    assert kinds == ["windowed", "windowed"], (cm.path("jac"), cm.path("hess"))
+
+
+@pytest.mark.parametrize("name,size", [("lv", 300_000), ("rocket", 60_000)])
+def test_windowed_equals_gather_at_scale(libs, name, size, monkeypatch):
+    """Same model compressed twice — windowed sweep and the reference's gather — many windows, multi-chunk passes,
+    shared entries with tens of thousands of terms."""
+    import torch
+    from exahip import CompressedExaModel, ExaModel, models
+    build = (lambda: models.luksan_vlcek_model(size)) if name == "lv" else (lambda: models.rocket_model(size))
+    m1 = ExaModel(build()); c1 = CompressedExaModel(m1)
+    monkeypatch.setenv("EXAHIP_CWINDOW", "0")
+    m0 = ExaModel(build()); c0 = CompressedExaModel(m0)
+    assert c1.path("hess")[0] == "windowed" and c1.path("jac")[0] == "windowed" and c0.path("hess")[0] == "gather"
+    x, y, sigma = point(m1.meta.x0, m1.meta.ncon, seed=8)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    for a, b in ((c1.jac_coord(xd), c0.jac_coord(xd)), (c1.hess_coord(xd, yd, sigma), c0.hess_coord(xd, yd, sigma))):
+        a, b = a.cpu().numpy(), b.cpu().numpy()
+        scale = np.abs(b).max()
+        assert np.all(np.abs(a - b) <= 1e-12 * np.abs(b) + 1e-13 * scale), np.abs(a - b).max()
+    for p, q in zip(c1.hess_structure(), c0.hess_structure()):
+        assert torch.equal(p, q)

@@ -120,8 +120,16 @@ def run(name, core, reps=50):
     ch = torch.empty(cm.meta.nnzh, dtype=torch.float64, device=dev)
     cj = torch.empty(cm.meta.nnzj, dtype=torch.float64, device=dev)
     out["compressed"] = {"setup_ms": setup_ms, "cnnzj": cm.meta.nnzj, "cnnzh": cm.meta.nnzh,
+                         "path_hess": cm.path("hess"), "path_jac": cm.path("jac"),
                          "chess_ms": timed(lambda: cm.hess_coord(x, y, 0.5, out=ch), 20),
                          "cjac_ms": timed(lambda: cm.jac_coord(x, out=cj), 20)}
+    # the reference's scheme on the same model: uncompressed evaluation + sorted gather
+    import os
+    os.environ["EXAHIP_CWINDOW"] = "0"
+    cm0 = CompressedExaModel(m)
+    del os.environ["EXAHIP_CWINDOW"]
+    out["compressed"]["gather_chess_ms"] = timed(lambda: cm0.hess_coord(x, y, 0.5, out=ch), 20)
+    out["compressed"]["gather_cjac_ms"] = timed(lambda: cm0.jac_coord(x, out=cj), 20)
     out["hess_nnz_per_s"] = m.meta.nnzh * out["callbacks"]["hess"]["evals_per_s"]
     print(json.dumps(out), flush=True)
 
