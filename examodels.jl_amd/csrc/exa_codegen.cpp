@@ -1603,7 +1603,7 @@ static void gen_window_fn(std::ostringstream &os, const WindowPat &wp, int j, bo
             std::string sum;
             for (int s = 0; s < S; s++)
                 if (wp.group[s] == g) sum += (sum.empty() ? "" : " + ") + ("v[" + std::to_string(s) + "]");
-            os << "    { const long c = Q[" << wp.qbase + 5 + g << "] + cb_; if (act && (unsigned long)c < (unsigned long)W) win[c] += " << sum << "; }\n";
+            os << "    { const long c = Q[" << wp.qbase + 5 + g << "] + cb_; if (act && (unsigned long)c < (unsigned long)W) win[EXA_WPOS((int)c)] += " << sum << "; }\n";
         }
     }
     os << "}\n";
@@ -1654,7 +1654,7 @@ static void gen_window_kernels(std::ostringstream &os, const Model &m, const std
            << "(P, x, y, th, sigma, I, v);\n            __syncthreads();\n            w" << j << "_" << fa << "(Q, I, act, c0, W, win, v);\n        }\n";
     }
     os << "    }\n    __syncthreads();\n"
-          "    for (int w = threadIdx.x; w < W; w += EXA_BLOCK) if (c0 + w < ncomp) __builtin_nontemporal_store(win[w], &cout[c0 + w]);\n}\n";
+          "    for (int w = threadIdx.x; w < W; w += EXA_BLOCK) if (c0 + w < ncomp) __builtin_nontemporal_store(win[EXA_WPOS(w)], &cout[c0 + w]);\n}\n";
 }
 
 // irregular end points: X = [pattern, I] per point (up to EXA_BLOCK of them); values go through xbuf; then one thread
@@ -1713,8 +1713,11 @@ std::string generate_window_module(const Model &m, const ParamLayout &L, const W
         pre.replace(pre.find(tag2), tag2.size(), std::to_string(L.pull_ppt));
         os << pre;
     }
-    os << "// windowed compressed-COO kernels\n"
-          ;
+    // LDS position of window entry c: the low four bits (the 64-bit bank) are XOR-ed with the next four, so that lanes
+    // striding through the window by 2, 3, 12 ... entries (the stride of a pass) spread over the banks instead of
+    // hitting the same 2-4 of them (rocket, stride 12: 8-way conflicts on every read-modify-write); a bijection within
+    // each aligned block of 16 entries, W is a multiple of 16
+    os << "// windowed compressed-COO kernels\n#define EXA_WPOS(c) " << (env_int("EXAHIP_CW_SWIZZLE", 1) ? "((c) ^ (((c) >> 4) & 15))" : "(c)") << "\n";
     os << R"HIP(// F = [ngroups, then per group: first partial, count, compressed entry]; groups in order (several may share an entry)
 extern "C" __global__ void __launch_bounds__(1024) exa_cfold(const double* __restrict__ part, const long* __restrict__ F, double* __restrict__ cout) {
     __shared__ double red[16];
