@@ -1609,20 +1609,21 @@ static void gen_window_fn(std::ostringstream &os, const WindowPat &wp, int j, bo
     os << "}\n";
 }
 
-static void gen_window_kernels(std::ostringstream &os, const Model &m, const std::vector<WindowPat> &pats, bool hess) {
+static void gen_window_kernels(std::ostringstream &os, const Model &m, const std::vector<WindowPat> &pats, bool hess, bool single) {
     const char *nm = hess ? "chess" : "cjac";
     const char *fa = hess ? "hessa" : "jaca";
     const char *fv = hess ? "hessv" : "jacv";
     const int np = (int)pats.size();
-    // R[window][pattern] = first and one-past-last data point touching the window (host-computed: no 64-bit divisions
-    // at the head of every workgroup's dependency chain)
-    // occupancy hint: the kernel is latency-bound between barriers (LV 1e7: 0.141 ms unhinted at 124 VGPRs, 0.122 ms at 8
-    // waves per SIMD); only for small bodies, which fit 64 / 80 registers without spilling
+    // R[window][pass] = first and one-past-last data point touching the window (host-computed: no 64-bit divisions at
+    // the head of every workgroup's dependency chain).
+    // Occupancy hint: the straight-line kernel is latency-bound between barriers (LV 1e7: 0.141 ms unhinted at 124
+    // VGPRs, 0.10 ms at 8 waves per SIMD); only for small bodies, which fit 64 / 80 registers without spilling — the
+    // chunk loops did spill under it (LV, two chunks per window: 0.118 -> 0.375 ms)
     int waves = env_int("EXAHIP_CW_WAVES", -1);
     if (waves < 0) {
         int slots = 0;
         for (const auto &wp : pats) slots += hess ? m.pats[wp.k].o2step : m.pats[wp.k].o1step;
-        waves = slots <= 16 ? 8 : (slots <= 40 ? 6 : 0);
+        waves = !single ? 0 : (slots <= 16 ? 8 : (slots <= 40 ? 6 : 0));
     }
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) ";
     if (waves > 0) os << "__attribute__((amdgpu_waves_per_eu(" << waves << "))) ";
@@ -1632,26 +1633,33 @@ static void gen_window_kernels(std::ostringstream &os, const Model &m, const std
           "    extern __shared__ double win[];\n    const long c0 = (long)blockIdx.x * W;\n"
           "    const int* r_ = R + (long)blockIdx.x * " << 2 * np << ";\n"
           "    for (int w = threadIdx.x; w < W; w += EXA_BLOCK) win[w] = 0.0;\n";
-    std::string single;
-    for (int j = 0; j < np; j++) {
-        os << "    const long lo" << j << " = r_[" << 2 * j << "], hi" << j << " = r_[" << 2 * j + 1 << "];\n";
-        single += (j ? " && " : "") + ("hi" + std::to_string(j) + " - lo" + std::to_string(j) + " <= EXA_BLOCK");
-    }
-    // common case: every pattern's range fits one chunk — all values first (their loads overlap), then the additions
-    os << "    if (" << single << ") {\n";
-    for (int j = 0; j < np; j++) {
-        const int S = hess ? m.pats[pats[j].k].o2step : m.pats[pats[j].k].o1step;
-        os << "        const bool act" << j << " = lo" << j << " + threadIdx.x < hi" << j << ";\n        const long I" << j << " = act" << j << " ? lo" << j
-           << " + threadIdx.x : 0;\n        double v" << j << "[" << S << "];\n        " << fn_name(pats[j].k, fv) << "(P, x, y, th, sigma, I" << j << ", v" << j << ");\n";
-    }
     for (int j = 0; j < np; j++)
-        os << "        __syncthreads();\n        w" << j << "_" << fa << "(Q, I" << j << ", act" << j << ", c0, W, win, v" << j << ");\n";
-    os << "    } else {\n";
-    for (int j = 0; j < np; j++) {
-        const int S = hess ? m.pats[pats[j].k].o2step : m.pats[pats[j].k].o1step;
-        os << "        for (long base = lo" << j << "; base < hi" << j << "; base += EXA_BLOCK) {\n            const bool act = base + threadIdx.x < hi" << j
-           << ";\n            const long I = act ? base + threadIdx.x : 0;\n            double v[" << S << "];\n            " << fn_name(pats[j].k, fv)
-           << "(P, x, y, th, sigma, I, v);\n            __syncthreads();\n            w" << j << "_" << fa << "(Q, I, act, c0, W, win, v);\n        }\n";
+        os << "    const long lo" << j << " = r_[" << 2 * j << "], hi" << j << " = r_[" << 2 * j + 1 << "];\n";
+    if (single) {
+        // every pass fits one chunk: all values first (the loads of all passes overlap), then the additions
+        os << "    {\n";
+        for (int j = 0; j < np; j++) {
+            const int S = hess ? m.pats[pats[j].k].o2step : m.pats[pats[j].k].o1step;
+            os << "        const bool act" << j << " = lo" << j << " + threadIdx.x < hi" << j << ";\n        const long I" << j << " = act" << j << " ? lo" << j
+               << " + threadIdx.x : 0;\n        double v" << j << "[" << S << "];\n        " << fn_name(pats[j].k, fv) << "(P, x, y, th, sigma, I" << j << ", v" << j << ");\n";
+        }
+        for (int j = 0; j < np; j++)
+            os << "        __syncthreads();\n        w" << j << "_" << fa << "(Q, I" << j << ", act" << j << ", c0, W, win, v" << j << ");\n";
+    } else {
+        // chunk loops, software-pipelined: the next chunk's values are computed (its loads issued) before the current
+        // chunk's additions wait at the barrier
+        os << "    {\n";
+        for (int j = 0; j < np; j++) {
+            const int S = hess ? m.pats[pats[j].k].o2step : m.pats[pats[j].k].o1step;
+            const std::string ev = fn_name(pats[j].k, fv);
+            os << "        if (lo" << j << " < hi" << j << ") {\n            long base = lo" << j << ";\n            bool act = base + threadIdx.x < hi" << j
+               << ";\n            long I = act ? base + threadIdx.x : 0;\n            double v[" << S << "], vn[" << S << "];\n            " << ev
+               << "(P, x, y, th, sigma, I, v);\n            while (base < hi" << j << ") {\n                const long nb = base + EXA_BLOCK;\n"
+               << "                const bool actn = nb + threadIdx.x < hi" << j << ";\n                const long In = actn ? nb + threadIdx.x : 0;\n"
+               << "                if (nb < hi" << j << ") " << ev << "(P, x, y, th, sigma, In, vn);\n                __syncthreads();\n                w" << j << "_" << fa
+               << "(Q, I, act, c0, W, win, v);\n                for (int s = 0; s < " << S << "; s++) v[s] = vn[s];\n                act = actn; I = In; base = nb;\n"
+               << "            }\n        }\n";
+        }
     }
     os << "    }\n    __syncthreads();\n"
           "    for (int w = threadIdx.x; w < W; w += EXA_BLOCK) if (c0 + w < ncomp) __builtin_nontemporal_store(win[EXA_WPOS(w)], &cout[c0 + w]);\n}\n";
@@ -1743,7 +1751,7 @@ extern "C" __global__ void __launch_bounds__(1024) exa_cfold(const double* __res
         for (const auto &q : sh) if (std::find(pk.begin(), pk.end(), q.k) == pk.end()) pk.push_back(q.k);
         for (int k : pk) gen_window_value_fn(os, m, L, k, hess != 0);
         for (size_t j = 0; j < pats.size(); j++) gen_window_fn(os, pats[j], (int)j, hess != 0, hess ? m.pats[pats[j].k].o2step : m.pats[pats[j].k].o1step);
-        gen_window_kernels(os, m, pats, hess != 0);
+        gen_window_kernels(os, m, pats, hess != 0, hess ? spec.hess_single : spec.jac_single);
         // every active pattern may own irregular end points
         std::vector<int> all;
         for (int k : L.active[hess ? CB_HESS : CB_JAC]) all.push_back(k);

@@ -122,6 +122,9 @@ struct WindowShared {          // slots of a pattern that land on ONE compressed
 struct WindowSpec {
     std::vector<WindowPat> hess, jac;
     std::vector<WindowShared> hess_shared, jac_shared;
+    // every pass of every window fits one chunk of kBlock points: straight-line kernel (all passes' loads first, then
+    // the additions), compiled for 8 waves per SIMD; otherwise chunk loops, no occupancy hint (it made them spill)
+    bool hess_single = false, jac_single = false;
 };
 // Source of the second module of a compressed model: exa_chessw / exa_chessx (and exa_cjacw / exa_cjacx).
 std::string generate_window_module(const Model &m, const ParamLayout &L, const WindowSpec &spec);

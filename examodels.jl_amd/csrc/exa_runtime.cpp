@@ -1077,7 +1077,7 @@ int exa_hess_structure64_host(int id, int64_t *r, int64_t *c) { return struct_ho
 //     straddling its window);
 //   * at most 256 irregular end points in total (added sequentially by exa_c*x).
 // Anything else (data-indexed targets, a variable shared by all points) keeps the gather path.
-bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPat> &pats, std::vector<WindowShared> &shared) {
+bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPat> &pats, std::vector<WindowShared> &shared, bool &single) {
     const Model &m = *h.m;
     const ParamLayout &L = h.gen.layout;
     Handle::Window &w = hess ? h.wh : h.wj;
@@ -1182,10 +1182,24 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
     if (pats.empty()) return no("no regular pattern");
     if (pats.size() > 24 || (double)passes_pts > 6.0 * (double)npts)
         return no(std::to_string(pats.size()) + " passes over " + std::to_string((double)passes_pts / std::max<double>(1.0, (double)npts)) + "x the points");
-    // window: the compressed entries that kBlock points of the WIDEST-striding pass produce (less the straddling points);
-    // passes with a smaller stride take several chunks of kBlock points per window
-    int64_t W = (kBlock - spread_max - 1) * bmax;
-    W = std::min<int64_t>(W, 4096) / 16 * 16;
+    // Window size.  If every pass advances with the same stride, W = what kBlock points produce (less the straddling
+    // points): every pass of every window is one chunk and the straight-line kernel applies (LV 1e7 chess: 0.097 ms
+    // against 0.112 with chunk loops at any W).  With mixed strides the small-stride passes need several chunks per
+    // window anyway, and large windows win (rocket 1e6 chess, W = 1008 / 2272 / 3024 / 4080: 0.334 / 0.175 / 0.145 /
+    // 0.122 ms; cjac 0.090 / 0.056 / 0.054 / 0.057): W = 4080 (32 KB of LDS, 5 workgroups per CU) unless that leaves
+    // fewer than ~8 windows per CU.
+    int64_t bmin = bmax;
+    for (const auto &wp : pats) bmin = std::min<int64_t>(bmin, std::llabs(Q[wp.qbase]));
+    int64_t W = std::min<int64_t>((kBlock - spread_max - 1) * bmax, 4096) / 16 * 16;
+    single = W >= 16 && W / bmin + spread_max + 1 <= kBlock;
+    if (!single) {
+        const int64_t fill = cc.cnnz / 2048 / 16 * 16;
+        W = std::max<int64_t>(std::min<int64_t>(4080, fill), std::min<int64_t>(W, 1024));
+    }
+    if (const char *wenv = getenv("EXAHIP_CW_W")) {    // experiments
+        W = std::max<int64_t>(16, atoll(wenv) / 16 * 16);
+        single = W / bmin + spread_max + 1 <= kBlock;
+    }
     if (W < 16) return no("window too small");
     const int64_t nwin = (cc.cnnz + W - 1) / W;
     // work amplification: points evaluated (whole chunks of kBlock) over points present
@@ -1197,7 +1211,7 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
         const double wins = std::min<double>((double)nwin, (double)n * (double)ab / (double)W + 1.0);
         work += wins * std::ceil(per / kBlock) * kBlock;
     }
-    if (work > 1.5 * (double)passes_pts + 4096.0 * pats.size())
+    if (work > 2.0 * (double)passes_pts + 4096.0 * pats.size())
         return no("windows would evaluate " + std::to_string(work / std::max<double>(1.0, (double)passes_pts)) + "x the points");
     // irregular points: targets straight from the slot map, grouped by distinct target
     w.nx = (int)exc.size();
@@ -1269,6 +1283,15 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
     }
     w.W = (int)W;
     w.nwin = nwin;
+    if (getenv("EXAHIP_CW_VERBOSE")) {
+        fprintf(stderr, "[exahip] windowed %s (%s): W=%ld windows=%ld passes=%zu shared-entry workgroups=%ld irregular points=%d\n", hess ? "hess" : "jac", single ? "one chunk per pass" : "chunk loops", (long)W,
+                (long)nwin, pats.size(), (long)w.ns_blocks, w.nx);
+        for (size_t q = 0; q < pats.size(); q++) {
+            const int64_t *t = &Q[pats[q].qbase];
+            fprintf(stderr, "[exahip]   pass %zu: pattern %d  b=%ld  points [%ld,%ld)  targets %ld..%ld  groups=%zu\n", q, pats[q].k, (long)t[0], (long)t[1], (long)t[2],
+                    (long)t[3], (long)t[4], pats[q].phase.size());
+        }
+    }
     return true;
 }
 
@@ -1287,11 +1310,11 @@ void window_setup(Handle &h) {
     try {
         build_slot_map(h.cj, (int32_t *)cmap.p, h.stream);
         HIPCHK(hipStreamSynchronize(h.stream));
-        okj = window_plan(h, false, (const int32_t *)cmap.p, spec.jac, spec.jac_shared);
+        okj = window_plan(h, false, (const int32_t *)cmap.p, spec.jac, spec.jac_shared, spec.jac_single);
         if (!okj) { spec.jac.clear(); spec.jac_shared.clear(); }
         build_slot_map(h.ch, (int32_t *)cmap.p, h.stream);
         HIPCHK(hipStreamSynchronize(h.stream));
-        okh = window_plan(h, true, (const int32_t *)cmap.p, spec.hess, spec.hess_shared);
+        okh = window_plan(h, true, (const int32_t *)cmap.p, spec.hess, spec.hess_shared, spec.hess_single);
         if (!okh) { spec.hess.clear(); spec.hess_shared.clear(); }
     } catch (...) { cmap.release(); throw; }
     cmap.release();
