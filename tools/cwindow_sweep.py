@@ -1,3 +1,5 @@
+"""Window-size sweep of the windowed compressed sweep (exa_chess / exa_cjac): `python tools/cwindow_sweep.py lv|rocket W...`
+(W = 0: the size exa_compress picks; EXAHIP_CW_VERBOSE=1 prints the pass table).  Source of the W table in DESIGN.md §5."""
 import sys, time, os
 sys.path.insert(0, '/root/repo/tests'); sys.path.insert(0, '/root/repo/examodels.jl_amd')
 import numpy as np, torch
