@@ -752,7 +752,13 @@ extern "C" __global__ void __launch_bounds__(EXA_BLOCK) exa_aug_gather(const lon
     if (e - b > EXA_AUG_LONG) return;          // rows collecting very many terms: exa_aug_long + exa_aug_fold
     const long r = rows[t];
     double s = c[r];
-    for (long j = b; j < e; j++) s += buf[perm[j]];
+    long j = b;
+    for (; j + 4 <= e; j += 4) {               // insertion order kept; four gathers in flight instead of one
+        const long q0 = perm[j], q1 = perm[j + 1], q2 = perm[j + 2], q3 = perm[j + 3];
+        const double a0 = buf[q0], a1 = buf[q1], a2 = buf[q2], a3 = buf[q3];
+        s += a0; s += a1; s += a2; s += a3;
+    }
+    for (; j < e; j++) s += buf[perm[j]];
     c[r] = s;
 }
 // A row that collects thousands of terms (a coupling constraint summing over every data point) would be one thread's
