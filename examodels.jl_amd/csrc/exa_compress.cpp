@@ -111,6 +111,14 @@ __global__ void __launch_bounds__(256) k_affine_check(const int32_t *__restrict_
     else atomicMin(&res[2], (unsigned long long)I);                    // e_hi candidate: first bad point of the tail
 }
 
+// colptr (1-based, like SparseMatrixCSC) of the (col,row)-sorted compressed entries
+__global__ void __launch_bounds__(256) k_colptr(const int64_t *__restrict__ cols, int64_t n, int64_t ncol, int64_t *__restrict__ colptr) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j > n) return;
+    const int64_t prev = j == 0 ? -1 : cols[j - 1] - 1;
+    const int64_t cur = j == n ? ncol : cols[j] - 1;
+    for (int64_t q = prev + 1; q <= cur; q++) colptr[q] = j + 1;
+}
 template <class T>
 __global__ void __launch_bounds__(256) k_narrow(const int64_t *__restrict__ src, T *__restrict__ dst, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -467,6 +475,11 @@ void affine_exceptions(const int32_t *cmap, int64_t o, int S, int64_t n, const i
     HIPCHK_C(hipStreamSynchronize(stream));
     (void)hipFree(da); (void)hipFree(dres);
     *count = (int64_t)res[0]; *e_lo = (int64_t)res[1]; *e_hi = (int64_t)res[2];
+}
+
+void compressed_csc(const CompressedCOO &c, int64_t ncol, int64_t *colptr, int64_t *rowval, hipStream_t stream) {
+    hipLaunchKernelGGL(k_colptr, dim3(grid_for(c.cnnz + 1)), dim3(256), 0, stream, (const int64_t *)c.cols, c.cnnz, ncol, colptr);
+    if (c.cnnz) HIPCHK_C(hipMemcpyAsync(rowval, c.rows, 8 * (size_t)c.cnnz, hipMemcpyDeviceToDevice, stream));
 }
 
 }  // namespace exa

@@ -31,6 +31,8 @@ void build_slot_map(const CompressedCOO &c, int32_t *cmap, hipStream_t stream);
 // below mid (0 if none), e_hi = the first such point at or above mid (n if none).  Synchronises the stream.
 void affine_exceptions(const int32_t *cmap, int64_t o, int S, int64_t n, const int64_t *a_host, const int64_t *b_host, int64_t mid, int64_t *count,
                        int64_t *e_lo, int64_t *e_hi, hipStream_t stream);
+// CSC view of the compressed entries (they are sorted by column, then row): colptr[ncol+1] and rowval[cnnz], 1-based
+void compressed_csc(const CompressedCOO &c, int64_t ncol, int64_t *colptr, int64_t *rowval, hipStream_t stream);
 void compressed_structure(const CompressedCOO &c, void *rows, void *cols, bool wide, hipStream_t stream);
 
 // COO entries grouped by one of their coordinates: entries perm[ptr[k] .. ptr[k+1]) have key k (0-based), in ascending

@@ -1398,6 +1398,15 @@ int exa_cjac_structure(int id, int32_t *r, int32_t *c) { return cstruct(id, fals
 int exa_chess_structure(int id, int32_t *r, int32_t *c) { return cstruct(id, true, false, r, c); }
 int exa_cjac_structure64(int id, int64_t *r, int64_t *c) { return cstruct(id, false, true, r, c); }
 int exa_chess_structure64(int id, int64_t *r, int64_t *c) { return cstruct(id, true, true, r, c); }
+static int ccsc(int id, bool hess, int64_t *colptr, int64_t *rowval) {
+    if (!colptr || !rowval) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if (!h.compressed) throw BadInput("exa_compress has not been called");
+        compressed_csc(hess ? h.ch : h.cj, h.m->nvar, colptr, rowval, h.stream);
+    });
+}
+int exa_cjac_csc(int id, int64_t *colptr, int64_t *rowval) { return ccsc(id, false, colptr, rowval); }
+int exa_chess_csc(int id, int64_t *colptr, int64_t *rowval) { return ccsc(id, true, colptr, rowval); }
 int exa_compress_info(int id, int hess, char *buf, int cap, int *len_out) {
     Handle *h = get(id);
     if (!h || !h->compressed) return -1;

@@ -23,7 +23,7 @@ SYMBOLS = [
     "exa_obj_host", "exa_grad_host", "exa_cons_host", "exa_jac_host", "exa_hess_host", "exa_jac_structure_host",
     "exa_hess_structure_host", "exa_jac_structure64_host", "exa_hess_structure64_host", "exa_time_callback", "exa_sync", "exa_block_order",
     "exa_eval_fused", "exa_set_product_mode", "exa_get_product_mode", "exa_compress", "exa_compress_info", "exa_cnnzj64", "exa_cnnzh64", "exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64",
-    "exa_chess_structure64", "exa_cjac", "exa_chess",
+    "exa_chess_structure64", "exa_cjac_csc", "exa_chess_csc", "exa_cjac", "exa_chess",
 ]
 # ... and include/exahip_recipe.h
 RECIPE_SYMBOLS = [
@@ -107,7 +107,7 @@ def lib():
     for f in ("exa_cnnzj64", "exa_cnnzh64"):
         getattr(L, f).argtypes = [i32]
         getattr(L, f).restype = i64
-    for f in ("exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64", "exa_chess_structure64", "exa_cjac"):
+    for f in ("exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64", "exa_chess_structure64", "exa_cjac", "exa_cjac_csc", "exa_chess_csc"):
         getattr(L, f).argtypes = [i32, vp, vp]
     L.exa_chess.argtypes = [i32, vp, vp, dbl, vp]
     L.exa_compress_info.argtypes = [i32, i32, ctypes.c_char_p, i32, vp]

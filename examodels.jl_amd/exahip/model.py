@@ -516,6 +516,16 @@ class CompressedExaModel:
         capi.check(getattr(self._L, f"exa_c{which}_structure64")(self.inner.id, rows.data_ptr(), cols.data_ptr()), which)
         return rows, cols
 
+    def csc(self, which, device="cuda:0"):
+        """(colptr [nvar+1], rowval [nnz]) of the compressed Jacobian ("jac") or lower-triangular Hessian ("hess"),
+        1-based: with the values of jac_coord / hess_coord as nzval this is the SparseMatrixCSC of the matrix."""
+        import torch
+        nnz = self.meta.nnzj if which == "jac" else self.meta.nnzh
+        colptr = torch.empty(self.meta.nvar + 1, dtype=torch.int64, device=device)
+        rowval = torch.empty(nnz, dtype=torch.int64, device=device)
+        capi.check(getattr(self._L, f"exa_c{which}_csc")(self.inner.id, colptr.data_ptr(), rowval.data_ptr()), which)
+        return colptr, rowval
+
     def jac_structure(self, device="cuda:0"):
         return self._structure("jac", self.meta.nnzj, device)
 

@@ -152,6 +152,11 @@ int exa_cjac_structure   (int id, int32_t *rows, int32_t *cols);              /*
 int exa_chess_structure  (int id, int32_t *rows, int32_t *cols);
 int exa_cjac_structure64 (int id, int64_t *rows, int64_t *cols);
 int exa_chess_structure64(int id, int64_t *rows, int64_t *cols);
+/* The compressed entries are sorted by column, then row: they ARE the nzval of a CSC matrix.  colptr [nvar+1] and
+ * rowval [cnnz], 1-based like Julia's SparseMatrixCSC(ncon | nvar, nvar, colptr, rowval, vals) — the values written by
+ * exa_cjac / exa_chess go straight into a sparse direct solver's KKT blocks, no reordering.  DEVICE pointers. */
+int exa_cjac_csc (int id, int64_t *colptr, int64_t *rowval);
+int exa_chess_csc(int id, int64_t *colptr, int64_t *rowval);
 int exa_cjac (int id, const double *x, double *vals);                          /* vals [cnnzj], DEVICE pointers */
 int exa_chess(int id, const double *x, const double *y, double obj_weight, double *vals);
 /* Which implementation exa_cjac (hess = 0) / exa_chess (hess = 1) run: 1 = windowed (the sweep adds straight into

@@ -232,3 +232,30 @@ def test_windowed_equals_gather_at_scale(libs, name, size, monkeypatch):
         assert np.all(np.abs(a - b) <= 1e-12 * np.abs(b) + 1e-13 * scale), np.abs(a - b).max()
     for p, q in zip(c1.hess_structure(), c0.hess_structure()):
         assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("name", ["lv20", "acopf30", "rocket50", "mixed"])
+def test_compressed_csc_view(libs, name):
+    """colptr / rowval of the compressed entries + the values of jac_coord / hess_coord = the CSC matrix (scipy
+    csc_matrix built from them equals the duplicate-summed COO); empty leading / trailing columns get equal pointers."""
+    import scipy.sparse as sp
+    import torch
+    from exahip import CompressedExaModel, ExaModel
+    m = ExaModel(ZOO[name]())
+    cm = CompressedExaModel(m)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=6)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    for which, nrow in (("jac", m.meta.ncon), ("hess", m.meta.nvar)):
+        colptr, rowval = (t.cpu().numpy() for t in cm.csc(which))
+        vals = (cm.jac_coord(xd) if which == "jac" else cm.hess_coord(xd, yd, sigma)).cpu().numpy()
+        assert colptr[0] == 1 and colptr[-1] == len(vals) + 1 and np.all(np.diff(colptr) >= 0)
+        A = sp.csc_matrix((vals, rowval - 1, colptr - 1), shape=(max(nrow, 1), m.meta.nvar))
+        if which == "jac":
+            r, c = m.jac_structure(); v = m.jac_coord(x)
+        else:
+            r, c = m.hess_structure(); v = m.hess_coord(x, y, sigma)
+        B = sp.coo_matrix((v, (r - 1, c - 1)), shape=A.shape).tocsc()
+        B.sum_duplicates()
+        assert abs(A - B).max() <= 1e-12 * max(1.0, abs(B).max())
+        assert A.has_sorted_indices or A.nnz == 0
