@@ -1108,7 +1108,7 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
         }
         int64_t cnt = 0, e_lo = 0, e_hi = n;
         affine_exceptions(cmap, o, S, n, a.data(), bs.data(), mid, &cnt, &e_lo, &e_hi, h.stream);
-        if (e_lo + (n - e_hi) > 256) return no("pattern " + std::to_string(k) + ": " + std::to_string(cnt) + " points off the regular structure");
+        if (e_lo + (n - e_hi) > kBlock) return no("pattern " + std::to_string(k) + ": " + std::to_string(cnt) + " points off the regular structure");
         for (int64_t I = 0; I < e_lo; I++) exc.push_back({k, I});
         for (int64_t I = e_hi; I < n; I++) exc.push_back({k, I});
         if (e_hi <= e_lo) continue;     // every point of the pattern is irregular (tiny pattern): exa_c*x does it all
@@ -1178,7 +1178,7 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
             }
         }
     }
-    if (exc.size() > 256) return no(std::to_string(exc.size()) + " irregular end points");
+    if ((int64_t)exc.size() > kBlock) return no(std::to_string(exc.size()) + " irregular end points");
     if (pats.empty()) return no("no regular pattern");
     if (pats.size() > 24 || (double)passes_pts > 6.0 * (double)npts)
         return no(std::to_string(pats.size()) + " passes over " + std::to_string((double)passes_pts / std::max<double>(1.0, (double)npts)) + "x the points");
