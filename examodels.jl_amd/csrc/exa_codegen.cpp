@@ -1615,7 +1615,9 @@ static void gen_window_fn(std::ostringstream &os, const WindowPat &wp, int j, bo
     os << "}\n";
 }
 
-static void gen_window_kernels(std::ostringstream &os, const Model &m, const std::vector<WindowPat> &pats, bool hess, bool single) {
+static void emit_window_shared_body(std::ostringstream &os, const Model &m, const std::vector<WindowShared> &sh, bool hess);
+static void gen_window_kernels(std::ostringstream &os, const Model &m, const std::vector<WindowPat> &pats, const std::vector<WindowShared> &sh,
+                               bool hess, bool single) {
     const char *nm = hess ? "chess" : "cjac";
     const char *fa = hess ? "hessa" : "jaca";
     const char *fv = hess ? "hessv" : "jacv";
@@ -1636,7 +1638,8 @@ static void gen_window_kernels(std::ostringstream &os, const Model &m, const std
     os << "exa_" << nm << "w(const long* __restrict__ P, const long* __restrict__ Q, "
           "const int* __restrict__ R, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
           "double* __restrict__ cout, double sigma, long ncomp, int W) {\n"
-          "    extern __shared__ double win[];\n    const long c0 = (long)blockIdx.x * W;\n"
+          "    extern __shared__ double win[];\n";
+    os << "    const long c0 = (long)blockIdx.x * W;\n"
           "    const int* r_ = R + (long)blockIdx.x * " << 2 * np << ";\n"
           "    for (int w = threadIdx.x; w < W; w += EXA_BLOCK) win[w] = 0.0;\n";
     for (int j = 0; j < np; j++)
@@ -1681,39 +1684,51 @@ static void gen_window_x(std::ostringstream &os, const Model &m, const std::vect
     for (int k : pk) smax = std::max(smax, hess ? m.pats[k].o2step : m.pats[k].o1step);
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_" << nm << "x(const long* __restrict__ P, const long* __restrict__ X, "
           "const int* __restrict__ T, const int* __restrict__ E, const double* __restrict__ x, const double* __restrict__ y, "
-          "const double* __restrict__ th, double* __restrict__ xbuf, double* __restrict__ cout, double sigma, int nx) {\n"
+          "const double* __restrict__ th, double* __restrict__ xbuf, double* __restrict__ cout, double sigma, int nx, "
+          "const double* __restrict__ part, const long* __restrict__ F) {\n"
           "    const int t = threadIdx.x;\n    if (t < nx) {\n        const long pk_ = X[2 * t], I = X[2 * t + 1];\n        double v[" << smax << "];\n"
           "        for (int s = 0; s < " << smax << "; s++) v[s] = 0.0;\n";
     for (size_t j = 0; j < pk.size(); j++)
         os << "        " << (j ? "else " : "") << "if (pk_ == " << pk[j] << ") " << fn_name(pk[j], fv) << "(P, x, y, th, sigma, I, v);\n";
     os << "        for (int s = 0; s < " << smax << "; s++) xbuf[t * " << smax << " + s] = v[s];\n    }\n    __syncthreads();\n"
-          "    for (int q = t; q < T[0]; q += EXA_BLOCK) {\n        const int c = T[1 + 3 * q];\n        double s = cout[c];\n"
-          "        for (int e = T[2 + 3 * q]; e < T[3 + 3 * q]; e++) s += xbuf[E[e]];\n        cout[c] = s;\n    }\n}\n";
+          "    for (int q = t; q < (nx > 0 ? T[0] : 0); q += EXA_BLOCK) {\n        const int c = T[1 + 3 * q];\n        double s = cout[c];\n"
+          "        for (int e = T[2 + 3 * q]; e < T[3 + 3 * q]; e++) s += xbuf[E[e]];\n        cout[c] = s;\n    }\n"
+          // fold of the shared-entry partial sums: F = [ngroups, then per group: first partial, count, compressed entry];
+          // groups in order (several may share an entry), fixed summation order
+          "    __shared__ double red[EXA_BLOCK / 64];\n"
+          "    for (long g = 0; g < F[0]; g++) {\n        __syncthreads();\n        const long off = F[1 + 3 * g], n = F[2 + 3 * g];\n        double a = 0.0;\n"
+          "        for (long i = t; i < n; i += EXA_BLOCK) a += part[off + i];\n        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);\n"
+          "        if ((t & 63) == 0) red[t >> 6] = a;\n        __syncthreads();\n"
+          "        if (t == 0) { double s = 0.0; for (int w = 0; w < EXA_BLOCK / 64; w++) s += red[w]; cout[F[3 + 3 * g]] += s; }\n    }\n}\n";
 }
-
-// entries every data point adds to: per-workgroup sums of the regular points (S = [per pattern j: e_lo, e_hi, first
-// workgroup, first partial] + sentinel), folded by exa_cfold
-static void gen_window_shared(std::ostringstream &os, const Model &m, const std::vector<WindowShared> &sh, bool hess) {
-    const char *nm = hess ? "chess" : "cjac";
+static void emit_window_shared_body(std::ostringstream &os, const Model &m, const std::vector<WindowShared> &sh, bool hess) {
     const char *fv = hess ? "hessv" : "jacv";
-    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_" << nm << "s(const long* __restrict__ P, const long* __restrict__ S, "
-          "const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ part, double sigma) {\n"
-          "    const long b = blockIdx.x;\n";
     for (size_t j = 0; j < sh.size(); j++) {
         const int St = hess ? m.pats[sh[j].k].o2step : m.pats[sh[j].k].o1step;
-        os << "    " << (j ? "else " : "") << "if (b < S[" << 4 * (j + 1) + 2 << "]) {\n        const long tile = b - S[" << 4 * j + 2 << "], nt = S["
-           << 4 * (j + 1) + 2 << "] - S[" << 4 * j + 2 << "];\n        const long I0 = S[" << 4 * j << "] + tile * EXA_BLOCK + threadIdx.x;\n"
-           << "        const bool act = I0 < S[" << 4 * j + 1 << "];\n        const long I = act ? I0 : 0;\n        double v[" << St << "];\n        "
+        os << "        " << (j ? "else " : "") << "if (b < S[" << 4 * (j + 1) + 2 << "]) {\n            const long tile = b - S[" << 4 * j + 2 << "], nt = S["
+           << 4 * (j + 1) + 2 << "] - S[" << 4 * j + 2 << "];\n            const long I0 = S[" << 4 * j << "] + tile * EXA_BLOCK + threadIdx.x;\n"
+           << "            const bool act = I0 < S[" << 4 * j + 1 << "];\n            const long I = act ? I0 : 0;\n            double v[" << St << "];\n            "
            << fn_name(sh[j].k, fv) << "(P, x, y, th, sigma, I, v);\n";
         for (size_t g = 0; g < sh[j].groups.size(); g++) {
             std::string sum;
             for (int s : sh[j].groups[g]) sum += (sum.empty() ? "" : " + ") + ("v[" + std::to_string(s) + "]");
-            os << "        { const double s = exa_block_sum(act ? " << sum << " : 0.0); if (threadIdx.x == 0) part[S[" << 4 * j + 3 << "] + " << g
+            os << "            { const double s = exa_block_sum(act ? " << sum << " : 0.0); if (threadIdx.x == 0) part[S[" << 4 * j + 3 << "] + " << g
                << " * nt + tile] = s; __syncthreads(); }\n";
         }
-        os << "    }\n";
+        os << "        }\n";
     }
-    os << "}\n";
+}
+
+// entries EVERY point adds to (b = 0: the rocket's step length): per-workgroup sums over the regular points (S = [per
+// pattern j: e_lo, e_hi, first workgroup, first partial] + sentinel), folded by the tail kernel.  A launch of its own:
+// as extra workgroups of the window kernel they each reserved a window's LDS and cost more than the launch (rocket chess
+// 0.125 -> 0.137 ms)
+static void gen_window_shared(std::ostringstream &os, const Model &m, const std::vector<WindowShared> &sh, bool hess) {
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_" << (hess ? "chess" : "cjac") << "s(const long* __restrict__ P, const long* __restrict__ S, "
+          "const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ part, double sigma) {\n"
+          "    {\n        const long b = blockIdx.x;\n";
+    emit_window_shared_body(os, m, sh, hess);
+    os << "    }\n}\n";
 }
 
 std::string generate_window_module(const Model &m, const ParamLayout &L, const WindowSpec &spec) {
@@ -1732,21 +1747,6 @@ std::string generate_window_module(const Model &m, const ParamLayout &L, const W
     // hitting the same 2-4 of them (rocket, stride 12: 8-way conflicts on every read-modify-write); a bijection within
     // each aligned block of 16 entries, W is a multiple of 16
     os << "// windowed compressed-COO kernels\n#define EXA_WPOS(c) " << (env_int("EXAHIP_CW_SWIZZLE", 1) ? "((c) ^ (((c) >> 4) & 15))" : "(c)") << "\n";
-    os << R"HIP(// F = [ngroups, then per group: first partial, count, compressed entry]; groups in order (several may share an entry)
-extern "C" __global__ void __launch_bounds__(1024) exa_cfold(const double* __restrict__ part, const long* __restrict__ F, double* __restrict__ cout) {
-    __shared__ double red[16];
-    for (long g = 0; g < F[0]; g++) {
-        const long off = F[1 + 3 * g], n = F[2 + 3 * g];
-        double a = 0.0;
-        for (long i = threadIdx.x; i < n; i += 1024) a += part[off + i];
-        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
-        __syncthreads();
-        if (threadIdx.x == 0) { double s = 0.0; for (int w = 0; w < 16; w++) s += red[w]; cout[F[3 + 3 * g]] += s; }
-        __syncthreads();
-    }
-}
-)HIP";
     for (int hess = 1; hess >= 0; hess--) {
         const auto &pats = hess ? spec.hess : spec.jac;
         const auto &sh = hess ? spec.hess_shared : spec.jac_shared;
@@ -1757,7 +1757,7 @@ extern "C" __global__ void __launch_bounds__(1024) exa_cfold(const double* __res
         for (const auto &q : sh) if (std::find(pk.begin(), pk.end(), q.k) == pk.end()) pk.push_back(q.k);
         for (int k : pk) gen_window_value_fn(os, m, L, k, hess != 0);
         for (size_t j = 0; j < pats.size(); j++) gen_window_fn(os, pats[j], (int)j, hess != 0, hess ? m.pats[pats[j].k].o2step : m.pats[pats[j].k].o1step);
-        gen_window_kernels(os, m, pats, hess != 0, hess ? spec.hess_single : spec.jac_single);
+        gen_window_kernels(os, m, pats, sh, hess != 0, hess ? spec.hess_single : spec.jac_single);
         // every active pattern may own irregular end points
         std::vector<int> all;
         for (int k : L.active[hess ? CB_HESS : CB_JAC]) all.push_back(k);

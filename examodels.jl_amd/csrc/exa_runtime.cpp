@@ -86,7 +86,6 @@ struct Handle {
         std::string why;                   // why the fast path was not taken (exa_window_info)
     } wj, wh;
     hipModule_t wmodule = nullptr;
-    hipFunction_t f_cfold = nullptr;
     std::vector<BlockInfo> blocks;          // named blocks (recipes; empty for plain pattern tables)
     std::vector<exa_pattern_t> view_pats;   // exa_describe: pattern-table view of the host copy
     std::vector<std::vector<exa_column_t>> view_cols;
@@ -1241,6 +1240,11 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
     }
     // shared entries: workgroup map, partial-sum layout, fold list
     w.ns_blocks = 0;
+    {
+        const int64_t zero = 0;        // F[0] = 0 groups unless filled below
+        w.F.ensure(8);
+        HIPCHK(hipMemcpy(w.F.p, &zero, 8, hipMemcpyHostToDevice));
+    }
     if (!shs.empty()) {
         std::vector<int64_t> St, F{0};
         int64_t blocks = 0, parts = 0;
@@ -1331,7 +1335,6 @@ void window_setup(Handle &h) {
     if (image.empty()) image = read_file(build_code_object(src));
     HIPCHK(hipModuleLoadData(&h.wmodule, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
-    h.f_cfold = fn("exa_cfold");
     if (okj) { h.wj.fw = fn("exa_cjacw"); h.wj.fx = fn("exa_cjacx"); if (h.wj.ns_blocks) h.wj.fs = fn("exa_cjacs"); h.wj.ok = true; }
     if (okh) { h.wh.fw = fn("exa_chessw"); h.wh.fx = fn("exa_chessx"); if (h.wh.ns_blocks) h.wh.fs = fn("exa_chesss"); h.wh.ok = true; }
 }
@@ -1342,24 +1345,20 @@ void do_window(Handle &h, bool hess, const double *x, const double *y, double si
     int64_t ncomp = hess ? h.ch.cnnz : h.cj.cnnz;
     int W = w.W;
     void *part = w.part.p;
-    if (w.ns_blocks) {
-        // independent of the windows: runs first so that its (small) grid overlaps the head of the window kernel
+    const int64_t ns = w.ns_blocks;
+    if (ns) {
         const void *S = w.S.p;
         void *a1[] = {&P, &S, &x, &y, &th, &part, &sigma};
-        HIPCHK(hipModuleLaunchKernel(w.fs, (unsigned)w.ns_blocks, 1, 1, kBlock, 1, 1, 0, h.stream, a1, nullptr));
+        HIPCHK(hipModuleLaunchKernel(w.fs, (unsigned)ns, 1, 1, kBlock, 1, 1, 0, h.stream, a1, nullptr));
     }
     void *a[] = {&P, &Q, &R, &x, &y, &th, &vals, &sigma, &ncomp, &W};
     HIPCHK(hipModuleLaunchKernel(w.fw, (unsigned)w.nwin, 1, 1, kBlock, 1, 1, (unsigned)(8 * W), h.stream, a, nullptr));
-    if (w.ns_blocks) {
-        const void *F = w.F.p;
-        void *a3[] = {&part, &F, &vals};
-        HIPCHK(hipModuleLaunchKernel(h.f_cfold, 1, 1, 1, 1024, 1, 1, 0, h.stream, a3, nullptr));
-    }
-    if (w.nx) {
-        const void *X = w.X.p, *T = w.T.p, *E = w.E.p;
+    if (w.nx || ns) {
+        // tail: the irregular end points, then the fold of the shared-entry partial sums (one workgroup)
+        const void *X = w.X.p, *T = w.T.p, *E = w.E.p, *F = w.F.p;
         void *xbuf = w.xbuf.p;
         int nx = w.nx;
-        void *a2[] = {&P, &X, &T, &E, &x, &y, &th, &xbuf, &vals, &sigma, &nx};
+        void *a2[] = {&P, &X, &T, &E, &x, &y, &th, &xbuf, &vals, &sigma, &nx, &part, &F};
         HIPCHK(hipModuleLaunchKernel(w.fx, 1, 1, 1, kBlock, 1, 1, 0, h.stream, a2, nullptr));
     }
 }
