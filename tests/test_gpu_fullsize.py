@@ -155,3 +155,55 @@ def test_config5_size_lv_1e8_on_one_gpu(libs):
     m.hess_structure(rows, cols)
     torch.cuda.synchronize()
     assert bool(torch.all(rows >= cols)) and int(rows.max()) == N and int(cols.min()) == 1
+
+
+@pytest.mark.parametrize("which", ["lv", "rocket", "acopf"])
+def test_compressed_full_size_equals_scattered_uncompressed(libs, which):
+    """Compressed COO (CompressedNLPModel) at full size, all on the device: every compressed entry equals the sum of the
+    uncompressed slots with its coordinates (torch index_add_ through a searchsorted on the (col,row) key), the entries
+    are strictly (col,row)-ascending, and the CSC colptr brackets them.  LV and the rocket take the windowed sweep, the
+    ACOPF the gather."""
+    import torch
+    from exahip import CompressedExaModel, ExaModel, models
+    core = {"lv": lambda: models.luksan_vlcek_model(10_000_000), "rocket": lambda: models.rocket_model(1_000_000),
+            "acopf": lambda: models.ac_power_model(models.synthetic_power_data(78_484, 126_015, 6_800, seed=0))}[which]()
+    m = ExaModel(core)
+    cm = CompressedExaModel(m)
+    assert cm.path("hess")[0] == ("gather" if which == "acopf" else "windowed"), cm.path("hess")
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=5)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    for kind in ("jac", "hess"):
+        nrow = max(m.meta.ncon if kind == "jac" else m.meta.nvar, 1)
+        nnz = m.meta.nnzj if kind == "jac" else m.meta.nnzh
+        r = torch.empty(nnz, dtype=torch.int64, device=dev)
+        c = torch.empty(nnz, dtype=torch.int64, device=dev)
+        (m.jac_structure if kind == "jac" else m.hess_structure)(r, c)
+        v = m.jac_coord(xd) if kind == "jac" else m.hess_coord(xd, yd, sigma)
+        cr, cc = cm.jac_structure() if kind == "jac" else cm.hess_structure()
+        cv = cm.jac_coord(xd) if kind == "jac" else cm.hess_coord(xd, yd, sigma)
+        ckey = (cc - 1) * nrow + (cr - 1)
+        assert bool(torch.all(ckey[1:] > ckey[:-1]))                       # sorted, no duplicates
+        pos = torch.searchsorted(ckey, (c - 1) * nrow + (r - 1))
+        assert bool(torch.all(ckey[pos] == (c - 1) * nrow + (r - 1)))      # every uncompressed slot has its entry
+        # entries collecting a million slots (the rocket's step length) are summed separately: FP64 index_add_ on one
+        # address is a CAS storm (175 s for this test)
+        cnt = torch.bincount(pos, minlength=cv.numel()).to(torch.float64)
+        heavy = torch.nonzero(cnt > 10_000).flatten()
+        light = ~(cnt > 10_000)[pos]
+        ref = torch.zeros_like(cv).index_add_(0, pos[light], v[light])
+        mag = torch.zeros_like(cv).index_add_(0, pos[light], v[light].abs())
+        assert heavy.numel() <= 8
+        for e in heavy.tolist():
+            sel = pos == e
+            ref[e] = v[sel].sum()
+            mag[e] = v[sel].abs().sum()
+        bound = (4e-16 * cnt.sqrt() + 1e-13) * mag + 1e-300
+        assert bool(torch.all((cv - ref).abs() <= bound)), float(((cv - ref).abs() / bound).max())
+        colptr, rowval = cm.csc(kind)
+        assert int(colptr[0]) == 1 and int(colptr[-1]) == cv.numel() + 1 and bool(torch.all(colptr[1:] >= colptr[:-1]))
+        assert torch.equal(rowval, cr)
+        # column of entry k is the j with colptr[j] <= k+1 < colptr[j+1]
+        k = torch.arange(0, cv.numel(), max(1, cv.numel() // 100_000), device=dev)
+        assert bool(torch.all(torch.searchsorted(colptr, k + 1, right=True) == cc[k]))
+        del r, c, v, pos, ref, mag, cnt, light
