@@ -1070,12 +1070,16 @@ int exa_hess_structure64_host(int id, int64_t *r, int64_t *c) { return struct_ho
 
 // ---- windowed compressed evaluation (kernels: exa_codegen.cpp generate_window_module) -----------------
 // Decides, per matrix, whether the sorted structure is regular enough for the fast path, and prepares its tables:
-//   * every slot s of every active pattern sits at compressed entry a_s + b*I for all points but a few at the ends
-//     (fit at the middle point, checked for every point on the device);
-//   * one stride b per pattern, and the slots of a point at most 64 points apart (a workgroup re-evaluates the points
-//     straddling its window);
-//   * at most 256 irregular end points in total (added sequentially by exa_c*x).
-// Anything else (data-indexed targets, a variable shared by all points) keeps the gather path.
+//   * every slot s of every active pattern sits at compressed entry a_s + b_s*I for all points but a few at the ends
+//     (fit at the middle point, checked for every point on the device); at most kBlock such end points in total — they are
+//     evaluated by the tail kernel exa_c*x;
+//   * the slots of a pattern are split into PASSES: one per stride b_s and per cluster of targets within 48 points (the
+//     x[i] and u[i] blocks of a discretised ODE lie millions of entries apart); slots with b_s = 0 (an entry every point
+//     adds to) go to the shared-entry kernel exa_c*s instead; at most 24 passes, at most 6 evaluations per point;
+//   * window size and kernel shape (one chunk per pass / chunk loops) from the strides, see below.
+// Anything else (data-indexed targets, stepped ranges of different lengths meeting in the same columns) keeps the gather.
+// Knobs (experiments): EXAHIP_CWINDOW=0 gather only; EXAHIP_CW_W window size; EXAHIP_CW_WAVES occupancy hint;
+// EXAHIP_CW_SWIZZLE=0 plain LDS positions; EXAHIP_CW_VERBOSE=1 prints the pass table; EXAHIP_DUMP_WINDOW=file the source.
 bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPat> &pats, std::vector<WindowShared> &shared, bool &single) {
     const Model &m = *h.m;
     const ParamLayout &L = h.gen.layout;
