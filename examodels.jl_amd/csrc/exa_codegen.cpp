@@ -1674,6 +1674,43 @@ static void gen_window_kernels(std::ostringstream &os, const Model &m, const std
           "    for (int w = threadIdx.x; w < W; w += EXA_BLOCK) if (c0 + w < ncomp) __builtin_nontemporal_store(win[EXA_WPOS(w)], &cout[c0 + w]);\n}\n";
 }
 
+// block-owned variant: see WindowSpec.  R[block][pattern] = the points of the pattern with a slot in one of the block's
+// windows (at most EXA_BLOCK of them: one chunk); every pattern is evaluated once, then each pass adds its slots into the
+// window of its space; windows are clipped to their space when streamed out
+static void gen_window_kernel_blocks(std::ostringstream &os, const Model &m, const std::vector<WindowPat> &pats, bool hess, int nspaces, int zs) {
+    const char *nm = hess ? "chess" : "cjac";
+    const char *fa = hess ? "hessa" : "jaca";
+    const char *fv = hess ? "hessv" : "jacv";
+    std::vector<int> pk;
+    for (const auto &wp : pats) if (std::find(pk.begin(), pk.end(), wp.k) == pk.end()) pk.push_back(wp.k);
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_" << nm << "w(const long* __restrict__ P, const long* __restrict__ Q, "
+          "const int* __restrict__ R, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
+          "double* __restrict__ cout, double sigma, long ncomp, int W) {\n"
+          "    extern __shared__ double win[];\n    const long j_ = blockIdx.x;\n"
+          "    const int* r_ = R + j_ * " << 2 * pk.size() << ";\n"
+          "    for (int w = threadIdx.x; w < W; w += EXA_BLOCK) win[w] = 0.0;\n";
+    for (size_t q = 0; q < pk.size(); q++) {
+        const int S = hess ? m.pats[pk[q]].o2step : m.pats[pk[q]].o1step;
+        os << "    const bool act" << q << " = r_[" << 2 * q << "] + (long)threadIdx.x < r_[" << 2 * q + 1 << "];\n    const long I" << q << " = act" << q
+           << " ? r_[" << 2 * q << "] + (long)threadIdx.x : 0;\n    double v" << q << "[" << S << "];\n    " << fn_name(pk[q], fv) << "(P, x, y, th, sigma, I" << q
+           << ", v" << q << ");\n";
+    }
+    for (size_t j = 0; j < pats.size(); j++) {
+        const size_t q = std::find(pk.begin(), pk.end(), pats[j].k) - pk.begin();
+        const int z = zs + 4 * pats[j].space;
+        os << "    __syncthreads();\n    w" << j << "_" << fa << "(Q, I" << q << ", act" << q << ", Q[" << z << "] + j_ * Q[" << z + 2 << "], (int)Q[" << z + 2
+           << "], win + Q[" << z + 3 << "], v" << q << ");\n";
+    }
+    os << "    __syncthreads();\n";
+    for (int sp = 0; sp < nspaces; sp++) {
+        const int z = zs + 4 * sp;
+        os << "    {\n        const long c0 = Q[" << z << "] + j_ * Q[" << z + 2 << "], end = Q[" << z + 1 << "];\n        const int We = (int)Q[" << z + 2
+           << "];\n        const double* wn = win + Q[" << z + 3 << "];\n"
+           << "        for (int w = threadIdx.x; w < We; w += EXA_BLOCK) if (c0 + w < end) __builtin_nontemporal_store(wn[EXA_WPOS(w)], &cout[c0 + w]);\n    }\n";
+    }
+    os << "    (void)ncomp;\n}\n";
+}
+
 // irregular end points: X = [pattern, I] per point (up to EXA_BLOCK of them); values go through xbuf; then one thread
 // per DISTINCT compressed target adds that target's values in (point, slot) order: T = [ntargets, then per target:
 // compressed entry, first, one-past-last position in E], E = positions in xbuf
@@ -1757,7 +1794,10 @@ std::string generate_window_module(const Model &m, const ParamLayout &L, const W
         for (const auto &q : sh) if (std::find(pk.begin(), pk.end(), q.k) == pk.end()) pk.push_back(q.k);
         for (int k : pk) gen_window_value_fn(os, m, L, k, hess != 0);
         for (size_t j = 0; j < pats.size(); j++) gen_window_fn(os, pats[j], (int)j, hess != 0, hess ? m.pats[pats[j].k].o2step : m.pats[pats[j].k].o1step);
-        gen_window_kernels(os, m, pats, sh, hess != 0, hess ? spec.hess_single : spec.jac_single);
+        if ((hess ? spec.hess_nspaces : spec.jac_nspaces) > 0)
+            gen_window_kernel_blocks(os, m, pats, hess != 0, hess ? spec.hess_nspaces : spec.jac_nspaces, hess ? spec.hess_zs : spec.jac_zs);
+        else
+            gen_window_kernels(os, m, pats, sh, hess != 0, hess ? spec.hess_single : spec.jac_single);
         // every active pattern may own irregular end points
         std::vector<int> all;
         for (int k : L.active[hess ? CB_HESS : CB_JAC]) all.push_back(k);

@@ -114,6 +114,7 @@ struct WindowPat {             // one (pattern, stride class) pass
     std::vector<int> group;     // slot -> group (-1: the slot advances with another stride; another pass adds it)
     std::vector<int> phase;     // group -> phase
     int qbase = 0;              // first word of this pass's table in Q: b, e_lo, e_hi, amin, amax, a[group]...
+    int space = 0;              // block-owned variant: which output space (column block) the pass writes to
 };
 struct WindowShared {          // slots of a pattern that land on ONE compressed entry for every data point (b = 0):
     int k = 0;                  // summed per workgroup (exa_c*s), folded in a fixed order by the tail kernel (exa_c*x)
@@ -125,6 +126,11 @@ struct WindowSpec {
     // every pass of every window fits one chunk of kBlock points: straight-line kernel (all passes' loads first, then
     // the additions), compiled for 8 waves per SIMD; otherwise chunk loops, no occupancy hint (it made them spill)
     bool hess_single = false, jac_single = false;
+    // Block-owned variant (models laid out as separate variable arrays: the outputs of one data point land in several
+    // far-apart column blocks = SPACES).  Workgroup j owns window j of EVERY space — the outputs of the same block of
+    // points — so each pattern is evaluated once per point instead of once per pass.  nspaces > 0 selects it; the space
+    // table [origin, end, window, LDS offset] x nspaces starts at word zs of Q.
+    int hess_nspaces = 0, jac_nspaces = 0, hess_zs = 0, jac_zs = 0;
 };
 // Source of the second module of a compressed model: exa_chessw / exa_chessx (and exa_cjacw / exa_cjacx).
 std::string generate_window_module(const Model &m, const ParamLayout &L, const WindowSpec &spec);

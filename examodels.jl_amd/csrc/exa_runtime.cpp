@@ -1080,7 +1080,8 @@ int exa_hess_structure64_host(int id, int64_t *r, int64_t *c) { return struct_ho
 // Anything else (data-indexed targets, stepped ranges of different lengths meeting in the same columns) keeps the gather.
 // Knobs (experiments): EXAHIP_CWINDOW=0 gather only; EXAHIP_CW_W window size; EXAHIP_CW_WAVES occupancy hint;
 // EXAHIP_CW_SWIZZLE=0 plain LDS positions; EXAHIP_CW_VERBOSE=1 prints the pass table; EXAHIP_DUMP_WINDOW=file the source.
-bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPat> &pats, std::vector<WindowShared> &shared, bool &single) {
+bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPat> &pats, std::vector<WindowShared> &shared, bool &single,
+                 int &nspaces, int &zs) {
     const Model &m = *h.m;
     const ParamLayout &L = h.gen.layout;
     Handle::Window &w = hess ? h.wh : h.wj;
@@ -1111,6 +1112,7 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
         }
         int64_t cnt = 0, e_lo = 0, e_hi = n;
         affine_exceptions(cmap, o, S, n, a.data(), bs.data(), mid, &cnt, &e_lo, &e_hi, h.stream);
+        if (n <= 8) { e_lo = n; e_hi = n; }       // a handful of points (boundary conditions): all of them go to the tail kernel
         if (e_lo + (n - e_hi) > kBlock) return no("pattern " + std::to_string(k) + ": " + std::to_string(cnt) + " points off the regular structure");
         for (int64_t I = 0; I < e_lo; I++) exc.push_back({k, I});
         for (int64_t I = e_hi; I < n; I++) exc.push_back({k, I});
@@ -1185,6 +1187,90 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
     if (pats.empty()) return no("no regular pattern");
     if (pats.size() > 24 || (double)passes_pts > 6.0 * (double)npts)
         return no(std::to_string(pats.size()) + " passes over " + std::to_string((double)passes_pts / std::max<double>(1.0, (double)npts)) + "x the points");
+    // ---- block-owned variant (WindowSpec): the passes fall into several far-apart output ranges (SPACES: the column
+    // blocks of a model laid out as separate variable arrays).  Workgroup j owns window j of every space — n points'
+    // worth of each — so a pattern is evaluated once per point, not once per pass (rocket chess: 1.84x the VALU
+    // instructions of the uncompressed sweep with one window space).  Needs: positive strides, one stride per space,
+    // every pattern's points of a block within one chunk.
+    nspaces = 0; zs = 0;
+    std::vector<int32_t> Rb;
+    int64_t Wtot = 0, nblocks = 0;
+    {
+        const char *be = getenv("EXAHIP_CW_BLOCKS");
+        bool ok = !(be && atoi(be) == 0) && pats.size() >= 2;
+        struct Sp { int64_t lo, hi, b, W = 0, off = 0, o = 0, end = 0; };
+        std::vector<Sp> sp;
+        std::vector<size_t> order(pats.size());
+        auto out_lo = [&](size_t q) { const int64_t *t = &Q[pats[q].qbase]; return t[3] + t[0] * t[1]; };
+        auto out_hi = [&](size_t q) { const int64_t *t = &Q[pats[q].qbase]; return t[4] + t[0] * (t[2] - 1) + 1; };
+        for (size_t q = 0; q < pats.size() && ok; q++) { order[q] = q; if (Q[pats[q].qbase] <= 0) ok = false; }
+        if (ok) {
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t c) { return out_lo(a) < out_lo(c); });
+            for (size_t q : order) {
+                const int64_t b = Q[pats[q].qbase];
+                if (!sp.empty() && out_lo(q) < sp.back().hi) {
+                    if (sp.back().b != b) { ok = false; break; }
+                    sp.back().hi = std::max(sp.back().hi, out_hi(q));
+                } else sp.push_back({out_lo(q), out_hi(q), b});
+                pats[q].space = (int)sp.size() - 1;
+            }
+        }
+        ok = ok && sp.size() >= 2 && sp.size() <= 16;
+        int64_t n = 0;
+        if (ok) {
+            int64_t sumb = 0;
+            for (const auto &q : sp) sumb += q.b;
+            const char *le = getenv("EXAHIP_CW_LDS");        // doubles of LDS per workgroup (experiments)
+            n = std::min<int64_t>(kBlock - 2 * spread_max - 2, (le ? atoll(le) : 6144) / sumb) / 16 * 16;
+            ok = n >= 64;
+        }
+        std::vector<int> pk;
+        if (ok) {
+            for (size_t q = 0; q < sp.size(); q++) {
+                sp[q].W = sp[q].b * n; sp[q].off = Wtot; Wtot += sp[q].W;
+                sp[q].o = q == 0 ? 0 : sp[q].lo;
+            }
+            for (size_t q = 0; q < sp.size(); q++) {
+                sp[q].end = q + 1 < sp.size() ? sp[q + 1].o : cc.cnnz;
+                nblocks = std::max(nblocks, (sp[q].end - sp[q].o + sp[q].W - 1) / sp[q].W);
+            }
+            for (const auto &wp : pats) if (std::find(pk.begin(), pk.end(), wp.k) == pk.end()) pk.push_back(wp.k);
+            ok = nblocks * (int64_t)pk.size() * 2 < (int64_t)1 << 28;
+        }
+        if (ok) {
+            auto fdiv = [](int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; };
+            auto cdiv = [&](int64_t a, int64_t b) { return -fdiv(-a, b); };
+            Rb.assign((size_t)nblocks * pk.size() * 2, 0);
+            for (int64_t j = 0; j < nblocks && ok; j++)
+                for (size_t u = 0; u < pk.size() && ok; u++) {
+                    int64_t lo = INT64_MAX, hi = INT64_MIN;
+                    for (const auto &wp : pats) {
+                        if (wp.k != pk[u]) continue;
+                        const Sp &q = sp[wp.space];
+                        const int64_t c0 = q.o + j * q.W, c1 = std::min(c0 + q.W, q.end) - 1;
+                        if (c1 < c0) continue;
+                        const int64_t *t = &Q[wp.qbase];
+                        int64_t l = std::max(cdiv(c0 - t[4], t[0]), t[1]), hh = std::min(fdiv(c1 - t[3], t[0]) + 1, t[2]);
+                        if (hh <= l) continue;
+                        lo = std::min(lo, l); hi = std::max(hi, hh);
+                    }
+                    if (hi <= lo) { lo = 0; hi = 0; }
+                    if (hi - lo > kBlock) ok = false;
+                    Rb[(j * pk.size() + u) * 2] = (int32_t)lo; Rb[(j * pk.size() + u) * 2 + 1] = (int32_t)hi;
+                }
+        }
+        if (ok) {
+            nspaces = (int)sp.size();
+            zs = (int)Q.size();
+            for (const auto &q : sp) { Q.push_back(q.o); Q.push_back(q.end); Q.push_back(q.W); Q.push_back(q.off); }
+            if (getenv("EXAHIP_CW_VERBOSE"))
+                for (size_t q = 0; q < sp.size(); q++)
+                    fprintf(stderr, "[exahip]   space %zu: entries [%ld,%ld) stride %ld window %ld\n", q, (long)sp[q].o, (long)sp[q].end, (long)sp[q].b, (long)sp[q].W);
+        } else {
+            for (auto &wp : pats) wp.space = 0;
+            Rb.clear();
+        }
+    }
     // Window size.  If every pass advances with the same stride, W = what kBlock points produce (less the straddling
     // points): every pass of every window is one chunk and the straight-line kernel applies (LV 1e7 chess: 0.097 ms
     // against 0.112 with chunk loops at any W).  With mixed strides the small-stride passes need several chunks per
@@ -1203,8 +1289,9 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
         W = std::max<int64_t>(16, atoll(wenv) / 16 * 16);
         single = W / bmin + spread_max + 1 <= kBlock;
     }
+    if (nspaces > 0) { W = Wtot; single = true; }
     if (W < 16) return no("window too small");
-    const int64_t nwin = (cc.cnnz + W - 1) / W;
+    const int64_t nwin = nspaces > 0 ? nblocks : (cc.cnnz + W - 1) / W;
     // work amplification: points evaluated (whole chunks of kBlock) over points present
     double work = 0.0;
     for (const auto &wp : pats) {
@@ -1214,7 +1301,7 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
         const double wins = std::min<double>((double)nwin, (double)n * (double)ab / (double)W + 1.0);
         work += wins * std::ceil(per / kBlock) * kBlock;
     }
-    if (work > 2.0 * (double)passes_pts + 4096.0 * pats.size())
+    if (nspaces == 0 && work > 2.0 * (double)passes_pts + 4096.0 * pats.size())
         return no("windows would evaluate " + std::to_string(work / std::max<double>(1.0, (double)passes_pts)) + "x the points");
     // irregular points: targets straight from the slot map, grouped by distinct target
     w.nx = (int)exc.size();
@@ -1268,7 +1355,10 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
     w.Q.ensure(8 * Q.size());
     HIPCHK(hipMemcpy(w.Q.p, Q.data(), 8 * Q.size(), hipMemcpyHostToDevice));
     // R[window][pass] = [lo, hi): the regular points with a slot of that pass inside the window
-    {
+    if (nspaces > 0) {
+        w.R.ensure(4 * Rb.size());
+        HIPCHK(hipMemcpy(w.R.p, Rb.data(), 4 * Rb.size(), hipMemcpyHostToDevice));
+    } else {
         auto fdiv = [](int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; };   // b > 0
         auto cdiv = [&](int64_t a, int64_t b) { return -fdiv(-a, b); };
         const size_t np = pats.size();
@@ -1291,8 +1381,9 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
     }
     w.W = (int)W;
     w.nwin = nwin;
+    w.why = nspaces > 0 ? "block-owned windows, " + std::to_string(nspaces) + " spaces" : (single ? "one chunk per pass" : "chunk loops");
     if (getenv("EXAHIP_CW_VERBOSE")) {
-        fprintf(stderr, "[exahip] windowed %s (%s): W=%ld windows=%ld passes=%zu shared-entry workgroups=%ld irregular points=%d\n", hess ? "hess" : "jac", single ? "one chunk per pass" : "chunk loops", (long)W,
+        fprintf(stderr, "[exahip] windowed %s (%s): W=%ld windows=%ld passes=%zu shared-entry workgroups=%ld irregular points=%d\n", hess ? "hess" : "jac", nspaces > 0 ? "block-owned, one evaluation per point" : (single ? "one chunk per pass" : "chunk loops"), (long)W,
                 (long)nwin, pats.size(), (long)w.ns_blocks, w.nx);
         for (size_t q = 0; q < pats.size(); q++) {
             const int64_t *t = &Q[pats[q].qbase];
@@ -1318,11 +1409,11 @@ void window_setup(Handle &h) {
     try {
         build_slot_map(h.cj, (int32_t *)cmap.p, h.stream);
         HIPCHK(hipStreamSynchronize(h.stream));
-        okj = window_plan(h, false, (const int32_t *)cmap.p, spec.jac, spec.jac_shared, spec.jac_single);
+        okj = window_plan(h, false, (const int32_t *)cmap.p, spec.jac, spec.jac_shared, spec.jac_single, spec.jac_nspaces, spec.jac_zs);
         if (!okj) { spec.jac.clear(); spec.jac_shared.clear(); }
         build_slot_map(h.ch, (int32_t *)cmap.p, h.stream);
         HIPCHK(hipStreamSynchronize(h.stream));
-        okh = window_plan(h, true, (const int32_t *)cmap.p, spec.hess, spec.hess_shared, spec.hess_single);
+        okh = window_plan(h, true, (const int32_t *)cmap.p, spec.hess, spec.hess_shared, spec.hess_single, spec.hess_nspaces, spec.hess_zs);
         if (!okh) { spec.hess.clear(); spec.hess_shared.clear(); }
     } catch (...) { cmap.release(); throw; }
     cmap.release();

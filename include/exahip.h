@@ -162,8 +162,9 @@ int exa_chess(int id, const double *x, const double *y, double obj_weight, doubl
 /* Which implementation exa_cjac (hess = 0) / exa_chess (hess = 1) run: 1 = windowed (the sweep adds straight into
  * LDS-resident windows of the compressed array: no uncompressed round trip; taken when every slot of every pattern sits
  * at compressed entry a_s + b*I — stencil models), 0 = uncompressed evaluation + sorted gather (the reference's scheme;
- * data-indexed targets, variables shared by all points), -1 = bad id / not compressed.  When 0, the reason is copied to
- * buf (needed byte length returned through *len_out if non-NULL).  EXAHIP_CWINDOW=0 forces the gather. */
+ * data-indexed targets, variables shared by all points), -1 = bad id / not compressed.  buf receives the reason (0) or
+ * the kernel shape (1: "one chunk per pass" | "chunk loops" | "block-owned windows, K spaces"); the needed byte length
+ * is returned through *len_out if non-NULL.  EXAHIP_CWINDOW=0 forces the gather. */
 int exa_compress_info(int id, int hess, char *buf, int cap, int *len_out);
 
 /* ---- measurement hooks --------------------------------------------------------------------------- */

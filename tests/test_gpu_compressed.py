@@ -259,3 +259,29 @@ def test_compressed_csc_view(libs, name):
         B.sum_duplicates()
         assert abs(A - B).max() <= 1e-12 * max(1.0, abs(B).max())
         assert A.has_sorted_indices or A.nnz == 0
+
+
+def test_block_owned_windows_for_separate_variable_arrays(libs):
+    """A discretised control problem laid out as separate arrays x[0..N], u[0..N], z[0..N]: the Hessian / Jacobian entries
+    of one time step land in three far-apart column blocks.  exa_compress must pick the block-owned windows (every
+    pattern evaluated once per point, one LDS window per column block) and reproduce the uncompressed sums; the step
+    length `h` shared by all steps goes through the shared-entry kernel, the boundary conditions through the tail."""
+    from exahip import CompressedExaModel, ExaCore, ExaModel
+    from exahip.core import rng
+    from exahip.graph import cos, exp, sin
+    N = 5000
+    c = ExaCore()
+    x = c.add_var(N + 1, start=np.linspace(0.2, 1.0, N + 1))
+    u = c.add_var(N + 1, start=np.linspace(-0.5, 0.5, N + 1))
+    z = c.add_var(N + 1, start=0.3)
+    h = c.add_var(1, start=0.01, lvar=1e-4)
+    c.add_obj(lambda i: h[1] * (u[i] ** 2 + x[i] ** 2 * z[i]), rng(1, N + 1))
+    c.add_con(lambda i: x[i + 1] - x[i] - h[1] * (sin(x[i]) * u[i] + z[i + 1] * x[i + 1]), rng(1, N))
+    c.add_con(lambda i: z[i + 1] - z[i] - 0.5 * h[1] * (exp(-x[i]) * z[i] + cos(u[i + 1]) * z[i + 1]), rng(1, N))
+    c.add_con(lambda i: x[i] - 0.2, rng(1, 1))
+    c.add_con(lambda i: z[i] ** 2 - 0.09, rng(1, 1))
+    m = ExaModel(c.to_ir())
+    cm = CompressedExaModel(m)
+    kinds = _check_against_uncompressed(m, cm, 3)
+    assert kinds == ["windowed", "windowed"]
+    assert "block-owned" in cm.path("hess")[1] and "block-owned" in cm.path("jac")[1], (cm.path("jac"), cm.path("hess"))
