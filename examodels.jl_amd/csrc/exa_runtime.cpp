@@ -1454,7 +1454,7 @@ void do_window(Handle &h, bool hess, const double *x, const double *y, double si
         void *xbuf = w.xbuf.p;
         int nx = w.nx;
         void *a2[] = {&P, &X, &T, &E, &x, &y, &th, &xbuf, &vals, &sigma, &nx, &part, &F};
-        HIPCHK(hipModuleLaunchKernel(w.fx, 1, 1, 1, kBlock, 1, 1, 0, h.stream, a2, nullptr));
+        HIPCHK(hipModuleLaunchKernel(w.fx, 1, 1, 1, 1024, 1, 1, 0, h.stream, a2, nullptr));     // 1024 threads: the fold is one workgroup's loop
     }
 }
 
