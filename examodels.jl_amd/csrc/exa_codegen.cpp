@@ -1742,16 +1742,23 @@ static void emit_window_shared_body(std::ostringstream &os, const Model &m, cons
     const char *fv = hess ? "hessv" : "jacv";
     for (size_t j = 0; j < sh.size(); j++) {
         const int St = hess ? m.pats[sh[j].k].o2step : m.pats[sh[j].k].o1step;
+        const size_t ng = sh[j].groups.size();
         os << "        " << (j ? "else " : "") << "if (b < S[" << 4 * (j + 1) + 2 << "]) {\n            const long tile = b - S[" << 4 * j + 2 << "], nt = S["
-           << 4 * (j + 1) + 2 << "] - S[" << 4 * j + 2 << "];\n            const long I0 = S[" << 4 * j << "] + tile * EXA_BLOCK + threadIdx.x;\n"
-           << "            const bool act = I0 < S[" << 4 * j + 1 << "];\n            const long I = act ? I0 : 0;\n            double v[" << St << "];\n            "
+           << 4 * (j + 1) + 2 << "] - S[" << 4 * j + 2 << "];\n            double acc[" << ng << "];\n            for (int g = 0; g < " << ng << "; g++) acc[g] = 0.0;\n"
+           << "#pragma unroll 1\n            for (int u = 0; u < " << kSharedTiles << "; u++) {\n"
+           << "                const long I0 = S[" << 4 * j << "] + (tile * " << kSharedTiles << " + u) * EXA_BLOCK + threadIdx.x;\n"
+           << "                if (I0 - threadIdx.x >= S[" << 4 * j + 1 << "]) break;\n"
+           << "                const bool act = I0 < S[" << 4 * j + 1 << "];\n                const long I = act ? I0 : 0;\n                double v[" << St << "];\n                "
            << fn_name(sh[j].k, fv) << "(P, x, y, th, sigma, I, v);\n";
-        for (size_t g = 0; g < sh[j].groups.size(); g++) {
+        for (size_t g = 0; g < ng; g++) {
             std::string sum;
             for (int s : sh[j].groups[g]) sum += (sum.empty() ? "" : " + ") + ("v[" + std::to_string(s) + "]");
-            os << "            { const double s = exa_block_sum(act ? " << sum << " : 0.0); if (threadIdx.x == 0) part[S[" << 4 * j + 3 << "] + " << g
-               << " * nt + tile] = s; __syncthreads(); }\n";
+            os << "                acc[" << g << "] += act ? " << sum << " : 0.0;\n";
         }
+        os << "            }\n";
+        for (size_t g = 0; g < ng; g++)
+            os << "            { const double s = exa_block_sum(acc[" << g << "]); if (threadIdx.x == 0) part[S[" << 4 * j + 3 << "] + " << g
+               << " * nt + tile] = s; __syncthreads(); }\n";
         os << "        }\n";
     }
 }

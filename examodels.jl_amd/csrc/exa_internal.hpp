@@ -116,6 +116,7 @@ struct WindowPat {             // one (pattern, stride class) pass
     int qbase = 0;              // first word of this pass's table in Q: b, e_lo, e_hi, amin, amax, a[group]...
     int space = 0;              // block-owned variant: which output space (column block) the pass writes to
 };
+constexpr int kSharedTiles = 8;   // chunks of kBlock points per workgroup of the shared-entry kernel (exa_c*s)
 struct WindowShared {          // slots of a pattern that land on ONE compressed entry for every data point (b = 0):
     int k = 0;                  // summed per workgroup (exa_c*s), folded in a fixed order by the tail kernel (exa_c*x)
     std::vector<std::vector<int>> groups;   // slots of each such entry

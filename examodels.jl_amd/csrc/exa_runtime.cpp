@@ -1340,7 +1340,7 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
         std::vector<int64_t> St, F{0};
         int64_t blocks = 0, parts = 0;
         for (const auto &sh : shs) {
-            const int64_t nt = (sh.e_hi - sh.e_lo + kBlock - 1) / kBlock;
+            const int64_t per = (int64_t)kBlock * kSharedTiles, nt = (sh.e_hi - sh.e_lo + per - 1) / per;
             St.push_back(sh.e_lo); St.push_back(sh.e_hi); St.push_back(blocks); St.push_back(parts);
             for (size_t g = 0; g < sh.target.size(); g++) { F.push_back(parts + (int64_t)g * nt); F.push_back(nt); F.push_back(sh.target[g]); F[0]++; }
             blocks += nt;
