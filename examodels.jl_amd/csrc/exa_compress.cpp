@@ -278,6 +278,10 @@ unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
+void CompressedCOO::release_gather() {
+    for (void **q : {&perm, &ptr, &long_list, &partial}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    nlong = maxlen = 0;
+}
 void CompressedCOO::release() {
     for (void **q : {&perm, &ptr, &rows, &cols, &long_list, &partial}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     cnnz = nnz = nlong = maxlen = 0;

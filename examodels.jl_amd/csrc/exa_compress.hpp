@@ -20,6 +20,7 @@ struct CompressedCOO {
     void *partial = nullptr;     // double[nlong * chunks]
     int64_t nlong = 0, maxlen = 0;
     void release();
+    void release_gather();   // drops perm / ptr / long-group lists (the windowed sweep never reads them); rows / cols stay
 };
 
 void build_compressed(CompressedCOO &c, const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t nrowdim, int64_t ncoldim,

@@ -1430,6 +1430,10 @@ void window_setup(Handle &h) {
     if (image.empty()) image = read_file(build_code_object(src));
     HIPCHK(hipModuleLoadData(&h.wmodule, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
+    // a matrix on the windowed sweep never gathers: its sorted permutation (4 B per uncompressed slot: 3.6 GB for LV 1e8)
+    // and pointer list can go
+    if (okj) h.cj.release_gather();
+    if (okh) h.ch.release_gather();
     if (okj) { h.wj.fw = fn("exa_cjacw"); h.wj.fx = fn("exa_cjacx"); if (h.wj.ns_blocks) h.wj.fs = fn("exa_cjacs"); h.wj.ok = true; }
     if (okh) { h.wh.fw = fn("exa_chessw"); h.wh.fx = fn("exa_chessx"); if (h.wh.ns_blocks) h.wh.fs = fn("exa_chesss"); h.wh.ok = true; }
 }
