@@ -12,13 +12,18 @@ NVAR, NPTS = 40, 7
 
 
 class Gen:
+    block_stride = 0      # > 0: symbolic indices also pick one of three variable blocks this far apart (x, u, z arrays)
+
     def __init__(self, seed):
         self.r = np.random.default_rng(seed)
 
     def leaf(self, x, th, d):
         k = self.r.integers(0, 10)
         if k < 5:
-            return x[d.i + int(self.r.integers(0, 4))]           # symbolic index with a literal offset
+            off = int(self.r.integers(0, 4))                      # symbolic index with a literal offset
+            if self.block_stride:
+                off += self.block_stride * int(self.r.integers(0, 3))
+            return x[d.i + off]
         if k == 5:
             return x[int(self.r.integers(1, NVAR + 1))]          # constant index
         if k == 6:
@@ -109,7 +114,7 @@ class _RangePoint:
         self.i, self.j, self.w, self.t = i, i + 1, 0.75, i if step == 1 else (i - 1) * 0 + 1
 
 
-def build_range_model(seed, npts=1000, npat=8, depth=4, unit=False):
+def build_range_model(seed, npts=1000, npat=8, depth=4, unit=False, blocks=False):
     """As build_model, but every pattern iterates a RANGE (unit or stepped), so indices are `range + c`: the
     gathered gradient, the LDS-window scatter of J'v / Hv, the multi-tile flush and partial wavefronts are exercised."""
     g = Gen(seed)
@@ -129,7 +134,10 @@ def build_range_model(seed, npts=1000, npat=8, depth=4, unit=False):
             if unit:                   # stencil-like: unit ranges of (almost) equal length — regular sorted structure
                 step, n = 1, npts - (k % 2)
             itr = rng(lo, lo + step * (n - 1), step)
-            fn = (lambda i, s=int(g.r.integers(0, 2**31)), st=step: Gen(s).tree(x, th, _RangePoint(i, st), depth))
+            def fn(i, s=int(g.r.integers(0, 2**31)), st=step):
+                gen = Gen(s)
+                gen.block_stride = npts if blocks else 0
+                return gen.tree(x, th, _RangePoint(i, st), depth)
             kind = k % 4
             if kind == 0:
                 c.add_obj(fn, itr)

@@ -146,7 +146,7 @@ def test_heavily_duplicated_entry(libs):
     assert (time.perf_counter() - t0) / 5 < 0.05          # seconds; the single-thread sum took 18 ms per 20000 points
 
 
-def _check_against_uncompressed(m, cm, seed):
+def _check_against_uncompressed(m, cm, seed, tol=1e-14):
     """compressed values == duplicate-summed uncompressed values, within rounding of the summed magnitudes; the path
     taken is returned"""
     import torch
@@ -172,7 +172,7 @@ def _check_against_uncompressed(m, cm, seed):
         assert np.array_equal(cr.cpu().numpy(), r[order][starts]) and np.array_equal(cc.cpu().numpy(), c[order][starts])
         fin = np.isfinite(ev)
         assert np.array_equal(np.isfinite(cv), fin)
-        bound = (2e-15 * np.sqrt(cnt) + 1e-14) * mag
+        bound = (2e-15 * np.sqrt(cnt) + tol) * mag
         err = np.abs(cv[fin] - ev[fin])
         assert np.all(err <= bound[fin]), (which, (err / np.maximum(bound[fin], 1e-300)).max())
         kinds.append(cm.path(which)[0])
@@ -285,3 +285,18 @@ def test_block_owned_windows_for_separate_variable_arrays(libs):
     kinds = _check_against_uncompressed(m, cm, 3)
     assert kinds == ["windowed", "windowed"]
     assert "block-owned" in cm.path("hess")[1] and "block-owned" in cm.path("jac")[1], (cm.path("jac"), cm.path("hess"))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_windowed_random_models_over_three_variable_blocks(libs, seed):
+    """Random unit-range models whose symbolic indices fall into three far-apart variable blocks (x[i+c], x[n+i+c],
+    x[2n+i+c]): the compressed entries of one point land in up to three column blocks — the shape the block-owned windows
+    are for (whichever shape exa_compress picks must reproduce the uncompressed sums)."""
+    import randexpr
+    from exahip import CompressedExaModel, ExaModel
+    m = ExaModel(randexpr.build_range_model(seed, npts=2000, npat=5, depth=3, unit=True, blocks=True).to_ir())
+    cm = CompressedExaModel(m)
+    # slot values that are themselves differences of large terms differ between two compilations of the same expression
+    # (FMA contraction) by more than the summation bound: 1e-11 of the summed magnitudes still exposes any wrong window
+    kinds = _check_against_uncompressed(m, cm, seed, tol=1e-11)
+    print(seed, kinds, cm.path("jac"), cm.path("hess"))
