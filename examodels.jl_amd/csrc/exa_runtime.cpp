@@ -1427,15 +1427,25 @@ void window_setup(Handle &h) {
         auto it = g_preloaded.find(name);
         if (it != g_preloaded.end()) image = it->second;
     }
-    if (image.empty()) image = read_file(build_code_object(src));
-    HIPCHK(hipModuleLoadData(&h.wmodule, image.data()));
-    auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
+    // the gather path needs no second module: a host without hipcc (a packed library's consumer) or a failed compilation
+    // must not take exa_compress down with it
+    try {
+        if (image.empty()) image = read_file(build_code_object(src));
+        HIPCHK(hipModuleLoadData(&h.wmodule, image.data()));
+        auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
+        if (okj) { h.wj.fw = fn("exa_cjacw"); h.wj.fx = fn("exa_cjacx"); if (h.wj.ns_blocks) h.wj.fs = fn("exa_cjacs"); }
+        if (okh) { h.wh.fw = fn("exa_chessw"); h.wh.fx = fn("exa_chessx"); if (h.wh.ns_blocks) h.wh.fs = fn("exa_chesss"); }
+    } catch (const std::exception &e) {
+        std::string msg = e.what();
+        if (msg.size() > 300) msg.resize(300);
+        h.wj.why = h.wh.why = "the windowed kernels could not be built (" + msg + ")";
+        if (h.wmodule) { (void)hipModuleUnload(h.wmodule); h.wmodule = nullptr; }
+        return;
+    }
     // a matrix on the windowed sweep never gathers: its sorted permutation (4 B per uncompressed slot: 3.6 GB for LV 1e8)
     // and pointer list can go
-    if (okj) h.cj.release_gather();
-    if (okh) h.ch.release_gather();
-    if (okj) { h.wj.fw = fn("exa_cjacw"); h.wj.fx = fn("exa_cjacx"); if (h.wj.ns_blocks) h.wj.fs = fn("exa_cjacs"); h.wj.ok = true; }
-    if (okh) { h.wh.fw = fn("exa_chessw"); h.wh.fx = fn("exa_chessx"); if (h.wh.ns_blocks) h.wh.fs = fn("exa_chesss"); h.wh.ok = true; }
+    if (okj) { h.cj.release_gather(); h.wj.ok = true; }
+    if (okh) { h.ch.release_gather(); h.wh.ok = true; }
 }
 
 void do_window(Handle &h, bool hess, const double *x, const double *y, double sigma, double *vals) {

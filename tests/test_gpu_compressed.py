@@ -300,3 +300,18 @@ def test_windowed_random_models_over_three_variable_blocks(libs, seed):
     # (FMA contraction) by more than the summation bound: 1e-11 of the summed magnitudes still exposes any wrong window
     kinds = _check_against_uncompressed(m, cm, seed, tol=1e-11)
     print(seed, kinds, cm.path("jac"), cm.path("hess"))
+
+
+def test_no_compiler_for_the_window_module_falls_back_to_the_gather(libs, monkeypatch, tmp_path):
+    """exa_compress generates a second module for the windowed sweep; where it cannot be compiled (a packed library's
+    consumer without hipcc) the call must still succeed and evaluate through the gather."""
+    import shutil
+    import torch
+    from exahip import CompressedExaModel, ExaModel, models
+    m = ExaModel(models.luksan_vlcek_model(777))                  # base module compiled (or cached) with the real compiler
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))          # empty cache: the window module is not there
+    monkeypatch.setenv("EXAHIP_HIPCC", "/nonexistent/hipcc")
+    cm = CompressedExaModel(m)
+    kind, why = cm.path("hess")
+    assert kind == "gather" and "could not be built" in why, (kind, why)
+    assert _check_against_uncompressed(m, cm, 1) == ["gather", "gather"]
