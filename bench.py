@@ -1,22 +1,31 @@
 #!/usr/bin/env python
 """bench.py — sparse Lagrangian Hessian evaluation throughput on MI355X (BASELINE.json metric).
 
-A "step" is one hess_coord!(m, x, y, H; obj_weight) of the Luksan-Vlcek model (BASELINE.json configs[1],
-benchmark/runbenchmark.jl:163-169) with x, y and H already resident in HBM.  Per-GPU work is fixed
-(--points data points of each pattern per GPU, default 1e7): with N GPUs the model is LV(N * points) and every
-rank evaluates its contiguous shard of each pattern's iterator, writing its disjoint slice of the global COO
-vector — no data-path collective => "scaling": "weak", value = aggregate Hessian nonzeros / s.
+A "step" is one hess_coord!(m, x, y, H; obj_weight) with x, y and H already resident in HBM.
 
-    python bench.py                       # 1 GPU, LV N=1e7
+    python bench.py                        1 GPU, config 2: Luksan-Vlcek N=1e7 (benchmark/runbenchmark.jl:163-169) — the
+                                           configuration the metric is quoted on; the line also carries the N=1 point of
+                                           config 5 (LV N=1e8 on one GPU) as "config5_n1"
+    python bench.py --config 3|4           Goddard rocket nh=1e6 / ACOPF at case78484 scale (synthetic topology), 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus 8 --steps K --warmup W
+                                           N > 1 defaults to config 5: LV N=1e8 split over the ranks (STRONG scaling);
+                                           every rank evaluates its contiguous shard of each pattern's iterator into a
+                                           slice-sized COO buffer (exa_set_coo_local) from the stretch of x / y it reads
+                                           — no data-path collective in hess_coord!.  The communicator
+                                           (RCCL through libexahip's exa_comm_init) is created all the same and the
+                                           secondary "collectives" object times grad! + ncclAllReduce through the C ABI.
 
-One JSON line on rank 0.  Extra objects: "roofline" (algorithmic HBM bytes / measured kernel time against the
-8 TB/s peak) and "cpu_baseline" (the C restatement of the reference CPU algorithm, oracle/, timed on this host).
+One JSON line on rank 0.  Extra objects: "roofline" (algorithmic HBM bytes / measured kernel time against the 8 TB/s
+peak) and "cpu_baseline" (the C restatement of the reference CPU algorithm, oracle/, timed on this host; the real
+reference is timed instead when a `julia` with ExaModels is found on the box).
 """
 import argparse
+import ctypes
 import json
 import os
+import shutil
+import subprocess
 import sys
 import time
 
@@ -27,23 +36,99 @@ for p in (os.path.join(ROOT, "examodels.jl_amd"), os.path.join(ROOT, "oracle")):
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+CONFIGS = {
+    2: "LuksanVlcek N=1e7, hess_coord!",
+    3: "Goddard rocket (COPS-3) nh=1e6, hess_coord!",
+    4: "ACOPF at PGLIB case78484_epigrids scale (synthetic topology: 78484 buses, 126015 branches, 6800 generators), hess_coord!",
+    5: "LuksanVlcek N=1e8 sharded across the GPUs, hess_coord! into local-slice COO",
+}
 
-def cpu_baseline(sample_n, threads_all):
-    """CPU baseline on this host (rank 0, N=1 only), kind = "port": the real reference is Julia and cannot run here.
 
-    value         hand-specialised straight-line C of the SAME algorithm (zero-fill + one `+=` per contribution in
-                  hessian.jl order; oracle/exa_oracle.c `ora_lv_hess_compiled`) on the FULL workload, single thread —
-                  the closest available proxy for ExaModels `backend = nothing`, whose patterns Julia compiles.
-    all_cores     the same with OpenMP over data points (proxy for the KernelAbstractions CPU() backend).
-    interpreter   the generic tree-walking test oracle on a 1e6-point sample (what the parity tests use)."""
+def build_core(config, points):
+    from exahip import models
+    if config in (2, 5):
+        return models.luksan_vlcek_model(points)
+    if config == 3:
+        return models.rocket_model(points)
+    return models.ac_power_model(models.synthetic_power_data(78_484, 126_015, 6_800, seed=0))
+
+
+def eval_point(config, core, m):
+    """x = x0 + 0.1 u (seed 0), y ~ N(0,1) (seed 1), sigma = 0.5; ACOPF: flat start."""
+    import numpy as np
+    from exahip import models
+    if config == 4:
+        x = models.acopf_start(core)
+    else:
+        x = m.meta.x0 + 0.1 * np.random.default_rng(0).uniform(-1, 1, m.meta.nvar)
+    y = np.random.default_rng(1).standard_normal(m.meta.ncon)
+    return x, y
+
+
+def iterator_bytes(m, world=1):
+    """HBM bytes of the iterator columns one pass reads (8 B per stored column entry; UnitRange columns cost nothing)."""
+    tot = 0
+    for k in range(m.npatterns):
+        pat = m.ir.patterns[k]
+        for c in range(pat.n_cols):
+            if pat.cols[c].type != 2:
+                tot += 8 * pat.n
+    return tot / world
+
+
+def resident_ranges(m, rank, world):
+    """0-based [vlo, vhi) of x and [ylo, yhi) of y that the data points of `rank` read.  x: exa_shard_var_range (the
+    stencil footprint; everything when an index comes from a data column).  y: a base constraint pattern reads the
+    multipliers of its own rows o0 + [lo, hi); an augmentation pattern reads its TARGET rows, which are data — then
+    all of y stays resident."""
+    from exahip.dist import shard_range
+    vlo, vhi = m.shard_var_range()
+    ylo, yhi = None, None
+    for k in range(m.npatterns):
+        info = m.pattern_info(k)
+        if info["kind"] == 2:                       # EXA_PAT_CONAUG
+            return vlo, vhi, 0, m.meta.ncon
+        if info["kind"] == 1 and info["o2step"] > 0:
+            lo, hi = shard_range(info["n"], rank, world)
+            if hi > lo:
+                ylo = info["o0"] + lo if ylo is None else min(ylo, info["o0"] + lo)
+                yhi = info["o0"] + hi if yhi is None else max(yhi, info["o0"] + hi)
+    return (vlo, vhi, 0, 0) if ylo is None else (vlo, vhi, ylo, yhi)
+
+
+def julia_reference(config, points):
+    """when the box has `julia` with ExaModels installed, time the REAL reference
+    (backend = nothing, one thread) with tools/julia_cpu_baseline.jl.  Returns None when that is not possible — the
+    expected case on the benchmark pool (no Julia in the image)."""
+    jl = shutil.which("julia")
+    if not jl:
+        return None
+    try:
+        out = subprocess.run([jl, "--startup-file=no", "-t", "1", os.path.join(ROOT, "tools", "julia_cpu_baseline.jl"), str(config), str(points)],
+                             capture_output=True, text=True, timeout=900)
+        for line in out.stdout.splitlines():
+            if line.startswith("{"):
+                return json.loads(line)
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(config, points, threads_all):
+    """CPU baseline on this host (rank 0, N=1 only).
+
+    kind "reference": the real ExaModels.jl timed through tools/julia_cpu_baseline.jl (only when Julia is on the box).
+    kind "port":      oracle/exa_oracle.c.  `value` = a hand-specialised straight-line C body of the SAME algorithm
+                      (zero-fill + one `+=` per contribution in hessian.jl order) — what Julia's compiler makes of the
+                      pattern — on one thread; `all_cores` the same with OpenMP over data points (proxy for the
+                      KernelAbstractions CPU() backend); `interpreter` the generic tree-walking test oracle."""
     import numpy as np
     import oracle
     from exahip import models
-    N = sample_n
-    x = models.lv_x0(N) + 0.1 * np.random.default_rng(0).uniform(-1, 1, N)
-    y = np.random.default_rng(1).standard_normal(N - 2)
-    nnzh = 9 * N - 15
-    out = np.empty(nnzh)
+    ref = julia_reference(config, points)
+    if ref is not None:
+        ref["kind"] = "reference"
+        return ref
 
     def timeit(fn, reps):
         fn()
@@ -52,41 +137,79 @@ def cpu_baseline(sample_n, threads_all):
             fn()
         return (time.perf_counter() - t0) / reps
 
-    t1 = timeit(lambda: oracle.lv_hess_compiled(N, x, y, 0.5, out=out, threads=1), 3)
-    res = {"value": nnzh / t1, "unit": "nnz/s", "cores": 1, "kind": "port",
-           "sample": f"LuksanVlcek N={N} hess_coord! (the full bench workload), 3 evals, hand-specialised C port, 1 thread",
-           "evals_per_s": 1.0 / t1}
-    if threads_all > 1:
-        th = min(threads_all, 64)
-        tn = timeit(lambda: oracle.lv_hess_compiled(N, x, y, 0.5, out=out, threads=th), 3)
-        res["all_cores"] = {"value": nnzh / tn, "cores": th, "evals_per_s": 1.0 / tn,
-                            "note": "OpenMP over data points (proxy for the KernelAbstractions CPU() backend)"}
-    n2 = min(N, 1_000_000)
-    o = oracle.OracleModel(models.luksan_vlcek_model(n2).to_ir(), threads=1)
-    o2 = np.empty(o.nnzh)
-    ti = timeit(lambda: o.hess_coord(x[:n2], y[:n2 - 2], 0.5, out=o2), 2)
-    res["interpreter"] = {"value": o.nnzh / ti, "cores": 1, "sample": f"LuksanVlcek N={n2}, generic test oracle"}
+    th = max(1, min(threads_all, 64))
+    if config in (2, 5):
+        N = min(points, 10_000_000)
+        x = models.lv_x0(N) + 0.1 * np.random.default_rng(0).uniform(-1, 1, N)
+        y = np.random.default_rng(1).standard_normal(N - 2)
+        nnzh = 9 * N - 15
+        out = np.empty(nnzh)
+        t1 = timeit(lambda: oracle.lv_hess_compiled(N, x, y, 0.5, out=out, threads=1), 3)
+        res = {"value": nnzh / t1, "unit": "nnz/s", "cores": 1, "kind": "port",
+               "sample": f"LuksanVlcek N={N} hess_coord!, 3 evals, hand-specialised C port of the two patterns, 1 thread",
+               "evals_per_s": 1.0 / t1}
+        if th > 1:
+            tn = timeit(lambda: oracle.lv_hess_compiled(N, x, y, 0.5, out=out, threads=th), 3)
+            res["all_cores"] = {"value": nnzh / tn, "cores": th, "evals_per_s": 1.0 / tn,
+                                "note": "OpenMP over data points (proxy for the KernelAbstractions CPU() backend)"}
+        n2 = min(N, 1_000_000)
+        o = oracle.OracleModel(models.luksan_vlcek_model(n2).to_ir(), threads=1)
+        o2 = np.empty(o.nnzh)
+        ti = timeit(lambda: o.hess_coord(x[:n2], y[:n2 - 2], 0.5, out=o2), 2)
+        res["interpreter"] = {"value": o.nnzh / ti, "cores": 1, "sample": f"LuksanVlcek N={n2}, generic test oracle"}
+        return res
+    # configs 3 / 4: the full model through the interpreter (1 thread and all cores) + the dominant pattern compiled
+    core = build_core(config, points if config == 3 else 0)
+    ir = core.to_ir()
+    o = oracle.OracleModel(ir, threads=1)
+    x = models.acopf_start(core) if config == 4 else ir.x0 + 0.1 * np.random.default_rng(0).uniform(-1, 1, o.nvar)
+    y = np.random.default_rng(1).standard_normal(o.ncon)
+    buf = np.empty(o.nnzh)
+    ti = timeit(lambda: o.hess_coord(x, y, 0.5, out=buf), 2)
+    res = {"value": o.nnzh / ti, "unit": "nnz/s", "cores": 1, "kind": "port",
+           "sample": f"{CONFIGS[config]}: the full model, 2 evals, generic tree-walking test oracle (an INTERPRETER: Julia "
+                     "compiles each pattern, see `compiled_pattern` for what that is worth), 1 thread",
+           "evals_per_s": 1.0 / ti}
+    if th > 1:
+        o.set_threads(th)
+        tn = timeit(lambda: o.hess_coord(x, y, 0.5, out=buf), 2)
+        res["all_cores"] = {"value": o.nnzh / tn, "cores": th, "evals_per_s": 1.0 / tn, "note": "interpreter, OpenMP over data points"}
+    if hasattr(oracle, "compiled_pattern_hess"):
+        res["compiled_pattern"] = oracle.compiled_pattern_hess(config, ir, x, y, 0.5, timeit, th)
     return res
+
+
+def traffic_for(m, config, per_gpu_points):
+    """HBM bytes per launch from the PMC counters: measured in separate rocprofv3 passes (cannot run inside the timed
+    process) and committed under profiles/ TOGETHER WITH the name of the module they were measured on — attached only
+    when this run executes exactly that module on exactly that workload, null otherwise (never a stale number)."""
+    path = os.path.join(ROOT, "profiles", f"r2_traffic_config{config}.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        t = json.load(fh)
+    if t.get("module") != m._L.exa_module_name(m.id).decode() or t.get("points") != per_gpu_points:
+        return None
+    return t.get("hbm_bytes_per_launch")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[k-1]; default 2 on one GPU, 5 (LV N=1e8, strong scaling) on several")
+    ap.add_argument("--points", type=float, default=None, help="LV N / rocket nh (GLOBAL size for config 5)")
+    ap.add_argument("--weak", action="store_true", help="N > 1: per-GPU work fixed instead (--points per GPU, default 1e7)")
     ap.add_argument("--preheat-ms", type=float, default=200.0,
                     help="untimed: keep the GPU busy with the same call this long before the W warmup steps, so that the "
                          "clock governor has left its idle state (sclk idles at ~570 MHz and takes tens of ms to ramp)")
-    ap.add_argument("--points", type=float, default=1e7, help="LV size per GPU (N)")
-    ap.add_argument("--strong", action="store_true",
-                    help="strong scaling instead: --points is the GLOBAL LV size, split over the ranks (BASELINE.json configs[4]: "
-                         "--points 1e8 --gpus 8); value is then evals/s-proportional nnz/s of the fixed model")
-    ap.add_argument("--cpu-sample", type=float, default=1e7)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-config5-n1", action="store_true", help="skip the LV N=1e8 single-GPU point attached to the default line")
+    ap.add_argument("--no-tune", action="store_true", help="skip exa_tune (block order stays sequential unless persisted)")
     ap.add_argument("--all-callbacks", action="store_true", help="also time obj/cons/grad/jac (secondary)")
-    ap.add_argument("--with-collectives", action="store_true",
-                    help="N>1 only, secondary: also time sharded grad! + RCCL all_reduce (off by default so that nothing "
-                         "optional can stall the contract run)")
+    ap.add_argument("--no-collectives", action="store_true", help="N > 1: skip the secondary grad! + RCCL all-reduce timing")
     args = ap.parse_args()
 
     import numpy as np
@@ -115,36 +238,103 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from exahip import ExaModel, models
-    per_gpu = int(args.points) // world if args.strong else int(args.points)
-    N = int(args.points) if args.strong else per_gpu * world
-    core = models.luksan_vlcek_model(N)
-    m = ExaModel(core)
-    m.set_shard(rank, world)
+    config = args.config or (2 if world == 1 else 5)
+    if config in (2, 5):
+        if args.weak and world > 1:
+            per = int(args.points or 1e7)
+            points = per * world
+        else:
+            points = int(args.points or (1e7 if config == 2 else 1e8))
+    elif config == 3:
+        points = int(args.points or 1e6)
+    else:
+        points = 0
+    strong = world > 1 and not args.weak
+    steps = args.steps if args.steps is not None else (1000 if config != 5 or world > 1 else 200)
+    warmup = args.warmup if args.warmup is not None else 100
 
-    r = np.random.default_rng(0)
-    x = m.meta.x0 + 0.1 * r.uniform(-1, 1, m.meta.nvar)
-    y = np.random.default_rng(1).standard_normal(m.meta.ncon)
-    xd = torch.from_numpy(x).to(dev)
-    yd = torch.from_numpy(y).to(dev)
-    del x, y
-    h = torch.empty(m.meta.nnzh, dtype=torch.float64, device=dev)
+    line = run_config(config, points, world, rank, dev, backend, steps, warmup, args, strong)
+    if rank == 0 and world == 1 and config == 2 and not args.no_config5_n1:
+        # the N=1 point of config 5's curve (LV N=1e8 on ONE GPU: x, y and the COO are far beyond the 256 MB MALL)
+        try:
+            sub = run_config(5, int(1e8), 1, 0, dev, backend, 100, 10, args, False, secondary=True)
+            line["config5_n1"] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "evals_per_s", "roofline", "config", "steps", "warmup")}
+        except Exception as e:      # never lose the contract line to the secondary measurement
+            line["config5_n1"] = {"error": repr(e)}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_config(config, points, world, rank, dev, backend, steps, warmup, args, strong, secondary=False):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from exahip import ExaModel
+    from exahip.dist import attach_communicator
+
+    t_build = time.perf_counter()
+    core = build_core(config, points)
+    m = ExaModel(core)
+    build_s = time.perf_counter() - t_build
+    how, compile_ms = m.build_info()
+    x, y = eval_point(config, core, m)
+    nvar, ncon, nnzh = m.meta.nvar, m.meta.ncon, m.meta.nnzh
     sigma = 0.5
+    L = m._L
+
+    if world > 1:
+        # shard + communicator behind the C ABI (RCCL; the gloo launch-path exercise uses the host-reducer hook), COO as a
+        # packed local slice, and only the stretch of x (and of y) this rank's data points read kept in HBM
+        attach_communicator(m, None, "rccl" if backend == "nccl" else "hook", coo_local=True)
+        vlo, vhi, ylo, yhi = resident_ranges(m, rank, world)
+    else:
+        vlo, vhi, ylo, yhi = 0, nvar, 0, ncon
+    xs = torch.from_numpy(np.ascontiguousarray(x[vlo:vhi])).to(dev)
+    ys = torch.from_numpy(np.ascontiguousarray(y[ylo:yhi])).to(dev) if yhi > ylo else torch.zeros(1, dtype=torch.float64, device=dev)
+    x_full = x if world > 1 and not args.no_collectives else None
+    del x, y
+    # the library indexes x[k] / y[row] from the pointers it is given: pass the slice's base shifted back by the
+    # slice's first index (never dereferenced outside [vlo, vhi) — exa_shard_var_range is exactly that guarantee)
+    xp = xs.data_ptr() - 8 * vlo
+    yp = ys.data_ptr() - 8 * ylo
+    n_local = m.local_nnzh
+    h = torch.empty(max(1, n_local), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    L.exa_set_stream(m.id, ctypes.c_void_p(stream))
+
+    def time_hess(reps):
+        ms = ctypes.c_float(0.0)
+        rc = L.exa_time_callback(m.id, 4, int(reps), ctypes.c_void_p(xp), ctypes.c_void_p(yp), sigma, ctypes.c_void_p(h.data_ptr()), ctypes.addressof(ms))
+        if rc:
+            raise RuntimeError(f"exa_time_callback: status {rc}: {L.exa_last_error().decode(errors='replace')}")
+        return ms.value
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_first = time.perf_counter()
+    time_hess(1)
+    first_call_ms = 1e3 * (time.perf_counter() - t_first)
+    tune_ms = 0.0
+    if not args.no_tune:
+        t_t = time.perf_counter()
+        rc = L.exa_tune(m.id, 1, ctypes.c_void_p(xp), ctypes.c_void_p(yp))     # explicit, blocking, persisted
+        if rc:
+            raise RuntimeError("exa_tune: " + L.exa_last_error().decode(errors="replace"))
+        tune_ms = 1e3 * (time.perf_counter() - t_t)
     t_pre = time.perf_counter()
     while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
-        m.time_callback("hess", 20, xd, yd, sigma, out=h)
-    for _ in range(args.warmup):
-        m.hess_coord(xd, yd, sigma, out=h)
+        time_hess(20 if nnzh < 3e8 else 4)
+    for _ in range(warmup):
+        L.exa_hess(m.id, ctypes.c_void_p(xp), ctypes.c_void_p(yp), sigma, ctypes.c_void_p(h.data_ptr()))
     barrier()
     t0 = time.perf_counter()
     # exactly K steps; the same K launches are bracketed by hipEvents on the launch stream inside libexahip
-    kernel_ms = m.time_callback("hess", args.steps, xd, yd, sigma, out=h)
+    kernel_ms = time_hess(steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -152,76 +342,82 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = t[0].item(), t[1].item()
 
-    nnzh = m.meta.nnzh
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = nnzh * args.steps / elapsed
-    # algorithmic HBM bytes of one launch on one GPU: write each COO slot once, read x and y once;
-    # the LV iterators are UnitRanges (no iterator bytes)
-    shard_nnzh = nnzh / world
-    alg_bytes = 8.0 * shard_nnzh + 8.0 * (m.meta.nvar / world) + 8.0 * (m.meta.ncon / world)
+    ms_per_step = 1e3 * elapsed / steps
+    value = nnzh * steps / elapsed
+    # algorithmic HBM bytes of one launch on one GPU: write each COO slot once, read x and y once, plus
+    # the iterator columns the patterns read (none for UnitRange iterators)
+    alg_bytes = 8.0 * (nnzh / world) + 8.0 * (nvar / world) + 8.0 * (ncon / world) + iterator_bytes(m, world)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    # HBM traffic per launch from the PMC counters: measured in separate rocprofv3 passes (cannot run inside the timed
-    # process), committed under profiles/ and attached only when the workload is the one that was profiled
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1_traffic_lv1e7.json")
-    if world == 1 and per_gpu == 10_000_000 and os.path.exists(tpath):
-        with open(tpath) as fh:
-            traffic = json.load(fh)["hbm_bytes_per_launch"]
+    per_gpu = points // world if config in (2, 3, 5) else 0
+    if config in (2, 5):
+        wl = f"LuksanVlcek N={points:.0e}" + (f" split over {world} GPUs ({per_gpu:.2e} points per GPU)" if world > 1 else "") + ", hess_coord!"
+    else:
+        wl = CONFIGS[config]
     out = {
         "metric": "sparse Lagrangian Hessian throughput (hess_coord!), nonzeros/s; evals/s in evals_per_s",
-        "value": value, "unit": "nnz/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "preheat_ms": args.preheat_ms,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
+        "value": value, "unit": "nnz/s", "n_gpus": world, "steps": steps, "warmup": warmup, "preheat_ms": args.preheat_ms,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"LuksanVlcek N={per_gpu:.0e} per GPU (global N={N:.0e}), hess_coord! sharded-output",
-                   "nvar": m.meta.nvar, "ncon": m.meta.ncon, "nnzh": nnzh, "obj_weight": sigma,
-                   "parallelism": f"iterator-shard x{world}, no data-path collective"},
-        "evals_per_s": args.steps / elapsed,
+        "config": {"workload": wl, "baseline_config": config, "nvar": nvar, "ncon": ncon, "nnzh": nnzh, "obj_weight": sigma,
+                   "parallelism": f"iterator-shard x{world}, local-slice COO, no data-path collective" if world > 1 else "1 GPU",
+                   "resident_per_gpu_bytes": 8 * (n_local + (vhi - vlo) + (yhi - ylo))},
+        "evals_per_s": steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_for(m, config, per_gpu if world > 1 else points),
                      "kernel": "exa_hess", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "block_order": {0: "sequential", 1: "interleaved-128"}.get(m._L.exa_block_order(m.id, 4), "n/a")},
+                     "block_order": {0: "sequential", 1: "interleaved-128"}.get(L.exa_block_order(m.id, 4), "n/a")},
+        "build": {"module": how, "compile_ms": compile_ms, "model_build_s": build_s, "first_hess_call_ms": first_call_ms,
+                  "tune_ms": tune_ms,
+                  "note": "first_hess_call_ms = host time of the first exa_hess + its completion (asynchronous launch, no measuring inside)"},
     }
+    if secondary:
+        return out
     # SURVEY §8d protocol: min and median over >= 30 individually event-bracketed calls (the reference harness reports
     # the BenchmarkTools minimum, benchmark/runbenchmark.jl:94); outside the contract timing above
-    per_call = sorted(m.time_callback("hess", 1, xd, yd, sigma, out=h) for _ in range(50))
+    per_call = sorted(time_hess(1) for _ in range(50))
     out["per_call_ms"] = {"min": per_call[0], "median": per_call[len(per_call) // 2], "n": len(per_call)}
-    if world > 1 and args.with_collectives:
-        # secondary (never part of `value`): the callbacks that DO need a collective, completed with RCCL all_reduce
-        # over xGMI through exahip.dist — sharded grad! + all_reduce(SUM) of the dense nvar vector, and obj.
+    if world > 1 and not args.no_collectives:
+        # secondary (never part of `value`): the callbacks that DO need a collective, completed INSIDE libexahip by
+        # ncclAllReduce over xGMI on the model's stream (exa_comm_init): grad! (nvar doubles) and obj (1 double)
         try:
-            from exahip.dist import ShardedEvaluator
-            ev = ShardedEvaluator(m)
-            g = torch.empty(m.meta.nvar, dtype=torch.float64, device=dev)
-            if backend != "nccl":
-                raise RuntimeError("collective timing needs the nccl (RCCL) backend")
+            xd = torch.from_numpy(x_full).to(dev)
+            g = torch.empty(nvar, dtype=torch.float64, device=dev)
+            kind = m.comm_info()[2]
             for _ in range(3):
-                ev.grad(xd, out=g)
+                m.grad(xd, out=g)
             barrier()
             t1 = time.perf_counter()
             reps = 10
             for _ in range(reps):
-                ev.grad(xd, out=g)
+                m.grad(xd, out=g)
             barrier()
-            out["collectives"] = {"grad_plus_allreduce_ms": 1e3 * (time.perf_counter() - t1) / reps,
-                                  "allreduce_bytes": 8 * m.meta.nvar, "backend": "rccl"}
+            t_with = 1e3 * (time.perf_counter() - t1) / reps
+            m.set_reduce(False)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                m.grad(xd, out=g)
+            barrier()
+            t_without = 1e3 * (time.perf_counter() - t1) / reps
+            m.set_reduce(True)
+            out["collectives"] = {"grad_plus_allreduce_ms": t_with, "grad_partial_only_ms": t_without, "allreduce_bytes": 8 * nvar,
+                                  "transport": kind, "where": "inside libexahip (exa_comm_init -> ncclAllReduce on the model's stream)"}
         except Exception as e:  # keep the contract line alive whatever happens here
             out["collectives"] = {"error": repr(e)}
-    if args.all_callbacks:
-        g = torch.empty(m.meta.nvar, dtype=torch.float64, device=dev)
-        c = torch.empty(m.meta.ncon, dtype=torch.float64, device=dev)
-        j = torch.empty(m.meta.nnzj, dtype=torch.float64, device=dev)
+    if args.all_callbacks and world == 1:
+        xd, yd = xs, ys
+        g = torch.empty(nvar, dtype=torch.float64, device=dev)
+        c = torch.empty(max(1, ncon), dtype=torch.float64, device=dev)
+        j = torch.empty(max(1, m.meta.nnzj), dtype=torch.float64, device=dev)
         sec = {}
         for name, buf in (("obj", None), ("cons", c), ("grad", g), ("jac", j)):
             m.time_callback(name, 3, xd, out=buf)
             sec[name + "_ms"] = m.time_callback(name, 20, xd, out=buf)
         out["secondary_callbacks"] = sec
     if rank == 0 and world == 1 and not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(int(args.cpu_sample), os.cpu_count() or 1)
+        out["cpu_baseline"] = cpu_baseline(config, points, os.cpu_count() or 1)
         out["cpu_baseline"]["gpu_over_cpu_1thread"] = value / out["cpu_baseline"]["value"]
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

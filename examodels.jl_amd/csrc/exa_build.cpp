@@ -1,0 +1,446 @@
+// exa_build.cpp — turns a generated HIP module (exa_codegen.cpp) into a gfx950 code object.
+//
+// The reference specialises its kernels inside the process at first call (Julia's JIT behind
+// ext/ExaModelsKernelAbstractions.jl:608-653).  Here:
+//   1. code objects handed over in memory (exa_cache_add: packed libraries, ExaModelsCompiler's compile_library role);
+//   2. the on-disk cache, keyed by SHA-256(source) and SHA-256(flags | compiler identity | arch);
+//   3. IN-PROCESS compilation with hiprtc (the copy that sits next to the HIP runtime this process has loaded, so a
+//      process hosting PyTorch uses PyTorch's ROCm and a Julia/C host the system one) — no hipcc on the consumer's box;
+//   4. hipcc --genco as a subprocess (EXAHIP_COMPILER=hipcc, or when hiprtc cannot be loaded).
+// Cache directory: $EXAHIP_CACHE_DIR, else <install>/kernel_cache when writable, else $XDG_CACHE_HOME/exahip or
+// ~/.cache/exahip created 0700.  A directory is only used when it is a real directory owned by this user (or root) and
+// not writable by group/others; files are created O_EXCL|O_NOFOLLOW under unpredictable names and renamed into place.
+// Nothing is ever read from or written to a shared location such as /tmp.
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <pwd.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <random>
+#include <sstream>
+
+#include "exa_build.hpp"
+
+namespace exa {
+namespace {
+
+// ---- SHA-256 (FIPS 180-4) ------------------------------------------------------------------------------------
+struct Sha256 {
+    uint32_t h[8] = {0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u};
+    unsigned char buf[64];
+    size_t fill = 0;
+    uint64_t total = 0;
+    static uint32_t rotr(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void block(const unsigned char *p) {
+        static const uint32_t K[64] = {
+            0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01, 0x243185be,
+            0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc, 0x2de92c6f, 0x4a7484aa,
+            0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147, 0x06ca6351, 0x14292967, 0x27b70a85,
+            0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85, 0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3,
+            0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08, 0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f,
+            0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208, 0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+        for (int i = 16; i < 64; i++) {
+            const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+            w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+        }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; i++) {
+            const uint32_t S1 = rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25), ch = (e & f) ^ (~e & g), t1 = hh + S1 + ch + K[i] + w[i];
+            const uint32_t S0 = rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22), mj = (a & b) ^ (a & c) ^ (b & c), t2 = S0 + mj;
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    void update(const void *data, size_t n) {
+        const unsigned char *p = (const unsigned char *)data;
+        total += n;
+        while (n) {
+            const size_t k = std::min(n, 64 - fill);
+            memcpy(buf + fill, p, k);
+            fill += k; p += k; n -= k;
+            if (fill == 64) { block(buf); fill = 0; }
+        }
+    }
+    std::string hex() {
+        const uint64_t bits = total * 8;
+        const unsigned char one = 0x80, zero = 0;
+        update(&one, 1);
+        while (fill != 56) update(&zero, 1);
+        unsigned char len[8];
+        for (int i = 0; i < 8; i++) len[i] = (unsigned char)(bits >> (56 - 8 * i));
+        update(len, 8);
+        char out[65];
+        for (int i = 0; i < 8; i++) snprintf(out + 8 * i, 9, "%08x", h[i]);
+        return out;
+    }
+};
+
+std::string lib_dir() {
+    Dl_info info;
+    if (dladdr((void *)&sha256_hex, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        auto k = p.find_last_of('/');
+        if (k != std::string::npos) return p.substr(0, k);
+    }
+    return ".";
+}
+
+// a directory this process may trust for code objects: a real directory (not a symlink), owned by this user or root,
+// not writable by group or others
+bool trusted_dir(const std::string &d) {
+    struct stat st;
+    if (lstat(d.c_str(), &st) != 0 || !S_ISDIR(st.st_mode)) return false;
+    if (st.st_uid != getuid() && st.st_uid != 0) return false;
+    return (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+bool mkdir_p(const std::string &d, mode_t mode) {
+    for (size_t k = 1; k <= d.size(); k++)
+        if (k == d.size() || d[k] == '/') {
+            const std::string sub = d.substr(0, k);
+            if (mkdir(sub.c_str(), mode) != 0 && errno != EEXIST) return false;
+        }
+    return true;
+}
+
+std::string primary_dir() {
+    const char *env = getenv("EXAHIP_CACHE_DIR");
+    return env && *env ? std::string(env) : lib_dir() + "/../kernel_cache";
+}
+std::string user_dir() {
+    const char *xdg = getenv("XDG_CACHE_HOME");
+    if (xdg && *xdg == '/') return std::string(xdg) + "/exahip";
+    const char *home = getenv("HOME");
+    if (!(home && *home == '/')) {
+        struct passwd *pw = getpwuid(getuid());
+        home = pw ? pw->pw_dir : nullptr;
+    }
+    return home && *home == '/' ? std::string(home) + "/.cache/exahip" : std::string();
+}
+
+// directories that may hold cached modules (read), in search order
+std::vector<std::string> read_dirs() {
+    std::vector<std::string> v;
+    for (const std::string &d : {primary_dir(), user_dir()})
+        if (!d.empty() && trusted_dir(d)) v.push_back(d);
+    return v;
+}
+
+std::atomic<uint64_t> g_tmp_counter{0};
+std::string unique_suffix() {
+    static const uint64_t seed = [] {
+        std::random_device rd;
+        return ((uint64_t)rd() << 32) ^ rd() ^ ((uint64_t)getpid() << 20) ^ (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+    }();
+    char b[64];
+    snprintf(b, sizeof b, ".%d.%016llx.%llu.tmp", (int)getpid(), (unsigned long long)seed, (unsigned long long)g_tmp_counter++);
+    return b;
+}
+// writes `data` to a fresh file next to `final_path` (O_EXCL | O_NOFOLLOW, 0600) and renames it into place
+void write_atomically(const std::string &final_path, const void *data, size_t n) {
+    const std::string tmp = final_path + unique_suffix();
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) throw std::runtime_error("cannot create " + tmp + ": " + strerror(errno));
+    const char *p = (const char *)data;
+    size_t left = n;
+    while (left) {
+        const ssize_t k = write(fd, p, left);
+        if (k < 0) { if (errno == EINTR) continue; const std::string e = strerror(errno); close(fd); unlink(tmp.c_str()); throw std::runtime_error("write " + tmp + ": " + e); }
+        p += k; left -= (size_t)k;
+    }
+    if (fchmod(fd, 0644) != 0) { /* readable cache entries are a convenience only */ }
+    close(fd);
+    if (rename(tmp.c_str(), final_path.c_str()) != 0) {
+        const std::string e = strerror(errno);
+        unlink(tmp.c_str());
+        throw std::runtime_error("rename " + tmp + " -> " + final_path + ": " + e);
+    }
+}
+
+bool read_regular_file(const std::string &p, std::vector<char> &out) {
+    const int fd = open(p.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size <= 0 || (st.st_uid != getuid() && st.st_uid != 0)) { close(fd); return false; }
+    out.resize((size_t)st.st_size);
+    size_t got = 0;
+    while (got < out.size()) {
+        const ssize_t k = read(fd, out.data() + got, out.size() - got);
+        if (k <= 0) { if (k < 0 && errno == EINTR) continue; break; }
+        got += (size_t)k;
+    }
+    close(fd);
+    return got == out.size();
+}
+
+// an AMDGPU code object: ELF64 little-endian, e_machine = EM_AMDGPU (224)
+bool looks_like_code_object(const void *blob, size_t len) {
+    const unsigned char *p = (const unsigned char *)blob;
+    if (len < 64 || memcmp(p, "\x7f" "ELF", 4) != 0 || p[4] != 2 || p[5] != 1) return false;
+    return (p[18] | (p[19] << 8)) == 224;
+}
+// hipcc --genco wraps the ELF in a clang offload bundle; hipModuleLoadData accepts both
+bool looks_like_bundle(const void *blob, size_t len) { return len > 24 && memcmp(blob, "__CLANG_OFFLOAD_BUNDLE__", 24) == 0; }
+
+const char *kArch = "gfx950";
+std::vector<std::string> base_flags() {
+    std::vector<std::string> f = {std::string("--offload-arch=") + kArch, "-O3", "-std=c++17", "-munsafe-fp-atomics", "-w"};
+    const char *extra = getenv("EXAHIP_HIPCC_FLAGS");
+    if (extra && *extra) {
+        std::istringstream ss(extra);
+        std::string t;
+        while (ss >> t) f.push_back(t);
+    }
+    return f;
+}
+std::string join(const std::vector<std::string> &v) {
+    std::string s;
+    for (const auto &t : v) { if (!s.empty()) s += ' '; s += t; }
+    return s;
+}
+
+// ---- hiprtc, loaded from next to the HIP runtime of this process -----------------------------------------------
+struct Rtc {
+    void *lib = nullptr;
+    std::string where, identity, why_not;
+    hiprtcResult (*create)(hiprtcProgram *, const char *, const char *, int, const char **, const char **) = nullptr;
+    hiprtcResult (*compile)(hiprtcProgram, int, const char **) = nullptr;
+    hiprtcResult (*log_size)(hiprtcProgram, size_t *) = nullptr;
+    hiprtcResult (*log)(hiprtcProgram, char *) = nullptr;
+    hiprtcResult (*code_size)(hiprtcProgram, size_t *) = nullptr;
+    hiprtcResult (*code)(hiprtcProgram, char *) = nullptr;
+    hiprtcResult (*destroy)(hiprtcProgram *) = nullptr;
+    hiprtcResult (*version)(int *, int *) = nullptr;
+};
+Rtc &rtc() {
+    static Rtc r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::vector<std::string> cands;
+        Dl_info info;
+        if (dladdr((void *)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::string p = info.dli_fname;
+            auto k = p.find_last_of('/');
+            if (k != std::string::npos) { cands.push_back(p.substr(0, k) + "/libhiprtc.so.7"); cands.push_back(p.substr(0, k) + "/libhiprtc.so"); }
+        }
+        cands.push_back("libhiprtc.so.7");
+        cands.push_back("libhiprtc.so");
+        for (const auto &c : cands) {
+            r.lib = dlopen(c.c_str(), RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) { r.where = c; break; }
+        }
+        if (!r.lib) { r.why_not = std::string("libhiprtc could not be loaded: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char *n) { void *s = dlsym(r.lib, n); if (!s && r.why_not.empty()) r.why_not = std::string("libhiprtc lacks ") + n; return s; };
+        r.create = (decltype(r.create))sym("hiprtcCreateProgram");
+        r.compile = (decltype(r.compile))sym("hiprtcCompileProgram");
+        r.log_size = (decltype(r.log_size))sym("hiprtcGetProgramLogSize");
+        r.log = (decltype(r.log))sym("hiprtcGetProgramLog");
+        r.code_size = (decltype(r.code_size))sym("hiprtcGetCodeSize");
+        r.code = (decltype(r.code))sym("hiprtcGetCode");
+        r.destroy = (decltype(r.destroy))sym("hiprtcDestroyProgram");
+        r.version = (decltype(r.version))sym("hiprtcVersion");
+        if (!r.why_not.empty()) { dlclose(r.lib); r.lib = nullptr; return; }
+        int mj = 0, mn = 0, rt = 0;
+        r.version(&mj, &mn);
+        (void)hipRuntimeGetVersion(&rt);
+        r.identity = "hiprtc-" + std::to_string(mj) + "." + std::to_string(mn) + "-hip" + std::to_string(rt);
+    });
+    return r;
+}
+
+std::string hipcc_path() {
+    const char *cc = getenv("EXAHIP_HIPCC");
+    return cc && *cc ? cc : "/opt/rocm/bin/hipcc";
+}
+// first line of `hipcc --version` (once per path and process)
+std::string hipcc_identity(const std::string &path) {
+    static std::mutex mu;
+    static std::map<std::string, std::string> memo;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = memo.find(path);
+    if (it != memo.end()) return it->second;
+    std::string id = "hipcc:" + path;
+    if (access(path.c_str(), X_OK) == 0) {
+        const std::string cmd = "'" + path + "' --version 2>/dev/null";
+        if (FILE *f = popen(cmd.c_str(), "r")) {
+            char line[512];
+            for (int k = 0; k < 4 && fgets(line, sizeof line, f); k++) id += std::string("|") + line;
+            pclose(f);
+        }
+    }
+    return memo[path] = id;
+}
+
+enum class Tool { Hiprtc, Hipcc };
+Tool pick_tool(std::string &identity) {
+    const char *env = getenv("EXAHIP_COMPILER");
+    const std::string want = env ? env : "auto";
+    if (want != "auto" && want != "hiprtc" && want != "hipcc") throw std::runtime_error("EXAHIP_COMPILER must be auto, hiprtc or hipcc");
+    if (want != "hipcc") {
+        Rtc &r = rtc();
+        if (r.lib) { identity = r.identity; return Tool::Hiprtc; }
+        if (want == "hiprtc") throw std::runtime_error("EXAHIP_COMPILER=hiprtc: " + r.why_not);
+    }
+    identity = hipcc_identity(hipcc_path());
+    return Tool::Hipcc;
+}
+
+std::vector<char> compile_hiprtc(const std::string &source) {
+    Rtc &r = rtc();
+    hiprtcProgram prog = nullptr;
+    if (r.create(&prog, source.c_str(), "exa_module.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) throw std::runtime_error("hiprtcCreateProgram failed");
+    const std::vector<std::string> flags = base_flags();
+    std::vector<const char *> opts;
+    for (const auto &f : flags) opts.push_back(f.c_str());
+    const hiprtcResult rc = r.compile(prog, (int)opts.size(), opts.data());
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        r.log_size(prog, &n);
+        std::string log(n + 1, '\0');
+        if (n) r.log(prog, log.data());
+        r.destroy(&prog);
+        if (log.size() > 4000) log.resize(4000);
+        throw std::runtime_error("hiprtc failed (" + r.where + ", " + join(flags) + "):\n" + log.c_str());
+    }
+    size_t n = 0;
+    r.code_size(prog, &n);
+    std::vector<char> image(n);
+    if (n) r.code(prog, image.data());
+    r.destroy(&prog);
+    if (!looks_like_code_object(image.data(), image.size())) throw std::runtime_error("hiprtc returned something that is not a gfx950 code object");
+    return image;
+}
+
+std::vector<char> compile_hipcc(const std::string &source, const std::string &workdir) {
+    if (workdir.empty()) throw std::runtime_error("hipcc needs a writable cache directory (set EXAHIP_CACHE_DIR) and none was found");
+    const std::string stem = workdir + "/build" + unique_suffix();
+    const std::string src = stem + ".hip", obj = stem + ".hsaco", log = stem + ".log";
+    write_atomically(src, source.data(), source.size());
+    auto q = [](const std::string &p) { return "'" + p + "'"; };   // paths may contain spaces; they never contain quotes
+    const std::string cmd = q(hipcc_path()) + " --genco " + join(base_flags()) + " -o " + q(obj) + " " + q(src) + " > " + q(log) + " 2>&1";
+    const int rc = std::system(cmd.c_str());
+    std::vector<char> image;
+    const bool ok = rc == 0 && read_regular_file(obj, image);
+    std::string msg;
+    if (!ok) {
+        std::vector<char> l;
+        if (read_regular_file(log, l)) msg.assign(l.begin(), l.end());
+        if (msg.size() > 4000) msg.resize(4000);
+    }
+    unlink(src.c_str()); unlink(obj.c_str()); unlink(log.c_str());
+    if (!ok) throw std::runtime_error("hipcc failed (" + cmd + "):\n" + msg);
+    return image;
+}
+
+std::mutex g_pre_mu;
+std::map<std::string, std::vector<char>> g_preloaded;      // source key -> code object
+
+}  // namespace
+
+std::string sha256_hex(const std::string &s) {
+    Sha256 h;
+    h.update(s.data(), s.size());
+    return h.hex();
+}
+
+std::string source_key(const std::string &source) { return "exa_" + sha256_hex(source).substr(0, 32); }
+
+std::string writable_cache_dir() {
+    const std::string p = primary_dir();
+    const bool from_env = getenv("EXAHIP_CACHE_DIR") && *getenv("EXAHIP_CACHE_DIR");
+    if (!trusted_dir(p)) { if (mkdir_p(p, from_env ? 0700 : 0755)) { /* created */ } }
+    if (trusted_dir(p) && access(p.c_str(), W_OK) == 0) return p;
+    const std::string u = user_dir();
+    if (!u.empty()) {
+        if (!trusted_dir(u)) mkdir_p(u, 0700);
+        if (trusted_dir(u) && access(u.c_str(), W_OK) == 0) return u;
+    }
+    return std::string();
+}
+
+bool cache_add(const std::string &name, const void *blob, size_t len) {
+    if (name.compare(0, 4, "exa_") != 0 || !blob) return false;
+    if (!looks_like_code_object(blob, len) && !looks_like_bundle(blob, len)) return false;
+    std::lock_guard<std::mutex> lk(g_pre_mu);
+    g_preloaded[name] = std::vector<char>((const char *)blob, (const char *)blob + len);
+    return true;
+}
+
+CodeObject get_code_object(const std::string &source, bool memory_only_ok) {
+    CodeObject co;
+    co.key = source_key(source);
+    const auto t0 = std::chrono::steady_clock::now();
+    if (memory_only_ok) {      // a caller that wants the FILE (exa_compile: packing) gets a real cache entry instead
+        std::lock_guard<std::mutex> lk(g_pre_mu);
+        auto it = g_preloaded.find(co.key);
+        if (it != g_preloaded.end()) { co.image = it->second; co.how = "preloaded"; co.path = "(preloaded) " + co.key; return co; }
+    }
+    std::string identity;
+    const Tool tool = pick_tool(identity);
+    const std::string file = co.key + "-" + sha256_hex(join(base_flags()) + "|" + identity + "|" + kArch).substr(0, 12) + ".hsaco";
+    for (const std::string &d : read_dirs()) {
+        const std::string p = d + "/" + file;
+        if (read_regular_file(p, co.image) && (looks_like_code_object(co.image.data(), co.image.size()) || looks_like_bundle(co.image.data(), co.image.size()))) {
+            co.how = "disk"; co.path = p;
+            return co;
+        }
+    }
+    const std::string wdir = writable_cache_dir();
+    if (tool == Tool::Hiprtc) { co.image = compile_hiprtc(source); co.how = "hiprtc"; }
+    else { co.image = compile_hipcc(source, wdir); co.how = "hipcc"; }
+    co.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (!wdir.empty()) {
+        co.path = wdir + "/" + file;
+        try {
+            write_atomically(co.path, co.image.data(), co.image.size());
+            if (getenv("EXAHIP_KEEP_SOURCE")) write_atomically(wdir + "/" + co.key + ".hip", source.data(), source.size());
+        } catch (const std::exception &) {
+            if (!memory_only_ok) throw;
+            co.path = "(memory) " + co.key;      // a cache that cannot be written is not an error for a loaded module
+        }
+    } else {
+        if (!memory_only_ok) throw std::runtime_error("no writable kernel cache directory (EXAHIP_CACHE_DIR, <install>/kernel_cache, ~/.cache/exahip)");
+        co.path = "(memory) " + co.key;
+    }
+    return co;
+}
+
+// ---- persisted tuning decisions: <cache>/<source key>.tune, lines "<signature> <value>" ---------------------------
+bool tune_lookup(const std::string &key, const std::string &signature, int *value) {
+    for (const std::string &d : read_dirs()) {
+        std::vector<char> txt;
+        if (!read_regular_file(d + "/" + key + ".tune", txt)) continue;
+        std::istringstream ss(std::string(txt.begin(), txt.end()));
+        std::string sig;
+        int v, found = 0;
+        while (ss >> sig >> v) if (sig == signature) { *value = v; found = 1; }    // the last line for a signature wins
+        if (found) return true;
+    }
+    return false;
+}
+void tune_store(const std::string &key, const std::string &signature, int value) {
+    const std::string d = writable_cache_dir();
+    if (d.empty()) return;
+    const std::string p = d + "/" + key + ".tune";
+    std::vector<char> old;
+    std::string txt;
+    if (read_regular_file(p, old)) txt.assign(old.begin(), old.end());
+    txt += signature + " " + std::to_string(value) + "\n";
+    try { write_atomically(p, txt.data(), txt.size()); } catch (const std::exception &) { /* tuning is an optimisation */ }
+}
+
+}  // namespace exa

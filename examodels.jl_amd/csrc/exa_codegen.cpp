@@ -618,7 +618,9 @@ void emit_lines(std::ostringstream &os, const Emitter &e, const char *indent = "
 }
 
 const char *kPrelude = R"HIP(// Generated by libexahip (examodels.jl_amd/csrc/exa_codegen.cpp) for gfx950.  Do not edit.
+#ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
+#endif
 #define EXA_LOG2 0.69314718055994530942
 #define EXA_LOG10 2.30258509299404568402
 #define EXA_PI 3.14159265358979323846
@@ -1551,6 +1553,24 @@ Generated generate_module(const Model &m) {
     }
     g.source = os.str();
     return g;
+}
+
+// Smallest and largest 1-based variable index the data points [lo, hi) of a pattern read, when every index expression
+// is affine in a range column (stencil models); false = some index comes from a data column (anywhere in 1..nvar).
+// Used by exa_shard_var_range: a rank of a sharded stencil model needs only that stretch of x (plus nothing else).
+bool pattern_var_range(const Pattern &p, int64_t lo, int64_t hi, int64_t *vmin, int64_t *vmax) {
+    int64_t a = INT64_MAX, b = INT64_MIN;
+    for (const ADNode &n : p.ad) {
+        if (n.kind != AD_VAR) continue;
+        const Affine f = affine(p, n.ir);
+        if (!f.ok) return false;
+        if (f.col < 0) { a = std::min(a, f.c); b = std::max(b, f.c); continue; }
+        const Column &c = p.cols[f.col];
+        const int64_t v0 = f.a * (c.start + c.step * lo) + f.c, v1 = f.a * (c.start + c.step * (hi - 1)) + f.c;
+        a = std::min(a, std::min(v0, v1)); b = std::max(b, std::max(v0, v1));
+    }
+    *vmin = a; *vmax = b;
+    return true;
 }
 
 // ---- windowed compressed COO ------------------------------------------------------------------

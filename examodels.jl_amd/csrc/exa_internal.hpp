@@ -105,6 +105,7 @@ int block_threads();
 #define kBlock (::exa::block_threads())
 
 Generated generate_module(const Model &m);
+bool pattern_var_range(const Pattern &p, int64_t lo, int64_t hi, int64_t *vmin, int64_t *vmax);   // exa_codegen.cpp
 
 // Windowed compressed-COO kernels (exa_cjac / exa_chess fast path).  One pattern of such a kernel: every
 // slot s of data point I lands on compressed entry a_s + b * I; slots with the same a_s are added in registers (group),

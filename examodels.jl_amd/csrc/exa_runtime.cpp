@@ -21,6 +21,8 @@
 #include <sstream>
 #include <stdexcept>
 
+#include "exa_build.hpp"
+#include "exa_comm.hpp"
 #include "exa_compress.hpp"
 #include "exa_internal.hpp"
 #include "../../include/exahip_recipe.h"
@@ -55,9 +57,22 @@ struct DevBuf {
 struct Handle {
     std::unique_ptr<Model> m;
     Generated gen;
-    std::string hsaco_path;
+    std::string hsaco_path, build_how;
+    double build_ms = 0.0;
     bool on_device = false;
     int rank = 0, world = 1;
+    // multi-GPU: either an RCCL communicator or a host-supplied reducer completes obj / grad / cons / products
+    void *nccl = nullptr;
+    bool nccl_owned = false;
+    exa_allreduce_fn hook = nullptr;
+    void *hook_ctx = nullptr;
+    bool reduce = true;
+    // COO outputs of a sharded model: false = global slot positions (ranks fill disjoint slices of one global vector),
+    // true = this rank's slots packed into a slice-sized buffer, pattern after pattern (exa_set_coo_local)
+    bool coo_local = false;
+    int64_t lnnzj = 0, lnnzh = 0;            // length of the jac / hess COO buffers in the current mode
+    std::vector<int64_t> lo1, lo2;            // local first slot per pattern (coo_local)
+    std::string devname;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
     hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
@@ -67,7 +82,8 @@ struct Handle {
     DevBuf dP, dtheta, dpart, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
     int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation
     DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] sequential, [1] interleaved
-    int order[CB_COUNT] = {0};              // which map is active; -1 = not yet measured
+    int order[CB_COUNT] = {0};              // which map is active
+    bool two_orders[CB_COUNT] = {false};    // a second (interleaved) map exists: exa_tune may measure both
     int64_t fused_nobj = 0;                 // objective partial sums written by exa_fused
     std::vector<DevBuf> dcols;              // flattened over patterns
     std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
@@ -112,6 +128,7 @@ struct Handle {
             if (ev1) (void)hipEventDestroy(ev1);
             if (module) (void)hipModuleUnload(module);
         }
+        if (nccl && nccl_owned) { try { rccl_comm_destroy(nccl); } catch (...) {} }
     }
 };
 
@@ -131,101 +148,11 @@ int put(std::unique_ptr<Handle> h) {
     return (int)g_models.size();
 }
 
-// ---- kernel module build ------------------------------------------------------------------------------
-uint64_t fnv1a(const std::string &s) {
-    uint64_t h = 1469598103934665603ull;
-    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
-    return h;
-}
-
-std::string lib_dir() {
-    Dl_info info;
-    if (dladdr((void *)&fnv1a, &info) && info.dli_fname) {
-        std::string p = info.dli_fname;
-        auto k = p.find_last_of('/');
-        if (k != std::string::npos) return p.substr(0, k);
-    }
-    return ".";
-}
-
-std::string cache_dir() {
-    const char *env = getenv("EXAHIP_CACHE_DIR");
-    std::string d = env && *env ? std::string(env) : lib_dir() + "/../kernel_cache";
-    mkdir(d.c_str(), 0755);
-    if (access(d.c_str(), W_OK) != 0) {
-        // read-only installation: modules that are already cached there are still found by build_code_object;
-        // new ones go to a per-user directory under /tmp
-        const std::string alt = "/tmp/exahip_kernel_cache_" + std::to_string((long)getuid());
-        mkdir(alt.c_str(), 0700);
-        if (access(alt.c_str(), W_OK) == 0) return alt;
-    }
-    return d;
-}
-
-const char *kArch = "gfx950";
-std::string compile_flags() {
-    const char *extra = getenv("EXAHIP_HIPCC_FLAGS");
-    std::string f = std::string("--genco --offload-arch=") + kArch + " -O3 -std=c++17 -munsafe-fp-atomics -Wno-unused-parameter -Wno-unused-variable";
-    if (extra && *extra) { f += " "; f += extra; }
-    return f;
-}
-
-bool file_exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && st.st_size > 0; }
-
-// Code objects handed over in memory (exa_cache_add): a packed library carries the module it was built with, so its
-// consumer needs neither hipcc nor a writable cache (the ahead-of-time half of ExaModelsCompiler's compile_library).
-std::mutex g_pre_mu;
-std::map<std::string, std::vector<char>> g_preloaded;      // "exa_<hash>" -> code object
-
-std::string module_name(const std::string &source) {
-    char name[64];
-    snprintf(name, sizeof name, "exa_%016llx", (unsigned long long)fnv1a(source + "|" + compile_flags()));
-    return name;
-}
-
-// Compiles `source` for gfx950 into the on-disk cache; returns the path of the code object.
-std::string build_code_object(const std::string &source) {
-    const std::string flags = compile_flags();
-    char name[64];
-    snprintf(name, sizeof name, "exa_%016llx", (unsigned long long)fnv1a(source + "|" + flags));
-    const std::string dir = cache_dir();
-    const std::string src = dir + "/" + name + ".hip", obj = dir + "/" + name + ".hsaco";
-    if (file_exists(obj)) return obj;
-    {   // a read-only primary cache (cache_dir fell back to /tmp) may still hold the module
-        const char *env = getenv("EXAHIP_CACHE_DIR");
-        const std::string primary = (env && *env ? std::string(env) : lib_dir() + "/../kernel_cache") + "/" + name + ".hsaco";
-        if (primary != obj && file_exists(primary)) return primary;
-    }
-    const std::string tag = "." + std::to_string((long)getpid());
-    {
-        std::ofstream o(src + tag);
-        if (!o) throw std::runtime_error("cannot write kernel source to " + src);
-        o << source;
-    }
-    rename((src + tag).c_str(), src.c_str());
-    const char *cc = getenv("EXAHIP_HIPCC");
-    std::string hipcc = cc && *cc ? cc : "/opt/rocm/bin/hipcc";
-    const std::string log = obj + tag + ".log";
-    auto q = [](const std::string &p) { return "'" + p + "'"; };   // paths may contain spaces; they never contain quotes
-    const std::string cmd = q(hipcc) + " " + flags + " -o " + q(obj + tag) + " " + q(src) + " > " + q(log) + " 2>&1";
-    const int rc = std::system(cmd.c_str());
-    if (rc != 0 || !file_exists(obj + tag)) {
-        std::ifstream l(log);
-        std::stringstream ss;
-        ss << l.rdbuf();
-        std::string msg = ss.str();
-        if (msg.size() > 4000) msg.resize(4000);
-        throw std::runtime_error("hipcc failed (" + cmd + "):\n" + msg);
-    }
-    unlink(log.c_str());
-    rename((obj + tag).c_str(), obj.c_str());
-    return obj;
-}
-
-std::vector<char> read_file(const std::string &p) {
-    std::ifstream f(p, std::ios::binary);
-    if (!f) throw std::runtime_error("cannot read " + p);
-    return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+// What a measured decision depends on: device, shard, sizes of every pattern (the module itself is the file's name).
+std::string tune_signature(const Handle &h, const std::string &what) {
+    std::string t = h.devname + "|" + std::to_string(h.rank) + "/" + std::to_string(h.world) + "|" + (h.coo_local ? "L" : "G");
+    for (const Pattern &p : h.m->pats) t += "," + std::to_string(p.n);
+    return what + ":" + sha256_hex(t).substr(0, 16);
 }
 
 // ---- parameter table -------------------------------------------------------------------------------------
@@ -233,16 +160,29 @@ void fill_params(Handle &h) {
     const Model &m = *h.m;
     const ParamLayout &L = h.gen.layout;
     h.P.assign((size_t)L.nwords, 0);
+    // Local-slice COO (exa_set_coo_local): this rank's slots of pattern k are the contiguous global range
+    // [o + step*lo, o + step*hi); packed pattern after pattern they start at local offset l.  Every kernel addresses a
+    // slot as P[o] + step*I, so installing P[o] = l - step*lo redirects all of them (values and structures) at once.
+    const bool local = h.coo_local && h.world > 1;
+    int64_t l1 = 0, l2 = 0;
+    h.lo1.assign(m.pats.size(), 0); h.lo2.assign(m.pats.size(), 0);
     for (size_t k = 0; k < m.pats.size(); k++) {
         const Pattern &p = m.pats[k];
         const auto &pp = L.pat[k];
         const int64_t lo = (int64_t)((__int128)p.n * h.rank / h.world), hi = (int64_t)((__int128)p.n * (h.rank + 1) / h.world);
         h.P[pp.lo] = lo; h.P[pp.hi] = hi; h.P[pp.o0] = p.o0; h.P[pp.o1] = p.o1; h.P[pp.o2] = p.o2; h.P[pp.oa] = p.oa;
+        h.lo1[k] = l1; h.lo2[k] = l2;
+        if (local) {
+            if (p.kind != EXA_PAT_OBJ) { h.P[pp.o1] = l1 - (int64_t)p.o1step * lo; l1 += (int64_t)p.o1step * (hi - lo); }
+            h.P[pp.o2] = l2 - (int64_t)p.o2step * lo; l2 += (int64_t)p.o2step * (hi - lo);
+        }
         for (size_t c = 0; c < p.cols.size(); c++) {
             if (p.cols[c].type == EXA_COL_RANGE) h.P[pp.col[c]] = p.cols[c].start;
             else h.P[pp.col[c]] = h.on_device ? (int64_t)(uintptr_t)h.dcols[h.colslot[k][c]].p : 0;
         }
     }
+    h.lnnzj = local ? l1 : m.nnzj;
+    h.lnnzh = local ? l2 : m.nnzh;
     // Block maps: workgroup b -> (pattern slot, tile).  Two orders are prepared per callback:
     //   [0] sequential  — patterns one after the other, each streaming its own contiguous COO range;
     //   [1] interleaved — patterns advance together in proportion to their tile counts, in runs of 128 workgroups: the
@@ -299,6 +239,7 @@ void fill_params(Handle &h) {
         const bool tunable = cb == CB_HESS || cb == CB_JAC || cb == CB_FUSED || cb == CB_CONS;
         const bool two = h.on_device && total > 0 && na > 1 && (il_forced > 0 || (il_forced < 0 && tunable && out_bytes >= 128e6));
         h.order[cb] = 0;
+        h.two_orders[cb] = false;
         h.P[L.blk[cb]] = 0;
         if (h.on_device && total > 0) {
             std::vector<int64_t> m0 = build(0);
@@ -310,7 +251,16 @@ void fill_params(Handle &h) {
                 h.dmap[cb][1].ensure(sizeof(int64_t) * m1.size());
                 HIPCHK(hipMemcpy(h.dmap[cb][1].p, m1.data(), sizeof(int64_t) * m1.size(), hipMemcpyHostToDevice));
                 if (il_forced > 0) { h.order[cb] = 1; h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][1].p; }
-                else h.order[cb] = -1;   // undecided: measured at the first call
+                else {
+                    // both orders exist: exa_tune measures them; until then (and in later processes) the persisted
+                    // decision for this module / device / sizes applies, else the sequential order
+                    h.two_orders[cb] = true;
+                    int v = 0;
+                    if (tune_lookup(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), &v) && (v == 0 || v == 1)) {
+                        h.order[cb] = v;
+                        h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][v].p;
+                    }
+                }
             }
         }
     }
@@ -327,16 +277,14 @@ void to_device(Handle &h) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
         throw HipError("no HIP device available (libexahip has no CPU fallback): " + std::string(hipGetErrorString(e)));
-    std::vector<char> image;
+    CodeObject co = get_code_object(h.gen.source, true);
+    std::vector<char> &image = co.image;
+    h.hsaco_path = co.path; h.build_how = co.how; h.build_ms = co.build_ms;
     {
-        const std::string name = module_name(h.gen.source);
-        std::lock_guard<std::mutex> lk(g_pre_mu);
-        auto it = g_preloaded.find(name);
-        if (it != g_preloaded.end()) { image = it->second; h.hsaco_path = "(preloaded) " + name; }
-    }
-    if (image.empty()) {
-        h.hsaco_path = build_code_object(h.gen.source);
-        image = read_file(h.hsaco_path);
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            h.devname = std::string(prop.gcnArchName) + "/" + std::to_string(prop.multiProcessorCount);
     }
     h.on_device = true;   // from here on the destructor releases whatever was acquired
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
@@ -396,17 +344,12 @@ void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **arg
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, block, 1, 1, 0, h.stream, args, nullptr));
 }
 
-// Chooses the block order of callback `cb` by measurement: 1 warm-up + 3 timed launches of each order on the model's
-// stream (the outputs are simply rewritten with the same values), then the faster map is installed in P[].
+// Chooses the block order of callback `cb` by measurement (exa_tune only — callbacks never measure): both orders are
+// timed on the model's stream (the outputs are simply rewritten with the same values), the faster map is installed in
+// P[] and the decision persisted next to the cached module.  Synchronises the stream.
 template <class F>
 void tune_order(Handle &h, int cb, F &&run) {
-    if (h.order[cb] >= 0) return;
-    // a stream that is being captured into a hipGraph cannot be synchronised: keep the default order for the captured
-    // launches and measure at the first call outside a capture
-    {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(h.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return;
-    }
+    if (!h.two_orders[cb]) return;
     const ParamLayout &L = h.gen.layout;
     float t[2] = {1e30f, 1e30f};
     // bring the clocks up first: the governor idles at ~570 MHz and needs tens of ms of load, and at low clocks the two
@@ -444,6 +387,7 @@ void tune_order(Handle &h, int cb, F &&run) {
     h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][best].p;
     HIPCHK(hipMemcpyAsync((int64_t *)h.dP.p + L.blk[cb], &h.P[L.blk[cb]], 8, hipMemcpyHostToDevice, h.stream));
     HIPCHK(hipStreamSynchronize(h.stream));
+    tune_store(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), best);
 }
 
 // second stage of cons_nln! / jprod_nln! / the fused sweep: add the buffered augmentation terms to their rows
@@ -463,16 +407,29 @@ void aug_gather(Handle &h, void *buf, double *c) {
     launch(h, h.f_augfold, (nlong + kBlock - 1) / kBlock, kBlock, a5);
 }
 
+// Completes a partial result of a sharded model: sum over the ranks, in place, on the model's stream — RCCL
+// (exa_comm_init / exa_comm_attach) or the host's reducer (exa_comm_hook).  A model without a communicator returns its
+// partial sums (exa_set_shard alone: the host layer reduces).
+void allreduce(Handle &h, double *buf, int64_t count) {
+    if (!h.reduce || count <= 0) return;
+    if (h.nccl) rccl_allreduce_sum_f64(h.nccl, buf, count, h.stream);
+    else if (h.hook) {
+        const int rc = h.hook(h.hook_ctx, buf, count, (void *)h.stream);
+        if (rc != 0) throw std::runtime_error("the host's all-reduce hook returned status " + std::to_string(rc));
+    }
+}
+
 // ---- callbacks (device pointers, asynchronous) ------------------------------------------------------------
 void do_obj(Handle &h, const double *x, double *out_dev) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *part = h.dpart.p;
     int64_t n = h.grid[CB_OBJ];
-    if (n == 0) { HIPCHK(hipMemsetAsync(out_dev, 0, sizeof(double), h.stream)); return; }
+    if (n == 0) { HIPCHK(hipMemsetAsync(out_dev, 0, sizeof(double), h.stream)); allreduce(h, out_dev, 1); return; }
     void *a1[] = {&P, &x, &th, &part};
     launch(h, h.f_obj, n, kBlock, a1);
     void *a2[] = {&part, &n, &out_dev};
     launch(h, h.f_red, 1, 1024, a2);
+    allreduce(h, out_dev, 1);
 }
 void do_grad(Handle &h, const double *x, double *g) {
     const void *P = h.dP.p, *th = h.dtheta.p;
@@ -487,6 +444,7 @@ void do_grad(Handle &h, const double *x, double *g) {
     }
     void *a[] = {&P, &x, &th, &g};
     launch(h, h.f_grad, h.grid[CB_GRAD], kBlock, a);   // scattered patterns: FP64 hardware atomics on top
+    allreduce(h, g, nvar);
 }
 void do_cons(Handle &h, const double *x, double *c) {
     if (h.m->ncon == 0) return;
@@ -498,21 +456,18 @@ void do_cons(Handle &h, const double *x, double *c) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     // one launch: base rows (plain stores into c) and augmentation terms (into the value buffer, coalesced)
     void *a[] = {&P, &x, &th, &c, &buf};
-    tune_order(h, CB_CONS, [&] { launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a); });
     launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a);
-    if (h.m->nconaug == 0) return;
-    aug_gather(h, buf, c);       // then one deterministic gather per target row
+    if (h.m->nconaug) aug_gather(h, buf, c);       // then one deterministic gather per target row
+    allreduce(h, c, h.m->ncon);
 }
 void do_jac(Handle &h, const double *x, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &th, &v};
-    tune_order(h, CB_JAC, [&] { launch(h, h.f_jac, h.grid[CB_JAC], kBlock, a); });
     launch(h, h.f_jac, h.grid[CB_JAC], kBlock, a);
 }
 void do_hess(Handle &h, const double *x, const double *y, double sigma, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &y, &th, &v, &sigma};
-    tune_order(h, CB_HESS, [&] { launch(h, h.f_hess, h.grid[CB_HESS], kBlock, a); });
     launch(h, h.f_hess, h.grid[CB_HESS], kBlock, a);
 }
 // fused obj + cons_nln! + jac_coord! + hess_coord! at one x
@@ -525,12 +480,13 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
     }
     int64_t n = h.grid[CB_FUSED];
     void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma};
-    tune_order(h, CB_FUSED, [&] { launch(h, h.f_fused, n, kBlock, a); });
     launch(h, h.f_fused, n, kBlock, a);
     int64_t nobj = h.fused_nobj;
     if (n > 0 && nobj > 0) { void *a2[] = {&part, &nobj, &obj_dev}; launch(h, h.f_red, 1, 1024, a2); }
     else HIPCHK(hipMemsetAsync(obj_dev, 0, sizeof(double), h.stream));
     if (h.m->nconaug) aug_gather(h, buf, c);
+    allreduce(h, obj_dev, 1);
+    if (h.m->ncon) allreduce(h, c, h.m->ncon);
 }
 // matrix-free products (jprod_nln! / jtprod_nln! / hprod!, nlp.jl:1882-1978)
 void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
@@ -543,8 +499,8 @@ void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &th, &v, &Jv, &buf};
     launch(h, h.f_jprod, h.grid[CB_JPROD], kBlock, a);
-    if (h.m->nconaug == 0) return;
-    aug_gather(h, buf, Jv);
+    if (h.m->nconaug) aug_gather(h, buf, Jv);
+    allreduce(h, Jv, h.m->ncon);
 }
 void do_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
     HIPCHK(hipMemsetAsync(Jtv, 0, sizeof(double) * (size_t)h.m->nvar, h.stream));
@@ -569,24 +525,31 @@ void do_hess(Handle &h, const double *x, const double *y, double sigma, double *
 // (rocket's shared step variable, ACOPF bus rows).
 void prod_setup(Handle &h, bool hess) {
     const Model &m = *h.m;
-    h.cbuf.ensure(8 * (size_t)std::max<int64_t>(std::max(m.nnzj, m.nnzh), 1));
+    // sorted lists describe the COO this process evaluates: the whole model, or (sharded) the local slice
+    if (h.world != 1 && !h.coo_local) throw BadInput("sorted products of a sharded model need the local-slice COO (exa_set_coo_local)");
+    const int64_t nnzj = h.lnnzj, nnzh = h.lnnzh;
+    h.cbuf.ensure(8 * (size_t)std::max<int64_t>(std::max(nnzj, nnzh), 1));
     if (!hess && !h.prod_ready_j) {
-        h.pjrows.ensure(8 * (size_t)std::max<int64_t>(m.nnzj, 1)); h.pjcols.ensure(8 * (size_t)std::max<int64_t>(m.nnzj, 1));
+        h.pjrows.ensure(8 * (size_t)std::max<int64_t>(nnzj, 1)); h.pjcols.ensure(8 * (size_t)std::max<int64_t>(nnzj, 1));
         do_struct(h, false, true, h.pjrows.p, h.pjcols.p);
-        build_sorted_index(h.jbycol, (const int64_t *)h.pjcols.p, m.nnzj, m.nvar, h.stream);
+        build_sorted_index(h.jbycol, (const int64_t *)h.pjcols.p, nnzj, m.nvar, h.stream);
         attach_other(h.jbycol, (const int64_t *)h.pjrows.p, nullptr, nullptr, false, m.ncon, h.stream);
         h.prod_ready_j = true;
     }
     if (hess && !h.prod_ready_h) {
-        h.phrows.ensure(8 * (size_t)std::max<int64_t>(m.nnzh, 1)); h.phcols.ensure(8 * (size_t)std::max<int64_t>(m.nnzh, 1));
+        h.phrows.ensure(8 * (size_t)std::max<int64_t>(nnzh, 1)); h.phcols.ensure(8 * (size_t)std::max<int64_t>(nnzh, 1));
         do_struct(h, true, true, h.phrows.p, h.phcols.p);
-        build_sorted_index(h.hbyrow, (const int64_t *)h.phrows.p, m.nnzh, m.nvar, h.stream);
-        build_sorted_index(h.hbycol, (const int64_t *)h.phcols.p, m.nnzh, m.nvar, h.stream);
+        build_sorted_index(h.hbyrow, (const int64_t *)h.phrows.p, nnzh, m.nvar, h.stream);
+        build_sorted_index(h.hbycol, (const int64_t *)h.phcols.p, nnzh, m.nvar, h.stream);
         const int64_t *r = (const int64_t *)h.phrows.p, *c = (const int64_t *)h.phcols.p;
         attach_other(h.hbyrow, c, r, c, false, m.nvar, h.stream);     // lower triangle incl. diagonal: gathers v[col]
         attach_other(h.hbycol, r, r, c, true, m.nvar, h.stream);      // its transpose, off-diagonal only: gathers v[row]
         h.prod_ready_h = true;
     }
+}
+void drop_sorted(Handle &h, bool hess) {
+    if (!hess) { h.jbycol.release(); h.pjrows.release(); h.pjcols.release(); h.prod_ready_j = false; }
+    else { h.hbyrow.release(); h.hbycol.release(); h.phrows.release(); h.phcols.release(); h.prod_ready_h = false; }
 }
 void do_jtprod_sorted(Handle &h, const double *x, const double *v, double *Jtv) {
     do_jac(h, x, (double *)h.cbuf.p);
@@ -692,20 +655,21 @@ int exa_new_from_table(const exa_model_desc_t *desc, int *id_out) { return creat
 int exa_plan_only(const exa_model_desc_t *desc, int *id_out) { return create(desc, id_out, false); }
 
 int exa_cache_add(const char *name, const void *code_object, size_t len) {
-    if (!name || !code_object || len == 0 || std::strncmp(name, "exa_", 4) != 0) return 1;
-    std::lock_guard<std::mutex> lk(g_pre_mu);
-    g_preloaded[name] = std::vector<char>((const char *)code_object, (const char *)code_object + len);
-    return 0;
+    if (!name || !code_object || len == 0) return 1;
+    return cache_add(name, code_object, len) ? 0 : 1;     // refuses anything that is not an AMDGPU code object
 }
 const char *exa_module_name(int id) {
     Handle *h = get(id);
     if (!h) return nullptr;
     static thread_local std::string name;
-    name = module_name(h->gen.source);
+    name = source_key(h->gen.source);
     return name.c_str();
 }
 int exa_compile(int id) {
-    return guard(id, false, [&](Handle &h) { h.hsaco_path = build_code_object(h.gen.source); });
+    return guard(id, false, [&](Handle &h) {
+        CodeObject co = get_code_object(h.gen.source, false);
+        h.hsaco_path = co.path; h.build_how = co.how; h.build_ms = co.build_ms;
+    });
 }
 const char *exa_code_object_path(int id) {
     Handle *h = get(id);
@@ -765,14 +729,25 @@ int exa_meta(int id, double *x0, double *lvar, double *uvar, double *lcon, doubl
 }
 const char *exa_kernel_source(int id) { Handle *h = get(id); return h ? h->gen.source.c_str() : nullptr; }
 
+// new shard and/or COO addressing: the parameter table, and everything derived from the local COO, start over
+static void reshard(Handle &h, int rank, int world, bool coo_local) {
+    if (h.on_device) HIPCHK(hipStreamSynchronize(h.stream));
+    if ((h.nccl || h.hook) && (rank != h.rank || world != h.world)) throw BadInput("the model's communicator fixes its shard (exa_comm_free first)");
+    h.rank = rank; h.world = world; h.coo_local = coo_local;
+    fill_params(h);
+    if (h.on_device) {
+        drop_sorted(h, false); drop_sorted(h, true);
+        if (h.compressed) {
+            h.cj.release(); h.ch.release(); h.compressed = false;
+            for (Handle::Window *w : {&h.wj, &h.wh}) { w->ok = false; w->why.clear(); }
+        }
+    }
+}
 int exa_set_stream(int id, void *s) { return guard(id, true, [&](Handle &h) { h.stream = (hipStream_t)s; }); }
 int exa_set_shard(int id, int rank, int world) {
     if (world < 1 || rank < 0 || rank >= world) return 1;
     return guard(id, false, [&](Handle &h) {
-        if (h.on_device) HIPCHK(hipStreamSynchronize(h.stream));
-        h.rank = rank; h.world = world;
-        fill_params(h);
-        if (world != 1) { if (h.jt_mode == 1) h.jt_mode = -1; if (h.hp_mode == 1) h.hp_mode = -1; }
+        reshard(h, rank, world, h.coo_local);
     });
 }
 int exa_set_value(int id, int64_t offset, const double *vals, int64_t len) {
@@ -893,34 +868,30 @@ int exa_jprod(int id, const double *x, const double *v, double *Jv) {
     if (!x || !v) return 1;
     return guard(id, true, [&](Handle &h) { if (h.m->ncon && !Jv) throw BadInput("null output"); do_jprod(h, x, v, Jv); });
 }
-static bool capturing(Handle &h) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    return hipStreamIsCapturing(h.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+// Which implementation a product runs is a property of the model fixed BEFORE the call: explicit (exa_set_product_mode),
+// measured once by exa_tune and persisted next to the cached module, or — undecided and never tuned — the atomics of the
+// sweep.  Callbacks never measure and never synchronise.
+static bool sorted_possible(Handle &h, bool hess) {
+    const int64_t nnz = hess ? h.lnnzh : h.lnnzj;
+    return (h.world == 1 || h.coo_local) && nnz > 0;
+}
+static int resolve_mode(Handle &h, bool hess) {
+    int &mode = hess ? h.hp_mode : h.jt_mode;
+    if (mode < 0) {
+        int v = 0;
+        mode = tune_lookup(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), &v) && v == 1 && sorted_possible(h, hess) ? 1 : 0;
+    }
+    if (mode == 1 && !sorted_possible(h, hess)) return 0;      // sharded at global positions: nothing to sort locally
+    if (mode == 1) prod_setup(h, hess);                          // no-op once the lists exist
+    return mode;
 }
 static void run_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
-    if (h.jt_mode < 0 && capturing(h)) { do_jtprod(h, x, v, Jtv); return; }   // measuring needs a synchronisation
-    if (h.jt_mode < 0) {
-        // sorted lists describe the unsharded COO; beyond 3e8 entries the trial's transient memory is not worth it
-        if (h.world != 1 || h.m->nnzj == 0 || h.m->nnzj > 300000000LL) h.jt_mode = 0;
-        else {
-            prod_setup(h, false);
-            h.jt_mode = pick_faster(h, [&] { do_jtprod(h, x, v, Jtv); }, [&] { do_jtprod_sorted(h, x, v, Jtv); });
-            if (h.jt_mode == 0) { h.jbycol.release(); h.pjrows.release(); h.pjcols.release(); h.prod_ready_j = false; }
-        }
-    }
-    if (h.jt_mode == 1 && h.world == 1) do_jtprod_sorted(h, x, v, Jtv); else do_jtprod(h, x, v, Jtv);
+    if (resolve_mode(h, false) == 1) do_jtprod_sorted(h, x, v, Jtv); else do_jtprod(h, x, v, Jtv);
+    allreduce(h, Jtv, h.m->nvar);
 }
 static void run_hprod(Handle &h, const double *x, const double *y, const double *v, double w, double *Hv) {
-    if (h.hp_mode < 0 && capturing(h)) { do_hprod(h, x, y, v, w, Hv); return; }
-    if (h.hp_mode < 0) {
-        if (h.world != 1 || h.m->nnzh == 0 || h.m->nnzh > 300000000LL) h.hp_mode = 0;
-        else {
-            prod_setup(h, true);
-            h.hp_mode = pick_faster(h, [&] { do_hprod(h, x, y, v, w, Hv); }, [&] { do_hprod_sorted(h, x, y, v, w, Hv); });
-            if (h.hp_mode == 0) { h.hbyrow.release(); h.hbycol.release(); h.phrows.release(); h.phcols.release(); h.prod_ready_h = false; }
-        }
-    }
-    if (h.hp_mode == 1 && h.world == 1) do_hprod_sorted(h, x, y, v, w, Hv); else do_hprod(h, x, y, v, w, Hv);
+    if (resolve_mode(h, true) == 1) do_hprod_sorted(h, x, y, v, w, Hv); else do_hprod(h, x, y, v, w, Hv);
+    allreduce(h, Hv, h.m->nvar);
 }
 int exa_jtprod(int id, const double *x, const double *v, double *Jtv) {
     if (!x || !Jtv) return 1;
@@ -933,15 +904,13 @@ int exa_hprod(int id, const double *x, const double *y, const double *v, double 
         run_hprod(h, x, y, v, w, Hv);
     });
 }
-/* 0 = atomics inside the sweep, 1 = COO + sorted gather, -1 = decide by measurement at the next call (default) */
+/* 0 = atomics inside the sweep, 1 = COO + sorted gather, -1 = undecided (default): the decision exa_tune persisted for
+ * this module / device / sizes if there is one, else 0 */
 int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode) {
     if (jtprod_mode < -1 || jtprod_mode > 1 || hprod_mode < -1 || hprod_mode > 1) return 1;
     return guard(id, true, [&](Handle &h) {
-        if (jtprod_mode == 1 || hprod_mode == 1) {
-            if (h.world != 1) throw BadInput("sorted products need the unsharded model");
-            if (jtprod_mode == 1) prod_setup(h, false);
-            if (hprod_mode == 1) prod_setup(h, true);
-        }
+        if (jtprod_mode == 1) prod_setup(h, false);      // refuses a sharded model at global positions (status 1)
+        if (hprod_mode == 1) prod_setup(h, true);
         h.jt_mode = jtprod_mode; h.hp_mode = hprod_mode;
     });
 }
@@ -952,10 +921,10 @@ int exa_get_product_mode(int id, int *jtprod_mode, int *hprod_mode) {
     return 0;
 }
 int exa_jac_structure(int id, int32_t *r, int32_t *c) {
-    return guard(id, true, [&](Handle &h) { if (h.m->nnzj > 0x7fffffffLL) throw std::runtime_error("nnzj exceeds int32"); do_struct(h, false, false, r, c); });
+    return guard(id, true, [&](Handle &h) { if (h.lnnzj > 0x7fffffffLL) throw std::runtime_error("nnzj exceeds int32"); do_struct(h, false, false, r, c); });
 }
 int exa_hess_structure(int id, int32_t *r, int32_t *c) {
-    return guard(id, true, [&](Handle &h) { if (h.m->nnzh > 0x7fffffffLL) throw std::runtime_error("nnzh exceeds int32"); do_struct(h, true, false, r, c); });
+    return guard(id, true, [&](Handle &h) { if (h.lnnzh > 0x7fffffffLL) throw std::runtime_error("nnzh exceeds int32"); do_struct(h, true, false, r, c); });
 }
 int exa_jac_structure64(int id, int64_t *r, int64_t *c) { return guard(id, true, [&](Handle &h) { do_struct(h, false, true, r, c); }); }
 int exa_hess_structure64(int id, int64_t *r, int64_t *c) { return guard(id, true, [&](Handle &h) { do_struct(h, true, true, r, c); }); }
@@ -993,7 +962,7 @@ int exa_cons_host(int id, const double *x, double *c) {
 int exa_jac_host(int id, const double *x, double *v) {
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) {
-        const size_t n = 8 * (size_t)h.m->nnzj;
+        const size_t n = 8 * (size_t)h.lnnzj;
         if (!n) return;
         h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
         h.sout.ensure(n);
@@ -1004,7 +973,7 @@ int exa_jac_host(int id, const double *x, double *v) {
 int exa_hess_host(int id, const double *x, const double *y, double w, double *v) {
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) {
-        const size_t n = 8 * (size_t)h.m->nnzh;
+        const size_t n = 8 * (size_t)h.lnnzh;
         if (!n) return;
         h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
         if (h.m->ncon) { if (!y) throw std::runtime_error("null multipliers"); h2d(h, h.sy, y, 8 * (size_t)h.m->ncon); }
@@ -1053,7 +1022,7 @@ int exa_hprod_host(int id, const double *x, const double *y, const double *v, do
 }
 static int struct_host(int id, bool hess, bool wide, void *r, void *c) {
     return guard(id, true, [&](Handle &h) {
-        const int64_t nz = hess ? h.m->nnzh : h.m->nnzj;
+        const int64_t nz = hess ? h.lnnzh : h.lnnzj;
         if (!nz) return;
         if (!wide && nz > 0x7fffffffLL) throw std::runtime_error("nnz exceeds int32");
         const size_t n = (wide ? 8 : 4) * (size_t)nz;
@@ -1400,6 +1369,7 @@ void window_setup(Handle &h) {
     if (h.wmodule) { (void)hipModuleUnload(h.wmodule); h.wmodule = nullptr; }
     const char *env = getenv("EXAHIP_CWINDOW");
     if (env && atoi(env) == 0) { h.wj.why = h.wh.why = "disabled (EXAHIP_CWINDOW=0)"; return; }
+    if (h.world != 1) { h.wj.why = h.wh.why = "sharded model: the windows are planned for whole patterns"; return; }
     const Model &m = *h.m;
     if (std::max(m.nnzj, m.nnzh) > 0x7fffffffLL) { h.wj.why = h.wh.why = "nnz exceeds int32"; return; }
     WindowSpec spec;
@@ -1421,16 +1391,10 @@ void window_setup(Handle &h) {
     const std::string src = generate_window_module(m, h.gen.layout, spec);
     if (const char *dump = getenv("EXAHIP_DUMP_WINDOW")) { FILE *f = fopen(dump, "w"); if (f) { fwrite(src.data(), 1, src.size(), f); fclose(f); } }
     std::vector<char> image;
-    {
-        const std::string name = module_name(src);
-        std::lock_guard<std::mutex> lk(g_pre_mu);
-        auto it = g_preloaded.find(name);
-        if (it != g_preloaded.end()) image = it->second;
-    }
     // the gather path needs no second module: a host without hipcc (a packed library's consumer) or a failed compilation
     // must not take exa_compress down with it
     try {
-        if (image.empty()) image = read_file(build_code_object(src));
+        image = get_code_object(src, true).image;
         HIPCHK(hipModuleLoadData(&h.wmodule, image.data()));
         auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
         if (okj) { h.wj.fw = fn("exa_cjacw"); h.wj.fx = fn("exa_cjacx"); if (h.wj.ns_blocks) h.wj.fs = fn("exa_cjacs"); }
@@ -1475,20 +1439,25 @@ void do_window(Handle &h, bool hess, const double *x, const double *y, double si
 // ---- compressed COO (CompressedNLPModel, src/utils.jl:425-579) ---------------------------------------------
 int exa_compress(int id) {
     return guard(id, true, [&](Handle &h) {
-        if (h.world != 1) throw std::runtime_error("exa_compress needs the unsharded model (every slot must be evaluated locally)");
+        // A sharded model compresses the COO it evaluates: its local slice.  Every rank then holds a duplicate-summed
+        // matrix of its own data points (its own structure, exa_c*_structure); the model's matrix is the SUM of the ranks'
+        // matrices — entries that data points of two ranks share (stencil neighbours at a shard boundary, bus rows) appear
+        // on both, which is what a distributed assembly expects.
+        if (h.world != 1 && !h.coo_local) throw BadInput("exa_compress of a sharded model needs the local-slice COO (exa_set_coo_local)");
         const Model &m = *h.m;
-        const int64_t mx = std::max(m.nnzj, m.nnzh);
+        const int64_t nnzj = h.lnnzj, nnzh = h.lnnzh;
+        const int64_t mx = std::max<int64_t>(std::max(nnzj, nnzh), 1);
         DevBuf r, c;
         r.ensure(8 * (size_t)mx); c.ensure(8 * (size_t)mx);
         try {
             do_struct(h, false, true, r.p, c.p);
-            build_compressed(h.cj, (const int64_t *)r.p, (const int64_t *)c.p, m.nnzj, std::max<int64_t>(m.ncon, 1), std::max<int64_t>(m.nvar, 1), h.stream);
+            build_compressed(h.cj, (const int64_t *)r.p, (const int64_t *)c.p, nnzj, std::max<int64_t>(m.ncon, 1), std::max<int64_t>(m.nvar, 1), h.stream);
             do_struct(h, true, true, r.p, c.p);
-            build_compressed(h.ch, (const int64_t *)r.p, (const int64_t *)c.p, m.nnzh, std::max<int64_t>(m.nvar, 1), std::max<int64_t>(m.nvar, 1), h.stream);
+            build_compressed(h.ch, (const int64_t *)r.p, (const int64_t *)c.p, nnzh, std::max<int64_t>(m.nvar, 1), std::max<int64_t>(m.nvar, 1), h.stream);
         } catch (...) { r.release(); c.release(); throw; }
         r.release(); c.release();
         window_setup(h);
-        if (!(h.wj.ok || m.nnzj == 0) || !(h.wh.ok || m.nnzh == 0)) h.cbuf.ensure(8 * (size_t)mx);
+        if (!(h.wj.ok || nnzj == 0) || !(h.wh.ok || nnzh == 0)) h.cbuf.ensure(8 * (size_t)mx);
         h.compressed = true;
     });
 }
@@ -1580,5 +1549,165 @@ int exa_block_order(int id, int which) {
     return cb < 0 ? -2 : h->order[cb];
 }
 int exa_sync(int id) { return guard(id, true, [&](Handle &h) { HIPCHK(hipStreamSynchronize(h.stream)); }); }
+
+// ---- explicit tuning (the only place that measures; callbacks never do) ------------------------------------------------
+int exa_tune(int id, int what, const double *x, const double *y) {
+    if (what < 0 || what > 3) return 1;
+    return guard(id, true, [&](Handle &h) {
+        const Model &m = *h.m;
+        struct Tmp { DevBuf b[8]; ~Tmp() { for (auto &q : b) q.release(); } } t;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(h.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) throw BadInput("exa_tune cannot run inside a stream capture");
+        if (!x) {
+            std::vector<double> x0 = m.x0;
+            if (x0.empty()) x0.assign((size_t)m.nvar, 0.0);
+            t.b[0].ensure(8 * x0.size());
+            HIPCHK(hipMemcpy(t.b[0].p, x0.data(), 8 * x0.size(), hipMemcpyHostToDevice));
+            x = (const double *)t.b[0].p;
+        }
+        if (!y && m.ncon) {
+            std::vector<double> ones((size_t)m.ncon, 1.0);
+            t.b[1].ensure(8 * ones.size());
+            HIPCHK(hipMemcpy(t.b[1].p, ones.data(), 8 * ones.size(), hipMemcpyHostToDevice));
+            y = (const double *)t.b[1].p;
+        }
+        const bool reduce = h.reduce;
+        h.reduce = false;                      // ranks measure on their own: no collective inside a measurement
+        struct Restore { Handle &h; bool r; ~Restore() { h.reduce = r; } } restore{h, reduce};
+        const double sigma = 0.5;
+        double *c = nullptr, *jv = nullptr, *hv = nullptr, *obj = (double *)h.dobj.p, *g = nullptr;
+        auto need = [&](int k, int64_t n) { t.b[k].ensure(8 * (size_t)std::max<int64_t>(n, 1)); return (double *)t.b[k].p; };
+        if (what & 1) {
+            if (h.two_orders[CB_CONS]) { c = need(2, m.ncon); tune_order(h, CB_CONS, [&] { do_cons(h, x, c); }); }
+            if (h.two_orders[CB_JAC]) { jv = need(3, h.lnnzj); tune_order(h, CB_JAC, [&] { do_jac(h, x, jv); }); }
+            if (h.two_orders[CB_HESS]) { hv = need(4, h.lnnzh); tune_order(h, CB_HESS, [&] { do_hess(h, x, y, sigma, hv); }); }
+            if (h.two_orders[CB_FUSED]) {
+                c = need(2, m.ncon); jv = need(3, h.lnnzj); hv = need(4, h.lnnzh);
+                tune_order(h, CB_FUSED, [&] { do_fused(h, x, y, sigma, obj, c, jv, hv); });
+            }
+        }
+        if (what & 2) {
+            g = need(5, m.nvar);
+            // beyond 3e8 entries the sorted lists' memory (16 B per entry + the COO itself) is not worth a trial
+            for (int hess = 0; hess < 2; hess++) {
+                int &mode = hess ? h.hp_mode : h.jt_mode;
+                const int64_t nnz = hess ? h.lnnzh : h.lnnzj;
+                int best = 0;
+                if (sorted_possible(h, hess != 0) && nnz <= 300000000LL) {
+                    prod_setup(h, hess != 0);
+                    if (hess) best = pick_faster(h, [&] { do_hprod(h, x, y, x, sigma, g); }, [&] { do_hprod_sorted(h, x, y, x, sigma, g); });
+                    else best = pick_faster(h, [&] { do_jtprod(h, x, y, g); }, [&] { do_jtprod_sorted(h, x, y, g); });
+                    if (best == 0) drop_sorted(h, hess != 0);
+                }
+                mode = best;
+                tune_store(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), best);
+            }
+        }
+        HIPCHK(hipStreamSynchronize(h.stream));
+    });
+}
+
+// ---- how the module was obtained ---------------------------------------------------------------------------------------
+int exa_build_info(int id, char *how, int cap, double *build_ms) {
+    Handle *h = get(id);
+    if (!h) return 1;
+    if (how && cap > 0) { snprintf(how, (size_t)cap, "%s", h->build_how.c_str()); }
+    if (build_ms) *build_ms = h->build_ms;
+    return 0;
+}
+
+// ---- multi-GPU: collectives behind the ABI ----------------------------------------------------------------
+int exa_comm_unique_id(void *out128) {
+    if (!out128) return 1;
+    try { rccl_unique_id(out128); return 0; } catch (const std::exception &e) { g_err = e.what(); return 2; }
+}
+int exa_comm_init(int id, int rank, int world, const void *unique_id128) {
+    if (!unique_id128 || world < 1 || rank < 0 || rank >= world) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if (h.nccl || h.hook) throw BadInput("the model already has a communicator (exa_comm_free first)");
+        reshard(h, rank, world, h.coo_local);
+        h.nccl = rccl_comm_init(rank, world, unique_id128);       // collective over all ranks; on the current HIP device
+        h.nccl_owned = true;
+    });
+}
+int exa_comm_attach(int id, void *nccl_comm) {
+    if (!nccl_comm) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if (h.nccl || h.hook) throw BadInput("the model already has a communicator (exa_comm_free first)");
+        int rank = 0, world = 1;
+        rccl_comm_shape(nccl_comm, &rank, &world);
+        reshard(h, rank, world, h.coo_local);
+        h.nccl = nccl_comm;
+        h.nccl_owned = false;
+    });
+}
+int exa_comm_hook(int id, int rank, int world, exa_allreduce_fn fn, void *ctx) {
+    if (!fn || world < 1 || rank < 0 || rank >= world) return 1;
+    return guard(id, false, [&](Handle &h) {
+        if (h.nccl || h.hook) throw BadInput("the model already has a communicator (exa_comm_free first)");
+        reshard(h, rank, world, h.coo_local);
+        h.hook = fn; h.hook_ctx = ctx;
+    });
+}
+int exa_comm_free(int id) {
+    return guard(id, false, [&](Handle &h) {
+        if (h.on_device) HIPCHK(hipStreamSynchronize(h.stream));
+        if (h.nccl && h.nccl_owned) rccl_comm_destroy(h.nccl);
+        h.nccl = nullptr; h.nccl_owned = false; h.hook = nullptr; h.hook_ctx = nullptr;
+    });
+}
+int exa_comm_info(int id, int *rank, int *world, int *kind) {
+    Handle *h = get(id);
+    if (!h) return 1;
+    if (rank) *rank = h->rank;
+    if (world) *world = h->world;
+    if (kind) *kind = h->nccl ? 1 : (h->hook ? 2 : 0);
+    return 0;
+}
+int exa_set_reduce(int id, int on) { return guard(id, false, [&](Handle &h) { h.reduce = on != 0; }); }
+int exa_allreduce(int id, double *dev_buf, int64_t count) {
+    if (!dev_buf || count < 0) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if (!h.nccl && !h.hook) throw BadInput("the model has no communicator");
+        const bool r = h.reduce;
+        h.reduce = true;
+        try { allreduce(h, dev_buf, count); } catch (...) { h.reduce = r; throw; }
+        h.reduce = r;
+    });
+}
+int exa_set_coo_local(int id, int on) { return guard(id, false, [&](Handle &h) { reshard(h, h.rank, h.world, on != 0); }); }
+int64_t exa_local_nnzj64(int id) { Handle *h = get(id); return h ? h->lnnzj : -1; }
+int64_t exa_local_nnzh64(int id) { Handle *h = get(id); return h ? h->lnnzh : -1; }
+int exa_coo_slices(int id, int hess, int64_t *out) {
+    Handle *h = get(id);
+    if (!h || !out) return 1;
+    const Model &m = *h->m;
+    for (size_t k = 0; k < m.pats.size(); k++) {
+        const Pattern &p = m.pats[k];
+        const int64_t lo = (int64_t)((__int128)p.n * h->rank / h->world), hi = (int64_t)((__int128)p.n * (h->rank + 1) / h->world);
+        const bool has = hess ? p.o2step > 0 : (p.kind != EXA_PAT_OBJ && p.o1step > 0);
+        const int64_t step = hess ? p.o2step : p.o1step, o = hess ? p.o2 : p.o1, cnt = has ? step * (hi - lo) : 0;
+        out[3 * k] = o + step * lo;                                                     // first global slot (0-based)
+        out[3 * k + 1] = h->coo_local && h->world > 1 ? (hess ? h->lo2[k] : h->lo1[k]) : o + step * lo;   // where it is in the caller's buffer
+        out[3 * k + 2] = cnt;
+    }
+    return 0;
+}
+int exa_shard_var_range(int id, int64_t *lo_out, int64_t *hi_out) {
+    Handle *h = get(id);
+    if (!h || !lo_out || !hi_out) return 1;
+    const Model &m = *h->m;
+    int64_t vmin = INT64_MAX, vmax = INT64_MIN;
+    for (const Pattern &p : m.pats) {
+        const int64_t lo = (int64_t)((__int128)p.n * h->rank / h->world), hi = (int64_t)((__int128)p.n * (h->rank + 1) / h->world);
+        if (hi <= lo) continue;
+        int64_t a = 0, b = 0;
+        if (!pattern_var_range(p, lo, hi, &a, &b)) { vmin = 1; vmax = m.nvar; break; }     // data-indexed: anywhere
+        if (a <= b) { vmin = std::min(vmin, a); vmax = std::max(vmax, b); }
+    }
+    if (vmin > vmax) { *lo_out = 0; *hi_out = 0; return 0; }
+    *lo_out = vmin - 1; *hi_out = vmax;       // 0-based [lo, hi)
+    return 0;
+}
 
 }  // extern "C"

@@ -24,6 +24,9 @@ SYMBOLS = [
     "exa_hess_structure_host", "exa_jac_structure64_host", "exa_hess_structure64_host", "exa_time_callback", "exa_sync", "exa_block_order",
     "exa_eval_fused", "exa_set_product_mode", "exa_get_product_mode", "exa_compress", "exa_compress_info", "exa_cnnzj64", "exa_cnnzh64", "exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64",
     "exa_chess_structure64", "exa_cjac_csc", "exa_chess_csc", "exa_cjac", "exa_chess",
+    "exa_build_info", "exa_tune", "exa_comm_unique_id", "exa_comm_init", "exa_comm_attach", "exa_comm_hook", "exa_comm_free",
+    "exa_comm_info", "exa_set_reduce", "exa_allreduce", "exa_set_coo_local", "exa_local_nnzj64", "exa_local_nnzh64",
+    "exa_coo_slices", "exa_shard_var_range",
 ]
 # ... and include/exahip_recipe.h
 RECIPE_SYMBOLS = [
@@ -36,7 +39,7 @@ RECIPE_SYMBOLS = [
 
 def build(force=False):
     """Compile libexahip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hpp"))]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".cpp", ".hpp")) or f == "Makefile"]
     srcs += [os.path.join(CSRC, "..", "..", "include", f) for f in ("exahip.h", "exahip_ir.h", "exahip_recipe.h")]
     newest = max(os.path.getmtime(s) for s in srcs)
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
@@ -111,6 +114,22 @@ def lib():
         getattr(L, f).argtypes = [i32, vp, vp]
     L.exa_chess.argtypes = [i32, vp, vp, dbl, vp]
     L.exa_compress_info.argtypes = [i32, i32, ctypes.c_char_p, i32, vp]
+    L.exa_build_info.argtypes = [i32, ctypes.c_char_p, i32, vp]
+    L.exa_tune.argtypes = [i32, i32, vp, vp]
+    L.exa_comm_unique_id.argtypes = [vp]
+    L.exa_comm_init.argtypes = [i32, i32, i32, vp]
+    L.exa_comm_attach.argtypes = [i32, vp]
+    L.exa_comm_hook.argtypes = [i32, i32, i32, vp, vp]
+    L.exa_comm_free.argtypes = [i32]
+    L.exa_comm_info.argtypes = [i32, vp, vp, vp]
+    L.exa_set_reduce.argtypes = [i32, i32]
+    L.exa_allreduce.argtypes = [i32, vp, i64]
+    L.exa_set_coo_local.argtypes = [i32, i32]
+    for f in ("exa_local_nnzj64", "exa_local_nnzh64"):
+        getattr(L, f).argtypes = [i32]
+        getattr(L, f).restype = i64
+    L.exa_coo_slices.argtypes = [i32, i32, vp]
+    L.exa_shard_var_range.argtypes = [i32, vp, vp]
     # include/exahip_recipe.h
     cp, sz = ctypes.c_char_p, ctypes.c_size_t
     L.exa_recipe_load.argtypes = [vp, sz]

@@ -2,13 +2,12 @@
 
 The reference has no multi-device path; this is new.  What needs communication and what does not:
   * jac_coord / hess_coord / structures: COO slots are private to a data point, so each rank fills a DISJOINT slice
-    of the global vector — no collective.  `gather_coo` is offered for consumers that want the whole vector on
-    every GPU, and is priced honestly in DESIGN.md (it moves ~G x more bytes than the evaluation itself).
-  * obj: one double  -> all_reduce(SUM).
-  * grad: dense nvar -> all_reduce(SUM) of the per-rank partial sums.
-  * cons: base rows are disjoint by data point, augmentation rows are shared -> all_reduce(SUM) (rows outside the
-    shard are zero on a rank, libexahip zero-fills when world > 1).
-Collectives go through torch.distributed: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests.
+    of the global vector (or, with `coo_local`, a packed slice-sized buffer) — no collective.
+  * obj (1 double), grad / jtprod / hprod (nvar), cons / jprod (ncon): all_reduce(SUM).
+The collectives live BEHIND THE C ABI (include/exahip.h, exa_comm_*): libexahip enqueues `ncclAllReduce` on the model's
+stream right after the kernels, so a Julia host gets the same multi-GPU path.  This module only distributes the
+ncclUniqueId (through torch.distributed, whatever its backend) and, where there is no RCCL — the gloo CPU/one-GPU test
+path — installs a host reducer through the same ABI hook (exa_comm_hook).
 """
 from __future__ import annotations
 
@@ -18,23 +17,69 @@ def shard_range(n: int, rank: int, world: int):
     return n * rank // world, n * (rank + 1) // world
 
 
-class ShardedEvaluator:
-    """Wraps a local evaluator (ExaModel, or any object with the same methods) whose iterators have been sharded with
-    set_shard(rank, world), and completes the callbacks that need a reduction."""
+def attach_communicator(model, group=None, transport=None, coo_local=False):
+    """Shards `model` (an exahip.ExaModel) over the ranks of the torch.distributed group and gives it a communicator:
+    transport "rccl" — exa_comm_init (rank 0's ncclUniqueId is broadcast through the group);
+    transport "hook" — exa_comm_hook with a reducer that stages the device buffer through the host and all-reduces it
+                       with the group's own backend (gloo): the test path on machines with fewer GPUs than ranks.
+    Default: "rccl" when the group's backend is nccl, else "hook"."""
+    import ctypes
 
-    def __init__(self, model, group=None):
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if transport is None:
+        transport = "rccl" if dist.get_backend(group) == "nccl" else "hook"
+    if coo_local:
+        model.set_coo_local(True)
+    if transport == "rccl":
+        box = [model.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        model.comm_init(rank, world, box[0])
+    else:
+        hip = ctypes.CDLL(None)      # the HIP runtime is already in the process (libexahip.so links it)
+
+        def reducer(ptr, count, stream):
+            # device -> host on the model's stream, host all-reduce, host -> device on the same stream
+            host = torch.empty(count, dtype=torch.float64)
+            nbytes = 8 * count
+            if hip.hipMemcpyAsync(ctypes.c_void_p(host.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 2, ctypes.c_void_p(stream)):
+                return 1
+            if hip.hipStreamSynchronize(ctypes.c_void_p(stream)):
+                return 1
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            if hip.hipMemcpyAsync(ctypes.c_void_p(ptr), ctypes.c_void_p(host.data_ptr()), ctypes.c_size_t(nbytes), 1, ctypes.c_void_p(stream)):
+                return 1
+            return 1 if hip.hipStreamSynchronize(ctypes.c_void_p(stream)) else 0     # `host` dies with this frame
+
+        model.comm_hook(rank, world, reducer)
+    return transport
+
+
+class ShardedEvaluator:
+    """A model whose iterators are sharded over the ranks of a torch.distributed group, complete on every rank.
+
+    For an exahip.ExaModel the reductions happen inside libexahip (attach_communicator).  Any other object with the
+    same methods and `set_shard` (the test oracle on CPU) is completed here with torch.distributed — the reference
+    semantics the ABI path is checked against."""
+
+    def __init__(self, model, group=None, transport=None, coo_local=False):
         import torch.distributed as dist
         self.dist = dist
         self.model = model
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        model.set_shard(self.rank, self.world)
+        self.in_library = hasattr(model, "comm_hook") and dist.is_initialized()
+        if self.in_library:
+            self.transport = attach_communicator(model, group, transport, coo_local)
+        else:
+            self.transport = "host"
+            model.set_shard(self.rank, self.world)
 
     def _allreduce(self, t):
         if self.world > 1:
             if t.is_cuda and self.dist.get_backend(self.group) == "gloo":
-                # gloo is the CPU test backend: stage device tensors through the host (RCCL reduces them in place)
                 h = t.cpu()
                 self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
                 t.copy_(h)
@@ -45,17 +90,30 @@ class ShardedEvaluator:
     def obj(self, x):
         import torch
         part = self.model.obj(x)
+        if self.in_library:
+            return part
         dev = x.device if hasattr(x, "device") else "cpu"
-        t = torch.tensor([part], dtype=torch.float64, device=dev)
-        return self._allreduce(t).item()
+        return self._allreduce(torch.tensor([part], dtype=torch.float64, device=dev)).item()
+
+    def _done(self, a):
+        return _as_tensor(a) if self.in_library else self._allreduce(_as_tensor(a))
 
     def grad(self, x, out=None):
-        return self._allreduce(_as_tensor(self.model.grad(x, out=out)))
+        return self._done(self.model.grad(x, out=out))
 
     def cons(self, x, out=None):
-        return self._allreduce(_as_tensor(self.model.cons(x, out=out)))
+        return self._done(self.model.cons(x, out=out))
 
-    # sharded outputs: this rank's slice of the global COO vector is valid, the rest is untouched
+    def jprod(self, x, v, out=None):
+        return self._done(self.model.jprod(x, v, out=out))
+
+    def jtprod(self, x, v, out=None):
+        return self._done(self.model.jtprod(x, v, out=out))
+
+    def hprod(self, x, y, v, obj_weight=1.0, out=None):
+        return self._done(self.model.hprod(x, y, v, obj_weight, out=out))
+
+    # sharded outputs: this rank's slice of the COO vector is valid, the rest is untouched
     def jac_coord(self, x, out=None):
         return self.model.jac_coord(x, out=out)
 
@@ -63,9 +121,13 @@ class ShardedEvaluator:
         return self.model.hess_coord(x, y, obj_weight, out=out)
 
     def gather_coo(self, buf):
-        """Make a sharded COO vector whole on every rank.  `buf` must have been ZERO-filled before the sharded
-        evaluation wrote into it; disjoint slices + zeros => all_reduce(SUM) is a gather."""
-        return self._allreduce(_as_tensor(buf))
+        """Make a sharded COO vector (global positions) whole on every rank.  `buf` must have been ZERO-filled before
+        the sharded evaluation wrote into it; disjoint slices + zeros => all_reduce(SUM) is a gather.  Moves ~world x the
+        bytes of the evaluation itself: offered, not the headline."""
+        t = _as_tensor(buf)
+        if self.in_library and t.is_cuda:
+            return self.model.allreduce(t)
+        return self._allreduce(t)
 
 
 def _as_tensor(a):

@@ -292,9 +292,87 @@ class ExaModel:
         capi.check(self._L.exa_compile(self.id), "exa_compile")
         return self._L.exa_code_object_path(self.id).decode()
 
+    def build_info(self):
+        """(how, build_ms): how the module was obtained — "preloaded" | "disk" | "hiprtc" | "hipcc" — and the compiler's time."""
+        buf, ms = ctypes.create_string_buffer(32), ctypes.c_double(0.0)
+        capi.check(self._L.exa_build_info(self.id, buf, 32, ctypes.addressof(ms)), "exa_build_info")
+        return buf.value.decode(), ms.value
+
+    def tune(self, what=3, x=None, y=None):
+        """exa_tune: the explicit, blocking measurement of block orders (bit 0) and product implementations (bit 1);
+        the decisions are persisted next to the cached module.  x, y: device tensors or None."""
+        if x is not None:
+            self._use_torch_stream(x)
+        capi.check(self._L.exa_tune(self.id, int(what), x.data_ptr() if x is not None else None,
+                                    y.data_ptr() if y is not None else None), "exa_tune")
+
     # ---- context ---------------------------------------------------------------------------------------------
     def set_shard(self, rank, world):
         capi.check(self._L.exa_set_shard(self.id, int(rank), int(world)), "exa_set_shard")
+
+    # ---- multi-GPU behind the ABI (include/exahip.h "multi-GPU") ---------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = ctypes.create_string_buffer(128)
+        capi.check(capi.lib().exa_comm_unique_id(buf), "exa_comm_unique_id")
+        return buf.raw
+
+    def comm_init(self, rank, world, unique_id):
+        """RCCL communicator on the current HIP device + shard; obj/grad/cons/products are complete on every rank afterwards."""
+        capi.check(self._L.exa_comm_init(self.id, int(rank), int(world), ctypes.c_char_p(bytes(unique_id))), "exa_comm_init")
+
+    def comm_hook(self, rank, world, fn):
+        """fn(device_ptr: int, count: int, stream: int) -> 0 must leave the sum over ranks in the device buffer."""
+        proto = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+        def tramp(_ctx, buf, count, stream):
+            try:
+                return int(fn(buf or 0, int(count), stream or 0) or 0)
+            except Exception:      # an exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._hook = proto(tramp)                       # keep the trampoline alive as long as the model
+        capi.check(self._L.exa_comm_hook(self.id, int(rank), int(world), ctypes.cast(self._hook, ctypes.c_void_p), None), "exa_comm_hook")
+
+    def comm_free(self):
+        capi.check(self._L.exa_comm_free(self.id), "exa_comm_free")
+        self._hook = None
+
+    def comm_info(self):
+        r, w, k = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        capi.check(self._L.exa_comm_info(self.id, ctypes.addressof(r), ctypes.addressof(w), ctypes.addressof(k)), "exa_comm_info")
+        return r.value, w.value, ("none", "rccl", "hook")[k.value]
+
+    def set_reduce(self, on):
+        capi.check(self._L.exa_set_reduce(self.id, 1 if on else 0), "exa_set_reduce")
+
+    def allreduce(self, t):
+        self._use_torch_stream(t)
+        capi.check(self._L.exa_allreduce(self.id, t.data_ptr(), t.numel()), "exa_allreduce")
+        return t
+
+    def set_coo_local(self, on=True):
+        capi.check(self._L.exa_set_coo_local(self.id, 1 if on else 0), "exa_set_coo_local")
+
+    @property
+    def local_nnzj(self):
+        return self._L.exa_local_nnzj64(self.id)
+
+    @property
+    def local_nnzh(self):
+        return self._L.exa_local_nnzh64(self.id)
+
+    def coo_slices(self, hess=True):
+        """[(first global slot, first position in the caller's buffer, length)] per pattern (exa_coo_slices)."""
+        out = np.zeros(3 * max(1, self.npatterns), dtype=np.int64)
+        capi.check(self._L.exa_coo_slices(self.id, 1 if hess else 0, out.ctypes.data), "exa_coo_slices")
+        return [tuple(out[3 * k:3 * k + 3].tolist()) for k in range(self.npatterns)]
+
+    def shard_var_range(self):
+        lo, hi = ctypes.c_int64(0), ctypes.c_int64(0)
+        capi.check(self._L.exa_shard_var_range(self.id, ctypes.addressof(lo), ctypes.addressof(hi)), "exa_shard_var_range")
+        return lo.value, hi.value
 
     def set_value(self, par, values):
         """set_value!(m, θ, vals): update a Parameter block without rebuilding (nlp.jl:1279-1287).  A vector of the
@@ -382,10 +460,10 @@ class ExaModel:
     cons_nln = cons
 
     def jac_coord(self, x, out=None):
-        return self._call("jac", x, self.meta.nnzj, out)
+        return self._call("jac", x, self.local_nnzj, out)
 
     def hess_coord(self, x, y, obj_weight=1.0, out=None):
-        return self._call("hess", x, self.meta.nnzh, out, extra=(y, obj_weight))
+        return self._call("hess", x, self.local_nnzh, out, extra=(y, obj_weight))
 
     def eval_fused(self, x, y, obj_weight=1.0, c=None, jac=None, hess=None, obj_out=None):
         """obj + cons + jac_coord + hess_coord at one x in ONE sweep (exa_eval_fused).  Device tensors only.
@@ -396,8 +474,8 @@ class ExaModel:
         dev = x.device
         f = torch.empty(1, dtype=torch.float64, device=dev) if obj_out is None else obj_out
         c = torch.empty(self.meta.ncon, dtype=torch.float64, device=dev) if c is None else c
-        jac = torch.empty(self.meta.nnzj, dtype=torch.float64, device=dev) if jac is None else jac
-        hess = torch.empty(self.meta.nnzh, dtype=torch.float64, device=dev) if hess is None else hess
+        jac = torch.empty(self.local_nnzj, dtype=torch.float64, device=dev) if jac is None else jac
+        hess = torch.empty(self.local_nnzh, dtype=torch.float64, device=dev) if hess is None else hess
         capi.check(self._L.exa_eval_fused(self.id, x.data_ptr(), y.data_ptr(), float(obj_weight), f.data_ptr(), c.data_ptr(),
                                           jac.data_ptr(), hess.data_ptr()), "exa_eval_fused")
         return f, c, jac, hess
@@ -428,7 +506,7 @@ class ExaModel:
         return out
 
     def set_product_mode(self, jtprod=-1, hprod=-1):
-        """0 atomics in the sweep, 1 COO + sorted gather, -1 measure both at the next call (default)."""
+        """0 atomics in the sweep, 1 COO + sorted gather, -1 undecided (default): what tune() persisted, else atomics."""
         capi.check(self._L.exa_set_product_mode(self.id, int(jtprod), int(hprod)), "exa_set_product_mode")
 
     def product_mode(self):
@@ -461,12 +539,12 @@ class ExaModel:
     def jac_structure(self, rows=None, cols=None, dtype=np.int64):
         if rows is not None:
             dtype = np.int64 if (rows.element_size() if _is_torch(rows) else rows.dtype.itemsize) == 8 else np.int32
-        return self._structure("jac", rows, cols, self.meta.nnzj, dtype)
+        return self._structure("jac", rows, cols, self.local_nnzj, dtype)
 
     def hess_structure(self, rows=None, cols=None, dtype=np.int64):
         if rows is not None:
             dtype = np.int64 if (rows.element_size() if _is_torch(rows) else rows.dtype.itemsize) == 8 else np.int32
-        return self._structure("hess", rows, cols, self.meta.nnzh, dtype)
+        return self._structure("hess", rows, cols, self.local_nnzh, dtype)
 
     # ---- measurement (hipEvents on the model's stream, include/exahip.h exa_time_callback) -------------------
     def time_callback(self, which, reps, x, y=None, obj_weight=1.0, out=None):

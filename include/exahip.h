@@ -25,7 +25,8 @@
  * of x (NaN/Inf propagate).
  *
  * Pointers: the unsuffixed callbacks take DEVICE pointers (what Julia passes as pointer(::ROCArray))
- * and are asynchronous on the model's stream (exa_set_stream; default the null stream), except exa_obj
+ * and are asynchronous on the model's stream (exa_set_stream; default the null stream) FROM THE FIRST CALL — no callback
+ * ever measures, tunes or synchronises (exa_tune is the explicit, blocking set-up step for that) — except exa_obj
  * whose `out` is a HOST double and therefore synchronises.  The *_host variants take host pointers,
  * stage through device scratch owned by the model, and synchronise (the role of WrapperNLPModel,
  * src/utils.jl:159-208).  One call in flight per model id (reference callbacks share scratch too,
@@ -33,6 +34,12 @@
  *
  * There is NO CPU fallback: if no HIP device or the kernel module cannot be built, exa_new_from_table
  * fails with status 2.
+ *
+ * Kernel build.  The generated module is compiled IN THE PROCESS with hiprtc (the copy next to the HIP runtime the process
+ * has loaded) — the consumer's machine needs no hipcc —, or by `hipcc --genco` as a subprocess (EXAHIP_COMPILER=hipcc, or
+ * when hiprtc cannot be loaded), and cached on disk under SHA-256(source) + SHA-256(flags | compiler identity | arch).
+ * Cache directory: $EXAHIP_CACHE_DIR, else <install>/kernel_cache, else $XDG_CACHE_HOME/exahip or ~/.cache/exahip (0700);
+ * only directories owned by the user (or root) and not writable by others are read or written; never /tmp.
  */
 #ifndef EXAHIP_H
 #define EXAHIP_H
@@ -44,7 +51,7 @@
 extern "C" {
 #endif
 
-#define EXAHIP_ABI_VERSION 1
+#define EXAHIP_ABI_VERSION 2
 
 int         exa_abi_version(void);
 const char *exa_last_error(void);                       /* thread-local text of the last status-2 failure */
@@ -62,12 +69,16 @@ int exa_plan_only(const exa_model_desc_t *desc, int *id_out);
  * the build check).  exa_code_object_path() then names the .hsaco. */
 int exa_compile(int id);
 const char *exa_code_object_path(int id);
-/* Cache key of the model's module ("exa_<16 hex digits>": hash of the generated source and the compile flags). */
+/* Name of the model's generated module: "exa_" + the first 128 bits of SHA-256(source), independent of the compiler. */
 const char *exa_module_name(int id);
-/* Hand a compiled code object to the library in memory under that key: models whose module has this key load it instead
- * of looking on disk or invoking hipcc.  A packed library (exahip.pack) ships its module this way — ahead-of-time, like
- * a compile_library product of ExaModelsCompiler (ExaModelsCompiler.jl:108-222). */
+/* Hand a compiled code object to the library in memory under that name: models whose module has this name load it
+ * instead of looking on disk or compiling.  A packed library (exahip.pack) ships its module this way — ahead-of-time,
+ * like a compile_library product of ExaModelsCompiler (ExaModelsCompiler.jl:108-222).  Status 1 for anything that is
+ * not an AMDGPU ELF code object (or a clang offload bundle of one). */
 int exa_cache_add(const char *name, const void *code_object, size_t len);
+/* How the module of a device model was obtained: how <- "preloaded" | "disk" | "hiprtc" | "hipcc", *build_ms <- the
+ * compiler's time (0 unless it ran).  The reference pays this at the first call of every callback (Julia's JIT). */
+int exa_build_info(int id, char *how, int cap, double *build_ms);
 int exa_free(int id);
 
 /* ---- sizes (cnlp: P_nvar/P_ncon/P_nnzj/P_nnzh, Compiler :1564-1582) ---------------------------- */
@@ -99,6 +110,50 @@ int exa_set_stream(int id, void *hip_stream);
  * sums (base constraint rows outside the shard are written as 0) and are completed by an allreduce(sum)
  * in the host layer.  rank=0, world=1 restores the unsharded model. */
 int exa_set_shard(int id, int rank, int world);
+
+/* ---- multi-GPU behind the ABI: one process per GPU, collectives on the model's stream -----------------
+ * What the reference accumulates on one device — obj (KA ext :253-271), grad! (:310-336), cons_nln! with its
+ * augmentation rows (:273-308) and the products — is a SUM over data points, so a sharded model needs
+ * all-reduce(sum) of: 1 double (obj), nvar doubles (grad, jtprod, hprod), ncon doubles (cons, jprod).  With a
+ * communicator attached, exa_obj / exa_obj_async / exa_grad / exa_cons / exa_jprod / exa_jtprod / exa_hprod /
+ * exa_eval_fused (and their *_host variants) enqueue that all-reduce right after the kernels and every rank receives the
+ * complete result.  jac_coord! / hess_coord! / the structures need NO collective: COO slots are private to a data point.
+ *
+ *   exa_comm_unique_id   rank 0 obtains an ncclUniqueId (128 bytes) and the host distributes it (MPI.bcast, a file, ...);
+ *   exa_comm_init        every rank: ncclCommInitRank on the process's current HIP device (collective) + exa_set_shard;
+ *   exa_comm_attach      adopt a communicator the host created itself (rank / world are read from it; not destroyed by
+ *                        exa_comm_free / exa_free);
+ *   exa_comm_hook        no RCCL: the host supplies `fn(ctx, device_buffer, count, hip_stream)` that must leave the sum
+ *                        over ranks in device_buffer, ordered after the work already enqueued on hip_stream (MPI.jl with
+ *                        a GPU-aware MPI, or a staged host all-reduce: the CPU/gloo test path); non-zero return = failure;
+ *   exa_comm_free        detach (the shard stays);   exa_set_reduce(id, 0) keeps the communicator but returns partial sums;
+ *   exa_allreduce        the same sum for a buffer of the host's own (e.g. a zero-filled COO vector it wants whole).
+ * librccl is loaded with dlopen at exa_comm_unique_id / exa_comm_init / exa_comm_attach: single-GPU use needs no RCCL. */
+#define EXA_UNIQUE_ID_BYTES 128
+typedef int (*exa_allreduce_fn)(void *ctx, double *device_buffer, int64_t count, void *hip_stream);
+int exa_comm_unique_id(void *out128);
+int exa_comm_init(int id, int rank, int world, const void *unique_id128);
+int exa_comm_attach(int id, void *nccl_comm);
+int exa_comm_hook(int id, int rank, int world, exa_allreduce_fn fn, void *ctx);
+int exa_comm_free(int id);
+int exa_comm_info(int id, int *rank, int *world, int *kind);      /* kind: 0 none, 1 RCCL, 2 host reducer */
+int exa_set_reduce(int id, int on);
+int exa_allreduce(int id, double *device_buffer, int64_t count);
+/* Local-slice COO.  By default a sharded rank writes its Jacobian / Hessian / structure slots at their GLOBAL positions
+ * (the caller's buffers have nnzj / nnzh entries, the rank fills its disjoint part).  With exa_set_coo_local(id, 1) the
+ * rank's slots are PACKED: pattern after pattern, each pattern's data points [lo, hi) in order — buffers of
+ * exa_local_nnzj64 / exa_local_nnzh64 entries (1/world of the model: LV N=1e8 on 8 GPUs: 0.9 GB instead of 7.2 GB per
+ * rank).  exa_coo_slices tells where each piece belongs: out[3k .. 3k+2] = first GLOBAL slot (0-based) of pattern k's
+ * piece, its first position in the caller's buffer, its length.  Sorted products and exa_compress work on the local
+ * slice of a sharded model (each rank compresses the matrix of its own data points; the model's matrix is the sum). */
+int     exa_set_coo_local(int id, int on);
+int64_t exa_local_nnzj64(int id);
+int64_t exa_local_nnzh64(int id);
+int     exa_coo_slices(int id, int hess, int64_t *out /* 3 * exa_npatterns */);
+/* 0-based [lo, hi): the stretch of x this rank's data points read.  The whole vector when some index comes from a data
+ * column; the shard's stencil footprint when all indices are range-affine — the host may then keep only that stretch
+ * resident and pass `x_slice - lo` as x (and analogously y rows [o0+lo, o0+hi) per constraint pattern). */
+int exa_shard_var_range(int id, int64_t *lo, int64_t *hi);
 /* theta update without rebuild (set_value!, nlp.jl:1279-1287; cnlp :1529-1535) */
 int exa_set_value(int id, int64_t offset, const double *vals, int64_t len);   /* theta[offset .. offset+len) <- vals (HOST) */
 
@@ -113,8 +168,9 @@ int exa_jprod (int id, const double *x, const double *v, double *Jv);           
 int exa_jtprod(int id, const double *x, const double *v, double *Jtv);            /* Jtv [nvar] = J(x)' v,  v [ncon] */
 int exa_hprod (int id, const double *x, const double *y, const double *v, double obj_weight, double *Hv);  /* Hv [nvar] */
 /* exa_jtprod / exa_hprod have two implementations: FP64 atomics inside the sweep, or COO + gather through build-time
- * sorted lists (the reference's prod helper, KA ext :56-178, :482-511).  mode: 0 atomics, 1 sorted gather, -1 (default)
- * decide by MEASURING both at the next call on this model ("chosen by measured contention"). */
+ * sorted lists (the reference's prod helper, KA ext :56-178, :482-511; deterministic).  mode: 0 atomics, 1 sorted gather,
+ * -1 (default) undecided: the decision exa_tune measured and persisted for this module / device / sizes ("chosen by
+ * measured contention") if there is one, else atomics.  The mode is fixed before a call; a callback never measures. */
 int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode);
 int exa_get_product_mode(int id, int *jtprod_mode, int *hprod_mode);
 int exa_jac_structure  (int id, int32_t *rows, int32_t *cols);
@@ -174,10 +230,16 @@ int exa_compress_info(int id, int hess, char *buf, int cap, int *len_out);
 int exa_time_callback(int id, int which, int reps, const double *x, const double *y, double obj_weight,
                       double *out, float *ms_out);
 int exa_sync(int id);
-/* Order of the (pattern, tile) workgroups of a multi-pattern callback, chosen by measurement at its first call:
- * 0 patterns one after the other, 1 interleaved in runs of 128 workgroups, -1 not measured yet, -2 bad argument.
- * which: 2 cons, 3 jac, 4 hess, 5 fused. */
+/* Order of the (pattern, tile) workgroups of a multi-pattern callback: 0 patterns one after the other (default),
+ * 1 interleaved in runs of 128 workgroups, -2 bad argument.  which: 2 cons, 3 jac, 4 hess, 5 fused. */
 int exa_block_order(int id, int which);
+/* Explicit, BLOCKING tuning — the only entry point that measures.  what: bit 0 = block order of cons / jac / hess / fused
+ * (models streaming >= 128 MB from several patterns), bit 1 = exa_jtprod / exa_hprod implementation.  Both candidates of
+ * each decision are timed on the model's stream at (x, y) (DEVICE pointers; NULL = x0 / ones; outputs go to scratch),
+ * the winner is installed and persisted next to the cached module under (module, device, shard, pattern sizes), so later
+ * processes start with it.  Call it once after the build (and after exa_set_shard / exa_comm_init), outside any stream
+ * capture. */
+int exa_tune(int id, int what, const double *x, const double *y);
 
 #ifdef __cplusplus
 }

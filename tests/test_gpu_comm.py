@@ -1,0 +1,185 @@
+"""-m gpu: the multi-GPU layer BEHIND THE C ABI (include/exahip.h exa_comm_*) and the explicit tuner.
+
+The test box has one MI355X, so:
+  * the RCCL code path runs with a world-1 communicator (ncclCommInitRank + ncclAllReduce execute on the hardware);
+  * two ranks share cuda:0 and reduce through exa_comm_hook over gloo (tests/test_gpu_dist.py) — the same ABI hook an
+    MPI.jl host would use.
+What needs reducing is what the reference accumulates over data points on one device: obj (KA ext :253-271),
+grad! (:310-336), cons_nln! (:273-308) and the products."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from zoo import ZOO, point
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def _all_outputs(m, xd, yd, vd, wd, s):
+    import torch
+    f, c, j, h = m.eval_fused(xd, yd, s)
+    out = {"obj": m.obj(xd), "grad": m.grad(xd), "cons": m.cons(xd), "jprod": m.jprod(xd, vd), "jtprod": m.jtprod(xd, wd),
+           "hprod": m.hprod(xd, yd, vd, s), "fused_obj": f, "fused_c": c, "jac": m.jac_coord(xd), "hess": m.hess_coord(xd, yd, s)}
+    torch.cuda.synchronize()
+    return {k: (v.cpu().numpy().copy() if hasattr(v, "cpu") else v) for k, v in out.items()}
+
+
+@pytest.mark.parametrize("name", ["acopf30", "rocket50", "lv1000"])
+def test_rccl_allreduce_runs_behind_the_abi_world1(libs, name):
+    """exa_comm_unique_id + exa_comm_init create a real RCCL communicator; every reducing callback then enqueues
+    ncclAllReduce on the model's stream.  With one rank the sum is the identity, so the results must not move."""
+    import torch
+    from exahip import ExaModel
+    m = ExaModel(ZOO[name]())
+    x, y, s = point(m.meta.x0, m.meta.ncon, seed=21)
+    dev = torch.device("cuda:0")
+    v = np.random.default_rng(1).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(2).standard_normal(m.meta.ncon)
+    xd, yd, vd, wd = (torch.from_numpy(a).to(dev) for a in (x, y, v, w))
+    m.set_product_mode(1, 1)                         # deterministic products: bitwise comparison below
+    before = _all_outputs(m, xd, yd, vd, wd, s)
+    uid = m.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    m.comm_init(0, 1, uid)
+    assert m.comm_info() == (0, 1, "rccl")
+    after = _all_outputs(m, xd, yd, vd, wd, s)
+    for k in before:
+        if k == "grad" and name == "acopf30":       # FP64 atomics on a data-indexed objective: order varies
+            np.testing.assert_allclose(after[k], before[k], rtol=1e-13, atol=1e-13)
+        else:
+            assert np.array_equal(np.asarray(after[k]), np.asarray(before[k])), k
+    t = torch.arange(5, dtype=torch.float64, device=dev)
+    assert torch.equal(m.allreduce(t.clone()), t)
+    m.set_reduce(False)
+    assert m.obj(xd) == before["obj"]
+    m.comm_free()
+    assert m.comm_info() == (0, 1, "none")
+
+
+def test_host_reducer_hook_is_called_for_every_reducing_callback(libs):
+    """exa_comm_hook: the library hands (device buffer, count, stream) of exactly the vectors that need the sum."""
+    import torch
+    from exahip import ExaModel
+    m = ExaModel(ZOO["acopf30"]())
+    x, y, s = point(m.meta.x0, m.meta.ncon, seed=3)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    vd, wd = torch.ones(m.meta.nvar, dtype=torch.float64, device=dev), torch.ones(m.meta.ncon, dtype=torch.float64, device=dev)
+    seen = []
+    m.comm_hook(0, 1, lambda ptr, count, stream: seen.append(count) or 0)
+    nv, nc = m.meta.nvar, m.meta.ncon
+    m.obj(xd); m.grad(xd); m.cons(xd); m.jprod(xd, vd); m.jtprod(xd, wd); m.hprod(xd, yd, vd, s)
+    assert seen == [1, nv, nc, nc, nv, nv]
+    seen.clear()
+    m.jac_coord(xd); m.hess_coord(xd, yd, s); m.jac_structure(); m.hess_structure()
+    assert seen == []                                 # COO outputs need no collective
+    m.eval_fused(xd, yd, s)
+    assert seen == [1, nc]
+    # a failing reducer is a status-2 error, not a crash
+    from exahip import capi
+    m.comm_free()
+    m.comm_hook(0, 1, lambda *a: 7)
+    with pytest.raises(capi.ExaHipError, match="status 2.*hook returned status 7"):
+        m.grad(xd)
+
+
+def test_tuning_is_explicit_persisted_and_never_inside_a_callback(libs, tmp_path, monkeypatch):
+    """exa_tune measures block orders / product implementations once and persists the decisions next to the cached
+    module; a later model with the same module, device and sizes starts with them, and no callback ever blocks to measure."""
+    import torch
+    from exahip import ExaModel, models
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))
+    N = 3_000_000                                    # two patterns streaming >= 128 MB: both block orders exist
+    dev = torch.device("cuda:0")
+    m = ExaModel(models.luksan_vlcek_model(N))
+    xd = torch.from_numpy(m.meta.x0 + 0.05).to(dev)
+    yd = torch.ones(m.meta.ncon, dtype=torch.float64, device=dev)
+    h = torch.empty(m.meta.nnzh, dtype=torch.float64, device=dev)
+    # first call of a fresh model: asynchronous, nothing measured (the old in-callback tuner spent >= 60 ms here)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m.hess_coord(xd, yd, 0.5, out=h)
+    first_call_ms = 1e3 * (time.perf_counter() - t0)
+    torch.cuda.synchronize()
+    assert first_call_ms < 30.0, first_call_ms
+    assert m._L.exa_block_order(m.id, 4) == 0 and m.product_mode() == (-1, -1)
+    ref = h.clone()
+    m.tune(3, xd, yd)
+    files = [f for f in os.listdir(tmp_path) if f.endswith(".tune")]
+    assert len(files) == 1 and files[0].startswith(m._L.exa_module_name(m.id).decode())
+    order = [m._L.exa_block_order(m.id, w) for w in (2, 3, 4, 5)]
+    modes = m.product_mode()
+    assert all(o in (0, 1) for o in order) and all(v in (0, 1) for v in modes)
+    m.hess_coord(xd, yd, 0.5, out=h)
+    assert torch.equal(h, ref)                       # the order of the workgroups does not change a single bit
+    m2 = ExaModel(models.luksan_vlcek_model(N))
+    assert [m2._L.exa_block_order(m2.id, w) for w in (2, 3, 4, 5)] == order
+    g = m2.jtprod(xd, yd); m2.hprod(xd, yd, xd, 0.5)
+    assert m2.product_mode() == modes
+    np.testing.assert_allclose(g.cpu().numpy(), m.jtprod(xd, yd).cpu().numpy(), rtol=1e-12, atol=1e-12)
+    # another size is another decision
+    m3 = ExaModel(models.luksan_vlcek_model(N + 1))
+    m3.jtprod(torch.from_numpy(m3.meta.x0).to(dev), torch.ones(m3.meta.ncon, dtype=torch.float64, device=dev))
+    assert m3.product_mode()[0] == 0 and m3._L.exa_block_order(m3.id, 4) == 0
+
+
+def test_build_info_reports_how_the_module_was_obtained(libs, tmp_path, monkeypatch):
+    from exahip import ExaModel, models
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("EXAHIP_HIPCC", "/nonexistent/hipcc")      # the in-process path needs no hipcc
+    t0 = time.perf_counter()
+    m = ExaModel(models.luksan_vlcek_model(100))
+    how, ms = m.build_info()
+    assert how == "hiprtc" and 0 < ms < 1e3 * (time.perf_counter() - t0)
+    assert ExaModel(models.luksan_vlcek_model(200)).build_info() == ("disk", 0.0)
+    import oracle
+    x = m.meta.x0 + 0.01
+    np.testing.assert_allclose(m.grad(x), oracle.OracleModel(m.ir).grad(x), rtol=1e-12)
+
+
+def test_eight_shards_from_resident_slices_reproduce_the_model(libs):
+    """What `bench.py --gpus 8` (config 5) runs on every rank, replayed rank by rank on one GPU: shard r of 8, COO as a
+    packed local slice, and ONLY the stretch of x / y the shard reads resident — handed over as a pointer shifted back
+    by the stretch's first index.  The eight local slices, placed by exa_coo_slices, are the unsharded Hessian."""
+    import ctypes
+    import sys
+    import torch
+    import oracle
+    from exahip import ExaModel, models
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import resident_ranges
+    N, world = 100_003, 8
+    m = ExaModel(models.luksan_vlcek_model(N))
+    o = oracle.OracleModel(m.ir)
+    x, y, s = point(m.meta.x0, m.meta.ncon, seed=5)
+    H = o.hess_coord(x, y, s)
+    Hr, Hc = o.hess_structure()
+    dev = torch.device("cuda:0")
+    got = np.full(m.meta.nnzh, np.nan)
+    L = m._L
+    for rank in range(world):
+        m.set_shard(rank, world)
+        m.set_coo_local(True)
+        vlo, vhi, ylo, yhi = resident_ranges(m, rank, world)
+        assert vhi - vlo <= N // world + 4 and yhi - ylo <= N // world + 1
+        xs = torch.from_numpy(x[vlo:vhi].copy()).to(dev)
+        ys = torch.from_numpy(y[ylo:yhi].copy()).to(dev)
+        n = m.local_nnzh
+        assert abs(n - m.meta.nnzh / world) <= 9
+        h = torch.full((n + 16,), float("nan"), dtype=torch.float64, device=dev)
+        rc = L.exa_hess(m.id, ctypes.c_void_p(xs.data_ptr() - 8 * vlo), ctypes.c_void_p(ys.data_ptr() - 8 * ylo), s, ctypes.c_void_p(h.data_ptr()))
+        assert rc == 0
+        rows = torch.zeros(n, dtype=torch.int64, device=dev)
+        cols = torch.zeros(n, dtype=torch.int64, device=dev)
+        assert L.exa_hess_structure64(m.id, ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(cols.data_ptr())) == 0
+        torch.cuda.synchronize()
+        hv, rv, cv = h.cpu().numpy(), rows.cpu().numpy(), cols.cpu().numpy()
+        assert np.all(np.isnan(hv[n:])) and not np.any(np.isnan(hv[:n]))          # exactly the slice, nothing beyond
+        for g0, l0, cnt in m.coo_slices(True):
+            assert np.all(np.isnan(got[g0:g0 + cnt]))
+            got[g0:g0 + cnt] = hv[l0:l0 + cnt]
+            assert np.array_equal(rv[l0:l0 + cnt], Hr[g0:g0 + cnt]) and np.array_equal(cv[l0:l0 + cnt], Hc[g0:g0 + cnt])
+    np.testing.assert_allclose(got, H, rtol=1e-10, atol=0)

@@ -310,6 +310,7 @@ def test_no_compiler_for_the_window_module_falls_back_to_the_gather(libs, monkey
     from exahip import CompressedExaModel, ExaModel, models
     m = ExaModel(models.luksan_vlcek_model(777))                  # base module compiled (or cached) with the real compiler
     monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))          # empty cache: the window module is not there
+    monkeypatch.setenv("EXAHIP_COMPILER", "hipcc")
     monkeypatch.setenv("EXAHIP_HIPCC", "/nonexistent/hipcc")
     cm = CompressedExaModel(m)
     kind, why = cm.path("hess")

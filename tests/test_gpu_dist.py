@@ -51,6 +51,42 @@ def _worker(rank, world, port, q):
             ok = (abs(f - o.obj(x)) <= 1e-10 * max(1, abs(o.obj(x))) and np.allclose(g, o.grad(x), rtol=1e-10, atol=1e-12)
                   and np.allclose(c, o.cons(x), rtol=1e-10, atol=1e-12) and np.allclose(whole, H, rtol=1e-10, atol=1e-12)
                   and np.allclose(jw, J, rtol=1e-10, atol=1e-12))
+            assert ev.transport == "hook" and m.comm_info() == (rank, world, "hook")       # reduced inside libexahip
+            # products through the same hook
+            v = np.random.default_rng(3).standard_normal(m.meta.nvar)
+            w = np.random.default_rng(4).standard_normal(m.meta.ncon)
+            vd, wd = torch.from_numpy(v).to(dev), torch.from_numpy(w).to(dev)
+            ok = ok and np.allclose(ev.jprod(xd, vd).cpu().numpy(), o.jprod(x, v), rtol=1e-10, atol=1e-12)
+            ok = ok and np.allclose(ev.jtprod(xd, wd).cpu().numpy(), o.jtprod(x, w), rtol=1e-10, atol=1e-12)
+            ok = ok and np.allclose(ev.hprod(xd, yd, vd, s).cpu().numpy(), o.hprod(x, y, v, s), rtol=1e-10, atol=1e-12)
+            # local-slice COO: slice-sized buffers, pieces placed by exa_coo_slices reproduce this rank's part exactly
+            m.set_coo_local(True)
+            hl = m.hess_coord(xd, yd, s).cpu().numpy()
+            jl = m.jac_coord(xd).cpu().numpy()
+            hr, hc = m.hess_structure()
+            jr, jc = m.jac_structure()
+            Hr, Hc = o.hess_structure()
+            Jr, Jc = o.jac_structure()
+            assert hl.size == m.local_nnzh < m.meta.nnzh and jl.size == m.local_nnzj
+            for (vals, rows, cols, ref, rref, cref, hess) in ((hl, hr, hc, H, Hr, Hc, True), (jl, jr, jc, J, Jr, Jc, False)):
+                for g0, l0, cnt in m.coo_slices(hess):
+                    ok = ok and np.allclose(vals[l0:l0 + cnt], ref[g0:g0 + cnt], rtol=1e-10, atol=1e-12)
+                    ok = ok and np.array_equal(rows[l0:l0 + cnt], rref[g0:g0 + cnt]) and np.array_equal(cols[l0:l0 + cnt], cref[g0:g0 + cnt])
+            # sorted (deterministic) products and the compressed COO work on the local slice; the model's matrix is the
+            # sum of the ranks' matrices
+            m.set_product_mode(1, 1)
+            ok = ok and np.allclose(ev.jtprod(xd, wd).cpu().numpy(), o.jtprod(x, w), rtol=1e-10, atol=1e-12)
+            ok = ok and np.allclose(ev.hprod(xd, yd, vd, s).cpu().numpy(), o.hprod(x, y, v, s), rtol=1e-10, atol=1e-12)
+            from exahip import CompressedExaModel
+            cm = CompressedExaModel(m)
+            cr, cc = cm.hess_structure()
+            cv = cm.hess_coord(xd, yd, s)
+            dense = torch.zeros(m.meta.nvar * m.meta.nvar, dtype=torch.float64, device=dev)
+            dense.index_add_(0, (cr - 1) * m.meta.nvar + (cc - 1), cv)
+            dense = ev.gather_coo(dense).cpu().numpy().reshape(m.meta.nvar, m.meta.nvar)
+            Hd = np.zeros((m.meta.nvar, m.meta.nvar))
+            np.add.at(Hd, (Hr - 1, Hc - 1), H)
+            ok = ok and np.allclose(dense, Hd, rtol=1e-10, atol=1e-11) and cm.meta.nnzh <= m.local_nnzh
             out[name] = (bool(ok), int(mine.sum()))
         q.put((rank, out))
     except Exception as e:      # noqa: BLE001

@@ -209,6 +209,7 @@ def test_packed_library_is_ahead_of_time(libs, tmp_path, monkeypatch):
     from exahip.pack import pack_library
     path = pack_library(str(tmp_path / "aot"), ("knob2", make(build_knob, (4,), True)))
     monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path / "empty_cache"))
+    monkeypatch.setenv("EXAHIP_COMPILER", "hipcc")
     monkeypatch.setenv("EXAHIP_HIPCC", "/nonexistent/hipcc")
     lib = ctypes.CDLL(path)
     m = Consumer(lib, "knob2", lib.knob2_new(9))

@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol(libs):
     for s in recipe:
         assert hasattr(L, s), f"libexahip.so does not export {s}"
     assert sorted(capi.RECIPE_SYMBOLS) == recipe, "capi.RECIPE_SYMBOLS and include/exahip_recipe.h disagree"
-    assert L.exa_abi_version() == 1
+    assert L.exa_abi_version() == 2
 
 
 def test_bad_ids_and_arguments_return_status_1(libs):
@@ -152,11 +152,12 @@ def test_module_source_is_size_independent(libs):
 
 
 def test_kernel_build_failure_is_status_2_with_message(libs, tmp_path, monkeypatch):
-    """A failing hipcc (internal error) must come back as status 2 with the compiler's text, never as a crash or a
+    """A failing compiler (internal error) must come back as status 2 with the compiler's text, never as a crash or a
     silent fallback."""
     from exahip import ExaModel, models
     from exahip.capi import ExaHipError
     monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))       # empty cache -> must invoke the compiler
+    monkeypatch.setenv("EXAHIP_COMPILER", "hipcc")
     monkeypatch.setenv("EXAHIP_HIPCC", "/bin/false")
     m = ExaModel(models.luksan_vlcek_model(10), device=False)
     with pytest.raises(ExaHipError, match="status 2.*hipcc failed"):
@@ -164,6 +165,73 @@ def test_kernel_build_failure_is_status_2_with_message(libs, tmp_path, monkeypat
     monkeypatch.setenv("EXAHIP_HIPCC", "/opt/rocm/bin/hipcc")
     path = m.compile()
     assert path.startswith(str(tmp_path)) and os.path.getsize(path) > 1000
+    assert not [f for f in os.listdir(tmp_path) if f.endswith((".tmp", ".log", ".hip"))]      # no build litter
+    # the in-process compiler reports the same way: a flag it cannot parse is a status-2 failure with its text
+    monkeypatch.setenv("EXAHIP_COMPILER", "hiprtc")
+    monkeypatch.setenv("EXAHIP_HIPCC_FLAGS", "--no-such-flag-xyz")
+    with pytest.raises(ExaHipError, match="status 2.*hiprtc failed"):
+        m.compile()
+
+
+def test_in_process_compilation_needs_no_hipcc(libs, tmp_path, monkeypatch):
+    """The default build path is hiprtc inside the process (the reference specialises in-process too, KA ext :608-653):
+    with NO hipcc on the machine and an empty cache a model still compiles, into a gfx950 ELF, and the second request
+    is a cache hit; the cache entry's name carries the source hash and the tool hash."""
+    from exahip import ExaModel, models
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))
+    monkeypatch.setenv("EXAHIP_HIPCC", "/nonexistent/hipcc")
+    monkeypatch.delenv("EXAHIP_COMPILER", raising=False)
+    m = ExaModel(models.luksan_vlcek_model(10), device=False)
+    path = m.compile()
+    how, ms = m.build_info()
+    assert how == "hiprtc" and ms > 0, (how, ms)
+    blob = open(path, "rb").read()
+    assert blob[:4] == b"\x7fELF" and int.from_bytes(blob[18:20], "little") == 224          # EM_AMDGPU
+    name = capi_name(m)
+    assert os.path.basename(path).startswith(name + "-") and len(name) == 4 + 32
+    m2 = ExaModel(models.luksan_vlcek_model(77), device=False)                                 # same module, another N
+    assert m2.compile() == path and m2.build_info()[0] == "disk"
+
+
+def capi_name(m):
+    return m._L.exa_module_name(m.id).decode()
+
+
+def test_cache_directory_must_be_private(libs, tmp_path, monkeypatch):
+    """A cache directory other users can write to is never used (a planted .hsaco would be run on the GPU): the library
+    falls back to ~/.cache/exahip (created 0700) — and never to a shared location such as /tmp."""
+    import stat
+    from exahip import ExaModel, models
+    shared = tmp_path / "shared"
+    shared.mkdir()
+    os.chmod(shared, 0o777)
+    home = tmp_path / "home"
+    home.mkdir()
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(shared))
+    monkeypatch.setenv("HOME", str(home))
+    monkeypatch.delenv("XDG_CACHE_HOME", raising=False)
+    m = ExaModel(models.luksan_vlcek_model(10), device=False)
+    path = m.compile()
+    assert path.startswith(str(home / ".cache" / "exahip")), path
+    assert not list(shared.iterdir())
+    assert stat.S_IMODE(os.stat(home / ".cache" / "exahip").st_mode) == 0o700
+    # a symlink in place of the directory is refused as well
+    link = tmp_path / "link"
+    link.symlink_to(home / ".cache" / "exahip")
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(link))
+    monkeypatch.setenv("HOME", str(tmp_path / "home2"))
+    (tmp_path / "home2").mkdir()
+    assert ExaModel(models.luksan_vlcek_model(10), device=False).compile().startswith(str(tmp_path / "home2"))
+
+
+def test_cache_add_refuses_what_is_not_a_code_object(libs):
+    L = libs[0]
+    junk = b"not an elf" * 20
+    assert L.exa_cache_add(b"exa_0123", junk, len(junk)) == 1
+    elf_other_machine = bytearray(b"\x7fELF\x02\x01\x01" + bytes(57))
+    elf_other_machine[18] = 62                                                              # EM_X86_64
+    assert L.exa_cache_add(b"exa_0123", bytes(elf_other_machine), len(elf_other_machine)) == 1
+    assert L.exa_cache_add(b"other_name", junk, len(junk)) == 1
 
 
 def test_out_of_range_indices_are_refused_at_build(libs):
