@@ -61,6 +61,8 @@ struct Emitter {
     std::vector<std::string> lines;
     std::map<std::string, Val> memo;
     int next = 0;
+    struct Def { int line; std::string name, expr; bool is_int; };
+    std::vector<Def> defs;        // the lines that are plain SSA definitions `const T name = expr;` (raw), in order
 
     static Val litf(double v) { Val r; r.k = Val::LF; r.f = v; return r; }
     static Val liti(int64_t v) { Val r; r.k = Val::LI; r.i = v; r.f = (double)v; return r; }
@@ -93,6 +95,7 @@ struct Emitter {
         r.k = is_int ? Val::SI : Val::SF;
         r.id = next++;
         lines.push_back(std::string(is_int ? "const long k" : "const double t") + std::to_string(r.id) + " = " + expr + ";");
+        defs.push_back({(int)lines.size() - 1, std::string(is_int ? "k" : "t") + std::to_string(r.id), expr, is_int});
         memo[expr] = r;
         return r;
     }
@@ -110,7 +113,17 @@ struct Emitter {
             const double x = a.litv(), y = b.litv();
             switch (op) { case '+': return litf(x + y); case '-': return litf(x - y); case '*': return litf(x * y); case '/': return litf(x / y); }
         }
-        // identities on exact literals.  (0*z -> 0 and z+0 -> z differ from IEEE only when z is Inf/NaN.)
+        // identities on exact literals.  1*z, z/1 and z-0 are exact for every z; 0*z -> 0, 0/z -> 0 (differ from IEEE
+        // when z is Inf/NaN: the reference, which multiplies at run time, has NaN there) and z+0 -> z (differs for
+        // z = -0.0) are dropped under EXAHIP_STRICT_IEEE=1 — the reference's special values entry for entry, at the
+        // price of the multiplications by literal zeros the reverse sweep is full of (DESIGN.md §4 has the numbers).
+        const bool strict = env_int("EXAHIP_STRICT_IEEE", 0) != 0;
+        if (strict && !ii) {
+            if (op == '*' && (a.lit_eq(1) || b.lit_eq(1))) return a.lit_eq(1) ? tod(b) : tod(a);
+            if (op == '/' && b.lit_eq(1)) return tod(a);
+            if (op == '-' && b.lit_eq(0)) return tod(a);
+            return raw(sd(a) + " " + op + " " + sd(b), false);
+        }
         switch (op) {
         case '+': if (a.lit_eq(0)) return ii ? b : tod(b); if (b.lit_eq(0)) return ii ? a : tod(a); break;
         case '-': if (b.lit_eq(0)) return ii ? a : tod(a); if (a.lit_eq(0)) return neg(ii ? b : tod(b)); break;
@@ -330,6 +343,17 @@ Six bin_rule(Emitter &e, int fn, Val x1, Val x2, int order) {
     case EXA_B_MUL: r.x = e.mul(x1, x2); r.y1 = e.tod(x2); r.y2 = e.tod(x1); r.h12 = O; return r;
     case EXA_B_DIV: {
         r.x = e.div(x1, x2);
+        if (order >= 1 && env_int("EXAHIP_STRICT_IEEE", 0)) {
+            // the table's own forms (functionlist.jl:75): 1/x2, -x1/x2^2, -1/x2^2, 2x1/x2^3 — three more divisions; they
+            // differ from the quotient forms below only where x2^2 or x2^3 over/underflows (|x2| > 1.3e154, < 1e-103)
+            r.y1 = e.div(O, x2);
+            r.y2 = e.div(e.neg(x1), e.sq(x2));
+            if (order >= 2) {
+                r.h12 = e.div(Emitter::litf(-1), e.sq(x2));
+                r.h22 = e.div(e.mul(Emitter::litf(2), x1), e.mul(e.sq(x2), x2));
+            }
+            return r;
+        }
         if (order >= 1) {
             Val inv = e.div(O, x2);
             r.y1 = inv;
@@ -617,6 +641,51 @@ void emit_lines(std::ostringstream &os, const Emitter &e, const char *indent = "
     for (const auto &l : e.lines) os << indent << l << "\n";
 }
 
+// ---- load stage / evaluation stage of a pattern body (chained, software-pipelined callbacks) ------------------------
+// The SSA lines of a body are split into what touches memory — the loads of x, y, theta and the iterator columns,
+// together with the integer index arithmetic they need — and the arithmetic that consumes the loaded values.  The
+// load stage hands its values over in `in[]` (doubles) and `ik[]` (integers read from data columns); the evaluation
+// stage re-derives the pure index arithmetic (scalar / cheap integer work) and reads everything else from there.
+struct Split {
+    std::vector<std::string> load, eval;
+    int nin = 0, nik = 0;
+};
+bool is_memory_read(const std::string &expr) {
+    for (const char *pre : {"x[", "y[", "th[", "v[", "((const long*)P[", "((const double*)P["})
+        if (expr.compare(0, strlen(pre), pre) == 0) return true;
+    return false;
+}
+Split split_body(const Emitter &e) {
+    Split sp;
+    size_t d = 0;
+    for (size_t li = 0; li < e.lines.size(); li++) {
+        const std::string &line = e.lines[li];
+        if (d < e.defs.size() && e.defs[d].line == (int)li) {
+            const Emitter::Def &df = e.defs[d++];
+            if (is_memory_read(df.expr)) {
+                sp.load.push_back(line);
+                if (df.is_int) {
+                    sp.load.push_back("ik[" + std::to_string(sp.nik) + "] = " + df.name + ";");
+                    sp.eval.push_back("const long " + df.name + " = ik[" + std::to_string(sp.nik++) + "];");
+                } else {
+                    sp.load.push_back("in[" + std::to_string(sp.nin) + "] = " + df.name + ";");
+                    sp.eval.push_back("const double " + df.name + " = in[" + std::to_string(sp.nin++) + "];");
+                }
+            } else if (df.is_int) {
+                sp.load.push_back(line);       // index arithmetic: needed by the loads, recomputed by the evaluation
+                sp.eval.push_back(line);
+            } else sp.eval.push_back(line);
+        } else sp.eval.push_back(line);        // multi-value statements (sincos): arithmetic
+    }
+    return sp;
+}
+// doubles / integers the load stage of (callback, pattern) hands over (per module generation)
+std::map<std::pair<int, int>, std::pair<int, int>> g_handover;
+int chain_len(int cb) {
+    if (cb == CB_HESSC) return env_int("EXAHIP_CHAIN", 4);       // tiles per workgroup of exa_hessc; 0 = no such kernel
+    return 0;
+}
+
 const char *kPrelude = R"HIP(// Generated by libexahip (examodels.jl_amd/csrc/exa_codegen.cpp) for gfx950.  Do not edit.
 #ifndef __HIPCC_RTC__
 #include <hip/hip_runtime.h>
@@ -632,9 +701,29 @@ const char *kPrelude = R"HIP(// Generated by libexahip (examodels.jl_amd/csrc/ex
 #define EXA_AUG_CHUNK 8192
 static __device__ __forceinline__ double exa_sq(double x) { return x * x; }
 static __device__ __forceinline__ double exa_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : x); }
-static __device__ __forceinline__ double exa_sind(double x) { return sin(EXA_D2R * fmod(x, 360.0)); }
-static __device__ __forceinline__ double exa_cosd(double x) { return cos(EXA_D2R * fmod(x, 360.0)); }
-static __device__ __forceinline__ double exa_tand(double x) { return tan(EXA_D2R * fmod(x, 180.0)); }
+// Base.sind / cosd / tand: exact rem(x, 360), quadrant selected before the conversion to radians — exact zeros and poles
+// at the multiples of 90 (sind(180) = 0, cosd(90) = 0, tand(90) = Inf), like Julia's; +-Inf -> NaN.
+static __device__ __forceinline__ double exa_sind(double x) {
+    if (!(fabs(x) < __builtin_inf())) return x != x ? x : __builtin_nan("");
+    const double rx = copysign(fmod(x, 360.0), x), arx = fabs(rx);
+    if (rx == 0.0) return rx;
+    if (arx < 45.0) return sin(EXA_D2R * rx);
+    if (arx <= 135.0) return copysign(cos(EXA_D2R * (90.0 - arx)), rx);
+    if (arx == 180.0) return copysign(0.0, rx);
+    if (arx < 225.0) return sin(EXA_D2R * ((180.0 - arx) * (rx > 0.0 ? 1.0 : -1.0)));
+    if (arx <= 315.0) return -copysign(cos(EXA_D2R * (270.0 - arx)), rx);
+    return sin(EXA_D2R * (rx - copysign(360.0, rx)));
+}
+static __device__ __forceinline__ double exa_cosd(double x) {
+    if (!(fabs(x) < __builtin_inf())) return x != x ? x : __builtin_nan("");
+    const double rx = fabs(fmod(x, 360.0));
+    if (rx <= 45.0) return cos(EXA_D2R * rx);
+    if (rx < 135.0) return sin(EXA_D2R * (90.0 - rx));
+    if (rx <= 225.0) return -cos(EXA_D2R * (180.0 - rx));
+    if (rx < 315.0) return sin(EXA_D2R * (rx - 270.0));
+    return cos(EXA_D2R * (360.0 - rx));
+}
+static __device__ __forceinline__ double exa_tand(double x) { return exa_sind(x) / exa_cosd(x); }
 static __device__ __forceinline__ double exa_sinc(double x) { return x == 0.0 ? 1.0 : sinpi(x) / (EXA_PI * x); }
 // sin and cos together, FP64.  FP64 transcendentals are software sequences on CDNA4 and the ocml pair costs ~50 FP64
 // instructions (it carries double-double terms for < 1 ulp); for |x| < 2^19 * pi/2 this version does a 3-term Cody-Waite
@@ -706,6 +795,32 @@ static __device__ __forceinline__ void exa_flush_points(double* __restrict__ out
             const int l2 = j / S, s2 = j - l2 * S;
             if (j < CNT && g * PP + l2 < npts) __builtin_nontemporal_store(tile[s2 * LD + l2], dst + j);
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// The same flush with a FIXED number of store instructions and no branch around any of them (chained callbacks): lanes
+// without a slot of their own store to `sink` (a scratch line per lane) instead of being masked off.  On gfx9 loads and
+// stores retire through ONE in-order counter (vmcnt); only when the number of stores between a load and its use is the
+// same on every path can the compiler wait for the load alone (vmcnt(N > 0)) instead of draining the stores as well.
+template <int S, int PP, int LD>
+static __device__ __forceinline__ void exa_flush_points_nb(double* __restrict__ out, double* __restrict__ sink, long obase, long npts, const double* tile,
+                                                            int lane, int g) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int CNT = S * PP;
+    double* __restrict__ dst = out + obase + (long)CNT * g;
+    const long left = npts - (long)g * PP;          // points of this group that exist
+#pragma unroll
+    for (int k = 0; k * 64 < CNT; k++) {
+        const int j = k * 64 + lane;
+        int l2 = j / S;
+        const int s2 = j - l2 * S;
+        const bool ok = ((k + 1) * 64 <= CNT || j < CNT) && l2 < left;
+        if ((k + 1) * 64 > CNT) l2 = l2 < PP ? l2 : PP - 1;
+        double* __restrict__ p = ok ? dst + j : sink + lane;
+        __builtin_nontemporal_store(tile[s2 * LD + l2], p);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -855,7 +970,14 @@ void emit_coo_prologue(std::ostringstream &os, const Body &b, const ParamLayout 
     }
 }
 void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, const std::vector<std::string> &vals, bool tile,
-                     const std::string &out = "out", const std::string &tag = "") {
+                     const std::string &out = "out", const std::string &tag = "", bool no_branch = false) {
+    if (no_branch && !tile) {
+        // narrow patterns (S < 2), chained: one store per slot, lanes beyond the shard store to the sink
+        os << "    {\n    double* __restrict__ po = I0 < hi ? " << out << " + " << b.P(word_o) << " + " << S << "L * I : sink + (threadIdx.x & 63);\n";
+        for (int s = 0; s < S; s++) os << "    po[" << (s == 0 ? "0" : "(I0 < hi ? " + std::to_string(s) + " : 0)") << "] = " << vals[s] << ";\n";
+        os << "    }\n";
+        return;
+    }
     if (tile) {
         const int pp = tile_pp(S), ld = tile_ld(S);
         // `lds` is this WAVEFRONT's private staging region (sized for the widest tile of the kernel): wavefronts never
@@ -870,7 +992,8 @@ void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, c
                 for (int s = 0; s < S; s++) os << "        tile[" << s * ld << " + (lane % " << pp << ")] = " << vals[s] << ";\n";
                 os << "    }\n";
             }
-            os << "    exa_flush_points<" << S << ", " << pp << ", " << ld << ">(" << out << ", obase, npts, tile, lane, " << g << ");\n";
+            if (no_branch) os << "    exa_flush_points_nb<" << S << ", " << pp << ", " << ld << ">(" << out << ", sink, obase, npts, tile, lane, " << g << ");\n";
+            else os << "    exa_flush_points<" << S << ", " << pp << ", " << ld << ">(" << out << ", obase, npts, tile, lane, " << g << ");\n";
         }
         os << "    }\n";
     } else {
@@ -1015,6 +1138,8 @@ void emit_scatter_prologue(std::ostringstream &os, const Body &b, const ParamLay
 }
 
 std::string fn_name(int pi, const char *cb) { return "p" + std::to_string(pi) + "_" + cb; }
+void emit_two_stage(std::ostringstream &os, Body &b, const ParamLayout &L, int pi, int cb, const char *name, bool hess, bool tile,
+                    int word_o, int S, const std::vector<std::string> &vals);
 
 // ---- per-pattern device functions -----------------------------------------------------------------
 void gen_value_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
@@ -1119,6 +1244,29 @@ void gen_pull_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     os << "    return g;\n}\n";
 }
 
+// COO-writing pattern function in two stages (see split_body): pK_<cb>L loads, pK_<cb>E evaluates and stores.
+void emit_two_stage(std::ostringstream &os, Body &b, const ParamLayout &L, int pi, int cb, const char *name, bool hess, bool tile,
+                    int word_o, int S, const std::vector<std::string> &vals) {
+    const Split sp = split_body(b.e);
+    g_handover[{cb, pi}] = {sp.nin, sp.nik};
+    os << "static __device__ __forceinline__ void " << fn_name(pi, name) << "L(const long* __restrict__ P, const double* __restrict__ x, "
+       << (hess ? "const double* __restrict__ y, " : "") << "const double* __restrict__ th, long tid, double* in, long* ik) {\n"
+       << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n"
+       // no branch: lanes (and whole tiles) beyond the shard re-read its last point — or point 0 when the shard holds
+       // nothing of this pattern (active patterns have n >= 1; exa_shard_var_range counts that point in)
+       << "    const long I = I0 < hi ? I0 : (hi > 0 ? hi - 1 : 0);\n";
+    for (const auto &l : sp.load) os << "    " << l << "\n";
+    os << "}\n";
+    os << "static __device__ __forceinline__ void " << fn_name(pi, name) << "E(const long* __restrict__ P, const double* in, const long* ik, "
+       << "double* __restrict__ out, double* __restrict__ sink, " << (hess ? "double sigma, " : "") << "long tid, double* lds) {\n"
+       << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n"
+       << "    const int lane = threadIdx.x & 63;\n    const long I = I0 < hi ? I0 : (hi > 0 ? hi - 1 : 0);\n";
+    for (const auto &l : sp.eval) os << "    " << l << "\n";
+    if (env_int("EXAHIP_NB", 1)) emit_coo_stores(os, b, word_o, S, vals, tile, "out", "", true);
+    else { os << "    const long npts_ = hi - (I0 - lane); (void)npts_;\n"; emit_coo_stores(os, b, word_o, S, vals, tile); }
+    os << "}\n";
+}
+
 void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
     Body b(m, pi, L);
     const Pattern &p = b.p;
@@ -1129,13 +1277,14 @@ void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     GenAlg a(b, p.comp2, p.o2step);
     hrpass0(p, p.ad_root, a, adj, zero_seed(b));
     const bool tile = use_tile(p.o2step);
+    std::vector<std::string> vals;
+    for (int s = 0; s < p.o2step; s++) vals.push_back(b.e.sd(a.acc[s]));
+    if (L.chain[CB_HESSC] > 0) emit_two_stage(os, b, L, pi, CB_HESSC, "hessc", true, tile, L.pat[pi].o2, p.o2step, vals);
     os << "static __device__ __forceinline__ void " << fn_name(pi, "hess")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
           "double* __restrict__ out, double sigma, long tid, double* lds) {\n";
     emit_coo_prologue(os, b, L, pi, tile);
     emit_lines(os, b.e);
-    std::vector<std::string> vals;
-    for (int s = 0; s < p.o2step; s++) vals.push_back(b.e.sd(a.acc[s]));
     emit_coo_stores(os, b, L.pat[pi].o2, p.o2step, vals, tile);
     os << "}\n";
 }
@@ -1352,6 +1501,59 @@ void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const st
     }
 }
 
+// Chained dispatch (jac / hess), see ParamLayout::chain: entry = (group, first tile); T tiles, all patterns of the
+// group per tile, the loads of the next (pattern, tile) issued before the current one is evaluated and stored.  Every
+// pattern of a group keeps its own hand-over registers, so no value ever merges across patterns.
+void gen_dispatch_chained(std::ostringstream &os, const ParamLayout &L, int cb, const char *name, bool hess) {
+    const int T = L.chain[cb];
+    const auto &groups = L.groups[cb];
+    auto ld = [&](int pk, const std::string &tid, const std::string &sfx) {
+        os << "p" << pk << "_" << name << "L(P, x, " << (hess ? "y, " : "") << "th, " << tid << ", in" << pk << sfx << ", ik" << pk << sfx << ");";
+    };
+    auto ev = [&](int pk, const std::string &tid) {
+        os << "p" << pk << "_" << name << "E(P, in" << pk << ", ik" << pk << ", out, sink, " << (hess ? "sigma, " : "") << tid << ", lds);";
+    };
+    os << "    const long e_ = ((const long*)P[" << L.blk[cb] << "])[blockIdx.x];\n    const int gs_ = (int)(e_ >> 40);\n"
+       << "    const long t0_ = (e_ & ((1L << 40) - 1)) * " << T << ";\n";
+    for (size_t g = 0; g < groups.size(); g++) {
+        const auto &grp = groups[g];
+        const int first = grp.front(), last = grp.back();
+        os << "    " << (g ? "else " : "") << "if (gs_ == " << g << ") {\n        const long tend_ = t0_ + " << T << " < P[" << L.gtiles[cb][g] << "] ? t0_ + " << T
+           << " : P[" << L.gtiles[cb][g] << "];\n";
+        for (int pk : grp) {
+            const auto ho = g_handover[{cb, pk}];
+            os << "        double in" << pk << "[" << std::max(1, ho.first) << "]; long ik" << pk << "[" << std::max(1, ho.second) << "];\n";
+        }
+        const auto h0 = g_handover[{cb, first}];
+        os << "        double in" << first << "n[" << std::max(1, h0.first) << "]; long ik" << first << "n[" << std::max(1, h0.second) << "];\n        ";
+        ld(first, "t0_ * EXA_BLOCK + threadIdx.x", "");
+        // (claimed before the loop too: at the loop header the two incoming paths must agree that these loads are done)
+        os << "\n#pragma unroll\n        for (int q = 0; q < " << std::max(1, h0.first) << "; q++) asm volatile(\"\" : \"+v\"(in" << first << "[q]));\n"
+           << "#pragma unroll\n        for (int q = 0; q < " << std::max(1, h0.second) << "; q++) asm volatile(\"\" : \"+v\"(ik" << first << "[q]));";
+        os << "\n#pragma unroll 1\n        for (long t = t0_; t < tend_; t++) {\n            const long tid = t * EXA_BLOCK + threadIdx.x;\n";
+        // (the next tile's load is unconditional — the last tile loads itself again —: the number of memory instructions
+        // per iteration is fixed)
+        if (env_int("EXAHIP_CHAIN_EARLY", 1)) {
+            // all loads of the iteration first — the other patterns of this tile AND the first pattern of the next tile —,
+            // then all evaluations: every load has at least one evaluation's arithmetic to land in
+            for (size_t j = 1; j < grp.size(); j++) { os << "            "; ld(grp[j], "tid", ""); os << "\n"; }
+            os << "            "; ld(first, "(t + 1 < tend_ ? t + 1 : t) * EXA_BLOCK + threadIdx.x", "n"); os << "\n";
+            for (size_t j = 0; j < grp.size(); j++) { os << "            "; ev(grp[j], "tid"); if (j + 1 < grp.size()) os << "\n"; }
+        } else {
+            for (size_t j = 1; j < grp.size(); j++) {
+                os << "            "; ld(grp[j], "tid", ""); os << "\n            "; ev(grp[j - 1], "tid"); os << "\n";
+            }
+            os << "            "; ld(first, "(t + 1 < tend_ ? t + 1 : t) * EXA_BLOCK + threadIdx.x", "n"); os << "\n            "; ev(last, "tid");
+        }
+        // The hand-over registers are claimed HERE, at the bottom of the iteration, where the only memory instructions
+        // issued after the loads are the fixed number of stores of the last pattern: the wait is vmcnt(#stores).  Left to
+        // itself the compiler merges in*n into in* and waits at the loop header, where the first entry (no stores behind
+        // its loads) forces vmcnt(0) — draining every store of the previous tile before the next evaluation starts.
+        os << "\n#pragma unroll\n            for (int q = 0; q < " << std::max(1, h0.first) << "; q++) { asm volatile(\"\" : \"+v\"(in" << first << "n[q])); in" << first << "[q] = in" << first << "n[q]; }\n"
+           << "#pragma unroll\n            for (int q = 0; q < " << std::max(1, h0.second) << "; q++) { asm volatile(\"\" : \"+v\"(ik" << first << "n[q])); ik" << first << "[q] = ik" << first << "n[q]; }\n        }\n    }\n";
+    }
+}
+
 }  // namespace
 
 Generated generate_module(const Model &m) {
@@ -1383,10 +1585,26 @@ Generated generate_module(const Model &m) {
             if (p.o1step > 0) L.active[CB_JTPROD].push_back(k);
             if (p.o1step > 0) { L.active[CB_JAC].push_back(k); L.active[CB_JSTRUCT].push_back(k); }
         }
-        if (p.o2step > 0) { L.active[CB_HESS].push_back(k); L.active[CB_HSTRUCT].push_back(k); L.active[CB_HPROD].push_back(k); }
+        if (p.o2step > 0) { L.active[CB_HESS].push_back(k); L.active[CB_HESSC].push_back(k); L.active[CB_HSTRUCT].push_back(k); L.active[CB_HPROD].push_back(k); }
         L.active[CB_FUSED].push_back(k);
     }
-    for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w++; L.ppt[cb] = 1; }
+    for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w++; L.ppt[cb] = 1; L.chain[cb] = std::max(0, chain_len(cb)); }
+    g_handover.clear();
+    // groups of co-indexed patterns (iterator lengths within 2 of each other), in dispatch order.  The lengths are what
+    // decides, so instances of a model family share one module unless two unrelated blocks happen to be equally long.
+    for (int cb : {CB_HESSC}) {
+        if (L.chain[cb] == 0) continue;
+        const int gmax = std::max(1, env_int("EXAHIP_GROUP_MAX", 8));
+        for (int k : L.active[cb]) {
+            bool placed = false;
+            if (env_int("EXAHIP_GROUP", 1))
+                for (auto &g : L.groups[cb])
+                    if ((int)g.size() < gmax && std::llabs(m.pats[g.front()].n - m.pats[k].n) <= 2) { g.push_back(k); placed = true; break; }
+            if (!placed) L.groups[cb].push_back({k});
+        }
+        for (size_t g = 0; g < L.groups[cb].size(); g++) L.gtiles[cb].push_back(w++);
+    }
+
     // streaming value kernels keep more loads in flight per wavefront with several points per thread (measured)
     L.ppt[CB_OBJ] = env_int("EXAHIP_PPT_OBJ", 8);
     L.ppt[CB_CONS] = env_int("EXAHIP_PPT_CONS", 1);
@@ -1485,16 +1703,28 @@ Generated generate_module(const Model &m) {
         if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all + (threadIdx.x >> 6) * " << mx << ";\n";
         else os << "    double* lds = nullptr;\n";
     };
-    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jac(const long* __restrict__ P, const double* __restrict__ x, "
+    // `sink`: 64 doubles nobody reads, the target of lanes that have no slot to store (chained kernels: exa_flush_points_nb)
+    auto occupancy_hint = [&](int cb) -> std::string {
+        const int w = L.chain[cb] > 0 ? env_int("EXAHIP_CHAIN_WAVES", 0) : 0;
+        return w > 0 ? "__attribute__((amdgpu_waves_per_eu(" + std::to_string(w) + "))) " : "";
+    };
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) " << occupancy_hint(CB_JAC) << "exa_jac(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out) {\n";
     lds_decl(CB_JAC, false);
     gen_dispatch(os, L, CB_JAC, "jac", "P, x, th, out", ", lds");
     os << "}\n";
-    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hess(const long* __restrict__ P, const double* __restrict__ x, "
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) " << occupancy_hint(CB_HESS) << "exa_hess(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma) {\n";
     lds_decl(CB_HESS, true);
     gen_dispatch(os, L, CB_HESS, "hess", "P, x, y, th, out, sigma", ", lds");
     os << "}\n";
+    if (L.chain[CB_HESSC] > 0) {
+        os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) " << occupancy_hint(CB_HESSC) << "exa_hessc(const long* __restrict__ P, const double* __restrict__ x, "
+              "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma, double* __restrict__ sink) {\n";
+        lds_decl(CB_HESS, true);
+        gen_dispatch_chained(os, L, CB_HESSC, "hessc", true);
+        os << "}\n";
+    }
     // fused cons + jac + hess (+ objective partial sums)
     {
         int mx = 0;

@@ -76,7 +76,9 @@ std::unique_ptr<Model> plan_model(const exa_model_desc_t *desc);   // throws std
 // Code generator (exa_codegen.cpp)
 // ---------------------------------------------------------------------------------------------------
 enum Callback { CB_OBJ = 0, CB_GRAD, CB_CONS, CB_JAC, CB_HESS, CB_JSTRUCT, CB_HSTRUCT,
-                CB_JPROD, CB_JTPROD, CB_HPROD, CB_FUSED, CB_COUNT };
+                CB_JPROD, CB_JTPROD, CB_HPROD, CB_FUSED,
+                CB_HESSC,      // hess_coord!, second kernel (exa_hessc): chained + grouped + software-pipelined, see ParamLayout::chain
+                CB_COUNT };
 
 struct ParamLayout {
     // word indices into the int64 parameter table P that every kernel receives
@@ -90,6 +92,19 @@ struct ParamLayout {
     int blk[CB_COUNT];                   // word holding the device address of the callback's block map: entry b =
                                          // (slot in active[cb] << 40) | tile index, built by the runtime (interleaved)
     int ppt[CB_COUNT];                   // data points per thread (a workgroup covers kBlock * ppt points)
+    // Chained callbacks (CB_HESSC: the streaming variant of hess_coord!; which of exa_hess / exa_hessc runs is a measured,
+    // persisted decision — the pipelined loop needs twice the registers, so cache-resident models prefer the plain
+    // kernel and models streaming gigabytes the chained one).  The active patterns are partitioned into GROUPS of co-indexed patterns (iterators of
+    // the same length: LV's constraint and objective, the four branch-flow constraints of ACOPF, the dynamics rows of a
+    // discretised ODE).  A block-map entry is (group, first tile); its workgroup walks `chain` consecutive tiles and, for
+    // every tile, all patterns of the group back to back — so co-indexed patterns read their stretch of x / their table
+    // rows from HBM once (the second reader hits L1 / L2) at ANY model size.  The walk is software-pipelined: the inputs
+    // of the next (pattern, tile) are loaded BEFORE the current one is evaluated and stored (on gfx9 loads and stores
+    // share vmcnt in order, so loads issued after a tile's stores would wait for those stores to drain).
+    // chain = 0: one (pattern, tile) per workgroup, the plain dispatch.  gtiles = P word with each group's tile count.
+    int chain[CB_COUNT];
+    std::vector<std::vector<int>> groups[CB_COUNT];
+    std::vector<int> gtiles[CB_COUNT];
     int nwords = 0;
     std::vector<int> pull;               // objective patterns whose gradient is GATHERED per variable (exa_grad_pull)
     int pull_ppt = 1;                    // variables per thread of exa_grad_pull

@@ -76,14 +76,17 @@ struct Handle {
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
     hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
-                  f_hess = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
+                  f_hess = nullptr, f_hessc = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
+    DevBuf dsink;                           // 64 doubles nobody reads (ParamLayout::sink)
     DevBuf dP, dtheta, dpart, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
     int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation
-    DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] sequential, [1] interleaved
+    DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] units one after the other, [1] interleaved in runs of 128
     int order[CB_COUNT] = {0};              // which map is active
-    bool two_orders[CB_COUNT] = {false};    // a second (interleaved) map exists: exa_tune may measure both
+    int norders[CB_COUNT] = {1};            // how many maps exist: exa_tune measures all of them
+    int hess_variant = 0;                   // hess_coord! kernel: 0 exa_hess (one tile per workgroup), 1 exa_hessc (chained, grouped, pipelined)
+    double hess_stream_bytes = 0.0;         // HBM bytes one hess_coord! of this shard streams (outputs + x + y)
     int64_t fused_nobj = 0;                 // objective partial sums written by exa_fused
     std::vector<DevBuf> dcols;              // flattened over patterns
     std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
@@ -114,7 +117,7 @@ struct Handle {
 
     ~Handle() {
         if (on_device) {
-            dP.release(); dtheta.release(); dpart.release(); dobj.release();
+            dsink.release(); dP.release(); dtheta.release(); dpart.release(); dobj.release();
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
             cj.release(); ch.release(); cbuf.release();
@@ -181,6 +184,7 @@ void fill_params(Handle &h) {
             else h.P[pp.col[c]] = h.on_device ? (int64_t)(uintptr_t)h.dcols[h.colslot[k][c]].p : 0;
         }
     }
+    if (h.on_device) h.dsink.ensure(8 * 64);
     h.lnnzj = local ? l1 : m.nnzj;
     h.lnnzh = local ? l2 : m.nnzh;
     // Block maps: workgroup b -> (pattern slot, tile).  Two orders are prepared per callback:
@@ -195,22 +199,37 @@ void fill_params(Handle &h) {
     const char *il_env = getenv("EXAHIP_INTERLEAVE");
     const int64_t il_forced = il_env ? atoll(il_env) : -1;
     for (int cb = 0; cb < CB_COUNT; cb++) {
-        const size_t na = L.active[cb].size();
+        // dispatch units: one per active pattern, or (chained callbacks) one per group of co-indexed patterns; nb = how
+        // many block-map entries (workgroups) a unit needs
+        const bool chained = L.chain[cb] > 0;
+        const size_t na = chained ? L.groups[cb].size() : L.active[cb].size();
         std::vector<int64_t> nb(na);
         int64_t total = 0;
         double out_bytes = 0.0;
+        auto per_point = [&](const Pattern &pt) {
+            if (cb == CB_HESS || cb == CB_HSTRUCT) return pt.o2step;
+            if (cb == CB_JAC || cb == CB_JSTRUCT) return pt.o1step;
+            if (cb == CB_FUSED) return 1 + pt.o1step + pt.o2step;
+            return 1;
+        };
         for (size_t j = 0; j < na; j++) {
-            const auto &pp = L.pat[L.active[cb][j]];
-            const Pattern &pt = m.pats[L.active[cb][j]];
-            const int64_t tile = (int64_t)kBlock * L.ppt[cb];
-            const int64_t cnt = h.P[pp.hi] - h.P[pp.lo];
-            nb[j] = (cnt + tile - 1) / tile;
+            if (chained) {
+                int64_t tiles = 0;
+                for (int k : L.groups[cb][j]) {
+                    const int64_t cnt = h.P[L.pat[k].hi] - h.P[L.pat[k].lo];
+                    tiles = std::max(tiles, (cnt + kBlock - 1) / kBlock);
+                    out_bytes += 8.0 * per_point(m.pats[k]) * (double)cnt;
+                }
+                h.P[L.gtiles[cb][j]] = tiles;
+                nb[j] = (tiles + L.chain[cb] - 1) / L.chain[cb];
+            } else {
+                const auto &pp = L.pat[L.active[cb][j]];
+                const int64_t tile = (int64_t)kBlock * L.ppt[cb];
+                const int64_t cnt = h.P[pp.hi] - h.P[pp.lo];
+                nb[j] = (cnt + tile - 1) / tile;
+                out_bytes += 8.0 * per_point(m.pats[L.active[cb][j]]) * (double)cnt;
+            }
             total += nb[j];
-            int per = 1;
-            if (cb == CB_HESS || cb == CB_HSTRUCT) per = pt.o2step;
-            else if (cb == CB_JAC || cb == CB_JSTRUCT) per = pt.o1step;
-            else if (cb == CB_FUSED) per = 1 + pt.o1step + pt.o2step;
-            out_bytes += 8.0 * per * (double)cnt;
         }
         h.grid[cb] = total;
         if (cb == CB_FUSED) {
@@ -226,7 +245,7 @@ void fill_params(Handle &h) {
             std::vector<int64_t> map, done(na, 0);
             map.reserve((size_t)total + 1);
             while ((int64_t)map.size() < total) {
-                size_t best = na;   // sequential: first unfinished pattern; interleaved: the one furthest behind
+                size_t best = na;   // sequential: first unfinished unit; interleaved: the one furthest behind
                 for (size_t j = 0; j < na; j++) {
                     if (done[j] >= nb[j]) continue;
                     if (best == na || (run_len > 0 && (__int128)done[j] * nb[best] < (__int128)done[best] * nb[j])) best = j;
@@ -236,10 +255,11 @@ void fill_params(Handle &h) {
             }
             return map;
         };
-        const bool tunable = cb == CB_HESS || cb == CB_JAC || cb == CB_FUSED || cb == CB_CONS;
+        const bool tunable = cb == CB_HESS || cb == CB_HESSC || cb == CB_JAC || cb == CB_FUSED || cb == CB_CONS;
+        if (cb == CB_HESS) h.hess_stream_bytes = out_bytes + 8.0 * (double)(m.nvar + m.ncon) / h.world;
         const bool two = h.on_device && total > 0 && na > 1 && (il_forced > 0 || (il_forced < 0 && tunable && out_bytes >= 128e6));
         h.order[cb] = 0;
-        h.two_orders[cb] = false;
+        h.norders[cb] = 1;
         h.P[L.blk[cb]] = 0;
         if (h.on_device && total > 0) {
             std::vector<int64_t> m0 = build(0);
@@ -254,15 +274,27 @@ void fill_params(Handle &h) {
                 else {
                     // both orders exist: exa_tune measures them; until then (and in later processes) the persisted
                     // decision for this module / device / sizes applies, else the sequential order
-                    h.two_orders[cb] = true;
-                    int v = 0;
-                    if (tune_lookup(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), &v) && (v == 0 || v == 1)) {
-                        h.order[cb] = v;
-                        h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][v].p;
+                    h.norders[cb] = 2;
+                    int pv = 0;
+                    if (tune_lookup(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), &pv) && (pv == 0 || pv == 1)) {
+                        h.order[cb] = pv;
+                        h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][pv].p;
                     }
                 }
             }
         }
+    }
+    // hess_coord! kernel: the persisted measurement (exa_tune) if there is one, else by size — the chained kernel pays
+    // for its pipelining with twice the registers: it wins where the call streams gigabytes through HBM (LV N = 3e7:
+    // 0.472 against 0.529 ms, N = 1e8: 1.52 against 1.76) and loses where x, y and much of the output sit in the 256 MB
+    // MALL or the arithmetic dominates (LV N = 1e7: 0.156 against 0.135 ms; rocket 0.108 / 0.086; ACOPF 0.034 / 0.018)
+    h.hess_variant = 0;
+    if (L.chain[CB_HESSC] > 0) {
+        const char *ce = getenv("EXAHIP_HESS_VARIANT");
+        int pv = 0;
+        if (ce) h.hess_variant = atoi(ce) != 0;
+        else if (tune_lookup(source_key(h.gen.source), tune_signature(h, "hessvariant"), &pv)) h.hess_variant = pv != 0;
+        else h.hess_variant = h.hess_stream_bytes >= 1.5e9;
     }
     if (h.on_device) {
         h.dP.ensure(sizeof(int64_t) * h.P.size());
@@ -294,6 +326,7 @@ void to_device(Handle &h) {
     h.f_auglong = fn("exa_aug_long"); h.f_augfold = fn("exa_aug_fold");
     h.f_fused = fn("exa_fused");
     h.f_jprod = fn("exa_jprod"); h.f_jtprod = fn("exa_jtprod"); h.f_hprod = fn("exa_hprod"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
+    if (h.gen.layout.chain[CB_HESSC] > 0) h.f_hessc = fn("exa_hessc");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
     h.colslot.resize(m.pats.size());
     for (size_t k = 0; k < m.pats.size(); k++) {
@@ -348,11 +381,11 @@ void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **arg
 // timed on the model's stream (the outputs are simply rewritten with the same values), the faster map is installed in
 // P[] and the decision persisted next to the cached module.  Synchronises the stream.
 template <class F>
-void tune_order(Handle &h, int cb, F &&run) {
-    if (!h.two_orders[cb]) return;
+float tune_order(Handle &h, int cb, F &&run) {
+    const int n = std::max(1, h.norders[cb]);
     const ParamLayout &L = h.gen.layout;
     float t[2] = {1e30f, 1e30f};
-    // bring the clocks up first: the governor idles at ~570 MHz and needs tens of ms of load, and at low clocks the two
+    // bring the clocks up first: the governor idles at ~570 MHz and needs tens of ms of load, and at low clocks the
     // orders rank differently than in steady state (measured: cold tuning picked the slower order 2 times out of 3)
     {
         HIPCHK(hipEventRecord(h.ev0, h.stream));
@@ -365,13 +398,17 @@ void tune_order(Handle &h, int cb, F &&run) {
             if (ms > 60.f) break;
         }
     }
-    // A/B/A/B rounds, minimum per order: the first launches run while the clock governor is still ramping, and a single
-    // sample per order is within the run-to-run noise of the difference being measured (5-7 %)
+    // A/B rounds, minimum per order: a single sample per order is within the run-to-run noise of the difference being
+    // measured (5-7 %); round 0 only warms up
+    auto install = [&](int k) {
+        if (n < 2) return;
+        h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][k].p;
+        HIPCHK(hipMemcpyAsync((int64_t *)h.dP.p + L.blk[cb], &h.P[L.blk[cb]], 8, hipMemcpyHostToDevice, h.stream));
+        h.order[cb] = k;
+    };
     for (int round = 0; round < 4; round++) {
-        for (int k = 0; k < 2; k++) {
-            h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][k].p;
-            HIPCHK(hipMemcpyAsync((int64_t *)h.dP.p + L.blk[cb], &h.P[L.blk[cb]], 8, hipMemcpyHostToDevice, h.stream));
-            h.order[cb] = k;
+        for (int k = 0; k < n; k++) {
+            install(k);
             run();
             HIPCHK(hipEventRecord(h.ev0, h.stream));
             for (int r = 0; r < 4; r++) run();
@@ -379,15 +416,15 @@ void tune_order(Handle &h, int cb, F &&run) {
             HIPCHK(hipEventSynchronize(h.ev1));
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, h.ev0, h.ev1));
-            if (round > 0 && ms < t[k]) t[k] = ms;     // round 0 only warms up
+            if (round > 0 && ms < t[k]) t[k] = ms;
         }
     }
-    const int best = t[1] < t[0] ? 1 : 0;
-    h.order[cb] = best;
-    h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][best].p;
-    HIPCHK(hipMemcpyAsync((int64_t *)h.dP.p + L.blk[cb], &h.P[L.blk[cb]], 8, hipMemcpyHostToDevice, h.stream));
+    const int best = n > 1 && t[1] < t[0] ? 1 : 0;
+    install(best);
     HIPCHK(hipStreamSynchronize(h.stream));
-    tune_store(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), best);
+    if (n > 1) tune_store(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), best);
+    if (getenv("EXAHIP_TUNE_VERBOSE")) fprintf(stderr, "[exahip] tune cb=%d: %.4f %.4f ms per 4 launches -> order %d\n", cb, t[0], n > 1 ? t[1] : 0.f, best);
+    return t[best];
 }
 
 // second stage of cons_nln! / jprod_nln! / the fused sweep: add the buffered augmentation terms to their rows
@@ -467,6 +504,12 @@ void do_jac(Handle &h, const double *x, double *v) {
 }
 void do_hess(Handle &h, const double *x, const double *y, double sigma, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
+    if (h.hess_variant == 1 && h.f_hessc) {
+        void *sink = h.dsink.p;
+        void *a[] = {&P, &x, &y, &th, &v, &sigma, &sink};
+        launch(h, h.f_hessc, h.grid[CB_HESSC], kBlock, a);
+        return;
+    }
     void *a[] = {&P, &x, &y, &th, &v, &sigma};
     launch(h, h.f_hess, h.grid[CB_HESS], kBlock, a);
 }
@@ -1545,8 +1588,14 @@ int exa_time_callback(int id, int which, int reps, const double *x, const double
 int exa_block_order(int id, int which) {
     Handle *h = get(id);
     if (!h) return -2;
-    const int cb = which == 3 ? CB_JAC : which == 4 ? CB_HESS : which == 2 ? CB_CONS : which == 5 ? CB_FUSED : -1;
+    const int cb = which == 3 ? CB_JAC : which == 4 ? (h->hess_variant == 1 ? CB_HESSC : CB_HESS) : which == 2 ? CB_CONS : which == 5 ? CB_FUSED : -1;
     return cb < 0 ? -2 : h->order[cb];
+}
+/* which hess_coord! kernel runs: 0 exa_hess (one tile per workgroup), 1 exa_hessc (chained over groups of co-indexed
+ * patterns, software-pipelined), -1 bad id */
+int exa_hess_variant(int id) {
+    Handle *h = get(id);
+    return h ? h->hess_variant : -1;
 }
 int exa_sync(int id) { return guard(id, true, [&](Handle &h) { HIPCHK(hipStreamSynchronize(h.stream)); }); }
 
@@ -1578,12 +1627,21 @@ int exa_tune(int id, int what, const double *x, const double *y) {
         double *c = nullptr, *jv = nullptr, *hv = nullptr, *obj = (double *)h.dobj.p, *g = nullptr;
         auto need = [&](int k, int64_t n) { t.b[k].ensure(8 * (size_t)std::max<int64_t>(n, 1)); return (double *)t.b[k].p; };
         if (what & 1) {
-            if (h.two_orders[CB_CONS]) { c = need(2, m.ncon); tune_order(h, CB_CONS, [&] { do_cons(h, x, c); }); }
-            if (h.two_orders[CB_JAC]) { jv = need(3, h.lnnzj); tune_order(h, CB_JAC, [&] { do_jac(h, x, jv); }); }
-            if (h.two_orders[CB_HESS]) { hv = need(4, h.lnnzh); tune_order(h, CB_HESS, [&] { do_hess(h, x, y, sigma, hv); }); }
-            if (h.two_orders[CB_FUSED]) {
+            if (h.norders[CB_CONS] > 1) { c = need(2, m.ncon); (void)tune_order(h, CB_CONS, [&] { do_cons(h, x, c); }); }
+            if (h.norders[CB_JAC] > 1) { jv = need(3, h.lnnzj); (void)tune_order(h, CB_JAC, [&] { do_jac(h, x, jv); }); }
+            if (h.f_hessc && h.lnnzh > 0) {
+                // the two hess_coord! kernels, each at the better of its block orders
+                hv = need(4, h.lnnzh);
+                h.hess_variant = 0;
+                const float t0 = tune_order(h, CB_HESS, [&] { do_hess(h, x, y, sigma, hv); });
+                h.hess_variant = 1;
+                const float t1 = tune_order(h, CB_HESSC, [&] { do_hess(h, x, y, sigma, hv); });
+                h.hess_variant = t1 < t0 ? 1 : 0;
+                tune_store(source_key(h.gen.source), tune_signature(h, "hessvariant"), h.hess_variant);
+            } else if (h.norders[CB_HESS] > 1) { hv = need(4, h.lnnzh); tune_order(h, CB_HESS, [&] { do_hess(h, x, y, sigma, hv); }); }
+            if (h.norders[CB_FUSED] > 1) {
                 c = need(2, m.ncon); jv = need(3, h.lnnzj); hv = need(4, h.lnnzh);
-                tune_order(h, CB_FUSED, [&] { do_fused(h, x, y, sigma, obj, c, jv, hv); });
+                (void)tune_order(h, CB_FUSED, [&] { do_fused(h, x, y, sigma, obj, c, jv, hv); });
             }
         }
         if (what & 2) {
@@ -1700,9 +1758,12 @@ int exa_shard_var_range(int id, int64_t *lo_out, int64_t *hi_out) {
     int64_t vmin = INT64_MAX, vmax = INT64_MIN;
     for (const Pattern &p : m.pats) {
         const int64_t lo = (int64_t)((__int128)p.n * h->rank / h->world), hi = (int64_t)((__int128)p.n * (h->rank + 1) / h->world);
-        if (hi <= lo) continue;
+        if (p.n <= 0) continue;
+        // a shard holding nothing of a pattern still re-reads one point of it (the branch-free loads of the chained
+        // kernels clamp there): the last point before the shard, or point 0
+        const int64_t lo_ = hi > lo ? lo : (hi > 0 ? hi - 1 : 0), hi_ = hi > lo ? hi : lo_ + 1;
         int64_t a = 0, b = 0;
-        if (!pattern_var_range(p, lo, hi, &a, &b)) { vmin = 1; vmax = m.nvar; break; }     // data-indexed: anywhere
+        if (!pattern_var_range(p, lo_, hi_, &a, &b)) { vmin = 1; vmax = m.nvar; break; }     // data-indexed: anywhere
         if (a <= b) { vmin = std::min(vmin, a); vmax = std::max(vmax, b); }
     }
     if (vmin > vmax) { *lo_out = 0; *hi_out = 0; return 0; }

@@ -37,20 +37,23 @@ def attach_communicator(model, group=None, transport=None, coo_local=False):
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         model.comm_init(rank, world, box[0])
     else:
-        hip = ctypes.CDLL(None)      # the HIP runtime is already in the process (libexahip.so links it)
+        # the HIP runtime libexahip.so is bound to is already in the process; dlopen by SONAME returns that copy
+        hip = ctypes.CDLL("libamdhip64.so.7")
+        hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
 
         def reducer(ptr, count, stream):
             # device -> host on the model's stream, host all-reduce, host -> device on the same stream
             host = torch.empty(count, dtype=torch.float64)
             nbytes = 8 * count
-            if hip.hipMemcpyAsync(ctypes.c_void_p(host.data_ptr()), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), 2, ctypes.c_void_p(stream)):
+            if hip.hipMemcpyAsync(host.data_ptr(), ptr, nbytes, 2, stream):           # hipMemcpyDeviceToHost
                 return 1
-            if hip.hipStreamSynchronize(ctypes.c_void_p(stream)):
+            if hip.hipStreamSynchronize(stream):
                 return 1
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
-            if hip.hipMemcpyAsync(ctypes.c_void_p(ptr), ctypes.c_void_p(host.data_ptr()), ctypes.c_size_t(nbytes), 1, ctypes.c_void_p(stream)):
+            if hip.hipMemcpyAsync(ptr, host.data_ptr(), nbytes, 1, stream):           # hipMemcpyHostToDevice
                 return 1
-            return 1 if hip.hipStreamSynchronize(ctypes.c_void_p(stream)) else 0     # `host` dies with this frame
+            return 1 if hip.hipStreamSynchronize(stream) else 0     # `host` dies with this frame
 
         model.comm_hook(rank, world, reducer)
     return transport

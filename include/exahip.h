@@ -233,6 +233,11 @@ int exa_sync(int id);
 /* Order of the (pattern, tile) workgroups of a multi-pattern callback: 0 patterns one after the other (default),
  * 1 interleaved in runs of 128 workgroups, -2 bad argument.  which: 2 cons, 3 jac, 4 hess, 5 fused. */
 int exa_block_order(int id, int which);
+/* hess_coord! has two generated kernels: 0 = exa_hess, one (pattern, 256-point tile) per workgroup; 1 = exa_hessc, a
+ * workgroup walks 4 consecutive tiles of a GROUP of co-indexed patterns with the next inputs loaded before the current
+ * tile is stored — wins where a call streams gigabytes through HBM, loses on cache-resident models (twice the registers).
+ * Which one runs: the decision exa_tune measured and persisted, else by size (>= 1.5 GB streamed per call -> 1). */
+int exa_hess_variant(int id);
 /* Explicit, BLOCKING tuning — the only entry point that measures.  what: bit 0 = block order of cons / jac / hess / fused
  * (models streaming >= 128 MB from several patterns), bit 1 = exa_jtprod / exa_hprod implementation.  Both candidates of
  * each decision are timed on the model's stream at (x, y) (DEVICE pointers; NULL = x0 / ones; outputs go to scratch),

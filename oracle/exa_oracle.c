@@ -71,9 +71,34 @@ static inline double sech_(double x) { return 1.0 / cosh(x); }
 static inline double csch_(double x) { return 1.0 / sinh(x); }
 static inline double coth_(double x) { return 1.0 / tanh(x); }
 static inline double d2r(double x) { return x * CD2R; }
-static inline double sind_(double x) { return sin(d2r(fmod(x, 360.0))); }
-static inline double cosd_(double x) { return cos(d2r(fmod(x, 360.0))); }
-static inline double tand_(double x) { return tan(d2r(fmod(x, 180.0))); }
+/* Base.sind / Base.cosd / Base.tand (Julia base/special/trig.jl — outside /root/reference, restated from its published
+ * algorithm): the argument is reduced with an EXACT rem(x, 360) and the quadrant is selected BEFORE the conversion to
+ * radians, so the functions are exact at the multiples of 90: sind(180) = 0, cosd(90) = 0, tand(90) = Inf,
+ * cscd(180) = Inf.  (Julia evaluates its sin/cos kernels at a double-double deg2rad; plain deg2rad here — a 1-ulp
+ * matter, inside the 1e-10 bar.  Julia throws DomainError at +-Inf; a kernel cannot: NaN.) */
+static inline double sind_(double x) {
+    if (isinf(x)) return NAN;
+    if (isnan(x)) return x;
+    const double rx = copysign(fmod(x, 360.0), x), arx = fabs(rx);
+    if (rx == 0.0) return rx;
+    if (arx < 45.0) return sin(d2r(rx));
+    if (arx <= 135.0) return copysign(cos(d2r(90.0 - arx)), rx);
+    if (arx == 180.0) return copysign(0.0, rx);
+    if (arx < 225.0) return sin(d2r((180.0 - arx) * (rx > 0 ? 1.0 : -1.0)));
+    if (arx <= 315.0) return -copysign(cos(d2r(270.0 - arx)), rx);
+    return sin(d2r(rx - copysign(360.0, rx)));
+}
+static inline double cosd_(double x) {
+    if (isinf(x)) return NAN;
+    if (isnan(x)) return x;
+    const double rx = fabs(fmod(x, 360.0));
+    if (rx <= 45.0) return cos(d2r(rx));
+    if (rx < 135.0) return sin(d2r(90.0 - rx));
+    if (rx <= 225.0) return -cos(d2r(180.0 - rx));
+    if (rx < 315.0) return sin(d2r(rx - 270.0));
+    return cos(d2r(360.0 - rx));
+}
+static inline double tand_(double x) { return sind_(x) / cosd_(x); }      /* Base: tand(x) = sind(x) / cosd(x) */
 static inline double cscd_(double x) { return 1.0 / sind_(x); }
 static inline double secd_(double x) { return 1.0 / cosd_(x); }
 static inline double cotd_(double x) { return 1.0 / tand_(x); }

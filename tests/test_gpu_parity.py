@@ -203,3 +203,56 @@ def test_null_pointers_are_status_1_not_device_faults(built):
     assert L.exa_eval_fused(m.id, xp, None, 1.0, hp, hp, hp, hp) == 1
     torch.cuda.synchronize()                                              # the device is still healthy
     assert m.obj(x) == m.obj(x)
+
+
+@pytest.mark.parametrize("name", list(ZOO))
+def test_chained_hess_kernel_is_the_same_function(libs, monkeypatch, name):
+    """hess_coord! has a second generated kernel (exa_hessc: a workgroup walks 4 tiles of a GROUP of co-indexed patterns,
+    the next inputs loaded before the current tile is stored; lanes without a slot store to a sink instead of branching).
+    Forced on every zoo model — whole, sharded 3 ways at global positions and as packed local slices, NaN-poisoned
+    outputs — it must write exactly the slots of the plain kernel with the oracle's values."""
+    import torch
+    import oracle
+    from exahip import ExaModel
+    monkeypatch.setenv("EXAHIP_HESS_VARIANT", "1")
+    m = ExaModel(ZOO[name]())
+    assert m._L.exa_hess_variant(m.id) == 1
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=9)
+    H = o.hess_coord(x, y, sigma)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    h = torch.full((m.meta.nnzh + 8,), float("nan"), dtype=torch.float64, device=dev)
+    m.hess_coord(xd, yd, sigma, out=h)
+    torch.cuda.synchronize()
+    got = h.cpu().numpy()
+    assert np.all(np.isnan(got[m.meta.nnzh:]))
+    assert relerr(got[:m.meta.nnzh], H) <= RTOL
+    monkeypatch.setenv("EXAHIP_HESS_VARIANT", "0")
+    plain = ExaModel(ZOO[name]())
+    assert plain._L.exa_hess_variant(plain.id) == 0
+    np.testing.assert_allclose(got[:m.meta.nnzh], plain.hess_coord(xd, yd, sigma).cpu().numpy(), rtol=1e-12, atol=1e-300)
+    monkeypatch.setenv("EXAHIP_HESS_VARIANT", "1")
+    world = 3
+    whole = np.full(m.meta.nnzh, np.nan)
+    for rank in range(world):
+        m.set_shard(rank, world)
+        m.set_coo_local(False)
+        assert m._L.exa_hess_variant(m.id) == 1
+        h.fill_(float("nan"))
+        m.hess_coord(xd, yd, sigma, out=h)
+        torch.cuda.synchronize()
+        part = h.cpu().numpy()[:m.meta.nnzh]
+        mine = ~np.isnan(part)
+        assert np.all(np.isnan(whole[mine]))
+        whole[mine] = part[mine]
+        m.set_coo_local(True)
+        n = m.local_nnzh
+        h.fill_(float("nan"))
+        m.hess_coord(xd, yd, sigma, out=h[:max(n, 1)] if n else h)
+        torch.cuda.synchronize()
+        loc = h.cpu().numpy()
+        assert np.all(np.isnan(loc[n:])) and int(mine.sum()) == n
+        for g0, l0, cnt in m.coo_slices(True):
+            assert relerr(loc[l0:l0 + cnt], H[g0:g0 + cnt]) <= RTOL
+    assert relerr(whole, H) <= RTOL
