@@ -477,11 +477,14 @@ struct Body {
     const Pattern &p;
     int pi;
     const ParamLayout &L;
-    Emitter e;
+    Emitter own_;
+    Emitter &e;                 // own_, or the emitter shared by the patterns of a fused group (one memo: common loads and
+                                // common subexpressions of co-indexed patterns are emitted once)
     std::vector<FV> fv;
     std::map<int, Val> cmemo;   // IR node -> value of constant subtree
 
-    Body(const Model &mm, int pidx, const ParamLayout &ll) : m(mm), p(mm.pats[pidx]), pi(pidx), L(ll) { fv.resize(p.ad.size()); }
+    Body(const Model &mm, int pidx, const ParamLayout &ll, Emitter *shared = nullptr)
+        : m(mm), p(mm.pats[pidx]), pi(pidx), L(ll), e(shared ? *shared : own_) { fv.resize(p.ad.size()); }
 
     std::string P(int w) const { return "P[" + std::to_string(w) + "]"; }
 
@@ -700,6 +703,15 @@ const char *kPrelude = R"HIP(// Generated by libexahip (examodels.jl_amd/csrc/ex
 #define EXA_AUG_LONG 512
 #define EXA_AUG_CHUNK 8192
 static __device__ __forceinline__ double exa_sq(double x) { return x * x; }
+// FP64 add to memory as ONE hardware instruction (global_atomic_add_f64 / ds_add_f64), by builtin: what
+// unsafeAtomicAdd becomes depends on the compiler's header and flags (the hiprtc bundled with PyTorch's ROCm 7.0 turns
+// it into a compare-and-swap LOOP — 10x slower on contended targets)
+static __device__ __forceinline__ void exa_atomic_add(double* p, double v) {
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)p, v);
+}
+static __device__ __forceinline__ void exa_lds_add(double* p, double v) {
+    (void)__builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double*)p, v);
+}
 static __device__ __forceinline__ double exa_sign(double x) { return x > 0.0 ? 1.0 : (x < 0.0 ? -1.0 : x); }
 // Base.sind / cosd / tand: exact rem(x, 360), quadrant selected before the conversion to radians — exact zeros and poles
 // at the multiples of 90 (sind(180) = 0, cosd(90) = 0, tand(90) = Inf), like Julia's; +-Inf -> NaN.
@@ -830,7 +842,7 @@ static __device__ __forceinline__ void exa_flush_points_nb(double* __restrict__ 
 // ONE atomic — 64x fewer same-address FP64 atomics, which otherwise serialise at the memory side.
 static __device__ __forceinline__ void exa_wave_atomic_add(double* p, double v) {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(p, v);
+    if ((threadIdx.x & 63) == 0) exa_atomic_add(p, v);
 }
 // Scatter through a DATA index: the target may be one variable shared by every data point (a step length, a slack, a
 // reference bus reached through a table column) — 64 same-address atomics per wavefront that serialise chip-wide at
@@ -843,9 +855,9 @@ static __device__ __forceinline__ void exa_scatter_add(double* __restrict__ out,
     if (__ballot(act && idx != first) == 0) {
         double s = act ? v : 0.0;
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&out[first], s);
+        if ((threadIdx.x & 63) == 0) exa_atomic_add(&out[first], s);
     } else if (act) {
-        unsafeAtomicAdd(&out[idx], v);
+        exa_atomic_add(&out[idx], v);
     }
 }
 // sum over the 256-thread workgroup: 64-lane wavefront butterflies, then 4 partials through LDS
@@ -1049,28 +1061,48 @@ int g_lds_need[CB_COUNT];   // doubles of LDS per wavefront needed by the scatte
 std::map<std::pair<int, int>, std::vector<std::string>> g_lit_idx;
 
 struct Scatter {
-    struct Item { int ir; Val vidx, val; };
-    Body &b;
+    struct Item { const Pattern *p; int pi; int ir; Val vidx, val; };
+    Emitter &e;
+    const ParamLayout &L;
     std::vector<Item> items;
     std::vector<std::string> lit_idx;
-    explicit Scatter(Body &bb) : b(bb) {}
-    void add(int ad_leaf, Val val) {
+    Scatter(Emitter &ee, const ParamLayout &ll) : e(ee), L(ll) {}
+    explicit Scatter(Body &bb) : e(bb.e), L(bb.L) {}
+    void add(Body &b, int ad_leaf, Val val) {
         if (val.lit_eq(0)) return;
-        items.push_back({b.p.ad[ad_leaf].ir, b.fv[ad_leaf].vidx, val});
+        items.push_back({&b.p, b.pi, b.p.ad[ad_leaf].ir, b.fv[ad_leaf].vidx, val});
+    }
+    // Contributions of ONE thread to the same variable are added in registers first: within a pattern (hprod: one item
+    // per distinct variable) and — fused groups — ACROSS patterns: the four branch-flow constraints of ACOPF, the
+    // angle-difference and the thermal-limit constraints all scatter to the voltage variables of the same two buses,
+    // 26 same-target atomics per branch that become 8 (index expressions compare by text: the patterns name the same
+    // aliased table column, exa_plan.cpp).
+    void merge() {
+        std::vector<Item> out;
+        for (const Item &it : items) {
+            const std::string key = e.s(it.vidx);
+            bool found = false;
+            for (Item &o : out)
+                if (e.s(o.vidx) == key) { o.val = e.add(o.val, it.val); found = true; break; }
+            if (!found) out.push_back(it);
+        }
+        items.swap(out);
     }
     // returns the LDS doubles needed per wavefront; fills `lines`; sets full_wave
     int emit(std::vector<std::string> &lines, bool &full_wave) {
+        merge();
         // candidates: index = (unit-step range value) + c, all on the same range column; clustered into windows of
         // offsets that lie within 64 of each other (one window per variable block the pattern touches)
         struct Cand { int item; int64_t c; };
         std::vector<Cand> cand;
-        int col = -1;
+        int colword = -1;
         if (env_int("EXAHIP_LDS_SCATTER", 1)) {
             for (size_t k = 0; k < items.size(); k++) {
-                Affine a = affine(b.p, items[k].ir);
-                if (!a.ok || a.col < 0 || a.a != 1 || b.p.cols[a.col].step != 1) continue;
-                if (col >= 0 && a.col != col) continue;
-                col = a.col;
+                Affine a = affine(*items[k].p, items[k].ir);
+                if (!a.ok || a.col < 0 || a.a != 1 || items[k].p->cols[a.col].step != 1) continue;
+                const int w = L.pat[items[k].pi].col[a.col];
+                if (colword >= 0 && w != colword) continue;
+                colword = w;
                 cand.push_back({(int)k, a.c});
             }
             std::stable_sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.c < y.c; });
@@ -1093,16 +1125,16 @@ struct Scatter {
                                 "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
                 std::string body = "if (act) {";
                 for (size_t q = g0; q < g1; q++) {
-                    body += " unsafeAtomicAdd(&" + reg + "[lane + " + std::to_string(cand[q].c - cmin) + "], " + b.e.sd(items[cand[q].item].val) + ");";
+                    body += " exa_lds_add(&" + reg + "[lane + " + std::to_string(cand[q].c - cmin) + "], " + e.sd(items[cand[q].item].val) + ");";
                     inwin[cand[q].item] = 1;
                 }
                 lines.push_back(body + " }");
                 lines.push_back("__builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); "
                                 "__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");");
                 // variable (0-based) held by the window's first word: range value of the wavefront's first point + cmin - 1
-                lines.push_back("{ const long wb = " + b.P(b.L.pat[b.pi].col[col]) + " + (I0 - lane) + (" + std::to_string(cmin) + "L) - 1L;");
+                lines.push_back("{ const long wb = P[" + std::to_string(colword) + "] + (I0 - lane) + (" + std::to_string(cmin) + "L) - 1L;");
                 lines.push_back("  for (int j = lane; j < " + std::to_string(W) + "; j += 64) { const double t_ = " + reg +
-                                "[j]; if (t_ != 0.0) unsafeAtomicAdd(&out[wb + j], t_); } }");
+                                "[j]; if (t_ != 0.0) exa_atomic_add(&out[wb + j], t_); } }");
                 total += W;
             }
             g0 = g1;
@@ -1110,19 +1142,19 @@ struct Scatter {
         const int W = total;
         for (size_t k = 0; k < items.size(); k++) {
             if (inwin[k]) continue;
-            const std::string idx = b.e.s(b.e.sub(items[k].vidx, Emitter::liti(1)));
+            const std::string idx = e.s(e.sub(items[k].vidx, Emitter::liti(1)));
             if (items[k].vidx.is_lit() && env_int("EXAHIP_WAVE_REDUCE", 1)) {
                 // same target for every data point: accumulate in a register across this thread's tiles; the kernel
                 // adds it to memory ONCE per wavefront after the tile loop (pK_*_fin)
                 full_wave = true;
-                lines.push_back("lit[" + std::to_string(lit_idx.size()) + "] += act ? " + b.e.sd(items[k].val) + " : 0.0;");
+                lines.push_back("lit[" + std::to_string(lit_idx.size()) + "] += act ? " + e.sd(items[k].val) + " : 0.0;");
                 lit_idx.push_back(idx);
-            } else if (!affine(b.p, items[k].ir).ok && env_int("EXAHIP_WAVE_REDUCE", 1)) {
+            } else if (!affine(*items[k].p, items[k].ir).ok && env_int("EXAHIP_WAVE_REDUCE", 1)) {
                 // reached through a data column: possibly the same variable for the whole wavefront (exa_scatter_add)
                 full_wave = true;
-                lines.push_back("exa_scatter_add(out, " + idx + ", " + b.e.sd(items[k].val) + ", act);");
+                lines.push_back("exa_scatter_add(out, " + idx + ", " + e.sd(items[k].val) + ", act);");
             } else {
-                lines.push_back("if (act) unsafeAtomicAdd(&out[" + idx + "], " + b.e.sd(items[k].val) + ");");
+                lines.push_back("if (act) exa_atomic_add(&out[" + idx + "], " + e.sd(items[k].val) + ");");
             }
         }
         return W;
@@ -1181,7 +1213,7 @@ void gen_first_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     bool full_wave = false;
     Scatter sc(b);
     for (int s = 0; s < p.o1step; s++) {
-        if (grad) sc.add(p.slotvar1[s], a.acc[s]);
+        if (grad) sc.add(b, p.slotvar1[s], a.acc[s]);
         else vals.push_back(b.e.sd(a.acc[s]));
     }
     if (grad) { g_lds_need[CB_GRAD] = std::max(g_lds_need[CB_GRAD], sc.emit(stores, full_wave)); g_lit_idx[{CB_GRAD, pi}] = sc.lit_idx; }
@@ -1356,33 +1388,19 @@ void gen_jprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
 }
 
 // J'v: out[k_s] += acc_s * v[row] (jacobian.jl:55-68) — shared targets, FP64 hardware atomics on a zeroed vector
-void gen_jtprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
-    Body b(m, pi, L);
+void jtprod_items(Body &b, Scatter &sc) {
     const Pattern &p = b.p;
     b.forward(p.ad_root, 1, false);
     GenAlg a(b, p.comp1, p.o1step);
     grpass(p, p.ad_root, a, Emitter::litf(1.0));
     Val w = b.e.raw("v[" + b.row0() + "]", false);
-    std::vector<std::string> stores;
-    bool full_wave = false;
-    Scatter sc(b);
-    for (int s = 0; s < p.o1step; s++) sc.add(p.slotvar1[s], b.e.mul(a.acc[s], w));
-    g_lds_need[CB_JTPROD] = std::max(g_lds_need[CB_JTPROD], sc.emit(stores, full_wave));
-    g_lit_idx[{CB_JTPROD, pi}] = sc.lit_idx;
-    os << "static __device__ __forceinline__ void " << fn_name(pi, "jtprod")
-       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, const double* __restrict__ v, "
-          "double* __restrict__ out, long tid, double* lds, double* lit) {\n";
-    emit_scatter_prologue(os, b, L, pi, full_wave);
-    emit_lines(os, b.e);
-    for (auto &st : stores) os << "    " << st << "\n";
-    os << "}\n";
+    for (int s = 0; s < p.o1step; s++) sc.add(b, p.slotvar1[s], b.e.mul(a.acc[s], w));
 }
 
 // Hv: for a lower-triangular COO entry (i, j, A): i == j -> Hv[i] += A v[i]; else Hv[i] += A v[j], Hv[j] += A v[i]
 // (hessian.jl:291-315, 566-579).  Contributions are merged per variable in registers first: one atomic per
 // distinct variable of the data point instead of one or two per slot.
-void gen_hprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
-    Body b(m, pi, L);
+void hprod_items(Body &b, Scatter &sc) {
     const Pattern &p = b.p;
     b.forward(p.ad_root, 2, false);
     Val adj;
@@ -1394,7 +1412,7 @@ void gen_hprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     std::vector<int> rep(nk, -1);
     for (size_t n = 0; n < p.ad.size(); n++)
         if (p.ad[n].kind == AD_VAR && rep[p.ad[n].key] < 0) rep[p.ad[n].key] = (int)n;
-    std::vector<Val> hv(nk, Emitter::litf(0.0)), vv(nk);
+    std::vector<Val> hv(nk, Emitter::litf(0.0));
     std::vector<char> used(nk, 0);
     auto vload = [&](int key) {
         Val vi = b.fv[rep[key]].vidx;
@@ -1419,18 +1437,35 @@ void gen_hprod_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
             used[k1] = used[k2] = 1;
         }
     }
+    for (int k = 0; k < nk; k++)
+        if (used[k]) sc.add(b, rep[k], hv[k]);
+}
+
+// One device function per GROUP of a scattering product (J'v / Hv): the patterns of a group iterate over the same data
+// points (equal length, same shard), thread I evaluates ALL of them at point I inside one emitter — loads of aliased
+// table columns, gathers of x and common subexpressions (one sincos(va_f - va_t) for the four branch flows) are shared —
+// and their contributions are merged per target before anything is added to memory (Scatter::merge).
+void gen_scatter_group_fn(std::ostringstream &os, const Model &m, const ParamLayout &L, int cb, int gi) {
+    const auto &grp = L.groups[cb][gi];
+    const bool hp = cb == CB_HPROD;
+    Emitter E;
+    Scatter sc(E, L);
+    std::vector<std::unique_ptr<Body>> bodies;
+    for (int pk : grp) {
+        bodies.emplace_back(new Body(m, pk, L, &E));
+        if (hp) hprod_items(*bodies.back(), sc); else jtprod_items(*bodies.back(), sc);
+    }
     std::vector<std::string> stores;
     bool full_wave = false;
-    Scatter sc(b);
-    for (int k = 0; k < nk; k++)
-        if (used[k]) sc.add(rep[k], hv[k]);
-    g_lds_need[CB_HPROD] = std::max(g_lds_need[CB_HPROD], sc.emit(stores, full_wave));
-    g_lit_idx[{CB_HPROD, pi}] = sc.lit_idx;
-    os << "static __device__ __forceinline__ void " << fn_name(pi, "hprod")
-       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
-          "const double* __restrict__ v, double* __restrict__ out, double sigma, long tid, double* lds, double* lit) {\n";
-    emit_scatter_prologue(os, b, L, pi, full_wave);
-    emit_lines(os, b.e);
+    g_lds_need[cb] = std::max(g_lds_need[cb], sc.emit(stores, full_wave));
+    g_lit_idx[{cb, gi}] = sc.lit_idx;
+    const char *name = hp ? "hprod" : "jtprod";
+    os << "static __device__ __forceinline__ void g" << gi << "_" << name
+       << "(const long* __restrict__ P, const double* __restrict__ x, " << (hp ? "const double* __restrict__ y, " : "")
+       << "const double* __restrict__ th, const double* __restrict__ v, double* __restrict__ out, " << (hp ? "double sigma, " : "")
+       << "long tid, double* lds, double* lit) {\n";
+    emit_scatter_prologue(os, *bodies.front(), L, grp.front(), full_wave);     // the group shares lo / hi
+    emit_lines(os, E);
     for (auto &st : stores) os << "    " << st << "\n";
     os << "}\n";
 }
@@ -1481,20 +1516,23 @@ void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const st
     os << "    const long e_ = ((const long*)P[" << L.blk[cb] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
           "    const long tid0 = (e_ & ((1L << 40) - 1)) * (EXA_BLOCK * " << ppt << ") + threadIdx.x;\n";
     const bool scatter = cb == CB_GRAD || cb == CB_JTPROD || cb == CB_HPROD;
+    const bool grouped = cb == CB_JTPROD || cb == CB_HPROD;        // dispatch units are fused groups (gen_scatter_group_fn)
+    const size_t nunits = grouped ? L.groups[cb].size() : act.size();
+    auto unit_key = [&](size_t k) { return grouped ? (int)k : act[k]; };
     size_t maxlit = 0;
-    if (scatter) for (int pk : act) maxlit = std::max(maxlit, g_lit_idx[{cb, pk}].size());
+    if (scatter) for (size_t k = 0; k < nunits; k++) maxlit = std::max(maxlit, g_lit_idx[{cb, unit_key(k)}].size());
     if (scatter) os << "    double lit[" << std::max<size_t>(maxlit, 1) << "] = {0.0};\n";
-    for (size_t k = 0; k < act.size(); k++) {
+    for (size_t k = 0; k < nunits; k++) {
         os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n";
         // no unrolling for the scatter kernels: two inlined copies of a large Hessian body exhaust the register file
         // (512 VGPRs + scratch spills were observed, and a spilling exa_hprod produced wrong sums on gfx950)
         if (ppt > 1) os << "#pragma unroll " << (scatter ? 1 : 2) << "\n        for (int u = 0; u < " << ppt << "; u++) ";
         else os << "        { const int u = 0; ";
-        os << "p" << act[k] << "_" << call_prefix << "(" << call_args << ", tid0 + u * EXA_BLOCK" << tail_args << (scatter ? ", lit" : "") << ");"
+        os << (grouped ? "g" : "p") << unit_key(k) << "_" << call_prefix << "(" << call_args << ", tid0 + u * EXA_BLOCK" << tail_args << (scatter ? ", lit" : "") << ");"
            << (ppt > 1 ? "" : " }") << "\n";
         if (scatter) {
             // targets shared by all data points: one wavefront reduction + one atomic per wavefront AFTER the tile loop
-            const auto &li = g_lit_idx[{cb, act[k]}];
+            const auto &li = g_lit_idx[{cb, unit_key(k)}];
             for (size_t q = 0; q < li.size(); q++) os << "        exa_wave_atomic_add(&out[" << li[q] << "], lit[" << q << "]);\n";
         }
         os << "    }\n";
@@ -1569,7 +1607,10 @@ Generated generate_module(const Model &m) {
     for (int k = 0; k < np; k++) {
         auto &pp = L.pat[k];
         pp.lo = w++; pp.hi = w++; pp.o0 = w++; pp.o1 = w++; pp.o2 = w++; pp.oa = w++; pp.ob = w++;
-        for (size_t c = 0; c < m.pats[k].cols.size(); c++) pp.col.push_back(w++);
+        for (size_t c = 0; c < m.pats[k].cols.size(); c++) {
+            const Column &col = m.pats[k].cols[c];
+            pp.col.push_back(col.alias_pat >= 0 ? L.pat[col.alias_pat].col[col.alias_col] : w++);      // one word per DISTINCT column
+        }
     }
     for (int k = 0; k < np; k++) {
         const Pattern &p = m.pats[k];
@@ -1581,6 +1622,7 @@ Generated generate_module(const Model &m) {
             else if (p.o1step > 0) L.active[CB_GRAD].push_back(k);
         } else {
             L.active[CB_CONS].push_back(k);      // base rows and augmentation terms share one launch
+            if (p.kind == EXA_PAT_CON) L.active[CB_CONS1].push_back(k);
             L.active[CB_JPROD].push_back(k);
             if (p.o1step > 0) L.active[CB_JTPROD].push_back(k);
             if (p.o1step > 0) { L.active[CB_JAC].push_back(k); L.active[CB_JSTRUCT].push_back(k); }
@@ -1603,6 +1645,17 @@ Generated generate_module(const Model &m) {
             if (!placed) L.groups[cb].push_back({k});
         }
         for (size_t g = 0; g < L.groups[cb].size(); g++) L.gtiles[cb].push_back(w++);
+    }
+    // fused groups of the scattering products: patterns of EXACTLY the same length (one thread evaluates point I of all)
+    for (int cb : {CB_JTPROD, CB_HPROD}) {
+        const int gmax = std::max(1, env_int("EXAHIP_GROUP_MAX", 8));
+        for (int k : L.active[cb]) {
+            bool placed = false;
+            if (env_int("EXAHIP_GROUP_SCATTER", 1))
+                for (auto &g : L.groups[cb])
+                    if ((int)g.size() < gmax && m.pats[g.front()].n == m.pats[k].n) { g.push_back(k); placed = true; break; }
+            if (!placed) L.groups[cb].push_back({k});
+        }
     }
 
     // streaming value kernels keep more loads in flight per wavefront with several points per thread (measured)
@@ -1637,17 +1690,19 @@ Generated generate_module(const Model &m) {
         else {
             gen_cons_fn(os, m, k, L);
             gen_jprod_fn(os, m, k, L);
-            if (p.o1step > 0) { gen_first_fn(os, m, k, L, false); gen_struct_fn(os, m, k, L, false); gen_jtprod_fn(os, m, k, L); }
+            if (p.o1step > 0) { gen_first_fn(os, m, k, L, false); gen_struct_fn(os, m, k, L, false); }
         }
-        if (p.o2step > 0) { gen_hess_fn(os, m, k, L); gen_struct_fn(os, m, k, L, true); gen_hprod_fn(os, m, k, L); }
+        if (p.o2step > 0) { gen_hess_fn(os, m, k, L); gen_struct_fn(os, m, k, L, true); }
         gen_fused_fn(os, m, k, L);
     }
+    for (int cb : {CB_JTPROD, CB_HPROD})
+        for (size_t g = 0; g < L.groups[cb].size(); g++) gen_scatter_group_fn(os, m, L, cb, (int)g);
     // scatter kernels whose patterns have targets shared by ALL data points process 16 tiles per workgroup: the shared
     // target then receives one atomic per wavefront per 16 tiles (same-address atomics serialise chip-wide at ~10 ns:
     // the rocket's step variable took 47 000 of them per J'v, 0.47 ms)
     for (int cb : {CB_GRAD, CB_JTPROD, CB_HPROD}) {
         bool any = false;
-        for (int pk : L.active[cb]) any = any || !g_lit_idx[{cb, pk}].empty();
+        for (const auto &kv : g_lit_idx) any = any || (kv.first.first == cb && !kv.second.empty());
         if (any) L.ppt[cb] = env_int("EXAHIP_PPT_LITERAL", 16);
     }
     // obj: per-workgroup partial sums
@@ -1694,6 +1749,52 @@ Generated generate_module(const Model &m) {
             os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n#pragma unroll\n        for (int u = 0; u < " << ppt
                << "; u++) v_[u] = p" << act[k] << "_consv(P, x, th, tid0 + u * EXA_BLOCK);\n#pragma unroll\n        for (int u = 0; u < " << ppt
                << "; u++) p" << act[k] << "_conss(P, out, aug, tid0 + u * EXA_BLOCK, v_[u]);\n    }\n";
+        }
+    }
+    os << "}\n";
+    // cons_nln! in ONE launch (unsharded models whose rows collect at most EXA_AUG_LONG terms).  The reference runs the base
+    // kernel, the augmentation kernels and compress_to_dense (KA ext :273-308, :691-697); exa_cons + exa_aug_gather are two
+    // dependent launches.  Here the thread that owns base row r walks the row's augmentation terms — listed at build time
+    // in insertion order as (pattern, data point) — and EVALUATES them itself: same terms, same order of additions, no
+    // buffer round trip, no second launch.  augptr [ncon + 1] / augsrc [nconaug]: CSR over constraint rows.
+    // When every term is coefficient * x[index] (aug_linear: evaluated at build) the walk is two loads per term, four
+    // terms in flight, the additions still in insertion order; otherwise (pattern, point) entries and a switch.
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_cons1(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ th, double* __restrict__ out, const long* __restrict__ augptr, const long* __restrict__ augsrc, "
+          "const double* __restrict__ augcoef) {\n";
+    {
+        const auto &act = L.active[CB_CONS1];
+        std::vector<int> augs;
+        for (int k = 0; k < np; k++) if (m.pats[k].n > 0 && m.pats[k].kind == EXA_PAT_CONAUG) augs.push_back(k);
+        os << "    const long e_ = ((const long*)P[" << L.blk[CB_CONS1] << "])[blockIdx.x];\n    const int ps_ = (int)(e_ >> 40);\n"
+              "    const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
+        for (size_t k = 0; k < act.size(); k++) {
+            const auto &pp = L.pat[act[k]];
+            bool target = false;
+            for (int a : augs) target = target || m.pats[a].base == act[k];
+            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n        const long I = P[" << pp.lo << "] + tid0;\n        if (I >= P[" << pp.hi
+               << "]) return;\n        double v = p" << act[k] << "_val(P, x, th, I);\n";
+            if (target && m.aug_linear) {
+                os << "        const long r_ = P[" << pp.o0 << "] + I;\n        long j = augptr[r_];\n        const long je = augptr[r_ + 1];\n"
+                      "        for (; j + 4 <= je; j += 4) {\n"
+                      "            const long i0 = augsrc[j], i1 = augsrc[j + 1], i2 = augsrc[j + 2], i3 = augsrc[j + 3];\n"
+                      "            const double c0 = augcoef[j], c1 = augcoef[j + 1], c2 = augcoef[j + 2], c3 = augcoef[j + 3];\n"
+                      "            const double x0 = x[i0], x1 = x[i1], x2 = x[i2], x3 = x[i3];\n"
+                      // (products rounded on their own, like the reference's c * x followed by +=: no FMA contraction)
+                      "            v += __dmul_rn(c0, x0); v += __dmul_rn(c1, x1); v += __dmul_rn(c2, x2); v += __dmul_rn(c3, x3);\n        }\n"
+                      "        for (; j < je; j++) v += __dmul_rn(augcoef[j], x[augsrc[j]]);\n";
+            } else if (target) {
+                os << "        const long r_ = P[" << pp.o0 << "] + I;\n        for (long j = augptr[r_], je = augptr[r_ + 1]; j < je; j++) {\n"
+                      "            const long s_ = augsrc[j];\n            const int ap_ = (int)(s_ >> 40);\n            const long J = s_ & ((1L << 40) - 1);\n";
+                bool first = true;
+                for (int a : augs) {
+                    if (m.pats[a].base != act[k]) continue;
+                    os << "            " << (first ? "" : "else ") << "if (ap_ == " << a << ") v += p" << a << "_val(P, x, th, J);\n";
+                    first = false;
+                }
+                os << "        }\n";
+            }
+            os << "        out[P[" << pp.o0 << "] + I] = v;\n    }\n";
         }
     }
     os << "}\n";

@@ -22,6 +22,10 @@ struct Column {
     std::vector<int64_t> idata;
     std::vector<double> fdata;
     int64_t start = 0, step = 0;
+    // the same column (type and contents) appeared earlier in the model — the branch table that ACOPF's four flow
+    // constraints all iterate over arrives once per pattern in the wire format: ONE copy goes to HBM and both patterns
+    // name the same parameter word, so their index expressions are textually equal (shared loads, merged scatter targets)
+    int alias_pat = -1, alias_col = -1;
 };
 
 // One node of the per-pattern AD tree: what the reference builds with its adjoint node types
@@ -67,6 +71,11 @@ struct Model {
     // Augmentation gather lists (the reference's conaugsparsity sorted by target row + conaugptr, KA ext :79-101):
     // target row aug_rows[t] receives buffer entries aug_perm[aug_ptr[t] .. aug_ptr[t+1])
     std::vector<int64_t> aug_rows, aug_ptr, aug_perm;
+    // every augmentation term is coefficient * x[index] (ACOPF: p[a.i], -pg[g.i]): per buffer entry the 0-based variable
+    // and the coefficient, evaluated once at build — the one-launch cons_nln! adds such a row with two loads per term
+    bool aug_linear = false;
+    std::vector<int64_t> aug_var;
+    std::vector<double> aug_coef;
 };
 
 // Planner (exa_plan.cpp): copies the description, builds AD trees, slot maps and running offsets.
@@ -77,6 +86,7 @@ std::unique_ptr<Model> plan_model(const exa_model_desc_t *desc);   // throws std
 // ---------------------------------------------------------------------------------------------------
 enum Callback { CB_OBJ = 0, CB_GRAD, CB_CONS, CB_JAC, CB_HESS, CB_JSTRUCT, CB_HSTRUCT,
                 CB_JPROD, CB_JTPROD, CB_HPROD, CB_FUSED,
+                CB_CONS1,      // cons_nln! in ONE launch (exa_cons1): the thread of a base row pulls the row's augmentation terms itself
                 CB_HESSC,      // hess_coord!, second kernel (exa_hessc): chained + grouped + software-pipelined, see ParamLayout::chain
                 CB_COUNT };
 

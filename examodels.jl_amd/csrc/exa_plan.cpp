@@ -5,6 +5,7 @@
 // (_add_obj), :1597-1611 (_add_con), :1730-1738 (_add_con!).  Instead of probing with NaNs it classifies every
 // IR subtree statically (constant for AD <=> contains no VAR) and replays the traversal order symbolically.
 #include <algorithm>
+#include <map>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -275,9 +276,54 @@ void check_index_bounds(const Model &m) {
     }
 }
 
+// Is the pattern's expression  c * x[index]  with c a literal or a Float64 data column (+x, -x, c*x, x*c)?  Then
+// (index node, coefficient node or -1, sign) describe it.
+bool linear_leaf(const Pattern &p, int k, int &var_idx, int &coef_node, double &lit) {
+    const exa_node_t &nd = p.nodes[k];
+    if (nd.op == EXA_OP_VAR) { var_idx = nd.a; coef_node = -1; lit = 1.0; return true; }
+    if (nd.op == EXA_OP_UN && (nd.fn == EXA_U_MINUS || nd.fn == EXA_U_PLUS)) {
+        if (p.nodes[nd.a].op != EXA_OP_VAR) return false;
+        var_idx = p.nodes[nd.a].a; coef_node = -1; lit = nd.fn == EXA_U_MINUS ? -1.0 : 1.0;
+        return true;
+    }
+    if (nd.op == EXA_OP_BIN && nd.fn == EXA_B_MUL) {
+        for (int side = 0; side < 2; side++) {
+            const int cv = side ? nd.b : nd.a, vv = side ? nd.a : nd.b;
+            if (p.nodes[vv].op != EXA_OP_VAR) continue;
+            const exa_node_t &c = p.nodes[cv];
+            if (c.op == EXA_OP_CONST_F) { var_idx = p.nodes[vv].a; coef_node = -1; lit = c.fval; return true; }
+            if (c.op == EXA_OP_CONST_I) { var_idx = p.nodes[vv].a; coef_node = -1; lit = (double)c.ival; return true; }
+            if (c.op == EXA_OP_DATA && p.cols[c.a].type == EXA_COL_F64) { var_idx = p.nodes[vv].a; coef_node = cv; lit = 1.0; return true; }
+        }
+    }
+    return false;
+}
+
 // sorted (target row -> contributing buffer entries) lists for the constraint augmentations
 void build_aug_lists(Model &m) {
     if (m.nconaug == 0) return;
+    {   // all terms of the form c * x[index]?  (evaluated per data point on the host, once)
+        bool lin = true;
+        for (const Pattern &p : m.pats) {
+            if (p.kind != EXA_PAT_CONAUG || p.n == 0) continue;
+            int vi, cn; double lit;
+            lin = lin && linear_leaf(p, p.root, vi, cn, lit);
+        }
+        if (lin) {
+            m.aug_var.resize((size_t)m.nconaug);
+            m.aug_coef.resize((size_t)m.nconaug);
+            for (const Pattern &p : m.pats) {
+                if (p.kind != EXA_PAT_CONAUG || p.n == 0) continue;
+                int vi = -1, cn = -1; double lit = 1.0;
+                linear_leaf(p, p.root, vi, cn, lit);
+                for (int64_t I = 0; I < p.n; I++) {
+                    m.aug_var[(size_t)(p.oa + I)] = eval_int(p, vi, I) - 1;
+                    m.aug_coef[(size_t)(p.oa + I)] = cn < 0 ? lit : p.cols[p.nodes[cn].a].fdata[(size_t)I];
+                }
+            }
+        }
+        m.aug_linear = lin;
+    }
     std::vector<int64_t> row((size_t)m.nconaug);
     for (const Pattern &p : m.pats) {
         if (p.kind != EXA_PAT_CONAUG) continue;
@@ -320,6 +366,7 @@ std::unique_ptr<Model> plan_model(const exa_model_desc_t *d) {
     m->uvar = keep(d->uvar, d->nvar);
     m->theta = copy_or<double>(d->theta0, d->npar, 0.0);
     m->pats.resize(d->n_patterns);
+    std::map<uint64_t, std::vector<std::pair<int, int>>> seen_cols;
     for (int k = 0; k < d->n_patterns; k++) {
         const exa_pattern_t &s = d->patterns[k];
         Pattern &p = m->pats[k];
@@ -340,6 +387,30 @@ std::unique_ptr<Model> plan_model(const exa_model_desc_t *d) {
             } else if (sc.type != EXA_COL_RANGE) {
                 fail("unknown column type");
             }
+        }
+        // columns this model already holds (same type, same contents): alias them to the first copy
+        for (int c = 0; c < s.n_cols; c++) {
+            Column &col = p.cols[c];
+            uint64_t hsh = 1469598103934665603ull ^ (uint64_t)col.type;
+            auto mix = [&](const void *data, size_t bytes) {
+                const unsigned char *q = (const unsigned char *)data;
+                for (size_t i = 0; i < bytes; i++) { hsh ^= q[i]; hsh *= 1099511628211ull; }
+            };
+            const int64_t rng_[2] = {col.start, col.step};
+            if (col.type == EXA_COL_RANGE) mix(rng_, sizeof rng_);
+            else if (col.type == EXA_COL_I64) mix(col.idata.data(), 8 * col.idata.size());
+            else mix(col.fdata.data(), 8 * col.fdata.size());
+            mix(&p.n, sizeof p.n);
+            auto &bucket = seen_cols[hsh];
+            for (const auto &kc : bucket) {
+                const Pattern &q = m->pats[kc.first];
+                const Column &o = q.cols[kc.second];
+                const bool same = o.type == col.type && q.n == p.n &&
+                                  (col.type == EXA_COL_RANGE ? (o.start == col.start && o.step == col.step)
+                                   : col.type == EXA_COL_I64 ? o.idata == col.idata : std::memcmp(o.fdata.data(), col.fdata.data(), 8 * col.fdata.size()) == 0);
+                if (same) { col.alias_pat = kc.first; col.alias_col = kc.second; break; }
+            }
+            if (col.alias_pat < 0) bucket.push_back({k, c});
         }
         if (p.kind != EXA_PAT_OBJ && p.kind != EXA_PAT_CON && p.kind != EXA_PAT_CONAUG) fail("unknown pattern kind");
         if (p.kind == EXA_PAT_CONAUG) {

@@ -76,9 +76,12 @@ struct Handle {
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
     hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
-                  f_hess = nullptr, f_hessc = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
+                  f_hess = nullptr, f_hessc = nullptr, f_cons1 = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
+    DevBuf daugcoef;
+    DevBuf daugcsr, daugsrc;                // exa_cons1: CSR over constraint rows of the augmentation terms (pattern << 40 | point)
+    bool cons1 = false;
     DevBuf dsink;                           // 64 doubles nobody reads (ParamLayout::sink)
     DevBuf dP, dtheta, dpart, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
     int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation
@@ -117,7 +120,7 @@ struct Handle {
 
     ~Handle() {
         if (on_device) {
-            dsink.release(); dP.release(); dtheta.release(); dpart.release(); dobj.release();
+            daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); dobj.release();
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
             cj.release(); ch.release(); cbuf.release();
@@ -201,8 +204,8 @@ void fill_params(Handle &h) {
     for (int cb = 0; cb < CB_COUNT; cb++) {
         // dispatch units: one per active pattern, or (chained callbacks) one per group of co-indexed patterns; nb = how
         // many block-map entries (workgroups) a unit needs
-        const bool chained = L.chain[cb] > 0;
-        const size_t na = chained ? L.groups[cb].size() : L.active[cb].size();
+        const bool chained = L.chain[cb] > 0, grouped = !L.groups[cb].empty();
+        const size_t na = grouped ? L.groups[cb].size() : L.active[cb].size();
         std::vector<int64_t> nb(na);
         int64_t total = 0;
         double out_bytes = 0.0;
@@ -213,15 +216,16 @@ void fill_params(Handle &h) {
             return 1;
         };
         for (size_t j = 0; j < na; j++) {
-            if (chained) {
+            if (grouped) {
+                const int64_t tile = (int64_t)kBlock * L.ppt[cb];
                 int64_t tiles = 0;
                 for (int k : L.groups[cb][j]) {
                     const int64_t cnt = h.P[L.pat[k].hi] - h.P[L.pat[k].lo];
-                    tiles = std::max(tiles, (cnt + kBlock - 1) / kBlock);
+                    tiles = std::max(tiles, (cnt + tile - 1) / tile);
                     out_bytes += 8.0 * per_point(m.pats[k]) * (double)cnt;
                 }
-                h.P[L.gtiles[cb][j]] = tiles;
-                nb[j] = (tiles + L.chain[cb] - 1) / L.chain[cb];
+                if (chained) { h.P[L.gtiles[cb][j]] = tiles; nb[j] = (tiles + L.chain[cb] - 1) / L.chain[cb]; }
+                else nb[j] = tiles;
             } else {
                 const auto &pp = L.pat[L.active[cb][j]];
                 const int64_t tile = (int64_t)kBlock * L.ppt[cb];
@@ -327,6 +331,7 @@ void to_device(Handle &h) {
     h.f_fused = fn("exa_fused");
     h.f_jprod = fn("exa_jprod"); h.f_jtprod = fn("exa_jtprod"); h.f_hprod = fn("exa_hprod"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
     if (h.gen.layout.chain[CB_HESSC] > 0) h.f_hessc = fn("exa_hessc");
+    h.f_cons1 = fn("exa_cons1");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
     h.colslot.resize(m.pats.size());
     for (size_t k = 0; k < m.pats.size(); k++) {
@@ -335,6 +340,12 @@ void to_device(Handle &h) {
         for (size_t c = 0; c < p.cols.size(); c++) {
             Column &col = p.cols[c];
             if (col.type == EXA_COL_RANGE) continue;
+            if (col.alias_pat >= 0) {      // a copy of a column that is already resident (exa_plan.cpp)
+                h.colslot[k][c] = h.colslot[col.alias_pat][col.alias_col];
+                std::vector<int64_t>().swap(col.idata);
+                std::vector<double>().swap(col.fdata);
+                continue;
+            }
             DevBuf b;
             b.ensure(8 * (size_t)p.n);
             const void *src = col.type == EXA_COL_I64 ? (const void *)col.idata.data() : (const void *)col.fdata.data();
@@ -365,6 +376,29 @@ void to_device(Handle &h) {
         h.aug_nlong = (int64_t)longs.size();
         h.aug_chunks = (maxlen + 8191) / 8192;                                                    // EXA_AUG_CHUNK
         if (h.aug_nlong) { up(h.dauglong, longs); h.daugpartial.ensure(8 * (size_t)(h.aug_nlong * h.aug_chunks)); }
+        // one-launch cons_nln! (exa_cons1): per constraint row, its terms as (pattern, data point) in insertion order
+        const char *c1 = getenv("EXAHIP_CONS1");
+        if (h.aug_nlong == 0 && !(c1 && atoi(c1) == 0)) {
+            std::vector<int64_t> rowptr((size_t)m.ncon + 1, 0), src((size_t)m.nconaug);
+            for (size_t t = 0; t < m.aug_rows.size(); t++) rowptr[(size_t)m.aug_rows[t] + 1] = m.aug_ptr[t + 1] - m.aug_ptr[t];
+            for (int64_t r = 0; r < m.ncon; r++) rowptr[(size_t)r + 1] += rowptr[(size_t)r];
+            std::vector<std::pair<int64_t, int>> starts;          // (first buffer entry, pattern) of the augmentation patterns
+            for (size_t k = 0; k < m.pats.size(); k++) if (m.pats[k].kind == EXA_PAT_CONAUG && m.pats[k].n > 0) starts.push_back({m.pats[k].oa, (int)k});
+            std::sort(starts.begin(), starts.end());
+            std::vector<double> coef;
+            if (m.aug_linear) coef.resize((size_t)m.nconaug);
+            for (int64_t j = 0; j < m.nconaug; j++) {
+                const int64_t q = m.aug_perm[(size_t)j];
+                if (m.aug_linear) { src[(size_t)j] = m.aug_var[(size_t)q]; coef[(size_t)j] = m.aug_coef[(size_t)q]; continue; }
+                auto it = std::upper_bound(starts.begin(), starts.end(), std::make_pair(q, INT32_MAX));
+                const auto &st = *(it - 1);
+                src[(size_t)j] = ((int64_t)st.second << 40) | (q - st.first);
+            }
+            up(h.daugcsr, rowptr); up(h.daugsrc, src);
+            h.daugcoef.ensure(8 * std::max<size_t>(coef.size(), 1));
+            if (!coef.empty()) HIPCHK(hipMemcpy(h.daugcoef.p, coef.data(), 8 * coef.size(), hipMemcpyHostToDevice));
+            h.cons1 = true;
+        }
     }
     HIPCHK(hipEventCreate(&h.ev0));
     HIPCHK(hipEventCreate(&h.ev1));
@@ -491,7 +525,15 @@ void do_cons(Handle &h, const double *x, double *c) {
         if (h.m->nconaug) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
     }
     const void *P = h.dP.p, *th = h.dtheta.p;
-    // one launch: base rows (plain stores into c) and augmentation terms (into the value buffer, coalesced)
+    if (h.cons1 && h.world == 1) {
+        // ONE launch: every base row's thread evaluates the row's augmentation terms itself (exa_cons1)
+        const void *ptr = h.daugcsr.p, *src = h.daugsrc.p, *coef = h.daugcoef.p;
+        void *a1[] = {&P, &x, &th, &c, &ptr, &src, &coef};
+        launch(h, h.f_cons1, h.grid[CB_CONS1], kBlock, a1);
+        allreduce(h, c, h.m->ncon);
+        return;
+    }
+    // base rows (plain stores into c) and augmentation terms (into the value buffer, coalesced)
     void *a[] = {&P, &x, &th, &c, &buf};
     launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a);
     if (h.m->nconaug) aug_gather(h, buf, c);       // then one deterministic gather per target row

@@ -13,6 +13,7 @@ import ExaModels
 import ExaModels: ExaCore, AbstractExaModel, Var, ParameterNode, DataSource, DataIndexed, Node1, Node2, Constant,
     Null, SumNode, ProdNode, Objective, Constraint, ConstraintAugmentation
 import NLPModels
+import AMDGPU
 using AMDGPU: ROCArray, ROCBackend
 
 const LIB = get(ENV, "EXAHIP_LIB", "libexahip.so")
@@ -62,10 +63,15 @@ lower!(l, n::Null) = push_node!(l, OP_NULLV, 0, -1, -1, n.value === nothing ? 0.
 lower!(l, d::Union{DataSource,DataIndexed}) = push_node!(l, OP_DATA, 0, col!(l, path(d)), -1, 0.0, 0)
 lower!(l, v::Var) = push_node!(l, OP_VAR, 0, lower!(l, v.i), -1, 0.0, 0)
 lower!(l, v::ParameterNode) = push_node!(l, OP_PAR, 0, lower!(l, v.i), -1, 0.0, 0)
-lower!(l, n::Node1{F}) where {F} = push_node!(l, OP_UN, UN[F.instance], lower!(l, n.inner), -1, 0.0, 0)
+# functions registered by the user (@register_univariate / @register_bivariate outside src/functionlist.jl) have no
+# entry in the library's derivative table: say so instead of failing with a bare KeyError
+fncode(tab, f, arity) = get(tab, f) do
+    error("ExaModelsHIP: the $arity function `$f` is not in libexahip's derivative table (src/functionlist.jl entries only)")
+end
+lower!(l, n::Node1{F}) where {F} = push_node!(l, OP_UN, fncode(UN, F.instance, "univariate"), lower!(l, n.inner), -1, 0.0, 0)
 function lower!(l, n::Node2{F}) where {F}
     a = lower!(l, n.inner1); b = lower!(l, n.inner2)
-    push_node!(l, OP_BIN, BIN[F.instance], a, b, 0.0, 0)
+    push_node!(l, OP_BIN, fncode(BIN, F.instance, "bivariate"), a, b, 0.0, 0)
 end
 lower!(l, n::SumNode) = foldl_nodes!(l, n.inners, BIN[+], 0.0)      # reduce(+, ...) (graph.jl:549-567)
 lower!(l, n::ProdNode) = foldl_nodes!(l, n.inners, BIN[*], 1.0)
@@ -128,9 +134,16 @@ function ExaModels.build_extension(c::ExaCore{T,VT,B}; prod = false) where {T,VT
         root = lower!(l, expr)
         kind, target, base = Int32(0), Int32(-1), Int32(-1)
         if blk isa Constraint
-            kind = Int32(1); basepos[blk.f.o0] = Int32(k - 1)
+            kind = Int32(1)
+            # an augmentation names its base block by its first row (f.o0, nlp.jl:1683).  A zero-length Constraint shares
+            # that number with the block after it: it never takes the entry of a block that has rows, and a block with rows
+            # always does — the rows an augmentation can target belong to the latter.
+            (length(blk.itr) > 0 || !haskey(basepos, blk.f.o0)) && (basepos[blk.f.o0] = Int32(k - 1))
         elseif blk isa ConstraintAugmentation
-            kind = Int32(2); target = lower_target!(l, f.first, blk.dims); base = basepos[blk.f.o0]
+            kind = Int32(2); target = lower_target!(l, f.first, blk.dims)
+            base = get(basepos, blk.f.o0) do
+                error("ExaModelsHIP: augmentation block $k has no base constraint starting at row $(blk.f.o0 + 1)")
+            end
         end
         cols = [column(blk.itr, p, keep) for p in l.paths]
         push!(keep, l.nodes); push!(keep, cols)
@@ -145,43 +158,85 @@ function ExaModels.build_extension(c::ExaCore{T,VT,B}; prod = false) where {T,VT
         st = ccall((:exa_new_from_table, LIB), Cint, (Ref{CModelDesc}, Ref{Cint}), desc, id)
     end
     st == 0 || error("exa_new_from_table: status $st: " * unsafe_string(ccall((:exa_last_error, LIB), Cstring, ())))
-    # the library recomputes the running offsets; they must equal the core's (layout contract)
-    @assert ccall((:exa_nnzh64, LIB), Int64, (Cint,), id[]) == c.nnzh
-    @assert ccall((:exa_nnzj64, LIB), Int64, (Cint,), id[]) == c.nnzj
+    # the library recomputes the running offsets; they must equal the core's (layout contract) — a hard error, not an
+    # @assert that an optimised build would drop
+    for (sym, want) in ((:exa_nnzh64, c.nnzh), (:exa_nnzj64, c.nnzj), (:exa_ncon64, c.ncon), (:exa_nvar64, c.nvar))
+        got = sym === :exa_nnzh64 ? ccall((:exa_nnzh64, LIB), Int64, (Cint,), id[]) :
+              sym === :exa_nnzj64 ? ccall((:exa_nnzj64, LIB), Int64, (Cint,), id[]) :
+              sym === :exa_ncon64 ? ccall((:exa_ncon64, LIB), Int64, (Cint,), id[]) : ccall((:exa_nvar64, LIB), Int64, (Cint,), id[])
+        got == want || (ccall((:exa_free, LIB), Cint, (Cint,), id[]); error("ExaModelsHIP: layout mismatch, $sym = $got, ExaCore has $want"))
+    end
     ext = HIPExtension(id[], Any[])
     finalizer(e -> ccall((:exa_free, LIB), Cint, (Cint,), e.id), ext)
     return ext
 end
 
-# ---- the seven callbacks (device pointers; asynchronous on the null stream except obj) ------------------------
+# Every callback runs on the CALLING TASK's AMDGPU stream (AMDGPU.jl streams are task-local and non-blocking, so the
+# library's default null stream would not be ordered against the arrays' producers and consumers).
+usestream(m) = chk(ccall((:exa_set_stream, LIB), Cint, (Cint, Ptr{Cvoid}), m.ext.id, AMDGPU.stream().stream), "exa_set_stream")
+
+# Explicit, blocking tuning (block orders, hess_coord! kernel, product implementations); persisted by the library.
+tune!(m; what = 3) = (usestream(m); chk(ccall((:exa_tune, LIB), Cint, (Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, what, C_NULL, C_NULL), "exa_tune"))
+
+# ---- multi-GPU: one Julia process per GPU (include/exahip.h "multi-GPU behind the ABI") ---------------------------------
+# rank 0:  uid = comm_unique_id();  uid = MPI.bcast(uid, 0, comm)       every rank:  comm_init!(model, rank, world, uid)
+# afterwards obj / grad! / cons_nln! / jprod / jtprod / hprod! return the COMPLETE result on every rank (ncclAllReduce over
+# xGMI on the model's stream, inside libexahip); jac_coord! / hess_coord! fill this rank's slice (coo_local!(model) packs it).
+function comm_unique_id()
+    uid = Vector{UInt8}(undef, 128)
+    chk(ccall((:exa_comm_unique_id, LIB), Cint, (Ptr{UInt8},), uid), "exa_comm_unique_id")
+    return uid
+end
+comm_init!(m, rank::Integer, world::Integer, uid::Vector{UInt8}) =
+    chk(ccall((:exa_comm_init, LIB), Cint, (Cint, Cint, Cint, Ptr{UInt8}), m.ext.id, rank, world, uid), "exa_comm_init")
+comm_free!(m) = chk(ccall((:exa_comm_free, LIB), Cint, (Cint,), m.ext.id), "exa_comm_free")
+coo_local!(m, on::Bool = true) = chk(ccall((:exa_set_coo_local, LIB), Cint, (Cint, Cint), m.ext.id, on), "exa_set_coo_local")
+local_nnzj(m) = ccall((:exa_local_nnzj64, LIB), Int64, (Cint,), m.ext.id)
+local_nnzh(m) = ccall((:exa_local_nnzh64, LIB), Int64, (Cint,), m.ext.id)
+function coo_slices(m; hess::Bool = true)          # rows of (first global slot, first local position, length), 0-based
+    np = ccall((:exa_npatterns, LIB), Cint, (Cint,), m.ext.id)
+    out = Vector{Int64}(undef, 3 * max(np, 1))
+    chk(ccall((:exa_coo_slices, LIB), Cint, (Cint, Cint, Ptr{Int64}), m.ext.id, hess, out), "exa_coo_slices")
+    return permutedims(reshape(out[1:3np], 3, np))
+end
+
+# ---- the seven callbacks (device pointers; asynchronous on the task's stream except obj) ------------------------
 const HM{T,VT} = AbstractExaModel{T,VT,E} where {E<:HIPExtension}
 chk(st, what) = st == 0 || error("$what: status $st: " * unsafe_string(ccall((:exa_last_error, LIB), Cstring, ())))
 
 function ExaModels.obj(m::HM, x::AbstractVector)
+    usestream(m)
     out = Ref{Cdouble}(0)
     chk(ccall((:exa_obj, LIB), Cint, (Cint, Ptr{Cdouble}, Ref{Cdouble}), m.ext.id, pointer(x), out), "exa_obj")
     return out[]
 end
 function ExaModels.cons_nln!(m::HM, x::AbstractVector, c::AbstractVector)
+    usestream(m)
     chk(ccall((:exa_cons, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, pointer(x), pointer(c)), "exa_cons"); c
 end
 function ExaModels.grad!(m::HM, x::AbstractVector, g::AbstractVector)
+    usestream(m)
     chk(ccall((:exa_grad, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, pointer(x), pointer(g)), "exa_grad"); g
 end
 function ExaModels.jac_coord!(m::HM, x::AbstractVector, v::AbstractVector)
+    usestream(m)
     chk(ccall((:exa_jac, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, pointer(x), pointer(v)), "exa_jac"); v
 end
 function ExaModels.hess_coord!(m::HM, x::AbstractVector, y::AbstractVector, v::AbstractVector; obj_weight = one(eltype(x)))
+    usestream(m)
     chk(ccall((:exa_hess, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
               m.ext.id, pointer(x), pointer(y), Float64(obj_weight), pointer(v)), "exa_hess"); v
 end
 function ExaModels.jprod_nln!(m::HM, x::AbstractVector, v::AbstractVector, Jv::AbstractVector)
+    usestream(m)
     chk(ccall((:exa_jprod, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, pointer(x), pointer(v), pointer(Jv)), "exa_jprod"); Jv
 end
 function ExaModels.jtprod_nln!(m::HM, x::AbstractVector, v::AbstractVector, Jtv::AbstractVector)
+    usestream(m)
     chk(ccall((:exa_jtprod, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, pointer(x), pointer(v), pointer(Jtv)), "exa_jtprod"); Jtv
 end
 function ExaModels.hprod!(m::HM, x::AbstractVector, y::AbstractVector, v::AbstractVector, Hv::AbstractVector; obj_weight = one(eltype(x)))
+    usestream(m)
     chk(ccall((:exa_hprod, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
               m.ext.id, pointer(x), pointer(y), pointer(v), Float64(obj_weight), pointer(Hv)), "exa_hprod"); Hv
 end
@@ -195,11 +250,13 @@ function ExaModels.set_value!(m::ExaModels.ExaModel{T,VT,E}, param::ExaModels.Pa
     return nothing
 end
 function ExaModels.jac_structure!(m::HM, rows::AbstractVector, cols::AbstractVector)
+    usestream(m)
     r, c = ROCArray{Int64}(undef, length(rows)), ROCArray{Int64}(undef, length(cols))
     chk(ccall((:exa_jac_structure64, LIB), Cint, (Cint, Ptr{Int64}, Ptr{Int64}), m.ext.id, pointer(r), pointer(c)), "exa_jac_structure64")
     copyto!(rows, r); copyto!(cols, c); rows, cols
 end
 function ExaModels.hess_structure!(m::HM, rows::AbstractVector, cols::AbstractVector)
+    usestream(m)
     r, c = ROCArray{Int64}(undef, length(rows)), ROCArray{Int64}(undef, length(cols))
     chk(ccall((:exa_hess_structure64, LIB), Cint, (Cint, Ptr{Int64}, Ptr{Int64}), m.ext.id, pointer(r), pointer(c)), "exa_hess_structure64")
     copyto!(rows, r); copyto!(cols, c); rows, cols
