@@ -192,7 +192,8 @@ def traffic_for(m, config, per_gpu_points):
         return None
     with open(path) as fh:
         t = json.load(fh)
-    if t.get("module") != m._L.exa_module_name(m.id).decode() or t.get("points") != per_gpu_points:
+    kernel = "exa_hessc" if m._L.exa_hess_variant(m.id) == 1 else "exa_hess"
+    if t.get("module") != m._L.exa_module_name(m.id).decode() or t.get("points") != per_gpu_points or t.get("kernel") != kernel:
         return None
     return t.get("hbm_bytes_per_launch")
 
@@ -362,15 +363,16 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
         "value": value, "unit": "nnz/s", "n_gpus": world, "steps": steps, "warmup": warmup, "preheat_ms": args.preheat_ms,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": wl, "baseline_config": config, "nvar": nvar, "ncon": ncon, "nnzh": nnzh, "obj_weight": sigma,
+        "config": {"workload": wl, "baseline_config": config, "points": points, "nvar": nvar, "ncon": ncon, "nnzh": nnzh, "obj_weight": sigma,
                    "parallelism": f"iterator-shard x{world}, local-slice COO, no data-path collective" if world > 1 else "1 GPU",
                    "resident_per_gpu_bytes": 8 * (n_local + (vhi - vlo) + (yhi - ylo))},
         "evals_per_s": steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_for(m, config, per_gpu if world > 1 else points),
-                     "kernel": "exa_hess", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel": "exa_hessc" if L.exa_hess_variant(m.id) == 1 else "exa_hess", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "block_order": {0: "sequential", 1: "interleaved-128"}.get(L.exa_block_order(m.id, 4), "n/a")},
-        "build": {"module": how, "compile_ms": compile_ms, "model_build_s": build_s, "first_hess_call_ms": first_call_ms,
+        "build": {"module": how, "module_name": L.exa_module_name(m.id).decode(), "hess_kernel": "exa_hessc" if L.exa_hess_variant(m.id) == 1 else "exa_hess",
+                  "compile_ms": compile_ms, "model_build_s": build_s, "first_hess_call_ms": first_call_ms,
                   "tune_ms": tune_ms,
                   "note": "first_hess_call_ms = host time of the first exa_hess + its completion (asynchronous launch, no measuring inside)"},
     }

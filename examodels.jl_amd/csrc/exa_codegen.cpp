@@ -265,11 +265,12 @@ Triple un_rule(Emitter &e, int fn, Val u, int order) {
     u = e.tod(u);
     if (u.is_lit() && host_un_ok(fn) && order == 0) { r.x = Emitter::litf(host_un(fn, u.f)); return r; }
     if (fn == EXA_U_SIN || fn == EXA_U_COS) {
-        if (order == 0) {
-            const bool fast = env_int("EXAHIP_FAST_TRIG", 1) != 0;
-            r.x = e.call(fn == EXA_U_SIN ? (fast ? "exa_sin($1)" : "sin($1)") : (fast ? "exa_cos($1)" : "cos($1)"), {u});
+        if (order == 0 && !env_int("EXAHIP_FAST_TRIG", 1)) {
+            r.x = e.call(fn == EXA_U_SIN ? "sin($1)" : "cos($1)", {u});
             return r;
         }
+        // (value-only contexts too: exa_sin / exa_cos each run the whole sincos, so a pattern — or a fused group — that
+        // needs both of one argument pays once)
         // one sincos per argument serves value and both derivatives (functionlist.jl:22-23)
         const std::string key = "sincos|" + e.s(u);
         Val sv, cv;
@@ -1646,8 +1647,9 @@ Generated generate_module(const Model &m) {
         }
         for (size_t g = 0; g < L.groups[cb].size(); g++) L.gtiles[cb].push_back(w++);
     }
-    // fused groups of the scattering products: patterns of EXACTLY the same length (one thread evaluates point I of all)
-    for (int cb : {CB_JTPROD, CB_HPROD}) {
+    // fused groups of the scattering products and of the one-launch cons_nln!: patterns of EXACTLY the same length (one
+    // thread evaluates point I of all)
+    for (int cb : {CB_JTPROD, CB_HPROD, CB_CONS1}) {
         const int gmax = std::max(1, env_int("EXAHIP_GROUP_MAX", 8));
         for (int k : L.active[cb]) {
             bool placed = false;
@@ -1759,42 +1761,60 @@ Generated generate_module(const Model &m) {
     // buffer round trip, no second launch.  augptr [ncon + 1] / augsrc [nconaug]: CSR over constraint rows.
     // When every term is coefficient * x[index] (aug_linear: evaluated at build) the walk is two loads per term, four
     // terms in flight, the additions still in insertion order; otherwise (pattern, point) entries and a switch.
+    // Dispatch units are FUSED GROUPS (patterns of exactly the same length): thread I evaluates the rows of all of them in
+    // one emitter — the branch table's columns, the gathered voltages and sincos(va_f - va_t) are loaded / computed once
+    // for ACOPF's four flow, one angle-difference and two thermal-limit rows of branch I.
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_cons1(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out, const long* __restrict__ augptr, const long* __restrict__ augsrc, "
           "const double* __restrict__ augcoef) {\n";
     {
-        const auto &act = L.active[CB_CONS1];
         std::vector<int> augs;
         for (int k = 0; k < np; k++) if (m.pats[k].n > 0 && m.pats[k].kind == EXA_PAT_CONAUG) augs.push_back(k);
         os << "    const long e_ = ((const long*)P[" << L.blk[CB_CONS1] << "])[blockIdx.x];\n    const int ps_ = (int)(e_ >> 40);\n"
               "    const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
-        for (size_t k = 0; k < act.size(); k++) {
-            const auto &pp = L.pat[act[k]];
-            bool target = false;
-            for (int a : augs) target = target || m.pats[a].base == act[k];
-            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n        const long I = P[" << pp.lo << "] + tid0;\n        if (I >= P[" << pp.hi
-               << "]) return;\n        double v = p" << act[k] << "_val(P, x, th, I);\n";
-            if (target && m.aug_linear) {
-                os << "        const long r_ = P[" << pp.o0 << "] + I;\n        long j = augptr[r_];\n        const long je = augptr[r_ + 1];\n"
-                      "        for (; j + 4 <= je; j += 4) {\n"
-                      "            const long i0 = augsrc[j], i1 = augsrc[j + 1], i2 = augsrc[j + 2], i3 = augsrc[j + 3];\n"
-                      "            const double c0 = augcoef[j], c1 = augcoef[j + 1], c2 = augcoef[j + 2], c3 = augcoef[j + 3];\n"
-                      "            const double x0 = x[i0], x1 = x[i1], x2 = x[i2], x3 = x[i3];\n"
-                      // (products rounded on their own, like the reference's c * x followed by +=: no FMA contraction)
-                      "            v += __dmul_rn(c0, x0); v += __dmul_rn(c1, x1); v += __dmul_rn(c2, x2); v += __dmul_rn(c3, x3);\n        }\n"
-                      "        for (; j < je; j++) v += __dmul_rn(augcoef[j], x[augsrc[j]]);\n";
-            } else if (target) {
-                os << "        const long r_ = P[" << pp.o0 << "] + I;\n        for (long j = augptr[r_], je = augptr[r_ + 1]; j < je; j++) {\n"
-                      "            const long s_ = augsrc[j];\n            const int ap_ = (int)(s_ >> 40);\n            const long J = s_ & ((1L << 40) - 1);\n";
-                bool first = true;
-                for (int a : augs) {
-                    if (m.pats[a].base != act[k]) continue;
-                    os << "            " << (first ? "" : "else ") << "if (ap_ == " << a << ") v += p" << a << "_val(P, x, th, J);\n";
-                    first = false;
-                }
-                os << "        }\n";
+        for (size_t g = 0; g < L.groups[CB_CONS1].size(); g++) {
+            const auto &grp = L.groups[CB_CONS1][g];
+            const auto &pp0 = L.pat[grp.front()];
+            os << "    " << (g ? "else " : "") << "if (ps_ == " << g << ") {\n        const long I = P[" << pp0.lo << "] + tid0;\n        if (I >= P[" << pp0.hi
+               << "]) return;\n";
+            Emitter E;
+            std::vector<std::unique_ptr<Body>> bodies;
+            std::vector<Val> vals;
+            for (int pk : grp) {
+                bodies.emplace_back(new Body(m, pk, L, &E));
+                vals.push_back(E.tod(bodies.back()->cval(m.pats[pk].root)));
             }
-            os << "        out[P[" << pp.o0 << "] + I] = v;\n    }\n";
+            emit_lines(os, E, "        ");
+            for (size_t q = 0; q < grp.size(); q++) {
+                const int pk = grp[q];
+                const auto &pp = L.pat[pk];
+                bool target = false;
+                for (int a : augs) target = target || m.pats[a].base == pk;
+                if (!target) { os << "        out[P[" << pp.o0 << "] + I] = " << E.sd(vals[q]) << ";\n"; continue; }
+                os << "        {\n        double v = " << E.sd(vals[q]) << ";\n        const long r_ = P[" << pp.o0 << "] + I;\n";
+                if (m.aug_linear) {
+                    os << "        long j = augptr[r_];\n        const long je = augptr[r_ + 1];\n"
+                          "        for (; j + 4 <= je; j += 4) {\n"
+                          "            const long i0 = augsrc[j], i1 = augsrc[j + 1], i2 = augsrc[j + 2], i3 = augsrc[j + 3];\n"
+                          "            const double c0 = augcoef[j], c1 = augcoef[j + 1], c2 = augcoef[j + 2], c3 = augcoef[j + 3];\n"
+                          "            const double x0 = x[i0], x1 = x[i1], x2 = x[i2], x3 = x[i3];\n"
+                          // (products rounded on their own, like the reference's c * x followed by +=: no FMA contraction)
+                          "            v += __dmul_rn(c0, x0); v += __dmul_rn(c1, x1); v += __dmul_rn(c2, x2); v += __dmul_rn(c3, x3);\n        }\n"
+                          "        for (; j < je; j++) v += __dmul_rn(augcoef[j], x[augsrc[j]]);\n";
+                } else {
+                    os << "        for (long j = augptr[r_], je = augptr[r_ + 1]; j < je; j++) {\n"
+                          "            const long s_ = augsrc[j];\n            const int ap_ = (int)(s_ >> 40);\n            const long J = s_ & ((1L << 40) - 1);\n";
+                    bool first = true;
+                    for (int a : augs) {
+                        if (m.pats[a].base != pk) continue;
+                        os << "            " << (first ? "" : "else ") << "if (ap_ == " << a << ") v += p" << a << "_val(P, x, th, J);\n";
+                        first = false;
+                    }
+                    os << "        }\n";
+                }
+                os << "        out[r_] = v;\n        }\n";
+            }
+            os << "    }\n";
         }
     }
     os << "}\n";

@@ -184,8 +184,8 @@ def test_the_two_declared_numeric_deviations(libs, monkeypatch):
             monkeypatch.setenv("EXAHIP_STRICT_IEEE", strict)
             m = ExaModel(plus_zero())
             o = oracle.OracleModel(m.ir)
-            assert not np.signbit(o.jac_coord(x).sum())
-            assert np.signbit(m.jac_coord(x).sum()) == (strict == "0")
+            assert not np.signbit(o.jac_coord(x)[0])
+            assert np.signbit(m.jac_coord(x)[0]) == (strict == "0")
             assert m.cons(x)[0] == 0.0 == o.cons(x)[0] and m.hess_coord(x, one, 1.0).sum() == o.hess_coord(x, one, 1.0).sum() == 2.0
         # ---- 2. x1 / x2 at |x2| = 1e300 (x2^2 overflows) and 1e-200 (x2^3 underflows)
         for x in (np.array([3.0, 1e300]), np.array([3.0, -1e300]), np.array([1e-10, 1e-200])):

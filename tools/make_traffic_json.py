@@ -1,0 +1,36 @@
+#!/usr/bin/env python
+"""profiles/r2_traffic_config<k>.json from the PMC passes of tools/refresh_profiles_r2.sh: HBM bytes per launch of the
+Hessian kernel = WRITE_SIZE + corrected FETCH_SIZE (separate rocprofv3 --pmc passes, per-dispatch averages), stamped with
+the NAME OF THE MODULE it was measured on and the workload size — bench.py attaches the number only when both match.
+usage: make_traffic_json.py CONFIG bench.json fetch_summary.txt write_summary.txt > profiles/r2_traffic_configK.json"""
+import json
+import re
+import sys
+
+config, bench, fetch, write = int(sys.argv[1]), sys.argv[2], sys.argv[3], sys.argv[4]
+line = json.loads(open(bench).read().strip().splitlines()[-1])
+kernel = line["roofline"]["kernel"]
+
+
+def counter(path, name):
+    for ln in open(path):
+        m = re.match(r"\s*(\S+)\s+" + name + r"\s+n=\s*(\d+)\s+avg=\s*([\d.eE+-]+)", ln)
+        if m and m.group(1).startswith(kernel):
+            return float(m.group(3)), int(m.group(2))
+    raise SystemExit(f"{name} of {kernel} not found in {path}")
+
+
+f_kb, nf = counter(fetch, "FETCH_SIZE")
+w_kb, nw = counter(write, "WRITE_SIZE")
+CORR = 1.9391      # profiles/r1_pmc_calibration_store_bench.txt: a kernel reading a known 156250 KB in this 8-B/lane pattern reports 80578.89 KB
+out = {
+    "workload": line["config"]["workload"], "baseline_config": config, "points": line["config"].get("points"),
+    "module": line["build"]["module_name"], "kernel": kernel,
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/refresh_profiles_r2.sh), per-dispatch averages",
+    "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb, "dispatches": [nf, nw],
+    "fetch_correction": CORR,
+    "fetch_correction_source": "profiles/r1_pmc_calibration_store_bench.txt (the guide's gfx950 'FETCH_SIZE reports 1/2', calibrated on this access pattern); WRITE_SIZE needs none",
+    "hbm_bytes_per_launch": int(round(1024 * (w_kb + CORR * f_kb))),
+    "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
+}
+print(json.dumps(out, indent=1))
