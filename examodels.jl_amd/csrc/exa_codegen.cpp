@@ -667,6 +667,9 @@ Split split_body(const Emitter &e) {
         if (d < e.defs.size() && e.defs[d].line == (int)li) {
             const Emitter::Def &df = e.defs[d++];
             if (is_memory_read(df.expr)) {
+                if (env_int("EXAHIP_NT_LOADS", 0) && (df.expr.compare(0, 2, "x[") == 0 || df.expr.compare(0, 2, "y[") == 0))
+                    sp.load.push_back(std::string(df.is_int ? "const long " : "const double ") + df.name + " = __builtin_nontemporal_load(&" + df.expr + ");");
+                else
                 sp.load.push_back(line);
                 if (df.is_int) {
                     sp.load.push_back("ik[" + std::to_string(sp.nik) + "] = " + df.name + ";");
