@@ -1019,6 +1019,13 @@ void emit_coo_stores(std::ostringstream &os, const Body &b, int word_o, int S, c
     }
 }
 
+// slots stored through a position table (exa_c*p): slot q of the uncompressed COO goes to out[pos[q]]
+void emit_coo_stores_permuted(std::ostringstream &os, const Body &b, int word_o, int S, const std::vector<std::string> &vals, const std::string &tag) {
+    os << "    if (I0 < hi) {\n    const long o" << tag << " = " << b.P(word_o) << " + " << S << "L * I;\n";
+    for (int s = 0; s < S; s++) os << "    out[pos[o" << tag << " + " << s << "]] = " << vals[s] << ";\n";
+    os << "    }\n";
+}
+
 // ---- gather ("pull") formulation of the objective gradient ------------------------------------------------
 // index expression == a * (RANGE column) + c ?
 struct Affine { bool ok = false; int col = -1; int64_t a = 0, c = 0; };
@@ -1316,12 +1323,50 @@ void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     std::vector<std::string> vals;
     for (int s = 0; s < p.o2step; s++) vals.push_back(b.e.sd(a.acc[s]));
     if (L.chain[CB_HESSC] > 0) emit_two_stage(os, b, L, pi, CB_HESSC, "hessc", true, tile, L.pat[pi].o2, p.o2step, vals);
-    os << "static __device__ __forceinline__ void " << fn_name(pi, "hess")
-       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
-          "double* __restrict__ out, double sigma, long tid, double* lds) {\n";
-    emit_coo_prologue(os, b, L, pi, tile);
-    emit_lines(os, b.e);
-    emit_coo_stores(os, b, L.pat[pi].o2, p.o2step, vals, tile);
+}
+
+// jac_coord! / hess_coord! (exa_jac / exa_hess): one device function per FUSED GROUP — the patterns of exactly the same
+// length, evaluated by thread I one after the other inside ONE emitter (shared loads, shared gathers, one sincos per
+// argument for all of them), each pattern's slots staged and flushed to ITS OWN contiguous COO range as soon as they are
+// complete (so only one pattern's values are live at a time).  A singleton group is the plain per-pattern function.
+void gen_coo_group_fn(std::ostringstream &os, const Model &m, const ParamLayout &L, int cb, int gi, bool permuted = false) {
+    const auto &grp = L.groups[cb][gi];
+    const bool hess = cb == CB_HESS;
+    bool any_tile = false;
+    for (int pk : grp) any_tile = any_tile || (!permuted && use_tile(hess ? m.pats[pk].o2step : m.pats[pk].o1step));
+    os << "static __device__ __forceinline__ void g" << gi << "_" << (hess ? "hess" : "jac") << (permuted ? "p" : "")
+       << "(const long* __restrict__ P, const double* __restrict__ x, " << (hess ? "const double* __restrict__ y, " : "")
+       << "const double* __restrict__ th, double* __restrict__ out, " << (hess ? "double sigma, " : "") << "long tid, "
+       << (permuted ? "const unsigned* __restrict__ pos" : "double* lds") << ") {\n";
+    {
+        Body b0(m, grp.front(), L);
+        emit_coo_prologue(os, b0, L, grp.front(), any_tile);      // the group shares lo / hi
+    }
+    Emitter E;
+    size_t emitted = 0;
+    for (int pk : grp) {
+        Body b(m, pk, L, &E);
+        const Pattern &p = b.p;
+        std::vector<std::string> vals;
+        int S, word;
+        if (hess) {
+            b.forward(p.ad_root, 2, false);
+            Val adj = p.kind == EXA_PAT_OBJ ? E.raw("sigma", false) : E.raw("y[" + b.row0() + "]", false);
+            GenAlg a(b, p.comp2, p.o2step);
+            hrpass0(p, p.ad_root, a, adj, zero_seed(b));
+            S = p.o2step; word = L.pat[pk].o2;
+            for (int s = 0; s < S; s++) vals.push_back(E.sd(a.acc[s]));
+        } else {
+            b.forward(p.ad_root, 1, false);
+            GenAlg a(b, p.comp1, p.o1step);
+            grpass(p, p.ad_root, a, Emitter::litf(1.0));
+            S = p.o1step; word = L.pat[pk].o1;
+            for (int s = 0; s < S; s++) vals.push_back(E.sd(a.acc[s]));
+        }
+        for (; emitted < E.lines.size(); emitted++) os << "    " << E.lines[emitted] << "\n";
+        if (permuted) emit_coo_stores_permuted(os, b, word, S, vals, "_" + std::to_string(pk));
+        else emit_coo_stores(os, b, word, S, vals, use_tile(S), "out", "_" + std::to_string(pk));
+    }
     os << "}\n";
 }
 
@@ -1520,7 +1565,7 @@ void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const st
     os << "    const long e_ = ((const long*)P[" << L.blk[cb] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
           "    const long tid0 = (e_ & ((1L << 40) - 1)) * (EXA_BLOCK * " << ppt << ") + threadIdx.x;\n";
     const bool scatter = cb == CB_GRAD || cb == CB_JTPROD || cb == CB_HPROD;
-    const bool grouped = cb == CB_JTPROD || cb == CB_HPROD;        // dispatch units are fused groups (gen_scatter_group_fn)
+    const bool grouped = cb == CB_JTPROD || cb == CB_HPROD || cb == CB_JAC || cb == CB_HESS;     // dispatch units are fused groups
     const size_t nunits = grouped ? L.groups[cb].size() : act.size();
     auto unit_key = [&](size_t k) { return grouped ? (int)k : act[k]; };
     size_t maxlit = 0;
@@ -1652,11 +1697,12 @@ Generated generate_module(const Model &m) {
     }
     // fused groups of the scattering products and of the one-launch cons_nln!: patterns of EXACTLY the same length (one
     // thread evaluates point I of all)
-    for (int cb : {CB_JTPROD, CB_HPROD, CB_CONS1}) {
+    for (int cb : {CB_JTPROD, CB_HPROD, CB_CONS1, CB_JAC, CB_HESS}) {
         const int gmax = std::max(1, env_int("EXAHIP_GROUP_MAX", 8));
         for (int k : L.active[cb]) {
             bool placed = false;
-            if (env_int("EXAHIP_GROUP_SCATTER", 1))
+            const bool coo = cb == CB_JAC || cb == CB_HESS;
+            if (env_int(coo ? "EXAHIP_GROUP_COO" : "EXAHIP_GROUP_SCATTER", 1))
                 for (auto &g : L.groups[cb])
                     if ((int)g.size() < gmax && m.pats[g.front()].n == m.pats[k].n) { g.push_back(k); placed = true; break; }
             if (!placed) L.groups[cb].push_back({k});
@@ -1695,13 +1741,15 @@ Generated generate_module(const Model &m) {
         else {
             gen_cons_fn(os, m, k, L);
             gen_jprod_fn(os, m, k, L);
-            if (p.o1step > 0) { gen_first_fn(os, m, k, L, false); gen_struct_fn(os, m, k, L, false); }
+            if (p.o1step > 0) gen_struct_fn(os, m, k, L, false);
         }
         if (p.o2step > 0) { gen_hess_fn(os, m, k, L); gen_struct_fn(os, m, k, L, true); }
         gen_fused_fn(os, m, k, L);
     }
     for (int cb : {CB_JTPROD, CB_HPROD})
         for (size_t g = 0; g < L.groups[cb].size(); g++) gen_scatter_group_fn(os, m, L, cb, (int)g);
+    for (int cb : {CB_JAC, CB_HESS})
+        for (size_t g = 0; g < L.groups[cb].size(); g++) gen_coo_group_fn(os, m, L, cb, (int)g);
     // scatter kernels whose patterns have targets shared by ALL data points process 16 tiles per workgroup: the shared
     // target then receives one atomic per wavefront per 16 tiles (same-address atomics serialise chip-wide at ~10 ns:
     // the rocket's step variable took 47 000 of them per J'v, 0.47 ms)
@@ -2165,6 +2213,20 @@ std::string generate_window_module(const Model &m, const ParamLayout &L, const W
     // hitting the same 2-4 of them (rocket, stride 12: 8-way conflicts on every read-modify-write); a bijection within
     // each aligned block of 16 entries, W is a multiple of 16
     os << "// windowed compressed-COO kernels\n#define EXA_WPOS(c) " << (env_int("EXAHIP_CW_SWIZZLE", 1) ? "((c) ^ (((c) >> 4) & 15))" : "(c)") << "\n";
+    for (int hess = 1; hess >= 0; hess--) {
+        if (!(hess ? spec.hess_scatter : spec.jac_scatter)) continue;
+        const int cb = hess ? CB_HESS : CB_JAC;
+        for (size_t g = 0; g < L.groups[cb].size(); g++) gen_coo_group_fn(os, m, L, cb, (int)g, true);
+        os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_" << (hess ? "chessp" : "cjacp")
+           << "(const long* __restrict__ P, const double* __restrict__ x, " << (hess ? "const double* __restrict__ y, " : "")
+           << "const double* __restrict__ th, double* __restrict__ out, " << (hess ? "double sigma, " : "") << "const unsigned* __restrict__ pos) {\n"
+           << "    const long e_ = ((const long*)P[" << L.blk[cb] << "])[blockIdx.x];\n    const int ps_ = (int)(e_ >> 40);\n"
+              "    const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
+        for (size_t g = 0; g < L.groups[cb].size(); g++)
+            os << "    " << (g ? "else " : "") << "if (ps_ == " << g << ") g" << g << "_" << (hess ? "hessp" : "jacp") << "(P, x, " << (hess ? "y, " : "")
+               << "th, out, " << (hess ? "sigma, " : "") << "tid0, pos);\n";
+        os << "}\n";
+    }
     for (int hess = 1; hess >= 0; hess--) {
         const auto &pats = hess ? spec.hess : spec.jac;
         const auto &sh = hess ? spec.hess_shared : spec.jac_shared;

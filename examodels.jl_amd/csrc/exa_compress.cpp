@@ -66,6 +66,27 @@ __global__ void __launch_bounds__(256) k_compress(double *__restrict__ V, const 
     for (; j < e; j++) s += buf[perm[j]];
     V[k] = s;
 }
+__global__ void __launch_bounds__(256) k_positions(const uint32_t *__restrict__ perm, uint32_t *__restrict__ pos, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < n) pos[perm[j]] = (uint32_t)j;
+}
+// the duplicates of entry k are CONTIGUOUS in `sorted`: sequential reads, same order of additions as k_compress
+__global__ void __launch_bounds__(256) k_compress_sorted(double *__restrict__ V, const double *__restrict__ sorted, const int64_t *__restrict__ ptr, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int64_t b = ptr[k], e = ptr[k + 1];
+    double s = 0.0;
+    int64_t j = b;
+    for (; j + 8 <= e; j += 8) {
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = sorted[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += a[u];
+    }
+    for (; j < e; j++) s += sorted[j];
+    V[k] = s;
+}
 // entries with very many duplicates: blockIdx.x = long entry, blockIdx.y = chunk of 8192 sorted positions -> partial sum
 __global__ void __launch_bounds__(256) k_compress_long(const uint32_t *__restrict__ list, const int64_t *__restrict__ ptr,
                                                        const uint32_t *__restrict__ perm, const double *__restrict__ buf,
@@ -445,6 +466,15 @@ void compress_values(const CompressedCOO &c, const double *buf, double *V, hipSt
         hipLaunchKernelGGL(k_compress_fold, dim3(grid_for(c.nlong)), dim3(256), 0, stream, (const uint32_t *)c.long_list,
                            (const double *)c.partial, chunks, V, c.nlong);
     }
+}
+
+void build_positions(const CompressedCOO &c, uint32_t *pos, hipStream_t stream) {
+    if (c.nnz == 0) return;
+    hipLaunchKernelGGL(k_positions, dim3(grid_for(c.nnz)), dim3(256), 0, stream, (const uint32_t *)c.perm, pos, c.nnz);
+}
+void compress_sorted(const CompressedCOO &c, const double *sorted, double *V, hipStream_t stream) {
+    if (c.cnnz == 0) return;
+    hipLaunchKernelGGL(k_compress_sorted, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, V, sorted, (const int64_t *)c.ptr, c.cnnz);
 }
 
 void compressed_structure(const CompressedCOO &c, void *rows, void *cols, bool wide, hipStream_t stream) {

@@ -26,6 +26,11 @@ struct CompressedCOO {
 void build_compressed(CompressedCOO &c, const int64_t *rows, const int64_t *cols, int64_t nnz, int64_t nrowdim, int64_t ncoldim,
                       hipStream_t stream);
 void compress_values(const CompressedCOO &c, const double *buf, double *V, hipStream_t stream);
+// permuted-store path: pos[slot] = position of the slot in the sorted order (the inverse of perm), and the reduction over
+// a buffer that is ALREADY in sorted order: V[k] = sum of sorted[ptr[k] .. ptr[k+1]), ascending (= ascending original slot:
+// the sort is stable), so the additions are the gather's, in the gather's order
+void build_positions(const CompressedCOO &c, uint32_t *pos, hipStream_t stream);
+void compress_sorted(const CompressedCOO &c, const double *sorted, double *V, hipStream_t stream);
 // windowed fast path (exa_runtime.cpp): cmap[e] = compressed entry of original slot e (int32, device)
 void build_slot_map(const CompressedCOO &c, int32_t *cmap, hipStream_t stream);
 // how many points I of [0, n) have a slot s with cmap[o + S*I + s] != a[s] + b[s]*I; e_lo = one past the last such point

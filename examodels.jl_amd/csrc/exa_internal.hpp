@@ -158,6 +158,11 @@ struct WindowSpec {
     // points — so each pattern is evaluated once per point instead of once per pass.  nspaces > 0 selects it; the space
     // table [origin, end, window, LDS offset] x nspaces starts at word zs of Q.
     int hess_nspaces = 0, jac_nspaces = 0, hess_zs = 0, jac_zs = 0;
+    // Matrices the windows do not fit (data-indexed targets: ACOPF): exa_cjacp / exa_chessp — the uncompressed sweep with
+    // every slot stored at its position in the (col, row)-SORTED order (pos[slot], built once), so that the duplicates of
+    // an entry are contiguous: the reduction reads sequentially instead of gathering 8-byte values at random, and a matrix
+    // without duplicates (ACOPF's Jacobian) needs no reduction at all.
+    bool jac_scatter = false, hess_scatter = false;
 };
 // Source of the second module of a compressed model: exa_chessw / exa_chessx (and exa_cjacw / exa_cjacx).
 std::string generate_window_module(const Model &m, const ParamLayout &L, const WindowSpec &spec);

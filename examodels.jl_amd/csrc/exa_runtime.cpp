@@ -108,6 +108,8 @@ struct Handle {
         std::string why;                   // why the fast path was not taken (exa_window_info)
     } wj, wh;
     hipModule_t wmodule = nullptr;
+    // permuted-store path of exa_cjac / exa_chess for matrices the windows do not fit (exa_c*p, see WindowSpec)
+    struct Scatter { bool ok = false; hipFunction_t f = nullptr; DevBuf pos; } sj, sh;
     std::vector<BlockInfo> blocks;          // named blocks (recipes; empty for plain pattern tables)
     std::vector<exa_pattern_t> view_pats;   // exa_describe: pattern-table view of the host copy
     std::vector<std::vector<exa_column_t>> view_cols;
@@ -125,6 +127,7 @@ struct Handle {
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
             cj.release(); ch.release(); cbuf.release();
             for (Window *w : {&wj, &wh}) { w->Q.release(); w->R.release(); w->X.release(); w->T.release(); w->E.release(); w->xbuf.release(); w->S.release(); w->F.release(); w->part.release(); }
+            sj.pos.release(); sh.pos.release();
             if (wmodule) (void)hipModuleUnload(wmodule);
             pjrows.release(); pjcols.release(); phrows.release(); phcols.release();
             jbycol.release(); hbyrow.release(); hbycol.release();
@@ -825,6 +828,7 @@ static void reshard(Handle &h, int rank, int world, bool coo_local) {
         if (h.compressed) {
             h.cj.release(); h.ch.release(); h.compressed = false;
             for (Handle::Window *w : {&h.wj, &h.wh}) { w->ok = false; w->why.clear(); }
+            h.sj.ok = h.sh.ok = false;
         }
     }
 }
@@ -1454,14 +1458,16 @@ void window_setup(Handle &h) {
     if (h.wmodule) { (void)hipModuleUnload(h.wmodule); h.wmodule = nullptr; }
     const char *env = getenv("EXAHIP_CWINDOW");
     if (env && atoi(env) == 0) { h.wj.why = h.wh.why = "disabled (EXAHIP_CWINDOW=0)"; return; }
-    if (h.world != 1) { h.wj.why = h.wh.why = "sharded model: the windows are planned for whole patterns"; return; }
+    h.sj.ok = h.sh.ok = false;
+    const bool plan_windows = h.world == 1;         // the windows are planned for whole patterns; a shard takes the permuted store
+    if (!plan_windows) h.wj.why = h.wh.why = "sharded model: the windows are planned for whole patterns";
     const Model &m = *h.m;
-    if (std::max(m.nnzj, m.nnzh) > 0x7fffffffLL) { h.wj.why = h.wh.why = "nnz exceeds int32"; return; }
+    if (std::max(h.lnnzj, h.lnnzh) > 0x7fffffffLL) { h.wj.why = h.wh.why = "nnz exceeds int32"; return; }
     WindowSpec spec;
     DevBuf cmap;
-    cmap.ensure(4 * (size_t)std::max<int64_t>(std::max(m.nnzj, m.nnzh), 1));
+    cmap.ensure(4 * (size_t)std::max<int64_t>(std::max(h.lnnzj, h.lnnzh), 1));
     bool okj = false, okh = false;
-    try {
+    if (plan_windows) try {
         build_slot_map(h.cj, (int32_t *)cmap.p, h.stream);
         HIPCHK(hipStreamSynchronize(h.stream));
         okj = window_plan(h, false, (const int32_t *)cmap.p, spec.jac, spec.jac_shared, spec.jac_single, spec.jac_nspaces, spec.jac_zs);
@@ -1472,7 +1478,14 @@ void window_setup(Handle &h) {
         if (!okh) { spec.hess.clear(); spec.hess_shared.clear(); }
     } catch (...) { cmap.release(); throw; }
     cmap.release();
-    if (!okj && !okh) return;
+    // what the windows do not cover goes through the permuted store when it can: 32-bit positions, no entry with more
+    // than 512 duplicates (those are summed cooperatively through the gather lists)
+    h.sj.ok = h.sh.ok = false;
+    const char *se = getenv("EXAHIP_CSCATTER");
+    const bool scatter_on = !(se && atoi(se) == 0);
+    spec.jac_scatter = scatter_on && !okj && h.cj.nnz > 0 && h.cj.nlong == 0;
+    spec.hess_scatter = scatter_on && !okh && h.ch.nnz > 0 && h.ch.nlong == 0;
+    if (!okj && !okh && !spec.jac_scatter && !spec.hess_scatter) return;
     const std::string src = generate_window_module(m, h.gen.layout, spec);
     if (const char *dump = getenv("EXAHIP_DUMP_WINDOW")) { FILE *f = fopen(dump, "w"); if (f) { fwrite(src.data(), 1, src.size(), f); fclose(f); } }
     std::vector<char> image;
@@ -1484,6 +1497,8 @@ void window_setup(Handle &h) {
         auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
         if (okj) { h.wj.fw = fn("exa_cjacw"); h.wj.fx = fn("exa_cjacx"); if (h.wj.ns_blocks) h.wj.fs = fn("exa_cjacs"); }
         if (okh) { h.wh.fw = fn("exa_chessw"); h.wh.fx = fn("exa_chessx"); if (h.wh.ns_blocks) h.wh.fs = fn("exa_chesss"); }
+        if (spec.jac_scatter) h.sj.f = fn("exa_cjacp");
+        if (spec.hess_scatter) h.sh.f = fn("exa_chessp");
     } catch (const std::exception &e) {
         std::string msg = e.what();
         if (msg.size() > 300) msg.resize(300);
@@ -1495,6 +1510,27 @@ void window_setup(Handle &h) {
     // and pointer list can go
     if (okj) { h.cj.release_gather(); h.wj.ok = true; }
     if (okh) { h.ch.release_gather(); h.wh.ok = true; }
+    for (int hess = 0; hess < 2; hess++) {
+        Handle::Scatter &sc = hess ? h.sh : h.sj;
+        CompressedCOO &cc = hess ? h.ch : h.cj;
+        if (!(hess ? spec.hess_scatter : spec.jac_scatter) || !sc.f) continue;
+        sc.pos.ensure(4 * (size_t)cc.nnz);
+        build_positions(cc, (uint32_t *)sc.pos.p, h.stream);
+        HIPCHK(hipStreamSynchronize(h.stream));
+        sc.ok = true;
+        (hess ? h.wh : h.wj).why = cc.cnnz == cc.nnz ? "permuted store (no duplicates: the sweep writes the compressed entries directly)"
+                                                      : "permuted store + sequential sums of the sorted duplicates";
+    }
+}
+void do_scatter(Handle &h, bool hess, const double *x, const double *y, double sigma, double *vals) {
+    Handle::Scatter &sc = hess ? h.sh : h.sj;
+    const CompressedCOO &cc = hess ? h.ch : h.cj;
+    const void *P = h.dP.p, *th = h.dtheta.p, *pos = sc.pos.p;
+    const bool direct = cc.cnnz == cc.nnz;          // a permutation: the sorted order IS the compressed array
+    double *out = direct ? vals : (double *)h.cbuf.p;
+    if (hess) { void *a[] = {&P, &x, &y, &th, &out, &sigma, &pos}; launch(h, sc.f, h.grid[CB_HESS], kBlock, a); }
+    else { void *a[] = {&P, &x, &th, &out, &pos}; launch(h, sc.f, h.grid[CB_JAC], kBlock, a); }
+    if (!direct) compress_sorted(cc, out, vals, h.stream);
 }
 
 void do_window(Handle &h, bool hess, const double *x, const double *y, double sigma, double *vals) {
@@ -1580,13 +1616,14 @@ int exa_compress_info(int id, int hess, char *buf, int cap, int *len_out) {
         memcpy(buf, why.data(), (size_t)c);
         buf[c] = 0;
     }
-    return w.ok ? 1 : 0;
+    return w.ok ? 1 : ((hess ? h->sh.ok : h->sj.ok) ? 2 : 0);
 }
 int exa_cjac(int id, const double *x, double *vals) {
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) {
         if (!h.compressed) throw BadInput("exa_compress has not been called");
         if (h.wj.ok) { do_window(h, false, x, nullptr, 0.0, vals); return; }
+        if (h.sj.ok) { do_scatter(h, false, x, nullptr, 0.0, vals); return; }
         do_jac(h, x, (double *)h.cbuf.p);
         compress_values(h.cj, (const double *)h.cbuf.p, vals, h.stream);
     });
@@ -1596,6 +1633,7 @@ int exa_chess(int id, const double *x, const double *y, double w, double *vals) 
     return guard(id, true, [&](Handle &h) {
         if (!h.compressed) throw BadInput("exa_compress has not been called");
         if (h.wh.ok) { do_window(h, true, x, y, w, vals); return; }
+        if (h.sh.ok) { do_scatter(h, true, x, y, w, vals); return; }
         do_hess(h, x, y, w, (double *)h.cbuf.p);
         compress_values(h.ch, (const double *)h.cbuf.p, vals, h.stream);
     });

@@ -570,13 +570,15 @@ class CompressedExaModel:
         self.meta.nnzh = self._L.exa_cnnzh64(m.id)
 
     def path(self, which):
-        """("windowed" | "gather", reason) for which = "jac" | "hess" (exa_compress_info)."""
+        """("windowed" | "scatter" | "gather", reason) for which = "jac" | "hess" (exa_compress_info): the windowed sweep
+        (stencil models), the permuted store (the sweep writes every slot at its sorted position; duplicates summed
+        sequentially), or the reference's scheme (uncompressed evaluation + sorted gather)."""
         import ctypes
         buf = ctypes.create_string_buffer(512)
         r = self._L.exa_compress_info(self.inner.id, 1 if which == "hess" else 0, buf, 512, None)
         if r < 0:
             raise RuntimeError("exa_compress_info")
-        return ("windowed" if r == 1 else "gather"), buf.value.decode()
+        return {1: "windowed", 2: "scatter"}.get(r, "gather"), buf.value.decode()
 
     def obj(self, x):
         return self.inner.obj(x)

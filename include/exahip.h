@@ -215,7 +215,10 @@ int exa_cjac_csc (int id, int64_t *colptr, int64_t *rowval);
 int exa_chess_csc(int id, int64_t *colptr, int64_t *rowval);
 int exa_cjac (int id, const double *x, double *vals);                          /* vals [cnnzj], DEVICE pointers */
 int exa_chess(int id, const double *x, const double *y, double obj_weight, double *vals);
-/* Which implementation exa_cjac (hess = 0) / exa_chess (hess = 1) run: 1 = windowed (the sweep adds straight into
+/* Which implementation exa_cjac (hess = 0) / exa_chess (hess = 1) run: 2 = permuted store (matrices the windows do not fit
+ * — data-indexed targets such as ACOPF's bus variables: the sweep stores every slot at its position in the (col, row)-sorted
+ * order, so the duplicates of an entry are contiguous and are summed with sequential reads, in ascending slot order like the
+ * gather; a matrix without duplicates is written in place with no reduction at all; EXAHIP_CSCATTER=0 disables), 1 = windowed (the sweep adds straight into
  * LDS-resident windows of the compressed array: no uncompressed round trip; taken when every slot of every pattern sits
  * at compressed entry a_s + b*I — stencil models), 0 = uncompressed evaluation + sorted gather (the reference's scheme;
  * data-indexed targets, variables shared by all points), -1 = bad id / not compressed.  buf receives the reason (0) or

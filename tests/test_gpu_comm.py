@@ -183,3 +183,33 @@ def test_eight_shards_from_resident_slices_reproduce_the_model(libs):
             got[g0:g0 + cnt] = hv[l0:l0 + cnt]
             assert np.array_equal(rv[l0:l0 + cnt], Hr[g0:g0 + cnt]) and np.array_equal(cv[l0:l0 + cnt], Hc[g0:g0 + cnt])
     np.testing.assert_allclose(got, H, rtol=1e-10, atol=0)
+
+
+def test_bench_launch_path_with_two_ranks(libs):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), on the one GPU of
+    the test box: EXAHIP_DIST_BACKEND=gloo makes the two ranks share cuda:0 and reduce through exa_comm_hook.  The numbers
+    mean nothing; the JSON contract, config 5 as the workload, the strong-scaling split, local-slice buffers and the
+    in-library collectives must all be there."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, EXAHIP_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--points", "400000",
+           "--preheat-ms", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "strong" and d["unit"] == "nnz/s"
+    assert d["config"]["baseline_config"] == 5 and "split over 2 GPUs" in d["config"]["workload"]
+    assert d["config"]["nnzh"] == 9 * 400000 - 15
+    # each rank holds half of the COO and its stencil stretch of x / y, not the model
+    assert d["config"]["resident_per_gpu_bytes"] < 0.51 * 8 * (9 + 1 + 1) * 400000 + 4096
+    assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["higher_is_better"] is True
+    assert d["collectives"].get("transport") == "hook" and d["collectives"]["grad_plus_allreduce_ms"] > 0, d["collectives"]
