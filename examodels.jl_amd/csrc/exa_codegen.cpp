@@ -1026,6 +1026,94 @@ void emit_coo_stores_permuted(std::ostringstream &os, const Body &b, int word_o,
     os << "    }\n";
 }
 
+// ---- merged slots of a fused group (compressed Hessian of data-indexed models) -------------------------------------
+// The patterns of a group put many of their Hessian slots on the SAME matrix entry for every data point: ACOPF's four
+// branch-flow constraints have 40 slots on the 10 pairs of {va_f, va_t, vm_f, vm_t}.  For the COMPRESSED Hessian those can
+// be added in registers before anything is stored: a merged slot per distinct unordered pair of index expressions.
+// Index expressions compare by a canonical text that does not depend on SSA numbering (columns by their aliased
+// parameter word), so the value kernel and the structure kernel — generated separately — agree on the merged slots.
+std::string index_key(const Pattern &p, const ParamLayout &L, int pi, int k) {
+    const exa_node_t &nd = p.nodes[k];
+    switch (nd.op) {
+    case EXA_OP_CONST_I: return "i" + std::to_string(nd.ival);
+    case EXA_OP_DATA: return "c" + std::to_string(L.pat[pi].col[nd.a]);
+    case EXA_OP_UN: return "u" + std::to_string(nd.fn) + "(" + index_key(p, L, pi, nd.a) + ")";
+    case EXA_OP_BIN: return "b" + std::to_string(nd.fn) + "(" + index_key(p, L, pi, nd.a) + "," + index_key(p, L, pi, nd.b) + ")";
+    default: return "?" + std::to_string(pi) + ":" + std::to_string(k);      // never equal to anything of another pattern
+    }
+}
+struct MergedSlot { std::string key; Val ia, ib, sum; bool has = false; };
+// slot s of pattern b.p (accumulated value `acc`, or structure only) joins the merged slot of its pair
+void merge_slot(std::vector<MergedSlot> &ms, Body &b, int s, const Val *acc) {
+    const Pattern &p = b.p;
+    const int la = p.slotvar2[s].first, lb = p.slotvar2[s].second;
+    std::string ka = index_key(p, b.L, b.pi, p.ad[la].ir), kb = index_key(p, b.L, b.pi, p.ad[lb].ir);
+    if (kb < ka) std::swap(ka, kb);
+    const std::string key = ka + "|" + kb;
+    for (MergedSlot &q : ms)
+        if (q.key == key) { if (acc) q.sum = q.has ? b.e.add(q.sum, *acc) : b.e.tod(*acc); q.has = q.has || acc; return; }
+    MergedSlot q;
+    q.key = key; q.ia = b.fv[la].vidx; q.ib = b.fv[lb].vidx;
+    if (acc) { q.sum = b.e.tod(*acc); q.has = true; }
+    ms.push_back(q);
+}
+int merged_slot_count(const Model &m, const ParamLayout &L, const std::vector<int> &grp) {
+    Emitter E;
+    std::vector<MergedSlot> ms;
+    for (int pk : grp) {
+        Body b(m, pk, L, &E);
+        b.forward(b.p.ad_root, 0, true);
+        for (int s = 0; s < b.p.o2step; s++) merge_slot(ms, b, s, nullptr);
+    }
+    return (int)ms.size();
+}
+// values of the merged slots of group gi, stored through pos[] (sorted order of the MERGED slot space); mo = first merged
+// slot of this group's data point 0
+void gen_merged_hess_fn(std::ostringstream &os, const Model &m, const ParamLayout &L, int gi) {
+    const auto &grp = L.groups[CB_HESS][gi];
+    os << "static __device__ __forceinline__ void g" << gi << "_hessm(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma, long tid, "
+          "const unsigned* __restrict__ pos, long mo) {\n";
+    { Body b0(m, grp.front(), L); emit_coo_prologue(os, b0, L, grp.front(), false); }
+    Emitter E;
+    std::vector<MergedSlot> ms;
+    for (int pk : grp) {
+        Body b(m, pk, L, &E);
+        const Pattern &p = b.p;
+        b.forward(p.ad_root, 2, false);
+        Val adj = p.kind == EXA_PAT_OBJ ? E.raw("sigma", false) : E.raw("y[" + b.row0() + "]", false);
+        GenAlg a(b, p.comp2, p.o2step);
+        hrpass0(p, p.ad_root, a, adj, zero_seed(b));
+        for (int s = 0; s < p.o2step; s++) merge_slot(ms, b, s, &a.acc[s]);
+    }
+    emit_lines(os, E);
+    const size_t S = ms.size();
+    os << "    const long o_ = mo + " << S << "L * (I - " << Body(m, grp.front(), L).P(L.pat[grp.front()].lo) << ");\n";
+    for (size_t j = 0; j < S; j++) os << "    out[pos[o_ + " << j << "]] = " << E.sd(ms[j].sum) << ";\n";
+    os << "}\n";
+}
+void gen_merged_struct_fn(std::ostringstream &os, const Model &m, const ParamLayout &L, int gi) {
+    const auto &grp = L.groups[CB_HESS][gi];
+    os << "static __device__ __forceinline__ void g" << gi << "_hstm(const long* __restrict__ P, long* __restrict__ rows, long* __restrict__ cols, "
+          "long tid, long mo) {\n";
+    { Body b0(m, grp.front(), L); emit_coo_prologue(os, b0, L, grp.front(), false); }
+    Emitter E;
+    std::vector<MergedSlot> ms;
+    for (int pk : grp) {
+        Body b(m, pk, L, &E);
+        b.forward(b.p.ad_root, 0, true);
+        for (int s = 0; s < b.p.o2step; s++) merge_slot(ms, b, s, nullptr);
+    }
+    emit_lines(os, E);
+    os << "    const long o_ = mo + " << ms.size() << "L * (I - " << Body(m, grp.front(), L).P(L.pat[grp.front()].lo) << ");\n";
+    for (size_t j = 0; j < ms.size(); j++) {
+        const std::string si = E.s(ms[j].ia), sj = E.s(ms[j].ib);
+        os << "    rows[o_ + " << j << "] = " << si << " >= " << sj << " ? " << si << " : " << sj << "; cols[o_ + " << j << "] = " << si << " >= " << sj
+           << " ? " << sj << " : " << si << ";\n";
+    }
+    os << "}\n";
+}
+
 // ---- gather ("pull") formulation of the objective gradient ------------------------------------------------
 // index expression == a * (RANGE column) + c ?
 struct Affine { bool ok = false; int col = -1; int64_t a = 0, c = 0; };
@@ -2197,6 +2285,12 @@ static void gen_window_shared(std::ostringstream &os, const Model &m, const std:
     os << "    }\n}\n";
 }
 
+std::vector<int> merged_hess_slots(const Model &m, const ParamLayout &L) {
+    std::vector<int> out;
+    for (const auto &grp : L.groups[CB_HESS]) out.push_back(merged_slot_count(m, L, grp));
+    return out;
+}
+
 std::string generate_window_module(const Model &m, const ParamLayout &L, const WindowSpec &spec) {
     static std::mutex gen_mu;
     std::lock_guard<std::mutex> gen_lock(gen_mu);
@@ -2213,6 +2307,23 @@ std::string generate_window_module(const Model &m, const ParamLayout &L, const W
     // hitting the same 2-4 of them (rocket, stride 12: 8-way conflicts on every read-modify-write); a bijection within
     // each aligned block of 16 entries, W is a multiple of 16
     os << "// windowed compressed-COO kernels\n#define EXA_WPOS(c) " << (env_int("EXAHIP_CW_SWIZZLE", 1) ? "((c) ^ (((c) >> 4) & 15))" : "(c)") << "\n";
+    if (spec.hess_merged) {
+        // exa_chessm / exa_hstructm: the merged slot space (see merge_slot); M[g] = first merged slot of group g
+        const auto &groups = L.groups[CB_HESS];
+        for (size_t g = 0; g < groups.size(); g++) { gen_merged_hess_fn(os, m, L, (int)g); gen_merged_struct_fn(os, m, L, (int)g); }
+        const std::string head = "    const long e_ = ((const long*)P[" + std::to_string(L.blk[CB_HESS]) + "])[blockIdx.x];\n    const int ps_ = (int)(e_ >> 40);\n"
+                                 "    const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
+        os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_chessm(const long* __restrict__ P, const double* __restrict__ x, "
+              "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma, const unsigned* __restrict__ pos, "
+              "const long* __restrict__ M) {\n" << head;
+        for (size_t g = 0; g < groups.size(); g++)
+            os << "    " << (g ? "else " : "") << "if (ps_ == " << g << ") g" << g << "_hessm(P, x, y, th, out, sigma, tid0, pos, M[" << g << "]);\n";
+        os << "}\nextern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hstructm(const long* __restrict__ P, long* __restrict__ rows, "
+              "long* __restrict__ cols, const long* __restrict__ M) {\n" << head;
+        for (size_t g = 0; g < groups.size(); g++)
+            os << "    " << (g ? "else " : "") << "if (ps_ == " << g << ") g" << g << "_hstm(P, rows, cols, tid0, M[" << g << "]);\n";
+        os << "}\n";
+    }
     for (int hess = 1; hess >= 0; hess--) {
         if (!(hess ? spec.hess_scatter : spec.jac_scatter)) continue;
         const int cb = hess ? CB_HESS : CB_JAC;

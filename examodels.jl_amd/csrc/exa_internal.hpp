@@ -163,7 +163,12 @@ struct WindowSpec {
     // an entry are contiguous: the reduction reads sequentially instead of gathering 8-byte values at random, and a matrix
     // without duplicates (ACOPF's Jacobian) needs no reduction at all.
     bool jac_scatter = false, hess_scatter = false;
+    // Compressed Hessian through MERGED slots (exa_chessm, see merge_slot in exa_codegen.cpp): the patterns of a fused group
+    // add the slots they put on one matrix entry in registers; the merged slots are stored at their sorted positions.
+    bool hess_merged = false;
 };
+// merged Hessian slots per data point of every fused group of CB_HESS (what exa_chessm would write)
+std::vector<int> merged_hess_slots(const Model &m, const ParamLayout &L);
 // Source of the second module of a compressed model: exa_chessw / exa_chessx (and exa_cjacw / exa_cjacx).
 std::string generate_window_module(const Model &m, const ParamLayout &L, const WindowSpec &spec);
 

@@ -110,6 +110,12 @@ struct Handle {
     hipModule_t wmodule = nullptr;
     // permuted-store path of exa_cjac / exa_chess for matrices the windows do not fit (exa_c*p, see WindowSpec)
     struct Scatter { bool ok = false; hipFunction_t f = nullptr; DevBuf pos; } sj, sh;
+    // ... and its merged-slot form for the Hessian (exa_chessm): the merged slot space has its own sorted lists
+    bool merged = false;
+    hipFunction_t f_chessm = nullptr, f_hstructm = nullptr;
+    CompressedCOO chm;
+    DevBuf dM;
+    int64_t nmerged = 0;
     std::vector<BlockInfo> blocks;          // named blocks (recipes; empty for plain pattern tables)
     std::vector<exa_pattern_t> view_pats;   // exa_describe: pattern-table view of the host copy
     std::vector<std::vector<exa_column_t>> view_cols;
@@ -127,7 +133,7 @@ struct Handle {
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
             cj.release(); ch.release(); cbuf.release();
             for (Window *w : {&wj, &wh}) { w->Q.release(); w->R.release(); w->X.release(); w->T.release(); w->E.release(); w->xbuf.release(); w->S.release(); w->F.release(); w->part.release(); }
-            sj.pos.release(); sh.pos.release();
+            sj.pos.release(); sh.pos.release(); chm.release(); dM.release();
             if (wmodule) (void)hipModuleUnload(wmodule);
             pjrows.release(); pjcols.release(); phrows.release(); phcols.release();
             jbycol.release(); hbyrow.release(); hbycol.release();
@@ -1455,6 +1461,8 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
 void window_setup(Handle &h) {
     // exa_compress may be called again (e.g. with another EXAHIP_CWINDOW): start from scratch
     for (Handle::Window *w : {&h.wj, &h.wh}) { w->ok = false; w->why.clear(); w->nx = 0; w->ns_blocks = 0; w->nwin = 0; }
+    h.sj.ok = h.sh.ok = false; h.sj.f = h.sh.f = nullptr;
+    h.merged = false; h.f_chessm = h.f_hstructm = nullptr; h.chm.release();
     if (h.wmodule) { (void)hipModuleUnload(h.wmodule); h.wmodule = nullptr; }
     const char *env = getenv("EXAHIP_CWINDOW");
     if (env && atoi(env) == 0) { h.wj.why = h.wh.why = "disabled (EXAHIP_CWINDOW=0)"; return; }
@@ -1485,6 +1493,19 @@ void window_setup(Handle &h) {
     const bool scatter_on = !(se && atoi(se) == 0);
     spec.jac_scatter = scatter_on && !okj && h.cj.nnz > 0 && h.cj.nlong == 0;
     spec.hess_scatter = scatter_on && !okh && h.ch.nnz > 0 && h.ch.nlong == 0;
+    // Hessian: merged slots when the fused groups collapse enough of them (ACOPF: 5.7 M slots -> 1.9 M)
+    std::vector<int64_t> M;
+    if (spec.hess_scatter && !(getenv("EXAHIP_CMERGE") && atoi(getenv("EXAHIP_CMERGE")) == 0)) {
+        const ParamLayout &L = h.gen.layout;
+        const std::vector<int> sm = merged_hess_slots(m, L);
+        int64_t nm = 0;
+        for (size_t g = 0; g < L.groups[CB_HESS].size(); g++) {
+            const auto &pp = L.pat[L.groups[CB_HESS][g].front()];
+            M.push_back(nm);
+            nm += (int64_t)sm[g] * (h.P[pp.hi] - h.P[pp.lo]);
+        }
+        if (nm > 0 && nm < 0xffffffffLL && (double)nm <= 0.8 * (double)h.ch.nnz) { spec.hess_merged = true; h.nmerged = nm; }
+    }
     if (!okj && !okh && !spec.jac_scatter && !spec.hess_scatter) return;
     const std::string src = generate_window_module(m, h.gen.layout, spec);
     if (const char *dump = getenv("EXAHIP_DUMP_WINDOW")) { FILE *f = fopen(dump, "w"); if (f) { fwrite(src.data(), 1, src.size(), f); fclose(f); } }
@@ -1499,6 +1520,7 @@ void window_setup(Handle &h) {
         if (okh) { h.wh.fw = fn("exa_chessw"); h.wh.fx = fn("exa_chessx"); if (h.wh.ns_blocks) h.wh.fs = fn("exa_chesss"); }
         if (spec.jac_scatter) h.sj.f = fn("exa_cjacp");
         if (spec.hess_scatter) h.sh.f = fn("exa_chessp");
+        if (spec.hess_merged) { h.f_chessm = fn("exa_chessm"); h.f_hstructm = fn("exa_hstructm"); }
     } catch (const std::exception &e) {
         std::string msg = e.what();
         if (msg.size() > 300) msg.resize(300);
@@ -1510,9 +1532,35 @@ void window_setup(Handle &h) {
     // and pointer list can go
     if (okj) { h.cj.release_gather(); h.wj.ok = true; }
     if (okh) { h.ch.release_gather(); h.wh.ok = true; }
+    if (spec.hess_merged && h.f_chessm) {
+        // structure of the merged slot space -> its own sorted lists; it must describe the same matrix as the slots'
+        DevBuf r, c;
+        try {
+            h.dM.ensure(8 * M.size());
+            HIPCHK(hipMemcpy(h.dM.p, M.data(), 8 * M.size(), hipMemcpyHostToDevice));
+            r.ensure(8 * (size_t)h.nmerged); c.ensure(8 * (size_t)h.nmerged);
+            const void *P = h.dP.p, *Mp = h.dM.p;
+            void *rp = r.p, *cp = c.p;
+            void *a[] = {&P, &rp, &cp, &Mp};
+            launch(h, h.f_hstructm, h.grid[CB_HESS], kBlock, a);
+            build_compressed(h.chm, (const int64_t *)r.p, (const int64_t *)c.p, h.nmerged, std::max<int64_t>(m.nvar, 1), std::max<int64_t>(m.nvar, 1), h.stream);
+            HIPCHK(hipStreamSynchronize(h.stream));
+        } catch (...) { r.release(); c.release(); throw; }
+        r.release(); c.release();
+        if (h.chm.cnnz == h.ch.cnnz && h.chm.nlong == 0) {
+            h.sh.pos.ensure(4 * (size_t)h.nmerged);
+            build_positions(h.chm, (uint32_t *)h.sh.pos.p, h.stream);
+            HIPCHK(hipStreamSynchronize(h.stream));
+            h.merged = true;
+            h.sh.ok = true;
+            h.wh.why = "merged slots (" + std::to_string(h.nmerged) + " for " + std::to_string(h.ch.nnz) + "), permuted store + sequential sums";
+            h.ch.release_gather();
+        } else h.chm.release();
+    }
     for (int hess = 0; hess < 2; hess++) {
         Handle::Scatter &sc = hess ? h.sh : h.sj;
         CompressedCOO &cc = hess ? h.ch : h.cj;
+        if (hess && h.merged) continue;
         if (!(hess ? spec.hess_scatter : spec.jac_scatter) || !sc.f) continue;
         sc.pos.ensure(4 * (size_t)cc.nnz);
         build_positions(cc, (uint32_t *)sc.pos.p, h.stream);
@@ -1526,6 +1574,15 @@ void do_scatter(Handle &h, bool hess, const double *x, const double *y, double s
     Handle::Scatter &sc = hess ? h.sh : h.sj;
     const CompressedCOO &cc = hess ? h.ch : h.cj;
     const void *P = h.dP.p, *th = h.dtheta.p, *pos = sc.pos.p;
+    if (hess && h.merged) {
+        const bool direct = h.chm.cnnz == h.chm.nnz;
+        double *out = direct ? vals : (double *)h.cbuf.p;
+        const void *Mp = h.dM.p;
+        void *a[] = {&P, &x, &y, &th, &out, &sigma, &pos, &Mp};
+        launch(h, h.f_chessm, h.grid[CB_HESS], kBlock, a);
+        if (!direct) compress_sorted(h.chm, out, vals, h.stream);
+        return;
+    }
     const bool direct = cc.cnnz == cc.nnz;          // a permutation: the sorted order IS the compressed array
     double *out = direct ? vals : (double *)h.cbuf.p;
     if (hess) { void *a[] = {&P, &x, &y, &th, &out, &sigma, &pos}; launch(h, sc.f, h.grid[CB_HESS], kBlock, a); }
