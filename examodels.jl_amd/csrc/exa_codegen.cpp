@@ -1462,40 +1462,52 @@ void gen_coo_group_fn(std::ostringstream &os, const Model &m, const ParamLayout 
 // A solver iteration asks for cons!, jac_coord! and hess_coord! at the same x; the second-order forward sweep already
 // holds the value and the first partials (graph.jl:416-447), so one kernel emits c, J and H (and the objective
 // partial sums) and the transcendental work is done once instead of three times.
-void gen_fused_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
-    Body b(m, pi, L);
-    const Pattern &p = b.p;
-    b.forward(p.ad_root, 2, false);
-    Val value = b.e.tod(b.fv[p.ad_root].x);
-    if (p.ad[p.ad_root].kind == AD_CONST) value = b.e.tod(b.cval(p.root));
-    const bool isobj = p.kind == EXA_PAT_OBJ;
-    GenAlg a1(b, p.comp1, p.o1step);
-    if (!isobj && p.o1step > 0) grpass(p, p.ad_root, a1, Emitter::litf(1.0));
-    Val adj;
-    if (isobj) adj = b.e.raw("sigma", false);
-    else adj = b.e.raw("y[" + b.row0() + "]", false);
-    GenAlg a2(b, p.comp2, p.o2step);
-    if (p.o2step > 0) hrpass0(p, p.ad_root, a2, adj, zero_seed(b));
-    const std::string rowtxt = isobj ? "" : (p.kind == EXA_PAT_CONAUG ? b.P(L.pat[pi].oa) + " + I" : b.P(L.pat[pi].o0) + " + I");
-    os << "static __device__ __forceinline__ double " << fn_name(pi, "fused")
+// One device function per fused group (objective patterns stay alone: their workgroups also produce the partial sums of
+// obj): thread I evaluates every pattern of the group in one emitter, storing each pattern's row value, Jacobian slots
+// and Hessian slots as soon as they are complete.
+void gen_fused_group_fn(std::ostringstream &os, const Model &m, const ParamLayout &L, int gi) {
+    const auto &grp = L.groups[CB_FUSED][gi];
+    os << "static __device__ __forceinline__ double g" << gi << "_fused"
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
           "double* __restrict__ cout, double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma, "
           "long tid, double* lds) {\n";
-    os << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n"
-       << "    const int lane = threadIdx.x & 63;\n    if (I0 - lane >= hi) return 0.0;\n    const long I = I0 < hi ? I0 : hi - 1;\n";
-    emit_lines(os, b.e);
-    if (!isobj) os << "    if (I0 < hi) " << (p.kind == EXA_PAT_CONAUG ? "augout" : "cout") << "[" << rowtxt << "] = " << b.e.sd(value) << ";\n";
-    if (!isobj && p.o1step > 0) {
-        std::vector<std::string> vals;
-        for (int s = 0; s < p.o1step; s++) vals.push_back(b.e.sd(a1.acc[s]));
-        emit_coo_stores(os, b, L.pat[pi].o1, p.o1step, vals, use_tile(p.o1step), "jout", "j");
+    {
+        Body b0(m, grp.front(), L);
+        os << "    const long I0 = " << b0.P(L.pat[grp.front()].lo) << " + tid;\n    const long hi = " << b0.P(L.pat[grp.front()].hi) << ";\n"
+           << "    const int lane = threadIdx.x & 63;\n    if (I0 - lane >= hi) return 0.0;\n    const long I = I0 < hi ? I0 : hi - 1;\n";
     }
-    if (p.o2step > 0) {
-        std::vector<std::string> vals;
-        for (int s = 0; s < p.o2step; s++) vals.push_back(b.e.sd(a2.acc[s]));
-        emit_coo_stores(os, b, L.pat[pi].o2, p.o2step, vals, use_tile(p.o2step), "hout", "h");
+    Emitter E;
+    size_t emitted = 0;
+    std::string ret = "0.0";
+    for (int pk : grp) {
+        Body b(m, pk, L, &E);
+        const Pattern &p = b.p;
+        b.forward(p.ad_root, 2, false);
+        Val value = E.tod(b.fv[p.ad_root].x);
+        if (p.ad[p.ad_root].kind == AD_CONST) value = E.tod(b.cval(p.root));
+        const bool isobj = p.kind == EXA_PAT_OBJ;
+        GenAlg a1(b, p.comp1, p.o1step);
+        if (!isobj && p.o1step > 0) grpass(p, p.ad_root, a1, Emitter::litf(1.0));
+        Val adj = isobj ? E.raw("sigma", false) : E.raw("y[" + b.row0() + "]", false);
+        GenAlg a2(b, p.comp2, p.o2step);
+        if (p.o2step > 0) hrpass0(p, p.ad_root, a2, adj, zero_seed(b));
+        const std::string rowtxt = isobj ? "" : (p.kind == EXA_PAT_CONAUG ? b.P(L.pat[pk].oa) + " + I" : b.P(L.pat[pk].o0) + " + I");
+        for (; emitted < E.lines.size(); emitted++) os << "    " << E.lines[emitted] << "\n";
+        if (!isobj) os << "    if (I0 < hi) " << (p.kind == EXA_PAT_CONAUG ? "augout" : "cout") << "[" << rowtxt << "] = " << E.sd(value) << ";\n";
+        const std::string tag = "_" + std::to_string(pk);
+        if (!isobj && p.o1step > 0) {
+            std::vector<std::string> vals;
+            for (int s = 0; s < p.o1step; s++) vals.push_back(E.sd(a1.acc[s]));
+            emit_coo_stores(os, b, L.pat[pk].o1, p.o1step, vals, use_tile(p.o1step), "jout", "j" + tag);
+        }
+        if (p.o2step > 0) {
+            std::vector<std::string> vals;
+            for (int s = 0; s < p.o2step; s++) vals.push_back(E.sd(a2.acc[s]));
+            emit_coo_stores(os, b, L.pat[pk].o2, p.o2step, vals, use_tile(p.o2step), "hout", "h" + tag);
+        }
+        if (isobj) ret = "(I0 < hi ? " + E.sd(value) + " : 0.0)";
     }
-    os << "    return " << (isobj ? "(I0 < hi ? " + b.e.sd(value) + " : 0.0)" : std::string("0.0")) << ";\n}\n";
+    os << "    return " << ret << ";\n}\n";
 }
 
 // ---- matrix-free products: same sweeps, different leaf actions ---------------------------------
@@ -1785,14 +1797,18 @@ Generated generate_module(const Model &m) {
     }
     // fused groups of the scattering products and of the one-launch cons_nln!: patterns of EXACTLY the same length (one
     // thread evaluates point I of all)
-    for (int cb : {CB_JTPROD, CB_HPROD, CB_CONS1, CB_JAC, CB_HESS}) {
+    for (int cb : {CB_JTPROD, CB_HPROD, CB_CONS1, CB_JAC, CB_HESS, CB_FUSED}) {
         const int gmax = std::max(1, env_int("EXAHIP_GROUP_MAX", 8));
         for (int k : L.active[cb]) {
             bool placed = false;
-            const bool coo = cb == CB_JAC || cb == CB_HESS;
-            if (env_int(coo ? "EXAHIP_GROUP_COO" : "EXAHIP_GROUP_SCATTER", 1))
+            const bool coo = cb == CB_JAC || cb == CB_HESS || cb == CB_FUSED;
+            // (fused sweep: an objective pattern stays alone — its workgroups also write the partial sums of obj)
+            const bool alone = cb == CB_FUSED && m.pats[k].kind == EXA_PAT_OBJ;
+            if (!alone && env_int(coo ? "EXAHIP_GROUP_COO" : "EXAHIP_GROUP_SCATTER", 1))
                 for (auto &g : L.groups[cb])
-                    if ((int)g.size() < gmax && m.pats[g.front()].n == m.pats[k].n) { g.push_back(k); placed = true; break; }
+                    if ((int)g.size() < gmax && m.pats[g.front()].n == m.pats[k].n && !(cb == CB_FUSED && m.pats[g.front()].kind == EXA_PAT_OBJ)) {
+                        g.push_back(k); placed = true; break;
+                    }
             if (!placed) L.groups[cb].push_back({k});
         }
     }
@@ -1832,12 +1848,12 @@ Generated generate_module(const Model &m) {
             if (p.o1step > 0) gen_struct_fn(os, m, k, L, false);
         }
         if (p.o2step > 0) { gen_hess_fn(os, m, k, L); gen_struct_fn(os, m, k, L, true); }
-        gen_fused_fn(os, m, k, L);
     }
     for (int cb : {CB_JTPROD, CB_HPROD})
         for (size_t g = 0; g < L.groups[cb].size(); g++) gen_scatter_group_fn(os, m, L, cb, (int)g);
     for (int cb : {CB_JAC, CB_HESS})
         for (size_t g = 0; g < L.groups[cb].size(); g++) gen_coo_group_fn(os, m, L, cb, (int)g);
+    for (size_t g = 0; g < L.groups[CB_FUSED].size(); g++) gen_fused_group_fn(os, m, L, (int)g);
     // scatter kernels whose patterns have targets shared by ALL data points process 16 tiles per workgroup: the shared
     // target then receives one atomic per wavefront per 16 tiles (same-address atomics serialise chip-wide at ~10 ns:
     // the rocket's step variable took 47 000 of them per J'v, 0.47 ms)
@@ -2003,12 +2019,12 @@ Generated generate_module(const Model &m) {
         os << "    const long b = blockIdx.x;\n"
            << "    const long e_ = ((const long*)P[" << L.blk[CB_FUSED] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
               "    const long tile_ = e_ & ((1L << 40) - 1);\n    const long tid0 = tile_ * EXA_BLOCK + threadIdx.x;\n";
-        const auto &act = L.active[CB_FUSED];
-        for (size_t k = 0; k < act.size(); k++) {
-            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") { const double v = p" << act[k]
+        const auto &grps = L.groups[CB_FUSED];
+        for (size_t k = 0; k < grps.size(); k++) {
+            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") { const double v = g" << k
                << "_fused(P, x, y, th, cout, augout, jout, hout, sigma, tid0, lds);";
-            if (m.pats[act[k]].kind == EXA_PAT_OBJ)
-                os << " const double s = exa_block_sum(v); if (threadIdx.x == 0) part[P[" << L.pat[act[k]].ob << "] + tile_] = s;";
+            if (m.pats[grps[k].front()].kind == EXA_PAT_OBJ)
+                os << " const double s = exa_block_sum(v); if (threadIdx.x == 0) part[P[" << L.pat[grps[k].front()].ob << "] + tile_] = s;";
             else os << " (void)v;";
             os << " }\n";
         }

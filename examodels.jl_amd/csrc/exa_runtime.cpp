@@ -249,7 +249,7 @@ void fill_params(Handle &h) {
             // objective partial sums of the fused sweep: one per workgroup of an OBJECTIVE pattern, at a compact index
             int64_t nobj = 0;
             for (size_t j = 0; j < na; j++) {
-                const int k = L.active[cb][j];
+                const int k = grouped ? L.groups[cb][j].front() : L.active[cb][j];       // objective patterns are groups of their own
                 if (m.pats[k].kind == EXA_PAT_OBJ) { h.P[L.pat[k].ob] = nobj; nobj += nb[j]; }
             }
             h.fused_nobj = nobj;
