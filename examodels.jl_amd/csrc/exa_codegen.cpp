@@ -1973,6 +1973,60 @@ Generated generate_module(const Model &m) {
         }
     }
     os << "}\n";
+    // jprod_nln! in ONE launch, when every augmentation term is c * x[k] (its Jacobian entry is the constant c): same
+    // dispatch units and row lists as exa_cons1; row r = sum_s J[r, k_s] v[k_s] + sum_terms c_j v[var_j]
+    if (m.aug_linear || m.nconaug == 0) {
+        os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jprod1(const long* __restrict__ P, const double* __restrict__ x, "
+              "const double* __restrict__ th, const double* __restrict__ v, double* __restrict__ out, const long* __restrict__ augptr, "
+              "const long* __restrict__ augsrc, const double* __restrict__ augcoef) {\n";
+        std::vector<int> augs;
+        for (int k = 0; k < np; k++) if (m.pats[k].n > 0 && m.pats[k].kind == EXA_PAT_CONAUG) augs.push_back(k);
+        os << "    const long e_ = ((const long*)P[" << L.blk[CB_CONS1] << "])[blockIdx.x];\n    const int ps_ = (int)(e_ >> 40);\n"
+              "    const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
+        for (size_t g = 0; g < L.groups[CB_CONS1].size(); g++) {
+            const auto &grp = L.groups[CB_CONS1][g];
+            const auto &pp0 = L.pat[grp.front()];
+            os << "    " << (g ? "else " : "") << "if (ps_ == " << g << ") {\n        const long I = P[" << pp0.lo << "] + tid0;\n        if (I >= P[" << pp0.hi
+               << "]) return;\n";
+            Emitter E;
+            std::vector<std::unique_ptr<Body>> bodies;
+            std::vector<Val> sums;
+            for (int pk : grp) {
+                bodies.emplace_back(new Body(m, pk, L, &E));
+                Body &b = *bodies.back();
+                const Pattern &p = b.p;
+                Val sum = Emitter::litf(0.0);
+                if (p.o1step > 0) {
+                    b.forward(p.ad_root, 1, false);
+                    GenAlg a(b, p.comp1, p.o1step);
+                    grpass(p, p.ad_root, a, Emitter::litf(1.0));
+                    for (int sl = 0; sl < p.o1step; sl++) {
+                        Val vi = b.fv[p.slotvar1[sl]].vidx;
+                        Val vv = E.raw("v[" + E.s(E.sub(vi, Emitter::liti(1))) + "]", false);
+                        sum = E.add(sum, E.mul(a.acc[sl], vv));
+                    }
+                }
+                sums.push_back(sum);
+            }
+            emit_lines(os, E, "        ");
+            for (size_t q = 0; q < grp.size(); q++) {
+                const int pk = grp[q];
+                bool target = false;
+                for (int a : augs) target = target || m.pats[a].base == pk;
+                if (!target) { os << "        out[P[" << L.pat[pk].o0 << "] + I] = " << E.sd(sums[q]) << ";\n"; continue; }
+                os << "        {\n        double s_ = " << E.sd(sums[q]) << ";\n        const long r_ = P[" << L.pat[pk].o0 << "] + I;\n"
+                      "        long j = augptr[r_];\n        const long je = augptr[r_ + 1];\n"
+                      "        for (; j + 4 <= je; j += 4) {\n"
+                      "            const long i0 = augsrc[j], i1 = augsrc[j + 1], i2 = augsrc[j + 2], i3 = augsrc[j + 3];\n"
+                      "            const double c0 = augcoef[j], c1 = augcoef[j + 1], c2 = augcoef[j + 2], c3 = augcoef[j + 3];\n"
+                      "            const double v0 = v[i0], v1 = v[i1], v2 = v[i2], v3 = v[i3];\n"
+                      "            s_ += __dmul_rn(c0, v0); s_ += __dmul_rn(c1, v1); s_ += __dmul_rn(c2, v2); s_ += __dmul_rn(c3, v3);\n        }\n"
+                      "        for (; j < je; j++) s_ += __dmul_rn(augcoef[j], v[augsrc[j]]);\n        out[r_] = s_;\n        }\n";
+            }
+            os << "    }\n";
+        }
+        os << "}\n";
+    }
     auto lds_decl = [&](int cb, bool hess) {
         int mx = 0;
         for (int k : L.active[cb]) { const int S = hess ? m.pats[k].o2step : m.pats[k].o1step; if (use_tile(S)) mx = std::max(mx, tile_doubles(S)); }

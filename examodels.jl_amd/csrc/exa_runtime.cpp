@@ -76,7 +76,7 @@ struct Handle {
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
     hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
-                  f_hess = nullptr, f_hessc = nullptr, f_cons1 = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
+                  f_hess = nullptr, f_hessc = nullptr, f_cons1 = nullptr, f_jprod1 = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
     DevBuf daugcoef;
@@ -341,6 +341,7 @@ void to_device(Handle &h) {
     h.f_jprod = fn("exa_jprod"); h.f_jtprod = fn("exa_jtprod"); h.f_hprod = fn("exa_hprod"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
     if (h.gen.layout.chain[CB_HESSC] > 0) h.f_hessc = fn("exa_hessc");
     h.f_cons1 = fn("exa_cons1");
+    if (m.aug_linear || m.nconaug == 0) h.f_jprod1 = fn("exa_jprod1");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
     h.colslot.resize(m.pats.size());
     for (size_t k = 0; k < m.pats.size(); k++) {
@@ -591,6 +592,14 @@ void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
         if (h.m->nconaug) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
     }
     const void *P = h.dP.p, *th = h.dtheta.p;
+    if (h.f_jprod1 && h.world == 1 && (h.cons1 || h.m->nconaug == 0)) {
+        // ONE launch (fused groups; augmentation terms c * x[k] contribute c * v[k] straight from the row lists)
+        const void *ptr = h.daugcsr.p, *src = h.daugsrc.p, *coef = h.daugcoef.p;
+        void *a1[] = {&P, &x, &th, &v, &Jv, &ptr, &src, &coef};
+        launch(h, h.f_jprod1, h.grid[CB_CONS1], kBlock, a1);
+        allreduce(h, Jv, h.m->ncon);
+        return;
+    }
     void *a[] = {&P, &x, &th, &v, &Jv, &buf};
     launch(h, h.f_jprod, h.grid[CB_JPROD], kBlock, a);
     if (h.m->nconaug) aug_gather(h, buf, Jv);

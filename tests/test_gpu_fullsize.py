@@ -162,14 +162,18 @@ def test_compressed_full_size_equals_scattered_uncompressed(libs, which):
     """Compressed COO (CompressedNLPModel) at full size, all on the device: every compressed entry equals the sum of the
     uncompressed slots with its coordinates (torch index_add_ through a searchsorted on the (col,row) key), the entries
     are strictly (col,row)-ascending, and the CSC colptr brackets them.  LV and the rocket take the windowed sweep, the
-    ACOPF the gather."""
+    ACOPF the permuted store (merged slots for the Hessian)."""
     import torch
     from exahip import CompressedExaModel, ExaModel, models
     core = {"lv": lambda: models.luksan_vlcek_model(10_000_000), "rocket": lambda: models.rocket_model(1_000_000),
             "acopf": lambda: models.ac_power_model(models.synthetic_power_data(78_484, 126_015, 6_800, seed=0))}[which]()
     m = ExaModel(core)
     cm = CompressedExaModel(m)
-    assert cm.path("hess")[0] == ("gather" if which == "acopf" else "windowed"), cm.path("hess")
+    # (ACOPF: bus variables are reached through table columns — no windows; the sweep stores the merged slots of every
+    # fused group at their sorted positions instead of gathering 5.7 M values at random)
+    assert cm.path("hess")[0] == ("scatter" if which == "acopf" else "windowed"), cm.path("hess")
+    if which == "acopf":
+        assert "merged slots" in cm.path("hess")[1] and cm.path("jac")[0] == "scatter"
     x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=5)
     dev = torch.device("cuda:0")
     xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
