@@ -44,12 +44,18 @@ CONFIGS = {
 }
 
 
+CASE_FILE = None      # --case / $EXAHIP_PGLIB_CASE: a MATPOWER file (the PGLIB case itself, if the box has it) for config 4
+
+
 def build_core(config, points):
     from exahip import models
     if config in (2, 5):
         return models.luksan_vlcek_model(points)
     if config == 3:
         return models.rocket_model(points)
+    if CASE_FILE:
+        from exahip import matpower
+        return models.ac_power_model(matpower.load(CASE_FILE))
     return models.ac_power_model(models.synthetic_power_data(78_484, 126_015, 6_800, seed=0))
 
 
@@ -210,6 +216,9 @@ def main():
     ap.add_argument("--preheat-ms", type=float, default=200.0,
                     help="untimed: keep the GPU busy with the same call this long before the W warmup steps, so that the "
                          "clock governor has left its idle state (sclk idles at ~570 MHz and takes tens of ms to ramp)")
+    ap.add_argument("--case", default=os.environ.get("EXAHIP_PGLIB_CASE"),
+                    help="config 4: a MATPOWER case file (pglib_opf_case78484_epigrids.m where available) read by exahip.matpower "
+                         "instead of the synthetic topology of the same size")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-config5-n1", action="store_true", help="skip the LV N=1e8 single-GPU point attached to the default line")
     ap.add_argument("--no-tune", action="store_true", help="skip exa_tune (block order stays sequential unless persisted)")
@@ -243,6 +252,11 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    global CASE_FILE
+    if args.case:
+        if not os.path.exists(args.case):
+            raise SystemExit(f"--case {args.case}: no such file")
+        CASE_FILE = args.case
     config = args.config or (2 if world == 1 else 5)
     if config in (2, 5):
         if args.weak and world > 1:
@@ -366,6 +380,8 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
     per_gpu = points // world if config in (2, 3, 5) else 0
     if config in (2, 5):
         wl = f"LuksanVlcek N={points:.0e}" + (f" split over {world} GPUs ({per_gpu:.2e} points per GPU)" if world > 1 else "") + ", hess_coord!"
+    elif config == 4 and CASE_FILE:
+        wl = f"ACOPF (test/NLPTest/power.jl model) on {os.path.basename(CASE_FILE)}, hess_coord!"
     else:
         wl = CONFIGS[config]
     out = {
