@@ -1804,11 +1804,19 @@ Generated generate_module(const Model &m) {
             const bool coo = cb == CB_JAC || cb == CB_HESS || cb == CB_FUSED;
             // (fused sweep: an objective pattern stays alone — its workgroups also write the partial sums of obj)
             const bool alone = cb == CB_FUSED && m.pats[k].kind == EXA_PAT_OBJ;
+            // (a group's body is the concatenation of its patterns' bodies: bounded by the slots it computes, so that a
+            // model with many equally long wide patterns does not produce one register-starved monster)
+            auto slots = [&](int q) { const Pattern &t = m.pats[q]; return cb == CB_JAC || cb == CB_JTPROD || cb == CB_CONS1 ? t.o1step : t.o1step + t.o2step; };
+            const int cap = env_int("EXAHIP_GROUP_SLOTS", 128);
             if (!alone && env_int(coo ? "EXAHIP_GROUP_COO" : "EXAHIP_GROUP_SCATTER", 1))
-                for (auto &g : L.groups[cb])
-                    if ((int)g.size() < gmax && m.pats[g.front()].n == m.pats[k].n && !(cb == CB_FUSED && m.pats[g.front()].kind == EXA_PAT_OBJ)) {
+                for (auto &g : L.groups[cb]) {
+                    int have = 0;
+                    for (int q : g) have += slots(q);
+                    if ((int)g.size() < gmax && have + slots(k) <= cap && m.pats[g.front()].n == m.pats[k].n &&
+                        !(cb == CB_FUSED && m.pats[g.front()].kind == EXA_PAT_OBJ)) {
                         g.push_back(k); placed = true; break;
                     }
+                }
             if (!placed) L.groups[cb].push_back({k});
         }
     }
