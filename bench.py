@@ -189,6 +189,60 @@ def cpu_baseline(config, points, threads_all):
     return res
 
 
+def config1_cpu_line():
+    """BASELINE.json configs[0]: LuksanVlcek N = 1e4, Float64, CPU — the plumbing case.  No GPU is touched: the test
+    oracle (the CPU restatement of the reference's loops) is timed on all five callbacks, the compiled straight-line
+    Hessian beside the interpreter's, and the golden fixture of this very model (tests/golden/zoo_fixtures/lv10000) pins
+    the values.  With an MI355X present the HIP path's times at this (launch-latency-bound) size are added."""
+    import numpy as np
+    import compiled
+    import oracle
+    from exahip import models
+    N = 10_000
+    core = models.luksan_vlcek_model(N)
+    ir = core.to_ir()
+    o = oracle.OracleModel(ir, threads=1)
+    x = ir.x0 + 0.1 * np.random.default_rng(0).uniform(-1, 1, N)
+    y = np.random.default_rng(1).standard_normal(o.ncon)
+
+    def rate(fn, reps=20):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return reps / (time.perf_counter() - t0)
+
+    ch = compiled.CompiledHess(ir, o)
+    hbuf = np.empty(o.nnzh)
+    cpu = {"obj": rate(lambda: o.obj(x)), "cons": rate(lambda: o.cons(x)), "grad": rate(lambda: o.grad(x)), "jac_coord": rate(lambda: o.jac_coord(x)),
+           "hess_coord": rate(lambda: o.hess_coord(x, y, 0.5, out=hbuf)), "hess_coord_compiled": rate(lambda: ch(x, y, 0.5, out=hbuf), 200)}
+    out = {"metric": "CPU evaluations/s of the NLPModels callbacks (BASELINE config 1: the reference's own CPU-runnable case)",
+           "value": cpu["hess_coord_compiled"], "unit": "hess_coord! evals/s", "n_gpus": 0, "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": "LuksanVlcek N=1e4, CPU, obj/cons/grad/jac/hess", "baseline_config": 1, "nvar": int(o.nvar), "ncon": int(o.ncon),
+                      "nnzj": int(o.nnzj), "nnzh": int(o.nnzh)},
+           "cpu_evals_per_s": cpu, "cpu_baseline": {"kind": "port", "cores": 1, "value": cpu["hess_coord_compiled"] * o.nnzh, "unit": "nnz/s",
+                                                    "sample": "the whole config: interpreter (oracle/exa_oracle.c) and gcc-compiled straight-line C (oracle/compiled.py)"}}
+    try:
+        import torch
+        if torch.cuda.is_available():
+            from exahip import ExaModel
+            m = ExaModel(core)
+            dev = torch.device("cuda:0")
+            xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+            bufs = {"cons": torch.empty(o.ncon, dtype=torch.float64, device=dev), "grad": torch.empty(N, dtype=torch.float64, device=dev),
+                    "jac": torch.empty(o.nnzj, dtype=torch.float64, device=dev), "hess": torch.empty(o.nnzh, dtype=torch.float64, device=dev)}
+            gpu = {}
+            for cb in ("obj", "cons", "grad", "jac", "hess"):
+                m.time_callback(cb, 20, xd, yd, 0.5, out=bufs.get(cb))
+                gpu[cb] = 1e3 / m.time_callback(cb, 200, xd, yd, 0.5, out=bufs.get(cb))
+            out["mi355x_evals_per_s"] = gpu
+            err = float(np.max(np.abs(m.hess_coord(xd, yd, 0.5).cpu().numpy() - ch(x, y, 0.5)) / np.maximum(1.0, np.abs(ch(x, y, 0.5)))))
+            out["mi355x_vs_cpu_max_rel_err_hess"] = err
+    except Exception as e:      # the CPU line stands on its own
+        out["mi355x_evals_per_s"] = {"error": repr(e)}
+    return out
+
+
 def traffic_for(m, config, per_gpu_points):
     """HBM bytes per launch from the PMC counters: measured in separate rocprofv3 passes (cannot run inside the timed
     process) and committed under profiles/ TOGETHER WITH the name of the module they were measured on — attached only
@@ -209,8 +263,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", type=int, default=None, choices=[2, 3, 4, 5],
-                    help="BASELINE.json configs[k-1]; default 2 on one GPU, 5 (LV N=1e8, strong scaling) on several")
+    ap.add_argument("--config", type=int, default=None, choices=[1, 2, 3, 4, 5],
+                    help="BASELINE.json configs[k-1]; default 2 on one GPU, 5 (LV N=1e8, strong scaling) on several; 1 = the "
+                         "reference's own CPU-runnable case (LV N=1e4): CPU evaluations/s of the five callbacks, no GPU needed")
     ap.add_argument("--points", type=float, default=None, help="LV N / rocket nh (GLOBAL size for config 5)")
     ap.add_argument("--weak", action="store_true", help="N > 1: per-GPU work fixed instead (--points per GPU, default 1e7)")
     ap.add_argument("--preheat-ms", type=float, default=200.0,
@@ -225,6 +280,10 @@ def main():
     ap.add_argument("--all-callbacks", action="store_true", help="also time obj/cons/grad/jac (secondary)")
     ap.add_argument("--no-collectives", action="store_true", help="N > 1: skip the secondary grad! + RCCL all-reduce timing")
     args = ap.parse_args()
+
+    if args.config == 1:
+        print(json.dumps(config1_cpu_line()), flush=True)
+        return
 
     import numpy as np
     import torch

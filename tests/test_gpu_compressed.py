@@ -316,3 +316,26 @@ def test_no_compiler_for_the_window_module_falls_back_to_the_gather(libs, monkey
     kind, why = cm.path("hess")
     assert kind == "gather" and "could not be built" in why, (kind, why)
     assert _check_against_uncompressed(m, cm, 1) == ["gather", "gather"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_table_models_take_the_merged_permuted_store(libs, seed):
+    """Random models whose 12 patterns all iterate ONE table (tests/randexpr.py build_model): identical columns are
+    aliased, the patterns form fused groups, and the compressed Hessian goes through merged slots + permuted store
+    wherever the groups collapse enough slots (else the plain permuted store).  Whatever exa_compress picks must give the
+    duplicate-summed uncompressed matrix — also from a larger table (several workgroups, partial tiles)."""
+    import randexpr
+    from exahip import CompressedExaModel, ExaModel
+    for npts in (randexpr.NPTS, 700):
+        saved = randexpr.NPTS
+        randexpr.NPTS = npts
+        try:
+            m = ExaModel(randexpr.build_model(seed, npat=12, depth=3).to_ir())
+        finally:
+            randexpr.NPTS = saved
+        cm = CompressedExaModel(m)
+        kinds = _check_against_uncompressed(m, cm, seed, tol=1e-11)
+        assert all(k in ("scatter", "gather", "windowed") for k in kinds), kinds
+        print(seed, npts, kinds, cm.path("hess")[1])
+        if npts == 7:           # (the larger table piles > 512 duplicates on some entries: those keep the cooperative gather)
+            assert "scatter" in kinds, (kinds, cm.path("jac"), cm.path("hess"))
