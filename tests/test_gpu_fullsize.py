@@ -202,7 +202,10 @@ def test_compressed_full_size_equals_scattered_uncompressed(libs, which):
             sel = pos == e
             ref[e] = v[sel].sum()
             mag[e] = v[sel].abs().sum()
-        bound = (4e-16 * cnt.sqrt() + 1e-13) * mag + 1e-300
+        # the compressed sweep is its own generated kernel (other common subexpressions, other FMA contraction): a slot
+        # whose value is what cancellation inside its expression leaves (5e-5 from terms of order 1 in the ACOPF flow
+        # rows) differs by rounding of the TERMS, hence the absolute part scaled by the largest value
+        bound = (4e-16 * cnt.sqrt() + 1e-13) * mag + 1e-15 * float(v.abs().max()) + 1e-300
         assert bool(torch.all((cv - ref).abs() <= bound)), float(((cv - ref).abs() / bound).max())
         colptr, rowval = cm.csc(kind)
         assert int(colptr[0]) == 1 and int(colptr[-1]) == cv.numel() + 1 and bool(torch.all(colptr[1:] >= colptr[:-1]))
