@@ -279,6 +279,7 @@ def main():
     ap.add_argument("--no-tune", action="store_true", help="skip exa_tune (block order stays sequential unless persisted)")
     ap.add_argument("--all-callbacks", action="store_true", help="also time obj/cons/grad/jac (secondary)")
     ap.add_argument("--no-collectives", action="store_true", help="N > 1: skip the secondary grad! + RCCL all-reduce timing")
+    ap.add_argument("--collective-timeout", type=float, default=120.0, help="N > 1: seconds the secondary collective timing may take before the line is printed without it")
     args = ap.parse_args()
 
     if args.config == 1:
@@ -339,8 +340,15 @@ def main():
             line["config5_n1"] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "evals_per_s", "roofline", "config", "steps", "warmup")}
         except Exception as e:      # never lose the contract line to the secondary measurement
             line["config5_n1"] = {"error": repr(e)}
+    hung = line.pop("_hung", False)
     if rank == 0:
         print(json.dumps(line), flush=True)
+    if hung:
+        # a worker thread of this rank is still inside a collective that will never complete: leave without the
+        # interpreter's shutdown (which would wait for it) and without tearing down the process group
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if world > 1:
         dist.destroy_process_group()
 
@@ -363,19 +371,11 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
     L = m._L
 
     if world > 1:
-        # shard + communicator behind the C ABI (RCCL; the gloo launch-path exercise uses the host-reducer hook), COO as a
-        # packed local slice, and only the stretch of x (and of y) this rank's data points read kept in HBM
-        comm_error = None
-        try:
-            attach_communicator(m, None, "rccl" if backend == "nccl" else "hook", coo_local=True)
-        except Exception as e:      # hess_coord! needs no collective: never lose the contract line to the communicator
-            comm_error = repr(e)
-            try:
-                m.comm_free()
-            except Exception:
-                pass
-            m.set_shard(rank, world)
-            m.set_coo_local(True)
+        # shard as a packed local slice, and only the stretch of x (and of y) this rank's data points read kept in HBM.
+        # hess_coord! needs no collective; the communicator (RCCL behind the C ABI) is attached after the contract
+        # measurement, under a watchdog, so a collective that cannot be set up never costs the contract line.
+        m.set_shard(rank, world)
+        m.set_coo_local(True)
         vlo, vhi, ylo, yhi = resident_ranges(m, rank, world)
     else:
         vlo, vhi, ylo, yhi = 0, nvar, 0, ncon
@@ -467,36 +467,51 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
     # the BenchmarkTools minimum, benchmark/runbenchmark.jl:94); outside the contract timing above
     per_call = sorted(time_hess(1) for _ in range(50))
     out["per_call_ms"] = {"min": per_call[0], "median": per_call[len(per_call) // 2], "n": len(per_call)}
-    if world > 1 and comm_error is not None:
-        out["collectives"] = {"error": comm_error}
-    elif world > 1 and not args.no_collectives:
+    if world > 1 and not args.no_collectives:
         # secondary (never part of `value`): the callbacks that DO need a collective, completed INSIDE libexahip by
-        # ncclAllReduce over xGMI on the model's stream (exa_comm_init): grad! (nvar doubles) and obj (1 double)
-        try:
-            xd = torch.from_numpy(x_full).to(dev)
-            g = torch.empty(nvar, dtype=torch.float64, device=dev)
-            kind = m.comm_info()[2]
-            for _ in range(3):
-                m.grad(xd, out=g)
-            barrier()
-            t1 = time.perf_counter()
-            reps = 10
-            for _ in range(reps):
-                m.grad(xd, out=g)
-            barrier()
-            t_with = 1e3 * (time.perf_counter() - t1) / reps
-            m.set_reduce(False)
-            barrier()
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                m.grad(xd, out=g)
-            barrier()
-            t_without = 1e3 * (time.perf_counter() - t1) / reps
-            m.set_reduce(True)
-            out["collectives"] = {"grad_plus_allreduce_ms": t_with, "grad_partial_only_ms": t_without, "allreduce_bytes": 8 * nvar,
-                                  "transport": kind, "where": "inside libexahip (exa_comm_init -> ncclAllReduce on the model's stream)"}
-        except Exception as e:  # keep the contract line alive whatever happens here
-            out["collectives"] = {"error": repr(e)}
+        # ncclAllReduce over xGMI on the model's stream (exa_comm_init): grad! (nvar doubles) and obj (1 double).
+        # Runs in a worker thread with a deadline: ctypes releases the GIL, so a rank stuck in ncclCommInitRank or in
+        # an all-reduce cannot keep rank 0 from printing the line.
+        import threading
+        result = {}
+
+        def collectives():
+            try:
+                torch.cuda.set_device(dev)          # the HIP current device is per thread
+                attach_communicator(m, None, "rccl" if backend == "nccl" else "hook", coo_local=True)
+                xd = torch.from_numpy(x_full).to(dev)
+                g = torch.empty(nvar, dtype=torch.float64, device=dev)
+                kind = m.comm_info()[2]
+                for _ in range(3):
+                    m.grad(xd, out=g)
+                barrier()
+                t1 = time.perf_counter()
+                reps = 10
+                for _ in range(reps):
+                    m.grad(xd, out=g)
+                barrier()
+                t_with = 1e3 * (time.perf_counter() - t1) / reps
+                m.set_reduce(False)
+                barrier()
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    m.grad(xd, out=g)
+                barrier()
+                t_without = 1e3 * (time.perf_counter() - t1) / reps
+                m.set_reduce(True)
+                result.update({"grad_plus_allreduce_ms": t_with, "grad_partial_only_ms": t_without, "allreduce_bytes": 8 * nvar,
+                               "transport": kind, "where": "inside libexahip (exa_comm_init -> ncclAllReduce on the model's stream)"})
+            except Exception as e:  # keep the contract line alive whatever happens here
+                result["error"] = repr(e)
+
+        th = threading.Thread(target=collectives, daemon=True)
+        th.start()
+        th.join(args.collective_timeout)
+        if th.is_alive():
+            out["collectives"] = {"error": f"no completion within {args.collective_timeout:.0f} s (communicator set-up or all-reduce hung)"}
+            out["_hung"] = True
+        else:
+            out["collectives"] = dict(result)
     if args.all_callbacks and world == 1:
         xd, yd = xs, ys
         g = torch.empty(nvar, dtype=torch.float64, device=dev)

@@ -112,6 +112,7 @@ struct Handle {
     struct Scatter { bool ok = false; hipFunction_t f = nullptr; DevBuf pos; } sj, sh;
     // ... and its merged-slot form for the Hessian (exa_chessm): the merged slot space has its own sorted lists
     bool merged = false;
+    int device = -1;            // the HIP device that was current in exa_create (DeviceScope)
     hipFunction_t f_chessm = nullptr, f_hstructm = nullptr;
     CompressedCOO chm;
     DevBuf dM;
@@ -328,7 +329,8 @@ void to_device(Handle &h) {
     {
         int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+        if (hipGetDevice(&dev) == hipSuccess) h.device = dev;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess)
             h.devname = std::string(prop.gcnArchName) + "/" + std::to_string(prop.multiProcessorCount);
     }
     h.on_device = true;   // from here on the destructor releases whatever was acquired
@@ -685,12 +687,27 @@ void do_struct(Handle &h, bool hess, bool wide, void *rows, void *cols) {
     launch(h, f, h.grid[hess ? CB_HSTRUCT : CB_JSTRUCT], kBlock, a);
 }
 
+// The HIP "current device" is per host thread; a model lives on the device that was current in exa_create.  A call from
+// a thread whose current device is another one (a Julia task that migrated, a worker thread that never called
+// hipSetDevice) would allocate its scratch buffers on the wrong GPU: every device call runs with the model's device
+// current and puts the caller's back.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int want) {
+        if (want < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != want) switched = hipSetDevice(want) == hipSuccess;
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+
 template <class F>
 int guard(int id, bool need_device, F &&f) {
     Handle *h = get(id);
     if (!h) return 1;
     if (need_device && !h->on_device) { g_err = "model was planned without a device (exa_plan_only)"; return 1; }
     try {
+        DeviceScope scope(h->on_device ? h->device : -1);
         f(*h);
         return 0;
     } catch (const BadInput &e) {
