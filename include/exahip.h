@@ -102,7 +102,15 @@ int     exa_meta(int id, double *x0, double *lvar, double *uvar, double *lcon, d
 /* Generated HIP source of the model's module (NUL-terminated, owned by the library). */
 const char *exa_kernel_source(int id);
 
-/* ---- execution context ------------------------------------------------------------------------- */
+/* ---- execution context -------------------------------------------------------------------------
+ * Device: a model lives on the HIP device that was current in the thread that created it; every device call makes that
+ * device current for its duration and restores the caller's (the HIP current device is per host thread — a Julia task
+ * that migrated, a worker thread that never called hipSetDevice).
+ * Graphs: once a callback has run once (its scratch buffers exist) it is a pure sequence of launches / memsets on the
+ * model's stream — no allocation, no synchronisation — so the host may capture a whole solver iteration (exa_obj_async,
+ * exa_grad, exa_cons, exa_jac, exa_hess, the products) with hipStreamBeginCapture on that stream and replay it on new
+ * iterates held in the same buffers (tests/test_gpu_graph.py).  exa_obj (host result), the *_host variants, exa_tune,
+ * exa_compress and the structure calls synchronise and cannot be captured. */
 int exa_set_stream(int id, void *hip_stream);
 /* Shard every pattern's iterator: this process evaluates data points [floor(n*rank/world), floor(n*(rank+1)/world))
  * of every pattern.  COO outputs (jac/hess/structures) are written at their GLOBAL slot
