@@ -63,6 +63,7 @@ struct Emitter {
     int next = 0;
     struct Def { int line; std::string name, expr; bool is_int; };
     std::vector<Def> defs;        // the lines that are plain SSA definitions `const T name = expr;` (raw), in order
+    std::map<std::string, std::string> expr_of;   // SSA name -> its defining expression text
 
     static Val litf(double v) { Val r; r.k = Val::LF; r.f = v; return r; }
     static Val liti(int64_t v) { Val r; r.k = Val::LI; r.i = v; r.f = (double)v; return r; }
@@ -96,6 +97,7 @@ struct Emitter {
         r.id = next++;
         lines.push_back(std::string(is_int ? "const long k" : "const double t") + std::to_string(r.id) + " = " + expr + ";");
         defs.push_back({(int)lines.size() - 1, std::string(is_int ? "k" : "t") + std::to_string(r.id), expr, is_int});
+        expr_of[defs.back().name] = expr;
         memo[expr] = r;
         return r;
     }
@@ -275,6 +277,31 @@ Triple un_rule(Emitter &e, int fn, Val u, int order) {
         const std::string key = "sincos|" + e.s(u);
         Val sv, cv;
         auto it = e.memo.find(key);
+        if (it == e.memo.end() && env_int("EXAHIP_SYM_TRIG", 1) && !env_int("EXAHIP_WHATIF_NOTRIG", 0)) {
+            // u = a - b where sincos(b - a) is already there (the two ends of an ACOPF branch: va_f - va_t and va_t - va_f):
+            // a - b == -(b - a) exactly and exa_sincos / ocml sincos are exactly odd / even, so sin u = 0.0 - sin(b - a)
+            // (written as a subtraction from +0.0: bit-identical to the direct evaluation for a == b too, where
+            // -(+0.0) would be -0.0) and cos u = cos(b - a).
+            auto ex = e.expr_of.find(e.s(u));
+            if (ex != e.expr_of.end()) {
+                const std::string &t = ex->second;
+                const size_t at = t.find(" - ");
+                if (at != std::string::npos && t.find(' ', at + 3) == std::string::npos && t.find(' ') == at) {
+                    auto rev = e.memo.find(t.substr(at + 3) + " - " + t.substr(0, at));
+                    if (rev != e.memo.end()) {
+                        const std::string rkey = "sincos|" + e.s(rev->second);
+                        auto rs = e.memo.find(rkey);
+                        if (rs != e.memo.end()) {
+                            sv = e.raw("0.0 - " + e.s(rs->second), false);
+                            cv = e.memo[rkey + "|c"];
+                            e.memo[key] = sv;
+                            e.memo[key + "|c"] = cv;
+                            it = e.memo.find(key);
+                        }
+                    }
+                }
+            }
+        }
         if (it == e.memo.end()) {
             sv.k = Val::SF; sv.id = e.next++;
             cv.k = Val::SF; cv.id = e.next++;
@@ -1470,7 +1497,7 @@ void gen_fused_group_fn(std::ostringstream &os, const Model &m, const ParamLayou
     os << "static __device__ __forceinline__ double g" << gi << "_fused"
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
           "double* __restrict__ cout, double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma, "
-          "long tid, double* lds) {\n";
+          "long tid, double* lds, const long* __restrict__ augptr, const long* __restrict__ augsrc, const double* __restrict__ augcoef) {\n";
     {
         Body b0(m, grp.front(), L);
         os << "    const long I0 = " << b0.P(L.pat[grp.front()].lo) << " + tid;\n    const long hi = " << b0.P(L.pat[grp.front()].hi) << ";\n"
@@ -1493,7 +1520,23 @@ void gen_fused_group_fn(std::ostringstream &os, const Model &m, const ParamLayou
         if (p.o2step > 0) hrpass0(p, p.ad_root, a2, adj, zero_seed(b));
         const std::string rowtxt = isobj ? "" : (p.kind == EXA_PAT_CONAUG ? b.P(L.pat[pk].oa) + " + I" : b.P(L.pat[pk].o0) + " + I");
         for (; emitted < E.lines.size(); emitted++) os << "    " << E.lines[emitted] << "\n";
-        if (!isobj) os << "    if (I0 < hi) " << (p.kind == EXA_PAT_CONAUG ? "augout" : "cout") << "[" << rowtxt << "] = " << E.sd(value) << ";\n";
+        // Linear augmentation terms (c * x[k], evaluated at build): with the row lists of exa_cons1 at hand (augptr != null:
+        // unsharded, no long rows) the thread that owns a base row adds the row's terms itself, in list order — no value
+        // buffer, no exa_aug_gather launch behind the sweep.  Otherwise the terms' values go to the buffer as before.
+        bool target = false;
+        for (const Pattern &q : m.pats) target = target || (q.kind == EXA_PAT_CONAUG && q.n > 0 && q.base == pk);
+        if (isobj) {}
+        else if (m.aug_linear && p.kind == EXA_PAT_CONAUG) os << "    if (I0 < hi && !augptr) augout[" << rowtxt << "] = " << E.sd(value) << ";\n";
+        else if (m.aug_linear && target)
+            os << "    if (I0 < hi) {\n        double v = " << E.sd(value) << ";\n        const long r_ = " << rowtxt << ";\n"
+                  "        if (augptr) {\n            long j = augptr[r_];\n            const long je = augptr[r_ + 1];\n"
+                  "            for (; j + 4 <= je; j += 4) {\n"
+                  "                const long i0 = augsrc[j], i1 = augsrc[j + 1], i2 = augsrc[j + 2], i3 = augsrc[j + 3];\n"
+                  "                const double c0 = augcoef[j], c1 = augcoef[j + 1], c2 = augcoef[j + 2], c3 = augcoef[j + 3];\n"
+                  "                const double x0 = x[i0], x1 = x[i1], x2 = x[i2], x3 = x[i3];\n"
+                  "                v += __dmul_rn(c0, x0); v += __dmul_rn(c1, x1); v += __dmul_rn(c2, x2); v += __dmul_rn(c3, x3);\n            }\n"
+                  "            for (; j < je; j++) v += __dmul_rn(augcoef[j], x[augsrc[j]]);\n        }\n        cout[r_] = v;\n    }\n";
+        else os << "    if (I0 < hi) " << (p.kind == EXA_PAT_CONAUG ? "augout" : "cout") << "[" << rowtxt << "] = " << E.sd(value) << ";\n";
         const std::string tag = "_" + std::to_string(pk);
         if (!isobj && p.o1step > 0) {
             std::vector<std::string> vals;
@@ -2073,7 +2116,8 @@ Generated generate_module(const Model &m) {
         }
         os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_fused(const long* __restrict__ P, const double* __restrict__ x, "
               "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ part, double* __restrict__ cout, "
-              "double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma) {\n";
+              "double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma, "
+              "const long* __restrict__ augptr, const long* __restrict__ augsrc, const double* __restrict__ augcoef) {\n";
         if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all + (threadIdx.x >> 6) * " << mx << ";\n";
         else os << "    double* lds = nullptr;\n";
         // only the workgroups of OBJECTIVE patterns have something to add to obj: they write one partial sum each, at a
@@ -2084,7 +2128,7 @@ Generated generate_module(const Model &m) {
         const auto &grps = L.groups[CB_FUSED];
         for (size_t k = 0; k < grps.size(); k++) {
             os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") { const double v = g" << k
-               << "_fused(P, x, y, th, cout, augout, jout, hout, sigma, tid0, lds);";
+               << "_fused(P, x, y, th, cout, augout, jout, hout, sigma, tid0, lds, augptr, augsrc, augcoef);";
             if (m.pats[grps[k].front()].kind == EXA_PAT_OBJ)
                 os << " const double s = exa_block_sum(v); if (threadIdx.x == 0) part[P[" << L.pat[grps[k].front()].ob << "] + tile_] = s;";
             else os << " (void)v;";

@@ -576,12 +576,15 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
         if (h.m->nconaug) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
     }
     int64_t n = h.grid[CB_FUSED];
-    void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma};
+    // linear augmentation terms are added inside the sweep through the row lists of exa_cons1 when those exist
+    const bool inline_aug = h.cons1 && h.world == 1 && h.m->aug_linear && h.m->nconaug > 0;
+    const void *ap = inline_aug ? h.daugcsr.p : nullptr, *as = inline_aug ? h.daugsrc.p : nullptr, *ac = inline_aug ? h.daugcoef.p : nullptr;
+    void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma, &ap, &as, &ac};
     launch(h, h.f_fused, n, kBlock, a);
     int64_t nobj = h.fused_nobj;
     if (n > 0 && nobj > 0) { void *a2[] = {&part, &nobj, &obj_dev}; launch(h, h.f_red, 1, 1024, a2); }
     else HIPCHK(hipMemsetAsync(obj_dev, 0, sizeof(double), h.stream));
-    if (h.m->nconaug) aug_gather(h, buf, c);
+    if (h.m->nconaug && !inline_aug) aug_gather(h, buf, c);
     allreduce(h, obj_dev, 1);
     if (h.m->ncon) allreduce(h, c, h.m->ncon);
 }

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import has_gpu
+from zoo import ZOO, point
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
 
@@ -209,3 +210,31 @@ def test_the_two_declared_numeric_deviations(libs, monkeypatch):
                 # its own arithmetic; first partial: reference -1e-10/1e-400 -> -Inf, quotient form -(1e190)(1e200) -> -Inf
                 assert np.isinf(jr[1]) and jd[1] == exact_d2 or np.isinf(jd[1])
     monkeypatch.delenv("EXAHIP_STRICT_IEEE", raising=False)
+
+
+def test_mirrored_sincos_arguments_share_one_evaluation_bit_for_bit(libs, monkeypatch):
+    """sin / cos of `a - b` where sincos(b - a) is already in the kernel (the two ends of an ACOPF branch,
+    test/NLPTest/power.jl:62-78: va_f - va_t and va_t - va_f) are taken from that evaluation: a - b == -(b - a) exactly and
+    the sincos is exactly odd / even.  Every output must be bit-identical to the kernels that evaluate both — including
+    where the two angles are EQUAL (sin(+0.0) = +0.0, not -0.0)."""
+    import torch
+    from exahip import ExaModel
+    core = ZOO["acopf30"]()
+    outs = {}
+    for sym in ("1", "0"):
+        monkeypatch.setenv("EXAHIP_SYM_TRIG", sym)
+        m = ExaModel(core)
+        assert ("0.0 - t" in m.kernel_source()) == (sym == "1")
+        x, y, s = point(m.meta.x0, m.meta.ncon, seed=9)
+        x[:30] = 0.25                                  # all voltage angles equal: every branch has a - b == +0.0
+        dev = torch.device("cuda:0")
+        xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+        f, c, j, h = m.eval_fused(xd, yd, s)
+        got = [m.cons(xd), m.jac_coord(xd), m.hess_coord(xd, yd, s), c, j, h, m.grad(xd)]
+        x2, _, _ = point(m.meta.x0, m.meta.ncon, seed=10)
+        x2d = torch.from_numpy(x2).to(dev)
+        got += [m.cons(x2d), m.jac_coord(x2d), m.hess_coord(x2d, yd, s)]
+        torch.cuda.synchronize()
+        outs[sym] = [t.cpu().numpy().view(np.int64).copy() for t in got]
+    for a, b in zip(outs["1"], outs["0"]):
+        assert np.array_equal(a, b)
