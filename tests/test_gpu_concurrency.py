@@ -85,3 +85,43 @@ def test_concurrent_model_builds(libs):
         x, y, s = point(m.meta.x0, m.meta.ncon, seed=2)
         np.testing.assert_allclose(m.hess_coord(x, y, s), o.hess_coord(x, y, s), rtol=1e-10, atol=1e-12)
         np.testing.assert_allclose(m.jtprod(x, y), o.jtprod(x, y), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("which", ["lv", "acopf"])
+def test_obj_is_reproducible_back_to_back(libs, which):
+    """obj = per-workgroup partial sums + a fold in a fixed order.  2000 back-to-back evaluations — interleaved with the
+    fused sweep, which shares the partial-sum buffer — must give one and the same bit pattern, and that value must be
+    the CPU sum's to rounding."""
+    import ctypes
+
+    import torch
+    from exahip import ExaModel, models
+    core = (models.luksan_vlcek_model(3_000_000) if which == "lv"
+            else models.ac_power_model(models.synthetic_power_data(78_484, 126_015, 6_800, seed=0)))
+    m = ExaModel(core)
+    L = m._L
+    dev = torch.device("cuda:0")
+    x, y, s = point(m.meta.x0, m.meta.ncon, seed=3)
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    n = 2000
+    f = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    c = torch.empty(m.meta.ncon, dtype=torch.float64, device=dev)
+    j = torch.empty(m.meta.nnzj, dtype=torch.float64, device=dev)
+    h = torch.empty(m.meta.nnzh, dtype=torch.float64, device=dev)
+    p = lambda t, k=0: ctypes.c_void_p(t.data_ptr() + 8 * k)
+    for k in range(n):
+        if k % 50 == 7:
+            assert L.exa_eval_fused(m.id, p(xd), p(yd), ctypes.c_double(s), p(f, k), p(c), p(j), p(h)) == 0
+        else:
+            assert L.exa_obj_async(m.id, p(xd), p(f, k)) == 0
+    torch.cuda.synchronize()
+    got = f.cpu().numpy()
+    fused = np.arange(n) % 50 == 7          # (another tiling of the data points: its own partial sums, its own last bits)
+    for sel in (fused, ~fused):
+        bits = got[sel].view(np.int64)
+        assert np.all(bits == bits[0]), np.unique(got[sel])
+    assert abs(got[7] - got[0]) <= 1e-12 * abs(got[0])
+    if which == "lv":
+        xs = x
+        ref = float(np.sum(100.0 * (xs[:-1] ** 2 - xs[1:]) ** 2 + (xs[:-1] - 1.0) ** 2))
+        assert abs(got[0] - ref) <= 1e-12 * abs(ref)
