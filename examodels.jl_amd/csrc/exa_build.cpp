@@ -436,11 +436,17 @@ void tune_store(const std::string &key, const std::string &signature, int value)
     const std::string d = writable_cache_dir();
     if (d.empty()) return;
     const std::string p = d + "/" + key + ".tune";
-    std::vector<char> old;
-    std::string txt;
-    if (read_regular_file(p, old)) txt.assign(old.begin(), old.end());
-    txt += signature + " " + std::to_string(value) + "\n";
-    try { write_atomically(p, txt.data(), txt.size()); } catch (const std::exception &) { /* tuning is an optimisation */ }
+    // one O_APPEND write per decision: the ranks of a multi-GPU job store their (rank-specific) lines into the same file
+    // at the same moment, and a read-modify-write would keep only the last writer's.  The directory is a trusted one
+    // (writable_cache_dir); the last line for a signature wins when the file is read.
+    int cur = 0;
+    if (tune_lookup(key, signature, &cur) && cur == value) return;      // nothing new: the file does not grow with every exa_tune
+    const std::string line = signature + " " + std::to_string(value) + "\n";
+    const int fd = open(p.c_str(), O_WRONLY | O_CREAT | O_APPEND | O_NOFOLLOW | O_CLOEXEC, 0644);
+    if (fd < 0) return;                                     // tuning is an optimisation
+    struct stat st;
+    if (fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid()) { const ssize_t k = write(fd, line.data(), line.size()); (void)k; }
+    close(fd);
 }
 
 }  // namespace exa
