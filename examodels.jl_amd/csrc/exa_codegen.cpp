@@ -173,6 +173,10 @@ struct UnSpec { const char *f, *df, *ddf; };
 const double kPi = 3.14159265358979323846;
 const double kD2R = kPi / 180.0, kR2D = 180.0 / kPi;
 
+// The generator keeps per-module state in file-level variables (g_handover, g_lit_idx, g_lds_need, ...): ONE lock for
+// generate_module and generate_window_module (models may be built and compressed from several host threads).
+std::mutex g_gen_mu;
+
 const UnSpec *un_spec(int fn) {
     static UnSpec T[EXA_U_COUNT];
     static bool init = false;
@@ -1789,8 +1793,7 @@ void gen_dispatch_chained(std::ostringstream &os, const ParamLayout &L, int cb, 
 Generated generate_module(const Model &m) {
     // the scatter bookkeeping above (g_lds_need, g_lit_idx) is module-level state of one generation: serialise
     // concurrent model builds here (planning and hipcc still run in parallel)
-    static std::mutex gen_mu;
-    std::lock_guard<std::mutex> gen_lock(gen_mu);
+    std::lock_guard<std::mutex> gen_lock(g_gen_mu);
     Generated g;
     ParamLayout &L = g.layout;
     const int np = (int)m.pats.size();
@@ -2414,8 +2417,7 @@ std::vector<int> merged_hess_slots(const Model &m, const ParamLayout &L) {
 }
 
 std::string generate_window_module(const Model &m, const ParamLayout &L, const WindowSpec &spec) {
-    static std::mutex gen_mu;
-    std::lock_guard<std::mutex> gen_lock(gen_mu);
+    std::lock_guard<std::mutex> gen_lock(g_gen_mu);
     std::ostringstream os;
     {
         std::string pre = kPrelude;

@@ -26,6 +26,7 @@ dev = torch.device("cuda:0")
 runs = {}
 x = y = None
 ref = None
+shared_out = None
 for spec in args:
     name, _, kv = spec.partition(":")
     env = {k: v.replace("+", " ") for k, v in (p.split("=", 1) for p in kv.split(",") if p)}      # "+" stands for a blank
@@ -44,7 +45,12 @@ for spec in args:
         x = torch.from_numpy(xh).to(dev)
         y = torch.from_numpy(np.random.default_rng(1).standard_normal(m.meta.ncon)).to(dev)
     n_out = {"hess": m.meta.nnzh, "jac": m.meta.nnzj, "cons": m.meta.ncon, "grad": m.meta.nvar}[cb]
-    out = torch.full((n_out,), float("nan"), dtype=torch.float64, device=dev)
+    # ONE output buffer for all variants: the same kernel differs by up to 9 % between two output buffers of one process
+    # (physical placement), more than most of the effects looked for
+    if shared_out is None:
+        shared_out = torch.empty((n_out,), dtype=torch.float64, device=dev)
+    out = shared_out
+    out.fill_(float("nan"))
     m.time_callback(cb, 1, x, y, 0.5, out=out)
     torch.cuda.synchronize()
     if ref is None:
