@@ -1194,21 +1194,29 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
         const int k = act[j];
         const Pattern &p = m.pats[k];
         const int S = hess ? p.o2step : p.o1step;
-        const int64_t n = p.n, o = hess ? p.o2 : p.o1;
-        const int64_t mid = n >= 2 ? std::min(n / 2, n - 2) : 0;
+        // This process's data points of the pattern are [lo, hi) (all of them unless sharded) and slot s of point I sits at
+        // o + S * I of the COO it writes — also for the packed local slice of a shard, whose offset word already holds
+        // local_offset - S * lo (fill_params).  Everything below is in ABSOLUTE point indices, which is what the window
+        // kernels evaluate.
+        const auto &pl = L.pat[k];
+        const int64_t lo = h.P[pl.lo], hi = h.P[pl.hi], n = hi - lo, o = h.P[hess ? pl.o2 : pl.o1];
+        if (n <= 0) continue;
+        const int64_t mid = lo + (n >= 2 ? std::min(n / 2, n - 2) : 0);
         std::vector<int32_t> two((size_t)2 * S);
         HIPCHK(hipMemcpy(two.data(), cmap + o + (int64_t)S * mid, 4 * (size_t)S * (n >= 2 ? 2 : 1), hipMemcpyDeviceToHost));
-        std::vector<int64_t> a((size_t)S), bs((size_t)S);
+        std::vector<int64_t> a((size_t)S), bs((size_t)S), aloc((size_t)S);
         for (int s = 0; s < S; s++) {
             bs[s] = n >= 2 ? (int64_t)two[S + s] - two[s] : 1;
             a[s] = (int64_t)two[s] - bs[s] * mid;
+            aloc[s] = a[s] + bs[s] * lo;            // the same map in the local index I - lo (what the check kernel walks)
         }
         int64_t cnt = 0, e_lo = 0, e_hi = n;
-        affine_exceptions(cmap, o, S, n, a.data(), bs.data(), mid, &cnt, &e_lo, &e_hi, h.stream);
+        affine_exceptions(cmap, o + (int64_t)S * lo, S, n, aloc.data(), bs.data(), mid - lo, &cnt, &e_lo, &e_hi, h.stream);
         if (n <= 8) { e_lo = n; e_hi = n; }       // a handful of points (boundary conditions): all of them go to the tail kernel
         if (e_lo + (n - e_hi) > kBlock) return no("pattern " + std::to_string(k) + ": " + std::to_string(cnt) + " points off the regular structure");
-        for (int64_t I = 0; I < e_lo; I++) exc.push_back({k, I});
-        for (int64_t I = e_hi; I < n; I++) exc.push_back({k, I});
+        e_lo += lo; e_hi += lo;
+        for (int64_t I = lo; I < e_lo; I++) exc.push_back({k, I});
+        for (int64_t I = e_hi; I < hi; I++) exc.push_back({k, I});
         if (e_hi <= e_lo) continue;     // every point of the pattern is irregular (tiny pattern): exa_c*x does it all
         npts += e_hi - e_lo;
         // stride classes
@@ -1405,7 +1413,7 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
         for (int t = 0; t < w.nx; t++) {
             const Pattern &p = m.pats[exc[t].k];
             const int S = hess ? p.o2step : p.o1step;
-            const int64_t o = hess ? p.o2 : p.o1;
+            const int64_t o = h.P[hess ? L.pat[exc[t].k].o2 : L.pat[exc[t].k].o1];
             X.push_back(exc[t].k); X.push_back(exc[t].I);
             HIPCHK(hipMemcpy(tgt.data() + (size_t)t * smax, cmap + o + (int64_t)S * exc[t].I, 4 * (size_t)S, hipMemcpyDeviceToHost));
         }
@@ -1496,8 +1504,7 @@ void window_setup(Handle &h) {
     const char *env = getenv("EXAHIP_CWINDOW");
     if (env && atoi(env) == 0) { h.wj.why = h.wh.why = "disabled (EXAHIP_CWINDOW=0)"; return; }
     h.sj.ok = h.sh.ok = false;
-    const bool plan_windows = h.world == 1;         // the windows are planned for whole patterns; a shard takes the permuted store
-    if (!plan_windows) h.wj.why = h.wh.why = "sharded model: the windows are planned for whole patterns";
+    const bool plan_windows = true;                 // (a shard plans the windows of its local slice: absolute point indices throughout)
     const Model &m = *h.m;
     if (std::max(h.lnnzj, h.lnnzh) > 0x7fffffffLL) { h.wj.why = h.wh.why = "nnz exceeds int32"; return; }
     WindowSpec spec;

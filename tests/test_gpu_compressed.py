@@ -339,3 +339,52 @@ def test_random_table_models_take_the_merged_permuted_store(libs, seed):
         print(seed, npts, kinds, cm.path("hess")[1])
         if npts == 7:           # (the larger table piles > 512 duplicates on some entries: those keep the cooperative gather)
             assert "scatter" in kinds, (kinds, cm.path("jac"), cm.path("hess"))
+
+
+@pytest.mark.parametrize("name,size", [("lv", 200_000), ("rocket", 40_000), ("lv", 1000)])
+def test_a_shard_compresses_its_local_slice_through_the_windows(libs, name, size, monkeypatch):
+    """exa_compress of a sharded model (local-slice COO): every rank plans the windowed sweep over ITS data points
+    (absolute point indices, the packed slice's offsets) — same kernels as the unsharded model, no gather.  Each rank's
+    compressed matrix must equal the reference compression (gather) of the same slice entry for entry, and the ranks'
+    matrices must add up to the unsharded compressed matrix."""
+    import torch
+    from exahip import CompressedExaModel, ExaModel, models
+    build = (lambda: models.luksan_vlcek_model(size)) if name == "lv" else (lambda: models.rocket_model(size))
+    world = 3
+    dev = torch.device("cuda:0")
+    whole = ExaModel(build())
+    cw = CompressedExaModel(whole)
+    x, y, sigma = point(whole.meta.x0, whole.meta.ncon, seed=12)
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    nvar, ncon = whole.meta.nvar, max(whole.meta.ncon, 1)
+    total = {"jac": {}, "hess": {}}
+    for rank in range(world):
+        both = []
+        for window in ("1", "0"):
+            monkeypatch.setenv("EXAHIP_CWINDOW", window)
+            monkeypatch.setenv("EXAHIP_CSCATTER", window)
+            m = ExaModel(build())
+            m.set_shard(rank, world)
+            m.set_coo_local(True)
+            c = CompressedExaModel(m)
+            if window == "1" and size > 1000:
+                assert c.path("hess")[0] == "windowed" and c.path("jac")[0] == "windowed", (c.path("hess"), c.path("jac"))
+            if window == "0":
+                assert c.path("hess")[0] == "gather" and c.path("jac")[0] == "gather"
+            both.append((c.jac_structure(), c.jac_coord(xd), c.hess_structure(), c.hess_coord(xd, yd, sigma)))
+        (js1, jv1, hs1, hv1), (js0, jv0, hs0, hv0) = both
+        for s1, s0 in ((js1, js0), (hs1, hs0)):
+            assert torch.equal(s1[0], s0[0]) and torch.equal(s1[1], s0[1])
+        for a, b in ((jv1, jv0), (hv1, hv0)):
+            a, b = a.cpu().numpy(), b.cpu().numpy()
+            assert np.all(np.abs(a - b) <= 1e-12 * np.abs(b) + 1e-13 * np.abs(b).max()), np.abs(a - b).max()
+        for kind, (rows, cols), vals, nrow in (("jac", js1, jv1, ncon), ("hess", hs1, hv1, nvar)):
+            key = ((cols - 1) * nrow + (rows - 1)).cpu().numpy()
+            for k, v in zip(key.tolist(), vals.cpu().numpy().tolist()):
+                total[kind][k] = total[kind].get(k, 0.0) + v
+    for kind, (rows, cols), vals, nrow in (("jac", cw.jac_structure(), cw.jac_coord(xd), ncon), ("hess", cw.hess_structure(), cw.hess_coord(xd, yd, sigma), nvar)):
+        key = ((cols - 1) * nrow + (rows - 1)).cpu().numpy()
+        ref = vals.cpu().numpy()
+        assert set(key.tolist()) == set(total[kind])                   # the union of the ranks' structures is the model's
+        got = np.array([total[kind][k] for k in key.tolist()])
+        assert np.all(np.abs(got - ref) <= 1e-11 * np.abs(ref) + 1e-12 * np.abs(ref).max()), np.abs(got - ref).max()
