@@ -880,20 +880,26 @@ static __device__ __forceinline__ void exa_wave_atomic_add(double* p, double v) 
     if ((threadIdx.x & 63) == 0) exa_atomic_add(p, v);
 }
 // Scatter through a DATA index: the target may be one variable shared by every data point (a step length, a slack, a
-// reference bus reached through a table column) — 64 same-address atomics per wavefront that serialise chip-wide at
-// ~12 ns each (1e7 points: 120 ms).  If all active lanes of the wavefront name the same variable, add the 64 values with
-// a butterfly and issue ONE atomic; otherwise one atomic per lane.  Must be reached by the whole wavefront.
+// reference bus reached through a table column) or one of a FEW shared variables in any order (design variables behind a
+// scenario column) — up to 64 same-address atomics per wavefront that serialise chip-wide at ~12 ns each (1e7 points on
+// one variable: 120 ms; on two, interleaved at random: 81 ms; on sixteen: 26 ms).  The wavefront therefore peels groups
+// of lanes that name the same variable — the first pending lane's target, a ballot, a butterfly over the group's values,
+// ONE atomic by its first lane — for as long as a group has at least two lanes; what is left (all lanes, when every
+// lane names its own variable: one ballot wasted) goes lane by lane.  Must be reached by the whole wavefront.
 static __device__ __forceinline__ void exa_scatter_add(double* __restrict__ out, long idx, double v, bool act) {
-    const unsigned long long m = __ballot(act);
-    if (m == 0) return;
-    const long first = __shfl(idx, __ffsll((long long)m) - 1, 64);
-    if (__ballot(act && idx != first) == 0) {
-        double s = act ? v : 0.0;
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if ((threadIdx.x & 63) == 0) exa_atomic_add(&out[first], s);
-    } else if (act) {
-        exa_atomic_add(&out[idx], v);
+    unsigned long long todo = __ballot(act);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const long t = __shfl(idx, leader, 64);
+        const unsigned long long grp = __ballot(act && idx == t) & todo;
+        if (__popcll(grp) < 2) break;
+        double s = ((grp >> lane) & 1ull) ? v : 0.0;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == leader) exa_atomic_add(&out[t], s);
+        todo &= ~grp;
     }
+    if ((todo >> lane) & 1ull) exa_atomic_add(&out[idx], v);
 }
 // sum over the 256-thread workgroup: 64-lane wavefront butterflies, then 4 partials through LDS
 static __device__ __forceinline__ double exa_block_sum(double v) {

@@ -156,6 +156,41 @@ def test_shared_variable_reached_through_a_data_index(libs):
     assert (time.perf_counter() - t0) / 10 < 1.5e-3                    # was 3.6 ms at this size
 
 
+def test_a_few_shared_variables_in_random_order_through_a_data_index(libs):
+    """Three shared variables named by a table column in RANDOM order (design variables behind a scenario column): no
+    wavefront is uniform, so the single-target reduction never applied and 64 atomics per wavefront landed on one cache
+    line (1e7 points, two targets: 81 ms).  The wavefront now peels the groups of lanes that share a target — here three
+    atomics per wavefront.  Values against the oracle, and a time bound."""
+    import time
+    import torch
+    from exahip import ExaCore, ExaModel, Table
+    from exahip.graph import sin
+    import oracle
+    N, K = 300_000, 3
+    c = ExaCore()
+    x = c.add_var(N + K, start=np.linspace(0.1, 1.0, N + K))
+    tab = Table(i=np.arange(1, N + 1), k=N + 1 + np.random.default_rng(0).integers(0, K, N), w=np.linspace(0.5, 1.5, N))
+    c.add_obj(lambda t: t.w * x[t.i] * sin(x[t.k]), tab)
+    c.add_con(lambda t: x[t.i] ** 2 * x[t.k], tab)
+    m = ExaModel(c)
+    m.set_product_mode(0, 0)
+    o = oracle.OracleModel(m.ir)
+    xs = np.asarray(m.meta.x0) + 0.01
+    y = np.linspace(-1, 1, N)
+    v = np.linspace(0.5, 1.5, N + K)
+    np.testing.assert_allclose(m.grad(xs), o.grad(xs), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(m.jtprod(xs, y), o.jtprod(xs, y), rtol=1e-10, atol=1e-9)
+    np.testing.assert_allclose(m.hprod(xs, y, v, 0.5), o.hprod(xs, y, v, 0.5), rtol=1e-10, atol=1e-9)
+    xd = torch.from_numpy(xs).cuda()
+    m.grad(xd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        m.grad(xd)
+    torch.cuda.synchronize()
+    assert (time.perf_counter() - t0) / 10 < 1.0e-3                    # was 2.5 ms at this size (64 atomics per wavefront)
+
+
 def test_steady_state_calls_allocate_nothing(libs):
     """test/NLPTest/alloc_test.jl: the callbacks do not allocate.  Here: after one warm call of each entry point the
     device's free memory does not move over hundreds of further calls with caller-provided outputs (scratch, block maps
