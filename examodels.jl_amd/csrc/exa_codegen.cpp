@@ -1701,6 +1701,31 @@ void gen_struct_fn(std::ostringstream &os, const Model &m, int pi, const ParamLa
     os << "}\n";
 }
 
+// grad! by the reference's scheme (KA ext :310-336): the first partials of every objective pattern go to their slots of a
+// gradient COO (ExaCore.nnzg entries, slot o1 + o1step * I + s), pK_gst names the variable of each slot; the runtime sorts
+// (variable, slot) once and adds each variable's slots in slot order — deterministic, and one variable shared by millions
+// of data points is summed cooperatively instead of by millions of atomics on one cache line.
+void gen_gradv_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
+    Body b(m, pi, L);
+    const Pattern &p = b.p;
+    b.forward(p.ad_root, 1, false);
+    GenAlg a(b, p.comp1, p.o1step);
+    grpass(p, p.ad_root, a, Emitter::litf(1.0));
+    os << "static __device__ __forceinline__ void " << fn_name(pi, "gradv")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ gout, long I) {\n";
+    emit_lines(os, b.e);
+    os << "    const long o = " << b.P(L.pat[pi].o1) << " + " << p.o1step << "L * I;\n";
+    for (int s = 0; s < p.o1step; s++) os << "    gout[o + " << s << "] = " << b.e.sd(a.acc[s]) << ";\n";
+    os << "}\n";
+    Body c(m, pi, L);
+    c.forward(p.ad_root, 0, true);
+    os << "static __device__ __forceinline__ void " << fn_name(pi, "gst") << "(const long* __restrict__ P, long* __restrict__ cols, long I) {\n";
+    emit_lines(os, c.e);
+    os << "    const long o = " << c.P(L.pat[pi].o1) << " + " << p.o1step << "L * I;\n";
+    for (int s = 0; s < p.o1step; s++) os << "    cols[o + " << s << "] = " << c.e.s(c.fv[p.slotvar1[s]].vidx) << ";\n";
+    os << "}\n";
+}
+
 // ---- fused kernels: blockIdx -> (pattern, tile) ------------------------------------------------------
 void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const std::string &call_prefix, const std::string &call_args,
                   const std::string &tail_args = "") {
@@ -1901,6 +1926,7 @@ Generated generate_module(const Model &m) {
         if (p.kind == EXA_PAT_OBJ) {
             if (std::find(L.pull.begin(), L.pull.end(), k) != L.pull.end()) gen_pull_fn(os, m, k, L);
             else if (p.o1step > 0) gen_first_fn(os, m, k, L, true);
+            gen_gradv_fn(os, m, k, L);
         }
         else {
             gen_cons_fn(os, m, k, L);
@@ -1938,6 +1964,26 @@ Generated generate_module(const Model &m) {
         }
     }
     os << "    const double s = exa_block_sum(v);\n    if (threadIdx.x == 0) part[b] = s;\n}\n";
+    // gradient COO + its structure (sorted grad!, gen_gradv_fn): the dispatch of exa_obj
+    for (int which = 0; which < 2; which++) {
+        const auto &act = L.active[CB_OBJ];
+        const int ppt = L.ppt[CB_OBJ];
+        if (which == 0)
+            os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_gradv(const long* __restrict__ P, const double* __restrict__ x, "
+                  "const double* __restrict__ th, double* __restrict__ gout) {\n";
+        else
+            os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_gstruct(const long* __restrict__ P, long* __restrict__ cols) {\n";
+        os << "    const long e_ = ((const long*)P[" << L.blk[CB_OBJ] << "])[blockIdx.x];\n    const int ps_ = (int)(e_ >> 40);\n"
+              "    const long t0_ = (e_ & ((1L << 40) - 1)) * (EXA_BLOCK * " << ppt << ") + threadIdx.x;\n";
+        for (size_t k = 0; k < act.size(); k++) {
+            const auto &pp = L.pat[act[k]];
+            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") {\n#pragma unroll 1\n        for (int u = 0; u < " << ppt
+               << "; u++) { const long I = P[" << pp.lo << "] + t0_ + u * EXA_BLOCK; if (I < P[" << pp.hi << "]) "
+               << (which == 0 ? fn_name(act[k], "gradv") + "(P, x, th, gout, I)" : fn_name(act[k], "gst") + "(P, cols, I)") << "; }\n    }\n";
+        }
+        if (act.empty()) os << "    (void)ps_; (void)t0_;\n";
+        os << "}\n";
+    }
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_grad(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out) {\n";
     auto scatter_lds = [&](int cb) {

@@ -455,6 +455,12 @@ void attach_other(SortedIndex &s, const int64_t *other, const int64_t *rows, con
                        (uint32_t *)s.oth, s.nnz);
 }
 
+void attach_unit(SortedIndex &s, hipStream_t stream) {
+    if (s.nnz == 0) return;
+    if (!s.oth) HIPCHK_C(hipMalloc(&s.oth, 4 * (size_t)s.nnz));
+    HIPCHK_C(hipMemsetAsync(s.oth, 0, 4 * (size_t)s.nnz, stream));
+}
+
 void compress_values(const CompressedCOO &c, const double *buf, double *V, hipStream_t stream) {
     if (c.cnnz == 0) return;
     hipLaunchKernelGGL(k_compress, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, V, buf, (const int64_t *)c.ptr, (const uint32_t *)c.perm,

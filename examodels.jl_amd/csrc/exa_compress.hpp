@@ -61,6 +61,8 @@ struct SortedIndex {
 void attach_other(SortedIndex &s, const int64_t *other, const int64_t *rows, const int64_t *cols, bool skip_diag, int64_t other_dim,
                   hipStream_t stream);
 void build_sorted_index(SortedIndex &s, const int64_t *keys1, int64_t nnz, int64_t ndim, hipStream_t stream);
+// every entry is gathered with v[0] (a plain sum when v = {1.0}: x * 1.0 == x exactly): s.oth = zeros
+void attach_unit(SortedIndex &s, hipStream_t stream);
 // out[k] (+)= sum_{e in group k, (skip_diag ? rows[e] != cols[e] : true)} vals[e] * v[other[e] - 1]
 void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other, const int64_t *rows, const int64_t *cols, bool skip_diag,
                  const double *v, double *out, bool accumulate, hipStream_t stream);

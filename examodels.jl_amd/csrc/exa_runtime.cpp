@@ -113,6 +113,12 @@ struct Handle {
     // ... and its merged-slot form for the Hessian (exa_chessm): the merged slot space has its own sorted lists
     bool merged = false;
     int device = -1;            // the HIP device that was current in exa_create (DeviceScope)
+    // grad! by sorted gather (the reference's scheme, deterministic): gradient COO + (variable, slot) lists, built on demand
+    hipFunction_t f_gradv = nullptr, f_gstruct = nullptr;
+    SortedIndex gbyvar;
+    DevBuf gbuf, gone;
+    bool grad_ready = false;
+    int grad_mode = -1;         // 0 pull + atomics, 1 sorted gather, -1 undecided (persisted exa_tune decision, else 0)
     hipFunction_t f_chessm = nullptr, f_hstructm = nullptr;
     CompressedCOO chm;
     DevBuf dM;
@@ -135,6 +141,7 @@ struct Handle {
             cj.release(); ch.release(); cbuf.release();
             for (Window *w : {&wj, &wh}) { w->Q.release(); w->R.release(); w->X.release(); w->T.release(); w->E.release(); w->xbuf.release(); w->S.release(); w->F.release(); w->part.release(); }
             sj.pos.release(); sh.pos.release(); chm.release(); dM.release();
+            gbyvar.release(); gbuf.release(); gone.release();
             if (wmodule) (void)hipModuleUnload(wmodule);
             pjrows.release(); pjcols.release(); phrows.release(); phcols.release();
             jbycol.release(); hbyrow.release(); hbycol.release();
@@ -343,6 +350,7 @@ void to_device(Handle &h) {
     h.f_jprod = fn("exa_jprod"); h.f_jtprod = fn("exa_jtprod"); h.f_hprod = fn("exa_hprod"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
     if (h.gen.layout.chain[CB_HESSC] > 0) h.f_hessc = fn("exa_hessc");
     h.f_cons1 = fn("exa_cons1");
+    h.f_gradv = fn("exa_gradv"); h.f_gstruct = fn("exa_gstruct");
     if (m.aug_linear || m.nconaug == 0) h.f_jprod1 = fn("exa_jprod1");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
     h.colslot.resize(m.pats.size());
@@ -528,6 +536,51 @@ void do_grad(Handle &h, const double *x, double *g) {
     void *a[] = {&P, &x, &th, &g};
     launch(h, h.f_grad, h.grid[CB_GRAD], kBlock, a);   // scattered patterns: FP64 hardware atomics on top
     allreduce(h, g, nvar);
+}
+// grad! by sorted gather: exa_gradv writes the gradient COO, every variable's slots are added in slot order (long lists
+// cooperatively).  Lists are built at the first use; a sharded model keeps the atomics (its ranks write disjoint parts of
+// one COO whose other parts nobody fills).
+bool grad_sorted_possible(const Handle &h) { return h.world == 1 && h.m->nnzg > 0 && h.m->nnzg < 0xffffffffLL && h.grid[CB_OBJ] > 0; }
+void grad_setup(Handle &h) {
+    if (h.grad_ready) return;
+    const Model &m = *h.m;
+    h.gbuf.ensure(8 * (size_t)m.nnzg);
+    DevBuf cols;
+    try {
+        cols.ensure(8 * (size_t)m.nnzg);
+        const void *P = h.dP.p;
+        void *cp = cols.p;
+        void *a[] = {&P, &cp};
+        launch(h, h.f_gstruct, h.grid[CB_OBJ], kBlock, a);
+        build_sorted_index(h.gbyvar, (const int64_t *)cols.p, m.nnzg, m.nvar, h.stream);
+        attach_unit(h.gbyvar, h.stream);
+        const double one = 1.0;
+        h.gone.ensure(8);
+        HIPCHK(hipMemcpy(h.gone.p, &one, 8, hipMemcpyHostToDevice));
+        HIPCHK(hipStreamSynchronize(h.stream));
+    } catch (...) { cols.release(); throw; }
+    cols.release();
+    h.grad_ready = true;
+}
+void do_grad_sorted(Handle &h, const double *x, double *g) {
+    const void *P = h.dP.p, *th = h.dtheta.p;
+    void *gb = h.gbuf.p;
+    void *a[] = {&P, &x, &th, &gb};
+    launch(h, h.f_gradv, h.grid[CB_OBJ], kBlock, a);
+    spmv_gather(h.gbyvar, (const double *)h.gbuf.p, nullptr, nullptr, nullptr, false, (const double *)h.gone.p, g, false, h.stream);
+}
+static int resolve_grad_mode(Handle &h) {
+    if (h.grad_mode < 0) {
+        int v = 0;
+        h.grad_mode = tune_lookup(source_key(h.gen.source), tune_signature(h, "grad"), &v) && v == 1 ? 1 : 0;
+    }
+    if (h.grad_mode == 1 && !grad_sorted_possible(h)) return 0;
+    if (h.grad_mode == 1) grad_setup(h);
+    return h.grad_mode;
+}
+static void run_grad(Handle &h, const double *x, double *g) {
+    if (resolve_grad_mode(h) == 1) { do_grad_sorted(h, x, g); allreduce(h, g, h.m->nvar); }
+    else do_grad(h, x, g);
 }
 void do_cons(Handle &h, const double *x, double *c) {
     if (h.m->ncon == 0) return;
@@ -963,7 +1016,7 @@ int exa_obj(int id, const double *x, double *out_host) {
 }
 int exa_grad(int id, const double *x, double *g) {
     if (!x || !g) return 1;
-    return guard(id, true, [&](Handle &h) { do_grad(h, x, g); });
+    return guard(id, true, [&](Handle &h) { run_grad(h, x, g); });
 }
 int exa_cons(int id, const double *x, double *c) {
     if (!x) return 1;
@@ -1038,6 +1091,22 @@ int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode) {
         h.jt_mode = jtprod_mode; h.hp_mode = hprod_mode;
     });
 }
+/* grad!: 0 = gathered (affine patterns) + FP64 atomics (data-indexed ones), 1 = gradient COO + sorted gather (the reference's
+ * scheme: deterministic, and immune to many data points sharing a few variables), -1 = undecided: the persisted exa_tune
+ * decision if there is one, else 0.  A sharded model always runs 0. */
+int exa_set_grad_mode(int id, int mode) {
+    if (mode < -1 || mode > 1) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if (mode == 1 && grad_sorted_possible(h)) grad_setup(h);
+        h.grad_mode = mode;
+    });
+}
+int exa_get_grad_mode(int id, int *mode) {
+    Handle *h = get(id);
+    if (!h || !mode) return 1;
+    *mode = h->grad_mode;
+    return 0;
+}
 int exa_get_product_mode(int id, int *jtprod_mode, int *hprod_mode) {
     Handle *h = get(id);
     if (!h || !jtprod_mode || !hprod_mode) return 1;
@@ -1068,7 +1137,7 @@ int exa_grad_host(int id, const double *x, double *g) {
         const size_t n = 8 * (size_t)h.m->nvar;
         h2d(h, h.sx, x, n);
         h.sout.ensure(n);
-        do_grad(h, (const double *)h.sx.p, (double *)h.sout.p);
+        run_grad(h, (const double *)h.sx.p, (double *)h.sout.p);
         d2h(h, g, h.sout.p, n);
     });
 }
@@ -1744,7 +1813,7 @@ int exa_time_callback(int id, int which, int reps, const double *x, const double
         for (int r = 0; r < reps; r++) {
             switch (which) {
             case 0: do_obj(h, x, (double *)h.dobj.p); break;
-            case 1: do_grad(h, x, out); break;
+            case 1: run_grad(h, x, out); break;
             case 2: do_cons(h, x, out); break;
             case 3: do_jac(h, x, out); break;
             case 4: do_hess(h, x, y, w, out); break;
@@ -1774,7 +1843,7 @@ int exa_sync(int id) { return guard(id, true, [&](Handle &h) { HIPCHK(hipStreamS
 
 // ---- explicit tuning (the only place that measures; callbacks never do) ------------------------------------------------
 int exa_tune(int id, int what, const double *x, const double *y) {
-    if (what < 0 || what > 3) return 1;
+    if (what < 0 || what > 7) return 1;
     return guard(id, true, [&](Handle &h) {
         const Model &m = *h.m;
         struct Tmp { DevBuf b[8]; ~Tmp() { for (auto &q : b) q.release(); } } t;
@@ -1833,6 +1902,19 @@ int exa_tune(int id, int what, const double *x, const double *y) {
                 mode = best;
                 tune_store(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), best);
             }
+        }
+        if (what & 4) {
+            // grad!: only worth a trial when some objective pattern scatters through a data index (the gathered patterns
+            // of a stencil model are already a plain coalesced store)
+            int best = 0;
+            if (!h.gen.layout.active[CB_GRAD].empty() && grad_sorted_possible(h) && m.nnzg <= 300000000LL) {
+                g = need(5, m.nvar);
+                grad_setup(h);
+                best = pick_faster(h, [&] { do_grad(h, x, g); }, [&] { do_grad_sorted(h, x, g); });
+                if (best == 0) { h.gbyvar.release(); h.gbuf.release(); h.grad_ready = false; }
+            }
+            h.grad_mode = best;
+            tune_store(source_key(h.gen.source), tune_signature(h, "grad"), best);
         }
         HIPCHK(hipStreamSynchronize(h.stream));
     });

@@ -298,9 +298,9 @@ class ExaModel:
         capi.check(self._L.exa_build_info(self.id, buf, 32, ctypes.addressof(ms)), "exa_build_info")
         return buf.value.decode(), ms.value
 
-    def tune(self, what=3, x=None, y=None):
-        """exa_tune: the explicit, blocking measurement of block orders (bit 0) and product implementations (bit 1);
-        the decisions are persisted next to the cached module.  x, y: device tensors or None."""
+    def tune(self, what=7, x=None, y=None):
+        """exa_tune: the explicit, blocking measurement of block orders (bit 0), product implementations (bit 1) and the
+        grad! implementation (bit 2); the decisions are persisted next to the cached module.  x, y: device tensors or None."""
         if x is not None:
             self._use_torch_stream(x)
         capi.check(self._L.exa_tune(self.id, int(what), x.data_ptr() if x is not None else None,
@@ -508,6 +508,15 @@ class ExaModel:
     def set_product_mode(self, jtprod=-1, hprod=-1):
         """0 atomics in the sweep, 1 COO + sorted gather, -1 undecided (default): what tune() persisted, else atomics."""
         capi.check(self._L.exa_set_product_mode(self.id, int(jtprod), int(hprod)), "exa_set_product_mode")
+
+    def set_grad_mode(self, mode=-1):
+        """grad!: 0 gathered + FP64 atomics, 1 gradient COO + sorted gather (deterministic), -1 whatever tune() persisted"""
+        capi.check(self._L.exa_set_grad_mode(self.id, int(mode)), "exa_set_grad_mode")
+
+    def grad_mode(self):
+        a = ctypes.c_int(0)
+        capi.check(self._L.exa_get_grad_mode(self.id, ctypes.addressof(a)), "exa_get_grad_mode")
+        return a.value
 
     def product_mode(self):
         a, b = ctypes.c_int(0), ctypes.c_int(0)

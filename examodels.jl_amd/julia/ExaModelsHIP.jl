@@ -176,7 +176,9 @@ end
 usestream(m) = chk(ccall((:exa_set_stream, LIB), Cint, (Cint, Ptr{Cvoid}), m.ext.id, AMDGPU.stream().stream), "exa_set_stream")
 
 # Explicit, blocking tuning (block orders, hess_coord! kernel, product implementations); persisted by the library.
-tune!(m; what = 3) = (usestream(m); chk(ccall((:exa_tune, LIB), Cint, (Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, what, C_NULL, C_NULL), "exa_tune"))
+tune!(m; what = 7) = (usestream(m); chk(ccall((:exa_tune, LIB), Cint, (Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, what, C_NULL, C_NULL), "exa_tune"))
+# grad!: 0 = gathered + FP64 atomics, 1 = gradient COO + sorted gather (the reference's scheme, deterministic), -1 = what tune! persisted
+grad_mode!(m, mode::Integer) = chk(ccall((:exa_set_grad_mode, LIB), Cint, (Cint, Cint), m.ext.id, mode), "exa_set_grad_mode")
 
 # ---- multi-GPU: one Julia process per GPU (include/exahip.h "multi-GPU behind the ABI") ---------------------------------
 # rank 0:  uid = comm_unique_id();  uid = MPI.bcast(uid, 0, comm)       every rank:  comm_init!(model, rank, world, uid)

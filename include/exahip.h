@@ -181,6 +181,13 @@ int exa_hprod (int id, const double *x, const double *y, const double *v, double
  * measured contention") if there is one, else atomics.  The mode is fixed before a call; a callback never measures. */
 int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode);
 int exa_get_product_mode(int id, int *jtprod_mode, int *hprod_mode);
+/* exa_grad likewise: 0 = affine-indexed objective patterns gathered per variable + data-indexed ones added with FP64
+ * atomics, 1 = the reference's scheme (KA ext :310-336: gradient COO of ExaCore.nnzg slots, (variable, slot) lists sorted
+ * once, every variable's slots added in slot order — deterministic; a variable shared by millions of data points is
+ * summed cooperatively instead of by as many atomics on one cache line), -1 (default) undecided: the persisted exa_tune
+ * decision (what & 4) if there is one, else 0.  A sharded model always runs 0. */
+int exa_set_grad_mode(int id, int mode);
+int exa_get_grad_mode(int id, int *mode);
 int exa_jac_structure  (int id, int32_t *rows, int32_t *cols);
 int exa_hess_structure (int id, int32_t *rows, int32_t *cols);
 int exa_jac_structure64 (int id, int64_t *rows, int64_t *cols);               /* Julia Vector{Int} */
@@ -250,7 +257,8 @@ int exa_block_order(int id, int which);
  * Which one runs: the decision exa_tune measured and persisted, else by size (>= 1.5 GB streamed per call -> 1). */
 int exa_hess_variant(int id);
 /* Explicit, BLOCKING tuning — the only entry point that measures.  what: bit 0 = block order of cons / jac / hess / fused
- * (models streaming >= 128 MB from several patterns), bit 1 = exa_jtprod / exa_hprod implementation.  Both candidates of
+ * (models streaming >= 128 MB from several patterns), bit 1 = exa_jtprod / exa_hprod implementation, bit 2 = exa_grad
+ * implementation (exa_set_grad_mode; only models whose objective scatters through a data index).  Both candidates of
  * each decision are timed on the model's stream at (x, y) (DEVICE pointers; NULL = x0 / ones; outputs go to scratch),
  * the winner is installed and persisted next to the cached module under (module, device, shard, pattern sizes), so later
  * processes start with it.  Call it once after the build (and after exa_set_shard / exa_comm_init), outside any stream
