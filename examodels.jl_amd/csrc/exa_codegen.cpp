@@ -901,6 +901,22 @@ static __device__ __forceinline__ void exa_scatter_add(double* __restrict__ out,
     }
     if ((todo >> lane) & 1ull) exa_atomic_add(&out[idx], v);
 }
+// The loop-free form (all lanes on ONE variable -> one atomic, else lane by lane) for bodies of thousands of SSA values:
+// such kernels run at the 512-VGPR limit with scratch spills, and the compiler bundled with PyTorch's ROCm 7.0 (hiprtc)
+// miscompiles the peeling loop there (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION in exa_hprod of
+// tests/test_random_expressions.py seed 541; the same source built by ROCm 7.2's hipcc is correct).
+static __device__ __forceinline__ void exa_scatter_add1(double* __restrict__ out, long idx, double v, bool act) {
+    const unsigned long long m = __ballot(act);
+    if (m == 0) return;
+    const long first = __shfl(idx, __ffsll((long long)m) - 1, 64);
+    if (__ballot(act && idx != first) == 0) {
+        double s = act ? v : 0.0;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if ((threadIdx.x & 63) == 0) exa_atomic_add(&out[first], s);
+    } else if (act) {
+        exa_atomic_add(&out[idx], v);
+    }
+}
 // sum over the 256-thread workgroup: 64-lane wavefront butterflies, then 4 partials through LDS
 static __device__ __forceinline__ double exa_block_sum(double v) {
     __shared__ double red[EXA_BLOCK / 64];
@@ -1195,6 +1211,14 @@ Affine affine(const Pattern &p, int k) {
 int g_lds_need[CB_COUNT];   // doubles of LDS per wavefront needed by the scatter windows of each callback (per module)
 // literal scatter targets of every (callback, pattern): 0-based variable indices, in the order of the pattern's `lit[]`
 std::map<std::pair<int, int>, std::vector<std::string>> g_lit_idx;
+// largest scatter body (SSA lines) per callback: bodies of thousands of values run at the 512-VGPR limit with scratch
+// spills, and such kernels have produced wrong sums / memory faults whenever a loop sat around or inside the body (the
+// 16-tile loop, the peeling loop of exa_scatter_add) — with the hiprtc of ROCm 7.0 and, less often, the hipcc of 7.2
+// (sweep over 120 random depth-5/6 models, tests/test_random_expressions.py).  Past kHugeBody lines the generator emits
+// no loop: one tile per workgroup, the loop-free exa_scatter_add1.
+std::map<int, size_t> g_scatter_lines;
+int huge_body() { return env_int("EXAHIP_HUGE_BODY", 1000); }
+bool g_loopfree[CB_COUNT];      // set from a dry pass over the callback's scatter bodies (generate_module)
 
 struct Scatter {
     struct Item { const Pattern *p; int pi; int ir; Val vidx, val; };
@@ -1202,6 +1226,7 @@ struct Scatter {
     const ParamLayout &L;
     std::vector<Item> items;
     std::vector<std::string> lit_idx;
+    bool loopfree = false;        // this callback has a huge body somewhere: no peeling loop (exa_scatter_add1)
     Scatter(Emitter &ee, const ParamLayout &ll) : e(ee), L(ll) {}
     explicit Scatter(Body &bb) : e(bb.e), L(bb.L) {}
     void add(Body &b, int ad_leaf, Val val) {
@@ -1288,7 +1313,8 @@ struct Scatter {
             } else if (!affine(*items[k].p, items[k].ir).ok && env_int("EXAHIP_WAVE_REDUCE", 1)) {
                 // reached through a data column: possibly the same variable for the whole wavefront (exa_scatter_add)
                 full_wave = true;
-                lines.push_back("exa_scatter_add(out, " + idx + ", " + e.sd(items[k].val) + ", act);");
+                const bool peel = !loopfree && (int)e.lines.size() <= huge_body();
+                lines.push_back(std::string(peel ? "exa_scatter_add" : "exa_scatter_add1") + "(out, " + idx + ", " + e.sd(items[k].val) + ", act);");
             } else {
                 lines.push_back("if (act) exa_atomic_add(&out[" + idx + "], " + e.sd(items[k].val) + ");");
             }
@@ -1300,7 +1326,18 @@ struct Scatter {
 void emit_scatter_prologue(std::ostringstream &os, const Body &b, const ParamLayout &L, int pi, bool full_wave) {
     os << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n";
     if (full_wave)
-        os << "    const int lane = threadIdx.x & 63;\n    if (I0 - lane >= hi) return;\n    const bool act = I0 < hi;\n    const long I = act ? I0 : hi - 1;\n";
+        // A wavefront whose 64 points all lie beyond the pattern skips the body.  Its first point, I0 - lane, is the same in
+        // every lane but the compiler cannot know: it would mask the lanes out (exec) around the whole body instead of
+        // branching — and values that live ACROSS the body in registers (the per-lane sums of shared targets, added up by a
+        // butterfly after the tile loop) were then spilled inside the masked region and reloaded behind it for all lanes:
+        // garbage in the lanes that were masked out whenever the body is large enough to spill (AGPRs / scratch), i.e.
+        // wrong or astronomically wrong J'v / Hv entries, intermittently, on random depth-6 models.  readfirstlane makes
+        // the test scalar: a real branch, no masking.
+        os << "    const int lane = threadIdx.x & 63;\n"
+              "    { const long w0_ = I0 - lane;\n"
+              "      const long wf_ = ((long)__builtin_amdgcn_readfirstlane((int)(w0_ >> 32)) << 32) | (long)(unsigned int)__builtin_amdgcn_readfirstlane((int)w0_);\n"
+              "      if (wf_ >= hi) return; }\n"
+              "    const bool act = I0 < hi;\n    const long I = act ? I0 : hi - 1;\n";
     else
         os << "    if (I0 >= hi) return;\n    const bool act = true;\n    const long I = I0;\n";
 }
@@ -1348,11 +1385,13 @@ void gen_first_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     std::vector<std::string> stores, vals;
     bool full_wave = false;
     Scatter sc(b);
+    sc.loopfree = g_loopfree[CB_GRAD];
     for (int s = 0; s < p.o1step; s++) {
         if (grad) sc.add(b, p.slotvar1[s], a.acc[s]);
         else vals.push_back(b.e.sd(a.acc[s]));
     }
-    if (grad) { g_lds_need[CB_GRAD] = std::max(g_lds_need[CB_GRAD], sc.emit(stores, full_wave)); g_lit_idx[{CB_GRAD, pi}] = sc.lit_idx; }
+    if (grad) { g_lds_need[CB_GRAD] = std::max(g_lds_need[CB_GRAD], sc.emit(stores, full_wave)); g_lit_idx[{CB_GRAD, pi}] = sc.lit_idx;
+                g_scatter_lines[CB_GRAD] = std::max(g_scatter_lines[CB_GRAD], b.e.lines.size()); }
     os << "static __device__ __forceinline__ void " << fn_name(pi, grad ? "grad" : "jac")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ out, long tid"
        << ", double* lds" << (grad ? ", double* lit" : "") << ") {\n";
@@ -1652,6 +1691,7 @@ void gen_scatter_group_fn(std::ostringstream &os, const Model &m, const ParamLay
     const bool hp = cb == CB_HPROD;
     Emitter E;
     Scatter sc(E, L);
+    sc.loopfree = g_loopfree[cb];
     std::vector<std::unique_ptr<Body>> bodies;
     for (int pk : grp) {
         bodies.emplace_back(new Body(m, pk, L, &E));
@@ -1661,6 +1701,7 @@ void gen_scatter_group_fn(std::ostringstream &os, const Model &m, const ParamLay
     bool full_wave = false;
     g_lds_need[cb] = std::max(g_lds_need[cb], sc.emit(stores, full_wave));
     g_lit_idx[{cb, gi}] = sc.lit_idx;
+    g_scatter_lines[cb] = std::max(g_scatter_lines[cb], E.lines.size());
     const char *name = hp ? "hprod" : "jtprod";
     os << "static __device__ __forceinline__ void g" << gi << "_" << name
        << "(const long* __restrict__ P, const double* __restrict__ x, " << (hp ? "const double* __restrict__ y, " : "")
@@ -1821,7 +1862,7 @@ void gen_dispatch_chained(std::ostringstream &os, const ParamLayout &L, int cb, 
 
 }  // namespace
 
-Generated generate_module(const Model &m) {
+Generated generate_module(const Model &m, bool loopfree_scatter) {
     // the scatter bookkeeping above (g_lds_need, g_lit_idx) is module-level state of one generation: serialise
     // concurrent model builds here (planning and hipcc still run in parallel)
     std::lock_guard<std::mutex> gen_lock(g_gen_mu);
@@ -1885,11 +1926,18 @@ Generated generate_module(const Model &m) {
             // model with many equally long wide patterns does not produce one register-starved monster)
             auto slots = [&](int q) { const Pattern &t = m.pats[q]; return cb == CB_JAC || cb == CB_JTPROD || cb == CB_CONS1 ? t.o1step : t.o1step + t.o2step; };
             const int cap = env_int("EXAHIP_GROUP_SLOTS", 128);
+            // (the scattering products also by the RAW contributions their reverse sweeps walk — what the body's length
+            // follows: fusing is for small bodies that share loads (ACOPF's branch rows: 48 first-order / 90 second-order
+            // contributions per group; the rocket: 25 / 103); bodies of thousands of SSA values gain nothing from it and,
+            // fused, were miscompiled by the hiprtc of ROCm 7.0 once wavefront operations sat in them — wrong entries of
+            // J'v / Hv in 4 of 60 random depth-6 models, none with the patterns on their own)
+            auto raw = [&](int q) { const Pattern &t = m.pats[q]; return (int)(cb == CB_JTPROD ? t.comp1.size() : cb == CB_HPROD ? t.comp2.size() : 0); };
+            const int rawcap = cb == CB_JTPROD ? env_int("EXAHIP_GROUP_RAW1", 64) : env_int("EXAHIP_GROUP_RAW2", 160);
             if (!alone && env_int(coo ? "EXAHIP_GROUP_COO" : "EXAHIP_GROUP_SCATTER", 1))
                 for (auto &g : L.groups[cb]) {
-                    int have = 0;
-                    for (int q : g) have += slots(q);
-                    if ((int)g.size() < gmax && have + slots(k) <= cap && m.pats[g.front()].n == m.pats[k].n &&
+                    int have = 0, have_raw = 0;
+                    for (int q : g) { have += slots(q); have_raw += raw(q); }
+                    if ((int)g.size() < gmax && have + slots(k) <= cap && have_raw + raw(k) <= rawcap && m.pats[g.front()].n == m.pats[k].n &&
                         !(cb == CB_FUSED && m.pats[g.front()].kind == EXA_PAT_OBJ)) {
                         g.push_back(k); placed = true; break;
                     }
@@ -1908,6 +1956,7 @@ Generated generate_module(const Model &m) {
 
     for (int &v : g_lds_need) v = 0;
     g_lit_idx.clear();
+    g_scatter_lines.clear();
     std::ostringstream os;
     L.pull_ppt = std::max(1, env_int("EXAHIP_PPT_PULL", 2));
     {
@@ -1918,6 +1967,23 @@ Generated generate_module(const Model &m) {
         os << pre;
     }
     os << "// patterns=" << np << " (sizes, offsets and column pointers are run-time parameters in P[])\n";
+    if (loopfree_scatter) os << "// scatter kernels without loops: the first build of this module spilled registers there\n";
+    {
+        // dry pass over the scatter bodies: which callbacks hold a huge body (g_scatter_lines) and must be generated
+        // without loops; its output and bookkeeping are discarded
+        for (int cb = 0; cb < CB_COUNT; cb++) g_loopfree[cb] = false;
+        std::ostringstream dry;
+        for (int k = 0; k < np; k++) {
+            const Pattern &p = m.pats[k];
+            if (p.n > 0 && p.kind == EXA_PAT_OBJ && p.o1step > 0 && std::find(L.pull.begin(), L.pull.end(), k) == L.pull.end()) gen_first_fn(dry, m, k, L, true);
+        }
+        for (int cb : {CB_JTPROD, CB_HPROD})
+            for (size_t g = 0; g < L.groups[cb].size(); g++) gen_scatter_group_fn(dry, m, L, cb, (int)g);
+        for (int cb : {CB_GRAD, CB_JTPROD, CB_HPROD}) g_loopfree[cb] = loopfree_scatter || (int)g_scatter_lines[cb] > huge_body();
+        g_lit_idx.clear();
+        g_scatter_lines.clear();
+        for (int cb = 0; cb < CB_COUNT; cb++) g_lds_need[cb] = 0;
+    }
     for (int k = 0; k < np; k++) {
         const Pattern &p = m.pats[k];
         if (p.n == 0) continue;
@@ -1946,7 +2012,7 @@ Generated generate_module(const Model &m) {
     for (int cb : {CB_GRAD, CB_JTPROD, CB_HPROD}) {
         bool any = false;
         for (const auto &kv : g_lit_idx) any = any || (kv.first.first == cb && !kv.second.empty());
-        if (any) L.ppt[cb] = env_int("EXAHIP_PPT_LITERAL", 16);
+        if (any && !g_loopfree[cb]) L.ppt[cb] = env_int("EXAHIP_PPT_LITERAL", 16);
     }
     // obj: per-workgroup partial sums
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_obj(const long* __restrict__ P, const double* __restrict__ x, "

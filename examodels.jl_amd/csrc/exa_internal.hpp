@@ -129,7 +129,10 @@ struct Generated {
 int block_threads();
 #define kBlock (::exa::block_threads())
 
-Generated generate_module(const Model &m);
+// loopfree_scatter: no loop around or inside the bodies of exa_grad / exa_jtprod / exa_hprod (see g_scatter_lines in
+// exa_codegen.cpp); the generator turns it on by itself for bodies past EXAHIP_HUGE_BODY lines, the runtime asks for it
+// when a scatter kernel of the compiled module turns out to spill registers.
+Generated generate_module(const Model &m, bool loopfree_scatter = false);
 bool pattern_var_range(const Pattern &p, int64_t lo, int64_t hi, int64_t *vmin, int64_t *vmax);   // exa_codegen.cpp
 
 // Windowed compressed-COO kernels (exa_cjac / exa_chess fast path).  One pattern of such a kernel: every

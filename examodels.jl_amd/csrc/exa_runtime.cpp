@@ -113,6 +113,7 @@ struct Handle {
     // ... and its merged-slot form for the Hessian (exa_chessm): the merged slot space has its own sorted lists
     bool merged = false;
     int device = -1;            // the HIP device that was current in exa_create (DeviceScope)
+    bool loopfree_scatter = false;     // the module was generated a second time without loops in the scatter kernels (to_device)
     // grad! by sorted gather (the reference's scheme, deterministic): gradient COO + (variable, slot) lists, built on demand
     hipFunction_t f_gradv = nullptr, f_gstruct = nullptr;
     SortedIndex gbyvar;
@@ -343,6 +344,32 @@ void to_device(Handle &h) {
     h.on_device = true;   // from here on the destructor releases whatever was acquired
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
+    // A scatter kernel that SPILLS registers (bodies of hundreds to thousands of SSA values) must not carry
+    // wavefront-level state across its body: with spills in play (scratch, or AGPRs used as spill space), the per-lane
+    // accumulators of shared targets (summed by a butterfly after a 16-tile loop) and the peeling loop of exa_scatter_add
+    // have returned wrong, NaN or garbage sums — depending on what the spill space held before (random depth-6 models of
+    // tests/test_random_expressions.py, with the hiprtc of ROCm 7.0 and, less often, the hipcc of 7.2; never with the
+    // wavefront operations off).  The generator avoids the loops for bodies it can see are huge; here the compiled
+    // kernels are asked, and a module whose scatter kernels spill is generated again without them.
+    if (!h.loopfree_scatter && !(getenv("EXAHIP_SPILL_CHECK") && atoi(getenv("EXAHIP_SPILL_CHECK")) == 0)) {
+        bool spills = false;
+        for (const char *name : {"exa_grad", "exa_jtprod", "exa_hprod"}) {
+            // (more than 256 registers = the 256 VGPRs are exhausted and values are parked in AGPRs: spilling all the same)
+            int local = 0, regs = 0;
+            if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn(name)) == hipSuccess && local > 0) spills = true;
+            if (hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn(name)) == hipSuccess && regs > 256) spills = true;
+            if (getenv("EXAHIP_SPILL_VERBOSE")) fprintf(stderr, "[exahip] %s: %d bytes of scratch per lane, %d registers\n", name, local, regs);
+        }
+        if (spills) {
+            (void)hipModuleUnload(h.module);
+            h.module = nullptr;
+            h.loopfree_scatter = true;
+            h.gen = generate_module(m, true);
+            co = get_code_object(h.gen.source, true);
+            h.hsaco_path = co.path; h.build_how = co.how; h.build_ms += co.build_ms;
+            HIPCHK(hipModuleLoadData(&h.module, co.image.data()));
+        }
+    }
     h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
     h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull");
     h.f_auglong = fn("exa_aug_long"); h.f_augfold = fn("exa_aug_fold");

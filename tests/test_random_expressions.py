@@ -61,11 +61,19 @@ def test_random_patterns_values_on_hip(libs, seed):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
-@pytest.mark.parametrize("seed", [523, 541])
+@pytest.mark.parametrize("seed", [523, 541, 1011, 1013, 1029])
 def test_deep_random_patterns_on_hip(libs, seed, monkeypatch):
-    """Depth-6 trees over 300 data points: Hessian bodies of several hundred SSA values per pattern, kernels at the
-    512-VGPR limit with scratch spills.  Seed 523 is the regression case of a wrong H*v (and an occasional memory fault)
-    when the 16-tile loop of the scatter kernels was unrolled twice; found by a one-off sweep over 260 such models."""
+    """Depth-6 trees over 300 data points: Hessian bodies of hundreds to thousands of SSA values per pattern, kernels at
+    the 512-register limit with AGPR / scratch spills.  Regression cases of the scatter kernels (J'v, H*v by atomics),
+    found by sweeps over a few hundred such models (tools/random_model_check.py):
+      523          wrong H*v and an occasional memory fault when the 16-tile loop was unrolled twice (round 1);
+      541          memory fault with a lane-group peeling loop inside a 5 000-line body;
+      1011, 1029   wrong / NaN entries of H*v once patterns were fused into groups — per-lane sums of shared targets
+                   carried in registers across a spilling body, lanes of skipped wavefronts masked instead of branched;
+      1013         J'v garbage after another kernel had run (stale spill space), NaN on some boxes.
+    What the generator does about it: the whole-wavefront skip is a scalar branch (readfirstlane), fused groups of the
+    products are capped by raw contributions, bodies past EXAHIP_HUGE_BODY lines get no loops, and a module whose
+    compiled scatter kernels spill (scratch, or more than 256 registers) is generated again without loops."""
     from exahip import ExaModel
     import oracle
     monkeypatch.setattr(randexpr, "NPTS", 300)

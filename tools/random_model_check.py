@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""One random model (tests/randexpr.py: `npat` patterns of depth `depth` over 300 data points) on the GPU against the
+oracle: H*v and J'v by atomics (twice, interleaved: stale spill space shows on the second kernel), grad! both ways.
+Prints one line; a GPU fault kills the process, so sweeps run one process per seed:
+
+    (for s in $(seq 1000 1099); do echo "$s 12 6"; done) | xargs -P 6 -L 1 sh -c \\
+        'timeout 300 python tools/random_model_check.py $0 $1 $2 2>&1 | grep seed || echo "seed $0 $1 $2 CRASH"'
+
+Entries whose Jacobian / Hessian values themselves differ from the oracle at 1e-6 (magnitudes of 1e20 and more: seeds
+2005, 2034 at depth 5) are conditioning of the random expression, not of the kernels."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("examodels.jl_amd", "tests", "oracle"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import numpy as np  # noqa: E402
+import randexpr  # noqa: E402
+import oracle  # noqa: E402
+from exahip import ExaModel  # noqa: E402
+
+seed, npat, depth = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+randexpr.NPTS = 300
+m = ExaModel(randexpr.build_model(seed, npat, depth))
+o = oracle.OracleModel(m.ir)
+m.set_product_mode(0, 0)
+x = m.meta.x0 + 0.05 * np.random.default_rng(seed).uniform(-1, 1, m.meta.nvar)
+y = np.random.default_rng(seed + 1).standard_normal(m.meta.ncon)
+v = np.random.default_rng(seed + 2).standard_normal(m.meta.nvar)
+w = np.random.default_rng(seed + 3).standard_normal(m.meta.ncon)
+
+
+def rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    ok = np.isfinite(b)
+    if not ok.any():
+        return 0.0
+    return float(np.max(np.abs(a[ok] - b[ok]) / (1.0 + np.abs(b[ok]))))
+
+
+errs = []
+for _ in range(2):
+    errs += [rel(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)), rel(m.jtprod(x, w), o.jtprod(x, w))]
+errs += [rel(m.grad(x), o.grad(x))]
+m.set_grad_mode(1)
+errs += [rel(m.grad(x), o.grad(x))]
+print("seed", seed, npat, depth, "maxerr %.2e" % max(errs), "BAD" if max(errs) > 1e-9 else "ok", ["%.1e" % e for e in errs], flush=True)
