@@ -25,6 +25,11 @@ namespace {
         hipError_t _e = (expr);                                                                               \
         if (_e != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(_e));     \
     } while (0)
+// FP64 add to memory as ONE hardware instruction (global_atomic_add_f64), by builtin: what unsafeAtomicAdd compiles to
+// depends on the compiler's flags (without -munsafe-fp-atomics: a compare-and-swap loop)
+static __device__ __forceinline__ void add_f64(double *p, double v) {
+    (void)__builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double *)p, v);
+}
 
 __global__ void __launch_bounds__(256) k_make_keys(const int64_t *__restrict__ rows, const int64_t *__restrict__ cols, int64_t nrowdim,
                                                    uint64_t *__restrict__ keys, uint32_t *__restrict__ idx, int64_t n) {
@@ -197,7 +202,7 @@ __global__ void __launch_bounds__(256) k_spmv_long(const uint32_t *__restrict__ 
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(&out[k], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) add_f64(&out[k], red[0] + red[1] + red[2] + red[3]);
 }
 
 __global__ void __launch_bounds__(256) k_other(const uint32_t *__restrict__ perm, const int64_t *__restrict__ other,
@@ -265,7 +270,7 @@ __global__ void __launch_bounds__(256) k_spmv_long2(const uint32_t *__restrict__
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(&out[k], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) add_f64(&out[k], red[0] + red[1] + red[2] + red[3]);
 }
 
 // one thread per group (variable / row): contributions added in ascending slot order -> deterministic
