@@ -44,4 +44,27 @@ for _ in range(2):
 errs += [rel(m.grad(x), o.grad(x))]
 m.set_grad_mode(1)
 errs += [rel(m.grad(x), o.grad(x))]
+if os.environ.get("CHECK_ALL"):
+    # the remaining callbacks: values, COO kernels, the fused sweep, the sorted products, the compressed COO
+    import torch
+    from exahip import CompressedExaModel
+    errs += [abs(m.obj(x) - o.obj(x)) / (1 + abs(o.obj(x))), rel(m.cons(x), o.cons(x)), rel(m.jac_coord(x), o.jac_coord(x)),
+             rel(m.hess_coord(x, y, 0.7), o.hess_coord(x, y, 0.7)), rel(m.jprod(x, v), o.jprod(x, v))]
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    f, c, j, h = m.eval_fused(xd, yd, 0.7)
+    errs += [abs(float(f[0]) - o.obj(x)) / (1 + abs(o.obj(x))), rel(c.cpu().numpy(), o.cons(x)), rel(j.cpu().numpy(), o.jac_coord(x)),
+             rel(h.cpu().numpy(), o.hess_coord(x, y, 0.7))]
+    m.set_product_mode(1, 1)
+    errs += [rel(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)), rel(m.jtprod(x, w), o.jtprod(x, w))]
+    cm = CompressedExaModel(m)
+    for kind, nrow in (("jac", max(m.meta.ncon, 1)), ("hess", m.meta.nvar)):
+        r, cc = (o.jac_structure() if kind == "jac" else o.hess_structure())
+        vals = o.jac_coord(x) if kind == "jac" else o.hess_coord(x, y, 0.7)
+        dense = np.zeros(nrow * m.meta.nvar)
+        np.add.at(dense, (cc - 1) * nrow + (r - 1), np.where(np.isfinite(vals), vals, 0.0))
+        cr, ccol = (cm.jac_structure() if kind == "jac" else cm.hess_structure())
+        cv = (cm.jac_coord(xd) if kind == "jac" else cm.hess_coord(xd, yd, 0.7)).cpu().numpy()
+        got = np.zeros_like(dense)
+        got[((ccol - 1) * nrow + (cr - 1)).cpu().numpy()] = np.where(np.isfinite(cv), cv, 0.0)
+        errs += [rel(got, dense)]
 print("seed", seed, npat, depth, "maxerr %.2e" % max(errs), "BAD" if max(errs) > 1e-9 else "ok", ["%.1e" % e for e in errs], flush=True)
