@@ -67,4 +67,29 @@ if os.environ.get("CHECK_ALL"):
         got = np.zeros_like(dense)
         got[((ccol - 1) * nrow + (cr - 1)).cpu().numpy()] = np.where(np.isfinite(cv), cv, 0.0)
         errs += [rel(got, dense)]
+if os.environ.get("SHARDS"):
+    # the same model cut into SHARDS shards (one after the other on this GPU): partial sums of obj / grad! / cons_nln! /
+    # products add up to the oracle's, the COO slices written at their global positions tile the unsharded COO
+    W = int(os.environ["SHARDS"])
+    m.set_product_mode(0, 0)
+    m.set_grad_mode(0)
+    acc = {k: 0.0 for k in ("obj", "grad", "cons", "jprod", "jtprod", "hprod", "jac", "hess")}
+    for r in range(W):
+        m.set_shard(r, W)
+        acc["obj"] = acc["obj"] + m.obj(x)
+        acc["grad"] = acc["grad"] + m.grad(x)
+        acc["cons"] = acc["cons"] + m.cons(x)
+        acc["jprod"] = acc["jprod"] + m.jprod(x, v)
+        acc["jtprod"] = acc["jtprod"] + m.jtprod(x, w)
+        acc["hprod"] = acc["hprod"] + m.hprod(x, y, v, 0.7)
+        # (COO at global positions: slots of other ranks are left untouched — start from zeros)
+        import torch
+        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        jz = torch.zeros(m.meta.nnzj, dtype=torch.float64, device="cuda"); hz = torch.zeros(m.meta.nnzh, dtype=torch.float64, device="cuda")
+        m.jac_coord(xd, out=jz); m.hess_coord(xd, yd, 0.7, out=hz)
+        acc["jac"] = acc["jac"] + jz.cpu().numpy(); acc["hess"] = acc["hess"] + hz.cpu().numpy()
+    m.set_shard(0, 1)
+    errs += [abs(acc["obj"] - o.obj(x)) / (1 + abs(o.obj(x))), rel(acc["grad"], o.grad(x)), rel(acc["cons"], o.cons(x)),
+             rel(acc["jprod"], o.jprod(x, v)), rel(acc["jtprod"], o.jtprod(x, w)), rel(acc["hprod"], o.hprod(x, y, v, 0.7)),
+             rel(acc["jac"], o.jac_coord(x)), rel(acc["hess"], o.hess_coord(x, y, 0.7))]
 print("seed", seed, npat, depth, "maxerr %.2e" % max(errs), "BAD" if max(errs) > 1e-9 else "ok", ["%.1e" % e for e in errs], flush=True)
