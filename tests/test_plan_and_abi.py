@@ -271,3 +271,60 @@ def test_julia_shim_binds_only_declared_symbols():
     used = sorted(set(re.findall(r":(exa_[a-z0-9_]+)", shim)))
     declared = set(header_symbols()) | set(header_symbols("exahip_recipe.h"))
     assert len(used) >= 10 and not [u for u in used if u not in declared]
+
+
+def test_julia_shim_wire_format_matches_the_header():
+    """No julia here, so the shim's `lower!` cannot run — but what it WRITES is checkable statically: the opcode numbers,
+    the order of the univariate / bivariate function tables (the codes are positions in those tuples) and the field order
+    and types of the four wire structs must be those of include/exahip_ir.h, or every model built from Julia would be
+    silently mis-decoded."""
+    shim = open(os.path.join(ROOT, "examodels.jl_amd", "julia", "ExaModelsHIP.jl")).read()
+    hdr = open(os.path.join(ROOT, "include", "exahip_ir.h")).read()
+
+    def enum_names(prefix, count_name=None):
+        body = next(b for b in re.findall(r"enum\s+\w+\s*\{(.*?)\}", hdr, re.S) if prefix in b)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        names = [t.split("=")[0].strip() for t in body.split(",") if t.strip()]
+        return [n[len(prefix):].lower() for n in names if n.startswith(prefix) and n != count_name]
+
+    # opcodes
+    ops = re.search(r"const\s+(OP_[A-Z_, ]+?)\s*=\s*Int32\.\(0:(\d+)\)", shim)
+    jl_ops = [o.strip()[3:].lower() for o in ops.group(1).split(",")]
+    assert jl_ops == enum_names("EXA_OP_")
+    assert int(ops.group(2)) == len(jl_ops) - 1
+    # function tables: Julia function -> header name
+    alias = {"+": "plus", "-": "minus", "*": "mul", "/": "div", "^": "pow"}
+    un = re.search(r"const UN = Dict\(.*?enumerate\(\((.*?)\)\)\)", shim, re.S).group(1)
+    jl_un = [alias.get(t.strip(), t.strip()) for t in un.replace("\n", " ").split(",")]
+    assert jl_un == enum_names("EXA_U_", "EXA_U_COUNT")
+    bn = re.search(r"const BIN = Dict\(.*?enumerate\(\((.*?)\)\)\)", shim, re.S).group(1)
+    jl_bin = [{"+": "add", "-": "sub", "atan": "atan2"}.get(t.strip(), alias.get(t.strip(), t.strip())) for t in bn.split(",")]
+    assert jl_bin == enum_names("EXA_B_", "EXA_B_COUNT")
+    # wire structs: (type, name) sequences
+    ctype = {"int32_t": "Int32", "int64_t": "Int64", "double": "Float64"}
+
+    def c_fields(name):
+        body = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + r"_t;", hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.replace("const", "").split())
+            if not decl:
+                continue
+            m = re.match(r"([\w ]+?)\s*(\*?)\s*(\w+)$", decl)
+            typ, ptr, field = m.group(1).strip(), m.group(2), m.group(3)
+            out.append(("Ptr" if ptr else ctype[typ], field.lstrip("_")))
+        return out
+
+    def jl_fields(name):
+        body = re.search(r"struct " + name + r";(.*?)end", shim, re.S).group(1)
+        out = []
+        for decl in body.replace("\n", " ").split(";"):
+            decl = decl.strip()
+            if decl:
+                field, typ = decl.split("::")
+                out.append(("Ptr" if typ.startswith("Ptr") else typ, field))
+        return out
+
+    for c, j in (("exa_node", "CNode"), ("exa_column", "CColumn"), ("exa_pattern", "CPattern"), ("exa_model_desc", "CModelDesc")):
+        assert c_fields(c) == jl_fields(j), (c, c_fields(c), jl_fields(j))
