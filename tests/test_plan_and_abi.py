@@ -328,3 +328,39 @@ def test_julia_shim_wire_format_matches_the_header():
 
     for c, j in (("exa_node", "CNode"), ("exa_column", "CColumn"), ("exa_pattern", "CPattern"), ("exa_model_desc", "CModelDesc")):
         assert c_fields(c) == jl_fields(j), (c, c_fields(c), jl_fields(j))
+
+
+def test_julia_shim_ccall_signatures_match_the_header():
+    """Every `ccall((:exa_x, LIB), Ret, (ArgTypes...), ...)` of the shim against the prototype of exa_x in the headers:
+    return type, number of arguments, and for each argument scalar-vs-pointer and the scalar's width (a Cint passed where
+    the ABI takes int64_t corrupts the following arguments without any error)."""
+    shim = open(os.path.join(ROOT, "examodels.jl_amd", "julia", "ExaModelsHIP.jl")).read()
+    hdr = "".join(open(os.path.join(ROOT, "include", f)).read() for f in ("exahip.h", "exahip_recipe.h"))
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for ret, name, args in re.findall(r"\n\s*((?:const\s+)?\w+\s*\*?)\s*(exa_\w+)\s*\(([^;{]*?)\)\s*;", hdr):
+        protos[name] = (ret.strip(), [] if args.strip() in ("", "void") else [a.strip() for a in args.split(",")])
+
+    def c_class(decl):
+        decl = decl.replace("const", " ")
+        if "*" in decl or "[" in decl or re.search(r"\bexa_allreduce_fn\b", decl):
+            return "ptr"
+        typ = decl.split()[0] if len(decl.split()) > 1 else decl.strip()
+        return {"int": "i32", "int32_t": "i32", "int64_t": "i64", "double": "f64", "float": "f32", "char": "i8"}[typ]
+
+    def jl_class(t):
+        t = t.strip()
+        if t.startswith(("Ptr{", "Ref{")) or t in ("Cstring",):
+            return "ptr"
+        return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Cdouble": "f64", "Float64": "f64", "Cfloat": "f32"}[t]
+
+    calls = re.findall(r"ccall\(\(:(exa_\w+), LIB\),\s*(\w+(?:\{\w+\})?),\s*\(([^)]*)\)", shim)
+    assert len(calls) >= 25
+    for name, ret, argt in calls:
+        assert name in protos, name
+        cret, cargs = protos[name]
+        jargs = [a for a in argt.split(",") if a.strip()]
+        assert len(jargs) == len(cargs), (name, jargs, cargs)
+        assert jl_class(ret) == c_class(cret + " x"), (name, ret, cret)
+        for ja, ca in zip(jargs, cargs):
+            assert jl_class(ja) == c_class(ca), (name, ja, ca)
