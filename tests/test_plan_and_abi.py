@@ -356,6 +356,11 @@ def test_julia_shim_ccall_signatures_match_the_header():
 
     calls = re.findall(r"ccall\(\(:(exa_\w+), LIB\),\s*(\w+(?:\{\w+\})?),\s*\(([^)]*)\)", shim)
     assert len(calls) >= 25
+    # the Julia snippets of INTEGRATION.md are held to the same prototypes
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    doc_calls = re.findall(r"ccall\(\(:(exa_\w+), \"libexahip\.so\"\),\s*(\w+(?:\{\w+\})?),\s*\(([^)]*)\)", doc)
+    assert len(doc_calls) >= 8
+    calls += doc_calls
     for name, ret, argt in calls:
         assert name in protos, name
         cret, cargs = protos[name]
