@@ -187,13 +187,12 @@ __global__ void __launch_bounds__(256) k_spmv_long(const uint32_t *__restrict__ 
                                                    const uint32_t *__restrict__ perm, const double *__restrict__ vals,
                                                    const int64_t *__restrict__ other, const int64_t *__restrict__ rows,
                                                    const int64_t *__restrict__ cols, int skip_diag, const double *__restrict__ v,
-                                                   double *__restrict__ out) {
+                                                   double *__restrict__ partial) {
     __shared__ double red[4];
     const int64_t k = list[blockIdx.x];
     const int64_t beg = ptr[k] + (int64_t)blockIdx.y * kChunk;
     const int64_t end = beg + kChunk < ptr[k + 1] ? beg + kChunk : ptr[k + 1];
-    if (beg >= ptr[k + 1]) return;
-    double s = 0.0;
+    double s = 0.0;   // (a chunk past the group's end leaves a zero)
     for (int64_t j = beg + threadIdx.x; j < end; j += 256) {
         const uint32_t e = perm[j];
         if (skip_diag && rows[e] == cols[e]) continue;
@@ -202,7 +201,7 @@ __global__ void __launch_bounds__(256) k_spmv_long(const uint32_t *__restrict__ 
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) add_f64(&out[k], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * gridDim.y + blockIdx.y] = red[0] + red[1] + red[2] + red[3];
 }
 
 __global__ void __launch_bounds__(256) k_other(const uint32_t *__restrict__ perm, const int64_t *__restrict__ other,
@@ -256,13 +255,12 @@ __global__ void __launch_bounds__(256) k_spmv_gather2(const int64_t *__restrict_
 }
 __global__ void __launch_bounds__(256) k_spmv_long2(const uint32_t *__restrict__ list, const int64_t *__restrict__ ptr,
                                                     const uint32_t *__restrict__ perm, const uint32_t *__restrict__ oth,
-                                                    const double *__restrict__ vals, const double *__restrict__ v, double *__restrict__ out) {
+                                                    const double *__restrict__ vals, const double *__restrict__ v, double *__restrict__ partial) {
     __shared__ double red[4];
     const int64_t k = list[blockIdx.x];
     const int64_t beg = ptr[k] + (int64_t)blockIdx.y * kChunk;
     const int64_t end = beg + kChunk < ptr[k + 1] ? beg + kChunk : ptr[k + 1];
-    if (beg >= ptr[k + 1]) return;
-    double s = 0.0;
+    double s = 0.0;   // (a chunk past the group's end leaves a zero)
     for (int64_t j = beg + threadIdx.x; j < end; j += 256) {
         const uint32_t o = oth[j];
         if (o != 0xffffffffu) s += vals[perm[j]] * v[o];
@@ -270,7 +268,7 @@ __global__ void __launch_bounds__(256) k_spmv_long2(const uint32_t *__restrict__
     for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) add_f64(&out[k], red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * gridDim.y + blockIdx.y] = red[0] + red[1] + red[2] + red[3];
 }
 
 // one thread per group (variable / row): contributions added in ascending slot order -> deterministic
@@ -382,7 +380,7 @@ void build_compressed(CompressedCOO &c, const int64_t *rows, const int64_t *cols
 }
 
 void SortedIndex::release() {
-    for (void **q : {&perm, &ptr, &long_rows, &oth}) { if (*q) (void)hipFree(*q); *q = nullptr; }
+    for (void **q : {&perm, &ptr, &long_rows, &oth, &partial}) { if (*q) (void)hipFree(*q); *q = nullptr; }
     nnz = ndim = nlong = maxlen = 0;
 }
 
@@ -424,6 +422,16 @@ void build_sorted_index(SortedIndex &s, const int64_t *keys1, int64_t nnz, int64
     }
 }
 
+// the chunk sums of a long group, added to out[group] in chunk order by one thread: the same bits every time
+__global__ void __launch_bounds__(256) k_spmv_fold(const uint32_t *__restrict__ list, const double *__restrict__ partial, int chunks,
+                                                   double *__restrict__ out, int64_t nlong) {
+    const int64_t l = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (l >= nlong) return;
+    double s = out[list[l]];
+    for (int c = 0; c < chunks; c++) s += partial[l * chunks + c];
+    out[list[l]] = s;
+}
+
 void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other, const int64_t *rows, const int64_t *cols, bool skip_diag,
                  const double *v, double *out, bool accumulate, hipStream_t stream) {
     if (s.ndim == 0) return;
@@ -438,8 +446,11 @@ void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other,
         }
         if (s.nlong) {
             const unsigned chunks = (unsigned)((s.maxlen + kChunk - 1) / kChunk);
+            if (!s.partial) HIPCHK_C(hipMalloc(&const_cast<SortedIndex &>(s).partial, 8 * (size_t)s.nlong * chunks));
             hipLaunchKernelGGL(k_spmv_long2, dim3((unsigned)s.nlong, chunks), dim3(256), 0, stream, (const uint32_t *)s.long_rows,
-                               (const int64_t *)s.ptr, (const uint32_t *)s.perm, (const uint32_t *)s.oth, vals, v, out);
+                               (const int64_t *)s.ptr, (const uint32_t *)s.perm, (const uint32_t *)s.oth, vals, v, (double *)s.partial);
+            hipLaunchKernelGGL(k_spmv_fold, dim3(grid_for(s.nlong)), dim3(256), 0, stream, (const uint32_t *)s.long_rows, (const double *)s.partial,
+                               (int)chunks, out, s.nlong);
         }
         return;
     }
@@ -447,8 +458,11 @@ void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other,
                        other, rows, cols, skip_diag ? 1 : 0, v, out, accumulate ? 1 : 0, s.ndim);
     if (s.nlong) {
         const unsigned chunks = (unsigned)((s.maxlen + kChunk - 1) / kChunk);
+        if (!s.partial) HIPCHK_C(hipMalloc(&const_cast<SortedIndex &>(s).partial, 8 * (size_t)s.nlong * chunks));
         hipLaunchKernelGGL(k_spmv_long, dim3((unsigned)s.nlong, chunks), dim3(256), 0, stream, (const uint32_t *)s.long_rows,
-                           (const int64_t *)s.ptr, (const uint32_t *)s.perm, vals, other, rows, cols, skip_diag ? 1 : 0, v, out);
+                           (const int64_t *)s.ptr, (const uint32_t *)s.perm, vals, other, rows, cols, skip_diag ? 1 : 0, v, (double *)s.partial);
+        hipLaunchKernelGGL(k_spmv_fold, dim3(grid_for(s.nlong)), dim3(256), 0, stream, (const uint32_t *)s.long_rows, (const double *)s.partial,
+                           (int)chunks, out, s.nlong);
     }
 }
 

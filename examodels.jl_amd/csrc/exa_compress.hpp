@@ -54,6 +54,7 @@ struct SortedIndex {
     // per sorted position: 0-based index of the OTHER coordinate of that entry (what v is gathered with), or
     // 0xffffffff for an entry this product skips — read sequentially instead of three random int64 loads per entry
     void *oth = nullptr;         // uint32[nnz], optional (attach_other)
+    void *partial = nullptr;     // double[nlong * chunks]: per-chunk sums of the long groups, folded in chunk order (deterministic)
     void release();
 };
 // fills s.oth from the structure arrays (1-based int64, device); entries with rows[e] == cols[e] are marked skipped when
