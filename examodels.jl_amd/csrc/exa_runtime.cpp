@@ -1128,6 +1128,17 @@ int exa_set_grad_mode(int id, int mode) {
         h.grad_mode = mode;
     });
 }
+/* All three at once: on = grad!, jtprod and hprod by sorted gather wherever the model allows it (bit-reproducible run to
+ * run, like every other callback); off = back to undecided (-1: the persisted exa_tune decisions, else atomics). */
+int exa_set_deterministic(int id, int on) {
+    return guard(id, true, [&](Handle &h) {
+        if (on) {
+            if (grad_sorted_possible(h)) { grad_setup(h); h.grad_mode = 1; }
+            if (sorted_possible(h, false)) { prod_setup(h, false); h.jt_mode = 1; }
+            if (sorted_possible(h, true)) { prod_setup(h, true); h.hp_mode = 1; }
+        } else { h.grad_mode = -1; h.jt_mode = -1; h.hp_mode = -1; }
+    });
+}
 int exa_get_grad_mode(int id, int *mode) {
     Handle *h = get(id);
     if (!h || !mode) return 1;

@@ -513,6 +513,10 @@ class ExaModel:
         """grad!: 0 gathered + FP64 atomics, 1 gradient COO + sorted gather (deterministic), -1 whatever tune() persisted"""
         capi.check(self._L.exa_set_grad_mode(self.id, int(mode)), "exa_set_grad_mode")
 
+    def set_deterministic(self, on=True):
+        """grad!, jtprod and hprod by sorted gather (bit-reproducible) / back to undecided"""
+        capi.check(self._L.exa_set_deterministic(self.id, 1 if on else 0), "exa_set_deterministic")
+
     def grad_mode(self):
         a = ctypes.c_int(0)
         capi.check(self._L.exa_get_grad_mode(self.id, ctypes.addressof(a)), "exa_get_grad_mode")

@@ -178,6 +178,7 @@ usestream(m) = chk(ccall((:exa_set_stream, LIB), Cint, (Cint, Ptr{Cvoid}), m.ext
 # Explicit, blocking tuning (block orders, hess_coord! kernel, product implementations); persisted by the library.
 tune!(m; what = 7) = (usestream(m); chk(ccall((:exa_tune, LIB), Cint, (Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, what, C_NULL, C_NULL), "exa_tune"))
 # grad!: 0 = gathered + FP64 atomics, 1 = gradient COO + sorted gather (the reference's scheme, deterministic), -1 = what tune! persisted
+deterministic!(m, on::Bool = true) = chk(ccall((:exa_set_deterministic, LIB), Cint, (Cint, Cint), m.ext.id, on), "exa_set_deterministic")
 grad_mode!(m, mode::Integer) = chk(ccall((:exa_set_grad_mode, LIB), Cint, (Cint, Cint), m.ext.id, mode), "exa_set_grad_mode")
 
 # ---- multi-GPU: one Julia process per GPU (include/exahip.h "multi-GPU behind the ABI") ---------------------------------

@@ -188,6 +188,10 @@ int exa_get_product_mode(int id, int *jtprod_mode, int *hprod_mode);
  * decision (what & 4) if there is one, else 0.  A sharded model always runs 0. */
 int exa_set_grad_mode(int id, int mode);
 int exa_get_grad_mode(int id, int *mode);
+/* All three switches at once.  on != 0: exa_grad, exa_jtprod and exa_hprod by sorted gather wherever the model allows it
+ * (not a model sharded at global COO positions) — with that, EVERY callback is bit-reproducible run to run; on == 0: back
+ * to undecided (-1). */
+int exa_set_deterministic(int id, int on);
 int exa_jac_structure  (int id, int32_t *rows, int32_t *cols);
 int exa_hess_structure (int id, int32_t *rows, int32_t *cols);
 int exa_jac_structure64 (int id, int64_t *rows, int64_t *cols);               /* Julia Vector{Int} */

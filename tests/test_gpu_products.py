@@ -202,3 +202,37 @@ def test_grad_tuning_picks_the_sorted_gather_for_hot_targets(libs, tmp_path, mon
     m2.grad(xd)
     assert m2.grad_mode() == 1                       # the persisted decision
     np.testing.assert_allclose(m2.grad(xd).cpu().numpy(), ref, rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["acopf30", "rocket50", "mixed", "lv1000"])
+def test_deterministic_switch_makes_every_callback_bit_reproducible(libs, name):
+    """exa_set_deterministic: grad!, jtprod and hprod by sorted gather.  Ten evaluations of everything, interleaved: one
+    bit pattern per output — and still the oracle's values."""
+    import torch
+    import oracle
+    from exahip import ExaModel
+    m = ExaModel(ZOO[name]())
+    o = oracle.OracleModel(m.ir)
+    m.set_deterministic(True)
+    assert m.grad_mode() == 1 and m.product_mode() == (1, 1)
+    x, y, s = point(m.meta.x0, m.meta.ncon, seed=29)
+    v = np.random.default_rng(5).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(6).standard_normal(max(m.meta.ncon, 1))[:m.meta.ncon]
+    dev = torch.device("cuda:0")
+    xd, yd, vd, wd = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (x, y, v, w))
+    first = None
+    for _ in range(10):
+        f, c, j, h = m.eval_fused(xd, yd, s)
+        outs = [m.grad(xd), m.jtprod(xd, wd), m.hprod(xd, yd, vd, s), m.cons(xd), m.jac_coord(xd), m.hess_coord(xd, yd, s), c, j, h, f,
+                m.jprod(xd, vd)]
+        torch.cuda.synchronize()
+        outs = [t.clone() for t in outs]
+        if first is None:
+            first = outs
+        else:
+            assert all(torch.equal(a, b) for a, b in zip(first, outs))
+    np.testing.assert_allclose(first[0].cpu().numpy(), o.grad(x), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(first[1].cpu().numpy(), o.jtprod(x, w), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(first[2].cpu().numpy(), o.hprod(x, y, v, s), rtol=1e-10, atol=1e-11)
+    m.set_deterministic(False)
+    assert m.grad_mode() == -1 and m.product_mode() == (-1, -1)
