@@ -4,8 +4,11 @@
 A "step" is one hess_coord!(m, x, y, H; obj_weight) with x, y and H already resident in HBM.
 
     python bench.py                        1 GPU, config 2: Luksan-Vlcek N=1e7 (benchmark/runbenchmark.jl:163-169) — the
-                                           configuration the metric is quoted on; the line also carries the N=1 point of
-                                           config 5 (LV N=1e8 on one GPU) as "config5_n1"
+                                           configuration the metric is quoted on; the line also carries, as objects of
+                                           the same shape (value, ms_per_step, roofline, cpu_baseline), "config3" (rocket
+                                           nh=1e6), "config4" (ACOPF 78k) and "config5_n1" (LV N=1e8 on one GPU), and
+                                           "scale_base" = the config-5 workload on ONE GPU: the base a scaling ratio of
+                                           the N > 1 lines (same workload, strong scaling) has to be computed against
     python bench.py --config 3|4           Goddard rocket nh=1e6 / ACOPF at case78484 scale (synthetic topology), 1 GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus 8 --steps K --warmup W
@@ -247,8 +250,8 @@ def traffic_for(m, config, per_gpu_points):
     """HBM bytes per launch from the PMC counters: measured in separate rocprofv3 passes (cannot run inside the timed
     process) and committed under profiles/ TOGETHER WITH the name of the module they were measured on — attached only
     when this run executes exactly that module on exactly that workload, null otherwise (never a stale number)."""
-    path = os.path.join(ROOT, "profiles", f"r2_traffic_config{config}.json")
-    if not os.path.exists(path):
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic_config{config}.json") for r in (3, 2)) if os.path.exists(q)), None)
+    if path is None:
         return None
     with open(path) as fh:
         t = json.load(fh)
@@ -256,6 +259,12 @@ def traffic_for(m, config, per_gpu_points):
     if t.get("module") != m._L.exa_module_name(m.id).decode() or t.get("points") != per_gpu_points or t.get("kernel") != kernel:
         return None
     return t.get("hbm_bytes_per_launch")
+
+
+def scale_base_of(sub):
+    return {"workload": sub["config"]["workload"], "n_gpus": 1, "value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
+            "roofline_frac": sub["roofline"]["frac"], "kernel": sub["roofline"]["kernel"], "steps": sub["steps"],
+            "note": "same workload as the N > 1 lines (config 5, strong scaling) on ONE GPU: divide their `value` by this one"}
 
 
 def main():
@@ -276,6 +285,8 @@ def main():
                          "instead of the synthetic topology of the same size")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-config5-n1", action="store_true", help="skip the LV N=1e8 single-GPU point attached to the default line")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the config3 / config4 objects attached to the default line")
+    ap.add_argument("--no-scale-base", action="store_true", help="N > 1: skip the one-GPU run of the same workload on rank 0 (scale_base)")
     ap.add_argument("--no-tune", action="store_true", help="skip exa_tune (block order stays sequential unless persisted)")
     ap.add_argument("--all-callbacks", action="store_true", help="also time obj/cons/grad/jac (secondary)")
     ap.add_argument("--no-collectives", action="store_true", help="N > 1: skip the secondary grad! + RCCL all-reduce timing")
@@ -333,13 +344,36 @@ def main():
     warmup = args.warmup if args.warmup is not None else 100
 
     line = run_config(config, points, world, rank, dev, backend, steps, warmup, args, strong)
+    keep = ("value", "unit", "ms_per_step", "evals_per_s", "per_call_ms", "roofline", "cpu_baseline", "config", "steps", "warmup")
     if rank == 0 and world == 1 and config == 2 and not args.no_config5_n1:
         # the N=1 point of config 5's curve (LV N=1e8 on ONE GPU: x, y and the COO are far beyond the 256 MB MALL)
         try:
             sub = run_config(5, int(1e8), 1, 0, dev, backend, 100, 10, args, False, secondary=True)
-            line["config5_n1"] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "evals_per_s", "roofline", "config", "steps", "warmup")}
+            line["config5_n1"] = {k: sub[k] for k in keep if k in sub}
+            line["scale_base"] = scale_base_of(sub)
         except Exception as e:      # never lose the contract line to the secondary measurement
             line["config5_n1"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and config == 2 and not args.no_extra_configs:
+        # configs 3 and 4 (BASELINE.json: rocket nh=1e6, ACOPF at case78484 scale) ride along in the driver's run: the
+        # same measurement as `bench.py --config 3|4`, cpu_baseline included (north_star names PGLIB-OPF for the >= 10x bar)
+        for c, pts in ((3, int(1e6)), (4, 0)):
+            try:
+                sub = run_config(c, pts, 1, 0, dev, backend, 1000, 100, args, False, secondary=True, with_cpu=not args.no_cpu)
+                line[f"config{c}"] = {k: sub[k] for k in keep if k in sub}
+            except Exception as e:
+                line[f"config{c}"] = {"error": repr(e)}
+    if world > 1 and config == 5 and strong and not args.no_scale_base:
+        # the SAME workload (all N points) on one GPU, measured by rank 0 in this very run while the other ranks wait:
+        # value / scale_base.value is the strong-scaling speed-up (the N = 1 default line runs config 2, another workload)
+        if rank == 0:
+            try:
+                sub = run_config(5, points, 1, 0, dev, backend, 50, 5, args, False, secondary=True)
+                line["scale_base"] = scale_base_of(sub)
+                line["speedup_vs_scale_base"] = line["value"] / sub["value"]
+            except Exception as e:
+                line["scale_base"] = {"error": repr(e)}
+        if not line.get("_hung", False):
+            dist.barrier()
     hung = line.pop("_hung", False)
     if rank == 0:
         print(json.dumps(line), flush=True)
@@ -353,7 +387,7 @@ def main():
         dist.destroy_process_group()
 
 
-def run_config(config, points, world, rank, dev, backend, steps, warmup, args, strong, secondary=False):
+def run_config(config, points, world, rank, dev, backend, steps, warmup, args, strong, secondary=False, with_cpu=False):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -461,12 +495,16 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
                   "tune_ms": tune_ms,
                   "note": "first_hess_call_ms = host time of the first exa_hess + its completion (asynchronous launch, no measuring inside)"},
     }
-    if secondary:
-        return out
     # SURVEY §8d protocol: min and median over >= 30 individually event-bracketed calls (the reference harness reports
     # the BenchmarkTools minimum, benchmark/runbenchmark.jl:94); outside the contract timing above
     per_call = sorted(time_hess(1) for _ in range(50))
-    out["per_call_ms"] = {"min": per_call[0], "median": per_call[len(per_call) // 2], "n": len(per_call)}
+    out["per_call_ms"] = {"min": per_call[0], "median": per_call[len(per_call) // 2], "n": len(per_call),
+                          "note": "50 individually event-bracketed calls; with few --steps (a timed region of a few ms) this is the better-conditioned number"}
+    if secondary:
+        if with_cpu:
+            out["cpu_baseline"] = cpu_baseline(config, points, os.cpu_count() or 1)
+            out["cpu_baseline"]["gpu_over_cpu_1thread"] = value / out["cpu_baseline"]["value"]
+        return out
     if world > 1 and not args.no_collectives:
         # secondary (never part of `value`): the callbacks that DO need a collective, completed INSIDE libexahip by
         # ncclAllReduce over xGMI on the model's stream (exa_comm_init): grad! (nvar doubles) and obj (1 double).
@@ -522,7 +560,8 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
             m.time_callback(name, 3, xd, out=buf)
             sec[name + "_ms"] = m.time_callback(name, 20, xd, out=buf)
         out["secondary_callbacks"] = sec
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and not args.no_cpu:
+        # rank 0's host cores, at N > 1 too (the bounded LV sample of the same workload; the other ranks wait at the barrier)
         out["cpu_baseline"] = cpu_baseline(config, points, os.cpu_count() or 1)
         out["cpu_baseline"]["gpu_over_cpu_1thread"] = value / out["cpu_baseline"]["value"]
     return out

@@ -439,8 +439,7 @@ void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other,
         {
             const double mean = (double)s.nnz / (double)std::max<int64_t>(s.ndim, 1);
             int G = mean <= 1.5 ? 1 : (mean <= 3.0 ? 2 : (mean <= 6.0 ? 4 : (mean <= 12.0 ? 8 : 16)));
-            if (const char *ge = getenv("EXAHIP_SPMV_G")) G = atoi(ge);
-            auto k = G == 1 ? k_spmv_gather2<1> : G == 2 ? k_spmv_gather2<2> : G == 4 ? k_spmv_gather2<4> : G == 8 ? k_spmv_gather2<8> : G == 16 ? k_spmv_gather2<16> : k_spmv_gather2<32>;
+            auto k = G == 1 ? k_spmv_gather2<1> : G == 2 ? k_spmv_gather2<2> : G == 4 ? k_spmv_gather2<4> : G == 8 ? k_spmv_gather2<8> : k_spmv_gather2<16>;
             hipLaunchKernelGGL(k, dim3(grid_for(s.ndim * G)), dim3(256), 0, stream, (const int64_t *)s.ptr, (const uint32_t *)s.perm,
                                (const uint32_t *)s.oth, vals, v, out, accumulate ? 1 : 0, s.ndim);
         }

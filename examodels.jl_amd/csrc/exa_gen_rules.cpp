@@ -1,0 +1,350 @@
+// exa_gen_rules.cpp — the derivative tables of the reference as symbolic rules.
+//
+// What it restates: _UNIVARIATES / _BIVARIATES of src/functionlist.jl:6-81 (closed-form f', f'' and the five bivariate
+// partials), the integer-power rewrite of src/specialization.jl:193-202 and the FirstFixed / SecondFixed forms of
+// src/register.jl:231-266.  Formulas are algebraically the table's; a few are written through the already-computed primal
+// to save FP64 divides (parity bar 1e-10 relative; EXAHIP_STRICT_IEEE=1 restores the table's own forms
+// where they differ in special values).
+#include "exa_gen.hpp"
+
+namespace exa {
+namespace gen {
+
+std::string fmt_double(double v) {
+    if (std::isnan(v)) return "__builtin_nan(\"\")";
+    if (std::isinf(v)) return v > 0 ? "__builtin_inf()" : "(-__builtin_inf())";
+    char buf[64];
+    if (v == std::floor(v) && std::fabs(v) < 1e15) snprintf(buf, sizeof buf, "%.1f", v);
+    else snprintf(buf, sizeof buf, "%.17g", v);
+    std::string s = buf;
+    if (s.find_first_of(".en") == std::string::npos) s += ".0";
+    if (v < 0 || (v == 0 && std::signbit(v))) s = "(" + s + ")";
+    return s;
+}
+// ---------------------------------------------------------------------------------------------------
+// function rules: (x, y, h) of a univariate; $1 = argument, $2 = primal f, $3 = first derivative
+// ---------------------------------------------------------------------------------------------------
+struct UnSpec { const char *f, *df, *ddf; };
+// A leading '=' marks an exact literal (lets the reverse sweep fold it).
+const double kPi = 3.14159265358979323846;
+const double kD2R = kPi / 180.0, kR2D = 180.0 / kPi;
+
+std::mutex g_gen_mu;
+
+static const UnSpec *un_spec(int fn) {
+    static UnSpec T[EXA_U_COUNT];
+    static bool init = false;
+    if (!init) {
+        init = true;
+        T[EXA_U_PLUS] = {"$1", "=1", "=0"};
+        T[EXA_U_MINUS] = {"-$1", "=-1", "=0"};
+        T[EXA_U_INV] = {"1.0 / $1", "-($2 * $2)", "2.0 * $2 * $2 * $2"};
+        T[EXA_U_SQRT] = {"sqrt($1)", "0.5 / $2", "-0.25 / ($2 * $2 * $2)"};
+        T[EXA_U_CBRT] = {"cbrt($1)", "1.0 / (3.0 * $2 * $2)", "-2.0 / (9.0 * $2 * $2 * $2 * $2 * $2)"};
+        T[EXA_U_ABS] = {"fabs($1)", "(__builtin_signbit($1) ? -1.0 : 1.0)", "=0"};
+        T[EXA_U_ABS2] = {"$1 * $1", "2.0 * $1", "=2"};
+        T[EXA_U_SIGN] = {"exa_sign($1)", "=0", "=0"};
+        T[EXA_U_EXP] = {"exp($1)", "$2", "$2"};
+        T[EXA_U_EXP2] = {"exp2($1)", "EXA_LOG2 * $2", "EXA_LOG2 * EXA_LOG2 * $2"};
+        T[EXA_U_EXP10] = {"exp10($1)", "EXA_LOG10 * $2", "EXA_LOG10 * EXA_LOG10 * $2"};
+        T[EXA_U_EXPM1] = {"expm1($1)", "exp($1)", "$3"};
+        T[EXA_U_LOG] = {"log($1)", "1.0 / $1", "-($3 * $3)"};
+        T[EXA_U_LOG2] = {"log2($1)", "1.0 / (EXA_LOG2 * $1)", "-$3 / $1"};
+        T[EXA_U_LOG1P] = {"log1p($1)", "1.0 / (1.0 + $1)", "-($3 * $3)"};
+        T[EXA_U_LOG10] = {"log10($1)", "1.0 / (EXA_LOG10 * $1)", "-$3 / $1"};
+        T[EXA_U_SIN] = {nullptr, nullptr, nullptr};   // handled through sincos
+        T[EXA_U_COS] = {nullptr, nullptr, nullptr};
+        T[EXA_U_TAN] = {"tan($1)", "1.0 + $2 * $2", "2.0 * $3 * $2"};
+        T[EXA_U_ASIN] = {"asin($1)", "1.0 / sqrt(1.0 - $1 * $1)", "$1 * $3 / (1.0 - $1 * $1)"};
+        T[EXA_U_ACOS] = {"acos($1)", "-1.0 / sqrt(1.0 - $1 * $1)", "$1 * $3 / (1.0 - $1 * $1)"};
+        T[EXA_U_ATAN] = {"atan($1)", "1.0 / (1.0 + $1 * $1)", "-2.0 * $1 * $3 * $3"};
+        T[EXA_U_ACOT] = {"atan(1.0 / $1)", "-1.0 / (1.0 + $1 * $1)", "2.0 * $1 * $3 * $3"};
+        T[EXA_U_CSC] = {"1.0 / sin($1)", "-$2 / tan($1)", "(1.0 + 2.0 * exa_sq(1.0 / tan($1))) * $2"};
+        T[EXA_U_SEC] = {"1.0 / cos($1)", "$2 * tan($1)", "$2 * $2 * $2 + $2 * exa_sq(tan($1))"};
+        T[EXA_U_COT] = {"1.0 / tan($1)", "-1.0 - $2 * $2", "-2.0 * $2 * $3"};
+        T[EXA_U_SINH] = {"sinh($1)", "cosh($1)", "$2"};
+        T[EXA_U_COSH] = {"cosh($1)", "sinh($1)", "$2"};
+        T[EXA_U_TANH] = {"tanh($1)", "1.0 - $2 * $2", "-2.0 * $2 * $3"};
+        T[EXA_U_ASINH] = {"asinh($1)", "1.0 / sqrt(1.0 + $1 * $1)", "-$1 * $3 / (1.0 + $1 * $1)"};
+        T[EXA_U_ACOSH] = {"acosh($1)", "1.0 / sqrt($1 * $1 - 1.0)", "-$1 * $3 / ($1 * $1 - 1.0)"};
+        T[EXA_U_CSCH] = {"1.0 / sinh($1)", "-$2 / tanh($1)", "$2 * $2 * $2 + $2 * exa_sq(1.0 / tanh($1))"};
+        T[EXA_U_SECH] = {"1.0 / cosh($1)", "-tanh($1) * $2", "(2.0 * exa_sq(tanh($1)) - 1.0) * $2"};
+        T[EXA_U_COTH] = {"1.0 / tanh($1)", "-exa_sq(1.0 / sinh($1))", "-2.0 * $3 * $2"};
+        T[EXA_U_SIND] = {"exa_sind($1)", "EXA_D2R * exa_cosd($1)", "-(EXA_D2R * EXA_D2R) * $2"};
+        T[EXA_U_COSD] = {"exa_cosd($1)", "-EXA_D2R * exa_sind($1)", "-(EXA_D2R * EXA_D2R) * $2"};
+        T[EXA_U_TAND] = {"exa_tand($1)", "EXA_D2R * (1.0 + $2 * $2)", "2.0 * EXA_D2R * $2 * $3"};
+        T[EXA_U_CSCD] = {"1.0 / exa_sind($1)", "-EXA_D2R * $2 / exa_tand($1)", "(EXA_D2R * EXA_D2R) * $2 * (1.0 + 2.0 * exa_sq(1.0 / exa_tand($1)))"};
+        T[EXA_U_SECD] = {"1.0 / exa_cosd($1)", "EXA_D2R * exa_tand($1) * $2", "(EXA_D2R * EXA_D2R) * $2 * (1.0 + 2.0 * exa_sq(exa_tand($1)))"};
+        T[EXA_U_COTD] = {"1.0 / exa_tand($1)", "-EXA_D2R * (1.0 + $2 * $2)", "-2.0 * EXA_D2R * $2 * $3"};
+        T[EXA_U_ATAND] = {"EXA_R2D * atan($1)", "1.0 / (EXA_D2R * (1.0 + $1 * $1))", "-2.0 * EXA_D2R * $1 * $3 * $3"};
+        T[EXA_U_ACOTD] = {"EXA_R2D * atan(1.0 / $1)", "-1.0 / (EXA_D2R * (1.0 + $1 * $1))", "2.0 * EXA_D2R * $1 * $3 * $3"};
+        T[EXA_U_SINPI] = {"sinpi($1)", "EXA_PI * cospi($1)", "-(EXA_PI * EXA_PI) * $2"};
+        T[EXA_U_COSPI] = {"cospi($1)", "-EXA_PI * sinpi($1)", "-(EXA_PI * EXA_PI) * $2"};
+        T[EXA_U_SINC] = {"exa_sinc($1)",
+                         "(-sinpi($1) + EXA_PI * $1 * cospi($1)) / (EXA_PI * ($1 * $1))",
+                         "((2.0 * EXA_PI * EXA_PI) * sinpi($1) - (2.0 * EXA_PI * EXA_PI * EXA_PI) * $1 * cospi($1) - "
+                         "(EXA_PI * EXA_PI * EXA_PI * EXA_PI) * ($1 * $1) * sinpi($1)) / ((EXA_PI * EXA_PI * EXA_PI) * ($1 * $1 * $1))"};
+        T[EXA_U_DEG2RAD] = {"EXA_D2R * $1", "=D2R", "=0"};
+        T[EXA_U_RAD2DEG] = {"EXA_R2D * $1", "=R2D", "=0"};
+        T[EXA_U_SIGNBIT] = {"(__builtin_signbit($1) ? 1.0 : 0.0)", "=0", "=0"};
+        T[EXA_U_FLOOR] = {"floor($1)", "=0", "=0"};
+        T[EXA_U_CEIL] = {"ceil($1)", "=0", "=0"};
+        T[EXA_U_ATANH] = {"atanh($1)", "(fabs($1) > 1.0 ? __builtin_nan(\"\") : 1.0 / (1.0 - $1 * $1))",
+                          "(fabs($1) > 1.0 ? __builtin_nan(\"\") : 2.0 * $1 * exa_sq(1.0 / (1.0 - $1 * $1)))"};
+        T[EXA_U_ACOTH] = {"atanh(1.0 / $1)", "(fabs($1) < 1.0 ? __builtin_nan(\"\") : 1.0 / (1.0 - $1 * $1))",
+                          "(fabs($1) < 1.0 ? __builtin_nan(\"\") : 2.0 * $1 * exa_sq(1.0 / (1.0 - $1 * $1)))"};
+    }
+    return &T[fn];
+}
+
+static double host_un(int fn, double x) {   // folding of literal arguments, primal only
+    switch (fn) {
+    case EXA_U_PLUS: return x; case EXA_U_MINUS: return -x; case EXA_U_ABS2: return x * x; case EXA_U_ABS: return std::fabs(x);
+    case EXA_U_INV: return 1.0 / x; case EXA_U_SQRT: return std::sqrt(x);
+    default: return NAN;
+    }
+}
+static bool host_un_ok(int fn) {
+    return fn == EXA_U_PLUS || fn == EXA_U_MINUS || fn == EXA_U_ABS2 || fn == EXA_U_ABS || fn == EXA_U_INV || fn == EXA_U_SQRT;
+}
+
+static Val lit_or_tmpl(Emitter &e, const char *spec, Val u, Val f, Val d) {
+    if (spec[0] == '=') {
+        std::string v = spec + 1;
+        if (v == "D2R") return Emitter::litf(kD2R);
+        if (v == "R2D") return Emitter::litf(kR2D);
+        return Emitter::litf(atof(v.c_str()));
+    }
+    return e.call(spec, {u, f, d});
+}
+
+Triple un_rule(Emitter &e, int fn, Val u, int order) {
+    Triple r;
+    u = e.tod(u);
+    if (u.is_lit() && host_un_ok(fn) && order == 0) { r.x = Emitter::litf(host_un(fn, u.f)); return r; }
+    if (fn == EXA_U_SIN || fn == EXA_U_COS) {
+        if (order == 0 && !env_int("EXAHIP_FAST_TRIG", 1)) {
+            r.x = e.call(fn == EXA_U_SIN ? "sin($1)" : "cos($1)", {u});
+            return r;
+        }
+        // (value-only contexts too: exa_sin / exa_cos each run the whole sincos, so a pattern — or a fused group — that
+        // needs both of one argument pays once)
+        // one sincos per argument serves value and both derivatives (functionlist.jl:22-23)
+        const std::string key = "sincos|" + e.s(u);
+        Val sv, cv;
+        auto it = e.memo.find(key);
+        if (it == e.memo.end() && env_int("EXAHIP_SYM_TRIG", 1)) {
+            // u = a - b where sincos(b - a) is already there (the two ends of an ACOPF branch: va_f - va_t and va_t - va_f):
+            // a - b == -(b - a) exactly and exa_sincos / ocml sincos are exactly odd / even, so sin u = 0.0 - sin(b - a)
+            // (written as a subtraction from +0.0: bit-identical to the direct evaluation for a == b too, where
+            // -(+0.0) would be -0.0) and cos u = cos(b - a).
+            auto ex = e.expr_of.find(e.s(u));
+            if (ex != e.expr_of.end()) {
+                const std::string &t = ex->second;
+                const size_t at = t.find(" - ");
+                if (at != std::string::npos && t.find(' ', at + 3) == std::string::npos && t.find(' ') == at) {
+                    auto rev = e.memo.find(t.substr(at + 3) + " - " + t.substr(0, at));
+                    if (rev != e.memo.end()) {
+                        const std::string rkey = "sincos|" + e.s(rev->second);
+                        auto rs = e.memo.find(rkey);
+                        if (rs != e.memo.end()) {
+                            sv = e.raw("0.0 - " + e.s(rs->second), false);
+                            cv = e.memo[rkey + "|c"];
+                            e.memo[key] = sv;
+                            e.memo[key + "|c"] = cv;
+                            it = e.memo.find(key);
+                        }
+                    }
+                }
+            }
+        }
+        if (it == e.memo.end()) {
+            sv.k = Val::SF; sv.id = e.next++;
+            cv.k = Val::SF; cv.id = e.next++;
+            e.lines.push_back("double t" + std::to_string(sv.id) + ", t" + std::to_string(cv.id) + "; " +
+                              (env_int("EXAHIP_FAST_TRIG", 1) ? "exa_sincos(" : "sincos(") + e.s(u) + ", &t" +
+                              std::to_string(sv.id) + ", &t" + std::to_string(cv.id) + ");");
+            e.memo[key] = sv;
+            e.memo[key + "|c"] = cv;
+        } else { sv = it->second; cv = e.memo[key + "|c"]; }
+        if (fn == EXA_U_SIN) { r.x = sv; r.y = cv; r.h = e.neg(sv); }
+        else { r.x = cv; r.y = e.neg(sv); r.h = e.neg(cv); }
+        return r;
+    }
+    if (fn == EXA_U_MINUS) { r.x = e.neg(u); r.y = Emitter::litf(-1); r.h = Emitter::litf(0); return r; }
+    if (fn == EXA_U_PLUS) { r.x = u; r.y = Emitter::litf(1); r.h = Emitter::litf(0); return r; }
+    if (fn == EXA_U_ABS2) { r.x = e.mul(u, u); r.y = e.mul(Emitter::litf(2), u); r.h = Emitter::litf(2); return r; }
+    const UnSpec *sp = un_spec(fn);
+    if (!sp->f) fail("univariate function without rule");
+    r.x = e.call(sp->f, {u});
+    if (order >= 1) r.y = lit_or_tmpl(e, sp->df, u, r.x, r.x);
+    if (order >= 2) r.h = lit_or_tmpl(e, sp->ddf, u, r.x, r.y);
+    return r;
+}
+
+// x^n for a literal integer n by repeated multiplication (Base.^(::Float64, ::Integer); n==3 -> x*x*x)
+static Val powi_lit(Emitter &e, Val x, int64_t n) {
+    x = e.tod(x);
+    if (n == 0) return Emitter::litf(1.0);
+    if (x.is_lit()) return Emitter::litf(std::pow(x.f, (double)n));
+    if (n < 0) { Val r = e.div(Emitter::litf(1.0), x); return powi_lit(e, r, -n); }
+    if (n == 1) return x;
+    if (n == 2) return e.mul(x, x);
+    if (n == 3) return e.mul(e.mul(x, x), x);
+    Val y; bool has = false;
+    Val b = x;
+    while (n > 1) {
+        if (n & 1) { y = has ? e.mul(y, b) : b; has = true; }
+        b = e.mul(b, b);
+        n >>= 1;
+    }
+    return has ? e.mul(b, y) : b;
+}
+
+// x1 ^ x2 where the exponent is a typed value
+Val pow_any(Emitter &e, Val x1, Val x2) {
+    if (x2.k == Val::LI) return powi_lit(e, x1, x2.i);
+    if (x2.k == Val::SI) return e.raw("exa_powi(" + e.sd(x1) + ", " + e.s(x2) + ")", false);
+    x1 = e.tod(x1);
+    if (x1.is_lit() && x2.is_lit()) return Emitter::litf(std::pow(x1.f, x2.f));
+    return e.call("pow($1, $2)", {x1, x2});
+}
+static Val add_i(Emitter &e, Val v, int64_t k) { return e.add(v, v.is_int() ? Emitter::liti(k) : Emitter::litf((double)k)); }
+
+// full bivariate rule (both operands differentiable), functionlist.jl:71-81
+Six bin_rule(Emitter &e, int fn, Val x1, Val x2, int order) {
+    Six r;
+    const Val Z = Emitter::litf(0), O = Emitter::litf(1);
+    r.h11 = r.h12 = r.h22 = Z;
+    switch (fn) {
+    case EXA_B_ADD: r.x = e.add(x1, x2); r.y1 = O; r.y2 = O; return r;
+    case EXA_B_SUB: r.x = e.sub(x1, x2); r.y1 = O; r.y2 = Emitter::litf(-1); return r;
+    case EXA_B_MUL: r.x = e.mul(x1, x2); r.y1 = e.tod(x2); r.y2 = e.tod(x1); r.h12 = O; return r;
+    case EXA_B_DIV: {
+        r.x = e.div(x1, x2);
+        if (order >= 1 && env_int("EXAHIP_STRICT_IEEE", 0)) {
+            // the table's own forms (functionlist.jl:75): 1/x2, -x1/x2^2, -1/x2^2, 2x1/x2^3 — three more divisions; they
+            // differ from the quotient forms below only where x2^2 or x2^3 over/underflows (|x2| > 1.3e154, < 1e-103)
+            r.y1 = e.div(O, x2);
+            r.y2 = e.div(e.neg(x1), e.sq(x2));
+            if (order >= 2) {
+                r.h12 = e.div(Emitter::litf(-1), e.sq(x2));
+                r.h22 = e.div(e.mul(Emitter::litf(2), x1), e.mul(e.sq(x2), x2));
+            }
+            return r;
+        }
+        if (order >= 1) {
+            Val inv = e.div(O, x2);
+            r.y1 = inv;
+            r.y2 = e.neg(e.mul(r.x, inv));                       // -x1/x2^2
+            if (order >= 2) {
+                r.h12 = e.neg(e.mul(inv, inv));                  // -1/x2^2
+                r.h22 = e.mul(Emitter::litf(-2), e.mul(r.y2, inv));   // 2 x1 / x2^3
+            }
+        }
+        return r;
+    }
+    case EXA_B_POW: {
+        r.x = pow_any(e, x1, x2);
+        if (order >= 1) {
+            Val pm1 = pow_any(e, x1, add_i(e, x2, -1));
+            Val lg = e.call("log($1)", {x1});
+            r.y1 = e.mul(x2, pm1);
+            r.y2 = e.mul(lg, r.x);
+            if (order >= 2) {
+                r.h11 = e.mul(e.mul(add_i(e, x2, -1), x2), pow_any(e, x1, add_i(e, x2, -2)));
+                r.h12 = e.add(pm1, e.mul(e.mul(x2, pm1), lg));
+                r.h22 = e.mul(e.mul(lg, lg), r.x);
+            }
+        }
+        return r;
+    }
+    case EXA_B_ATAN2: {
+        r.x = e.call("atan2($1, $2)", {x1, x2});
+        if (order >= 1) {
+            Val d = e.add(e.sq(x1), e.sq(x2));
+            r.y1 = e.div(x2, d);
+            r.y2 = e.div(e.neg(x1), d);
+            if (order >= 2) {
+                Val d2 = e.sq(d);
+                r.h11 = e.div(e.mul(e.mul(Emitter::litf(-2), x1), x2), d2);
+                r.h12 = e.div(e.sub(e.sq(x1), e.sq(x2)), d2);     // x1^4 + 2x1^2x2^2 + x2^4 == (x1^2+x2^2)^2
+                r.h22 = e.div(e.mul(e.mul(Emitter::litf(2), x1), x2), d2);
+            }
+        }
+        return r;
+    }
+    case EXA_B_HYPOT: {
+        r.x = e.call("hypot($1, $2)", {x1, x2});
+        if (order >= 1) {
+            r.y1 = e.div(x1, r.x);
+            r.y2 = e.div(x2, r.x);
+            if (order >= 2) {
+                Val h3 = e.mul(e.sq(r.x), r.x);
+                r.h11 = e.div(e.sub(e.sq(r.x), e.sq(x1)), h3);
+                r.h12 = e.div(e.neg(e.mul(x1, x2)), h3);
+                r.h22 = e.div(e.sub(e.sq(r.x), e.sq(x2)), h3);
+            }
+        }
+        return r;
+    }
+    case EXA_B_MAX:
+        r.x = e.call("(($1 > $2 || $1 != $1) ? $1 : $2)", {x1, x2});
+        r.y1 = e.call("($1 > $2 ? 1.0 : 0.0)", {x1, x2});
+        r.y2 = e.call("($1 > $2 ? 0.0 : 1.0)", {x1, x2});
+        return r;
+    case EXA_B_MIN:
+        r.x = e.call("(($1 < $2 || $1 != $1) ? $1 : $2)", {x1, x2});
+        r.y1 = e.call("($1 < $2 ? 1.0 : 0.0)", {x1, x2});
+        r.y2 = e.call("($1 < $2 ? 0.0 : 1.0)", {x1, x2});
+        return r;
+    }
+    fail("unknown bivariate function");
+}
+
+// one operand constant: SecondFixed (constant is 2nd: uses d1, d11) / FirstFixed (constant is 1st: d2, d22)
+Triple fixed_rule(Emitter &e, int fn, int fixed, Val v, Val c, int order) {
+    Triple r;
+    const Val Z = Emitter::litf(0), O = Emitter::litf(1);
+    const bool second = fixed == FX_SECOND;   // v OP c
+    switch (fn) {
+    case EXA_B_ADD: r.x = second ? e.add(v, c) : e.add(c, v); r.y = O; r.h = Z; return r;
+    case EXA_B_SUB:
+        r.x = second ? e.sub(v, c) : e.sub(c, v);
+        r.y = second ? O : Emitter::litf(-1); r.h = Z; return r;
+    case EXA_B_MUL: r.x = second ? e.mul(v, c) : e.mul(c, v); r.y = e.tod(c); r.h = Z; return r;
+    case EXA_B_DIV:
+        if (second) {     // v / c
+            r.x = e.div(v, c);
+            r.y = e.div(O, c); r.h = Z;
+        } else {          // c / v : d2 = -c/v^2, d22 = 2c/v^3
+            r.x = e.div(c, v);
+            if (order >= 1) {
+                Val inv = e.div(O, v);
+                r.y = e.neg(e.mul(r.x, inv));
+                if (order >= 2) r.h = e.mul(Emitter::litf(-2), e.mul(r.y, inv));
+            }
+        }
+        return r;
+    case EXA_B_POW:
+        if (second) {     // v ^ c
+            r.x = pow_any(e, v, c);
+            if (order >= 1) r.y = e.mul(c, pow_any(e, v, add_i(e, c, -1)));
+            if (order >= 2) r.h = e.mul(e.mul(add_i(e, c, -1), c), pow_any(e, v, add_i(e, c, -2)));
+        } else {          // c ^ v
+            r.x = pow_any(e, c, e.tod(v));
+            if (order >= 1) { Val lg = e.call("log($1)", {c}); r.y = e.mul(lg, r.x); if (order >= 2) r.h = e.mul(e.mul(lg, lg), r.x); }
+        }
+        return r;
+    default: {
+        Six s = second ? bin_rule(e, fn, v, e.tod(c), order) : bin_rule(e, fn, e.tod(c), v, order);
+        r.x = s.x;
+        r.y = second ? s.y1 : s.y2;
+        r.h = second ? s.h11 : s.h22;
+        return r;
+    }
+    }
+}
+
+}  // namespace gen
+}  // namespace exa

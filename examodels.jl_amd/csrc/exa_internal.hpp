@@ -82,7 +82,7 @@ struct Model {
 std::unique_ptr<Model> plan_model(const exa_model_desc_t *desc);   // throws std::runtime_error
 
 // ---------------------------------------------------------------------------------------------------
-// Code generator (exa_codegen.cpp)
+// Code generator (exa_gen_*.cpp; internals in exa_gen.hpp)
 // ---------------------------------------------------------------------------------------------------
 enum Callback { CB_OBJ = 0, CB_GRAD, CB_CONS, CB_JAC, CB_HESS, CB_JSTRUCT, CB_HSTRUCT,
                 CB_JPROD, CB_JTPROD, CB_HPROD, CB_FUSED,
@@ -125,15 +125,14 @@ struct Generated {
     ParamLayout layout;
 };
 
-// threads per workgroup (multiple of the 64-lane wavefront); 256 = 4 wavefronts measured best, EXAHIP_BLOCK overrides
-int block_threads();
-#define kBlock (::exa::block_threads())
+// threads per workgroup: 4 wavefronts (128 / 512 / 1024 measured within +-2 %, profiles/NOTES.md)
+constexpr int kBlock = 256;
 
-// loopfree_scatter: no loop around or inside the bodies of exa_grad / exa_jtprod / exa_hprod (see g_scatter_lines in
-// exa_codegen.cpp); the generator turns it on by itself for bodies past EXAHIP_HUGE_BODY lines, the runtime asks for it
-// when a scatter kernel of the compiled module turns out to spill registers.
+// loopfree_scatter: no loop around or inside the bodies of exa_grad / exa_jtprod / exa_hprod (see kHugeBody in
+// exa_gen.hpp); the generator turns it on by itself for huge bodies, the runtime asks for it when a scatter kernel of the
+// compiled module turns out to spill registers.
 Generated generate_module(const Model &m, bool loopfree_scatter = false);
-bool pattern_var_range(const Pattern &p, int64_t lo, int64_t hi, int64_t *vmin, int64_t *vmax);   // exa_codegen.cpp
+bool pattern_var_range(const Pattern &p, int64_t lo, int64_t hi, int64_t *vmin, int64_t *vmax);   // exa_gen_module.cpp
 
 // Windowed compressed-COO kernels (exa_cjac / exa_chess fast path).  One pattern of such a kernel: every
 // slot s of data point I lands on compressed entry a_s + b * I; slots with the same a_s are added in registers (group),
@@ -166,7 +165,7 @@ struct WindowSpec {
     // an entry are contiguous: the reduction reads sequentially instead of gathering 8-byte values at random, and a matrix
     // without duplicates (ACOPF's Jacobian) needs no reduction at all.
     bool jac_scatter = false, hess_scatter = false;
-    // Compressed Hessian through MERGED slots (exa_chessm, see merge_slot in exa_codegen.cpp): the patterns of a fused group
+    // Compressed Hessian through MERGED slots (exa_chessm, see merge_slot in exa_gen_coo.cpp): the patterns of a fused group
     // add the slots they put on one matrix entry in registers; the merged slots are stored at their sorted positions.
     bool hess_merged = false;
 };

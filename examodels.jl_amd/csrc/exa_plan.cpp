@@ -17,15 +17,6 @@
 
 namespace exa {
 
-int block_threads() {
-    static const int b = [] {
-        const char *e = getenv("EXAHIP_BLOCK");
-        const int v = e && *e ? atoi(e) : 256;
-        return (v >= 64 && v <= 1024 && v % 64 == 0) ? v : 256;
-    }();
-    return b;
-}
-
 namespace {
 
 [[noreturn]] void fail(const std::string &msg) { throw BadInput(msg); }

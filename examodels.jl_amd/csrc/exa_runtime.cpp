@@ -33,6 +33,8 @@ namespace {
 
 thread_local std::string g_err;
 std::mutex g_mu;
+// EXAHIP_VERBOSE=1: one stderr line per decision (tuning, register spills of the scatter kernels, window plans)
+bool verbose() { static const bool v = [] { const char *e = getenv("EXAHIP_VERBOSE"); return e && atoi(e) != 0; }(); return v; }
 
 struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
 #define HIPCHK(expr)                                                                                         \
@@ -215,10 +217,7 @@ void fill_params(Handle &h) {
     // Neither wins everywhere (MI355X, hess_coord!): LV N=1e7 0.143 -> 0.133 ms and rocket 0.087 -> 0.082 ms with [1],
     // but LV N=1e8 1.75 -> 1.86 ms and the cache-resident ACOPF 0.016 -> 0.019 ms; runs of <= 16 workgroups are always
     // slower (too many concurrent write streams).  So for callbacks that stream >= 128 MB from several patterns the
-    // order is CHOSEN BY MEASUREMENT at the first call (tune_order); everything else runs sequentially.
-    // EXAHIP_INTERLEAVE = 0 forces [0], = k forces interleaving with runs of k workgroups.
-    const char *il_env = getenv("EXAHIP_INTERLEAVE");
-    const int64_t il_forced = il_env ? atoll(il_env) : -1;
+    // order is CHOSEN BY MEASUREMENT (exa_tune, persisted); everything else runs sequentially.
     for (int cb = 0; cb < CB_COUNT; cb++) {
         // dispatch units: one per active pattern, or (chained callbacks) one per group of co-indexed patterns; nb = how
         // many block-map entries (workgroups) a unit needs
@@ -279,7 +278,7 @@ void fill_params(Handle &h) {
         };
         const bool tunable = cb == CB_HESS || cb == CB_HESSC || cb == CB_JAC || cb == CB_FUSED || cb == CB_CONS;
         if (cb == CB_HESS) h.hess_stream_bytes = out_bytes + 8.0 * (double)(m.nvar + m.ncon) / h.world;
-        const bool two = h.on_device && total > 0 && na > 1 && (il_forced > 0 || (il_forced < 0 && tunable && out_bytes >= 128e6));
+        const bool two = h.on_device && total > 0 && na > 1 && tunable && out_bytes >= 128e6;
         h.order[cb] = 0;
         h.norders[cb] = 1;
         h.P[L.blk[cb]] = 0;
@@ -289,19 +288,16 @@ void fill_params(Handle &h) {
             HIPCHK(hipMemcpy(h.dmap[cb][0].p, m0.data(), sizeof(int64_t) * m0.size(), hipMemcpyHostToDevice));
             h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][0].p;
             if (two) {
-                std::vector<int64_t> m1 = build(il_forced > 0 ? std::max<int64_t>(il_forced, 1) : 128);
+                std::vector<int64_t> m1 = build(128);
                 h.dmap[cb][1].ensure(sizeof(int64_t) * m1.size());
                 HIPCHK(hipMemcpy(h.dmap[cb][1].p, m1.data(), sizeof(int64_t) * m1.size(), hipMemcpyHostToDevice));
-                if (il_forced > 0) { h.order[cb] = 1; h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][1].p; }
-                else {
-                    // both orders exist: exa_tune measures them; until then (and in later processes) the persisted
-                    // decision for this module / device / sizes applies, else the sequential order
-                    h.norders[cb] = 2;
-                    int pv = 0;
-                    if (tune_lookup(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), &pv) && (pv == 0 || pv == 1)) {
-                        h.order[cb] = pv;
-                        h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][pv].p;
-                    }
+                // both orders exist: exa_tune measures them; until then (and in later processes) the persisted
+                // decision for this module / device / sizes applies, else the sequential order
+                h.norders[cb] = 2;
+                int pv = 0;
+                if (tune_lookup(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), &pv) && (pv == 0 || pv == 1)) {
+                    h.order[cb] = pv;
+                    h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][pv].p;
                 }
             }
         }
@@ -351,14 +347,14 @@ void to_device(Handle &h) {
     // tests/test_random_expressions.py, with the hiprtc of ROCm 7.0 and, less often, the hipcc of 7.2; never with the
     // wavefront operations off).  The generator avoids the loops for bodies it can see are huge; here the compiled
     // kernels are asked, and a module whose scatter kernels spill is generated again without them.
-    if (!h.loopfree_scatter && !(getenv("EXAHIP_SPILL_CHECK") && atoi(getenv("EXAHIP_SPILL_CHECK")) == 0)) {
+    if (!h.loopfree_scatter) {
         bool spills = false;
         for (const char *name : {"exa_grad", "exa_jtprod", "exa_hprod"}) {
             // (more than 256 registers = the 256 VGPRs are exhausted and values are parked in AGPRs: spilling all the same)
             int local = 0, regs = 0;
             if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn(name)) == hipSuccess && local > 0) spills = true;
             if (hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn(name)) == hipSuccess && regs > 256) spills = true;
-            if (getenv("EXAHIP_SPILL_VERBOSE")) fprintf(stderr, "[exahip] %s: %d bytes of scratch per lane, %d registers\n", name, local, regs);
+            if (verbose()) fprintf(stderr, "[exahip] %s: %d bytes of scratch per lane, %d registers\n", name, local, regs);
         }
         if (spills) {
             (void)hipModuleUnload(h.module);
@@ -424,8 +420,7 @@ void to_device(Handle &h) {
         h.aug_chunks = (maxlen + 8191) / 8192;                                                    // EXA_AUG_CHUNK
         if (h.aug_nlong) { up(h.dauglong, longs); h.daugpartial.ensure(8 * (size_t)(h.aug_nlong * h.aug_chunks)); }
         // one-launch cons_nln! (exa_cons1): per constraint row, its terms as (pattern, data point) in insertion order
-        const char *c1 = getenv("EXAHIP_CONS1");
-        if (h.aug_nlong == 0 && !(c1 && atoi(c1) == 0)) {
+        if (h.aug_nlong == 0) {
             std::vector<int64_t> rowptr((size_t)m.ncon + 1, 0), src((size_t)m.nconaug);
             for (size_t t = 0; t < m.aug_rows.size(); t++) rowptr[(size_t)m.aug_rows[t] + 1] = m.aug_ptr[t + 1] - m.aug_ptr[t];
             for (int64_t r = 0; r < m.ncon; r++) rowptr[(size_t)r + 1] += rowptr[(size_t)r];
@@ -504,7 +499,7 @@ float tune_order(Handle &h, int cb, F &&run) {
     install(best);
     HIPCHK(hipStreamSynchronize(h.stream));
     if (n > 1) tune_store(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), best);
-    if (getenv("EXAHIP_TUNE_VERBOSE")) fprintf(stderr, "[exahip] tune cb=%d: %.4f %.4f ms per 4 launches -> order %d\n", cb, t[0], n > 1 ? t[1] : 0.f, best);
+    if (verbose()) fprintf(stderr, "[exahip] tune cb=%d: %.4f %.4f ms per 4 launches -> order %d\n", cb, t[0], n > 1 ? t[1] : 0.f, best);
     return t[best];
 }
 
@@ -1278,8 +1273,8 @@ int exa_hess_structure64_host(int id, int64_t *r, int64_t *c) { return struct_ho
 //     adds to) go to the shared-entry kernel exa_c*s instead; at most 24 passes, at most 6 evaluations per point;
 //   * window size and kernel shape (one chunk per pass / chunk loops) from the strides, see below.
 // Anything else (data-indexed targets, stepped ranges of different lengths meeting in the same columns) keeps the gather.
-// Knobs (experiments): EXAHIP_CWINDOW=0 gather only; EXAHIP_CW_W window size; EXAHIP_CW_WAVES occupancy hint;
-// EXAHIP_CW_SWIZZLE=0 plain LDS positions; EXAHIP_CW_VERBOSE=1 prints the pass table; EXAHIP_DUMP_WINDOW=file the source.
+// Knobs: EXAHIP_CWINDOW=0 gather only (the reference's scheme, bit for bit); EXAHIP_VERBOSE=1 prints the pass table;
+// EXAHIP_KEEP_SOURCE=1 keeps the generated source next to the cached code object.
 bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPat> &pats, std::vector<WindowShared> &shared, bool &single,
                  int &nspaces, int &zs) {
     const Model &m = *h.m;
@@ -1404,8 +1399,7 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
     std::vector<int32_t> Rb;
     int64_t Wtot = 0, nblocks = 0;
     {
-        const char *be = getenv("EXAHIP_CW_BLOCKS");
-        bool ok = !(be && atoi(be) == 0) && pats.size() >= 2;
+        bool ok = pats.size() >= 2;
         struct Sp { int64_t lo, hi, b, W = 0, off = 0, o = 0, end = 0; };
         std::vector<Sp> sp;
         std::vector<size_t> order(pats.size());
@@ -1428,8 +1422,8 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
         if (ok) {
             int64_t sumb = 0;
             for (const auto &q : sp) sumb += q.b;
-            const char *le = getenv("EXAHIP_CW_LDS");        // doubles of LDS per workgroup (experiments)
-            n = std::min<int64_t>(kBlock - 2 * spread_max - 2, (le ? atoll(le) : 6144) / sumb) / 16 * 16;
+            // 6144 doubles of LDS per workgroup (3072 / 4096 / 5120 / 6144 / 7680 measured on the rocket: profiles/NOTES.md)
+            n = std::min<int64_t>(kBlock - 2 * spread_max - 2, 6144 / sumb) / 16 * 16;
             ok = n >= 64;
         }
         std::vector<int> pk;
@@ -1471,7 +1465,7 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
             nspaces = (int)sp.size();
             zs = (int)Q.size();
             for (const auto &q : sp) { Q.push_back(q.o); Q.push_back(q.end); Q.push_back(q.W); Q.push_back(q.off); }
-            if (getenv("EXAHIP_CW_VERBOSE"))
+            if (verbose())
                 for (size_t q = 0; q < sp.size(); q++)
                     fprintf(stderr, "[exahip]   space %zu: entries [%ld,%ld) stride %ld window %ld\n", q, (long)sp[q].o, (long)sp[q].end, (long)sp[q].b, (long)sp[q].W);
         } else {
@@ -1492,10 +1486,6 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
     if (!single) {
         const int64_t fill = cc.cnnz / 2048 / 16 * 16;
         W = std::max<int64_t>(std::min<int64_t>(4080, fill), std::min<int64_t>(W, 1024));
-    }
-    if (const char *wenv = getenv("EXAHIP_CW_W")) {    // experiments
-        W = std::max<int64_t>(16, atoll(wenv) / 16 * 16);
-        single = W / bmin + spread_max + 1 <= kBlock;
     }
     if (nspaces > 0) { W = Wtot; single = true; }
     if (W < 16) return no("window too small");
@@ -1590,7 +1580,7 @@ bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPa
     w.W = (int)W;
     w.nwin = nwin;
     w.why = nspaces > 0 ? "block-owned windows, " + std::to_string(nspaces) + " spaces" : (single ? "one chunk per pass" : "chunk loops");
-    if (getenv("EXAHIP_CW_VERBOSE")) {
+    if (verbose()) {
         fprintf(stderr, "[exahip] windowed %s (%s): W=%ld windows=%ld passes=%zu shared-entry workgroups=%ld irregular points=%d\n", hess ? "hess" : "jac", nspaces > 0 ? "block-owned, one evaluation per point" : (single ? "one chunk per pass" : "chunk loops"), (long)W,
                 (long)nwin, pats.size(), (long)w.ns_blocks, w.nx);
         for (size_t q = 0; q < pats.size(); q++) {
@@ -1638,7 +1628,7 @@ void window_setup(Handle &h) {
     spec.hess_scatter = scatter_on && !okh && h.ch.nnz > 0 && h.ch.nlong == 0;
     // Hessian: merged slots when the fused groups collapse enough of them (ACOPF: 5.7 M slots -> 1.9 M)
     std::vector<int64_t> M;
-    if (spec.hess_scatter && !(getenv("EXAHIP_CMERGE") && atoi(getenv("EXAHIP_CMERGE")) == 0)) {
+    if (spec.hess_scatter) {
         const ParamLayout &L = h.gen.layout;
         const std::vector<int> sm = merged_hess_slots(m, L);
         int64_t nm = 0;
@@ -1651,7 +1641,6 @@ void window_setup(Handle &h) {
     }
     if (!okj && !okh && !spec.jac_scatter && !spec.hess_scatter) return;
     const std::string src = generate_window_module(m, h.gen.layout, spec);
-    if (const char *dump = getenv("EXAHIP_DUMP_WINDOW")) { FILE *f = fopen(dump, "w"); if (f) { fwrite(src.data(), 1, src.size(), f); fclose(f); } }
     std::vector<char> image;
     // the gather path needs no second module: a host without hipcc (a packed library's consumer) or a failed compilation
     // must not take exa_compress down with it

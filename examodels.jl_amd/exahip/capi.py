@@ -43,7 +43,7 @@ def build(force=False):
     srcs += [os.path.join(CSRC, "..", "..", "include", f) for f in ("exahip.h", "exahip_ir.h", "exahip_recipe.h")]
     newest = max(os.path.getmtime(s) for s in srcs)
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
-        subprocess.check_call(["make", "-C", CSRC, "-s", "-B"])
+        subprocess.check_call(["make", "-C", CSRC, "-s"])
     return LIB_PATH
 
 

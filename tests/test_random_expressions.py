@@ -72,7 +72,7 @@ def test_deep_random_patterns_on_hip(libs, seed, monkeypatch):
                    carried in registers across a spilling body, lanes of skipped wavefronts masked instead of branched;
       1013         J'v garbage after another kernel had run (stale spill space), NaN on some boxes.
     What the generator does about it: the whole-wavefront skip is a scalar branch (readfirstlane), fused groups of the
-    products are capped by raw contributions, bodies past EXAHIP_HUGE_BODY lines get no loops, and a module whose
+    products are capped by raw contributions, bodies past 1000 lines (kHugeBody) get no loops, and a module whose
     compiled scatter kernels spill (scratch, or more than 256 registers) is generated again without loops."""
     from exahip import ExaModel
     import oracle
