@@ -14,6 +14,6 @@ void *rccl_comm_init(int rank, int world, const void *uid128);       // on the c
 void rccl_comm_destroy(void *comm);
 void rccl_comm_shape(void *comm, int *rank, int *world);
 void rccl_allreduce_sum_f64(void *comm, double *buf, int64_t count, hipStream_t stream);     // in place
-void rccl_allgather_f64(void *comm, const double *send, double *recv, int64_t count_per_rank, hipStream_t stream);
+void rccl_allgatherv_f64(void *comm, double *buf, const int64_t *off, const int64_t *count, const int *root, int npieces, hipStream_t stream);
 
 }  // namespace exa

@@ -149,17 +149,32 @@ struct WindowShared {          // slots of a pattern that land on ONE compressed
     int k = 0;                  // summed per workgroup (exa_c*s), folded in a fixed order by the tail kernel (exa_c*x)
     std::vector<std::vector<int>> groups;   // slots of each such entry
 };
-struct WindowSpec {
-    std::vector<WindowPat> hess, jac;
-    std::vector<WindowShared> hess_shared, jac_shared;
+// What a window kernel produces.  CJAC / CHESS: the compressed (duplicate-summed) COO arrays of exa_cjac / exa_chess — entry
+// = position in the (col, row)-sorted structure, fitted to a_s + b*I on the device at exa_compress.  JTPROD / HPROD: the
+// dense vectors J'v / Hv — entry = 0-based variable, a_s + b*I known statically from the index expressions (range value
+// times a literal plus a literal): the owner-computes form of the products, no zero-fill, no atomics, fixed summation
+// order.  The "slots" of a product pattern are its contributions merged per distinct variable (product_items).
+enum WKind { WK_CJAC = 0, WK_CHESS = 1, WK_JTPROD = 2, WK_HPROD = 3, WK_COUNT = 4 };
+struct WindowMatrix {
+    std::vector<WindowPat> pats;
+    std::vector<WindowShared> shared;
     // every pass of every window fits one chunk of kBlock points: straight-line kernel (all passes' loads first, then
     // the additions), compiled for 8 waves per SIMD; otherwise chunk loops, no occupancy hint (it made them spill)
-    bool hess_single = false, jac_single = false;
+    bool single = false;
     // Block-owned variant (models laid out as separate variable arrays: the outputs of one data point land in several
     // far-apart column blocks = SPACES).  Workgroup j owns window j of EVERY space — the outputs of the same block of
     // points — so each pattern is evaluated once per point instead of once per pass.  nspaces > 0 selects it; the space
     // table [origin, end, window, LDS offset] x nspaces starts at word zs of Q.
-    int hess_nspaces = 0, jac_nspaces = 0, hess_zs = 0, jac_zs = 0;
+    int nspaces = 0, zs = 0;
+    // PLANES form of the one-chunk kernels, when every pass advances by exactly one entry per data point (b = 1: the dense
+    // product vectors of stencil models): each lane writes the sums of its slot groups to LDS planes [group][lane], ONE
+    // barrier, then the lane that owns an entry adds the planes' values for it in (pass, group) order — instead of a
+    // zero-filled window and one read-modify-write phase + barrier per group.  Same additions in the same order.
+    bool planes = false;
+    bool empty() const { return pats.empty(); }
+};
+struct WindowSpec {
+    WindowMatrix mat[WK_COUNT];
     // Matrices the windows do not fit (data-indexed targets: ACOPF): exa_cjacp / exa_chessp — the uncompressed sweep with
     // every slot stored at its position in the (col, row)-SORTED order (pos[slot], built once), so that the duplicates of
     // an entry are contiguous: the reduction reads sequentially instead of gathering 8-byte values at random, and a matrix
@@ -169,6 +184,10 @@ struct WindowSpec {
     // add the slots they put on one matrix entry in registers; the merged slots are stored at their sorted positions.
     bool hess_merged = false;
 };
+// Product "slots" of pattern k for wk = WK_JTPROD / WK_HPROD: per merged contribution the target 0-based variable
+// a[s] + b[s] * I (b = 0: a literal index, the same variable for every data point).  false = some target is not affine in
+// a range column (data-indexed) — such a model keeps the atomics / the sorted gather.
+bool product_items(const Model &m, const ParamLayout &L, int wk, int k, std::vector<int64_t> &a, std::vector<int64_t> &b);
 // merged Hessian slots per data point of every fused group of CB_HESS (what exa_chessm would write)
 std::vector<int> merged_hess_slots(const Model &m, const ParamLayout &L);
 // Source of the second module of a compressed model: exa_chessw / exa_chessx (and exa_cjacw / exa_cjacx).

@@ -102,14 +102,27 @@ struct Handle {
     // windowed fast path of exa_cjac / exa_chess (window_setup): second module, per-matrix tables
     struct Window {
         bool ok = false;
-        int W = 0, nx = 0, smax = 1;
+        int W = 0, nx = 0, smax = 1, lds_bytes = 0;
         int64_t nwin = 0;
         hipFunction_t fw = nullptr, fx = nullptr, fs = nullptr;
         int64_t ns_blocks = 0;             // workgroups of the shared-entry pass (exa_c*s)
         DevBuf Q, R, X, T, E, xbuf, S, F, part;
-        std::string why;                   // why the fast path was not taken (exa_window_info)
-    } wj, wh;
+        // the tables as planned on the host (window_plan); window_upload puts them on the device.  Product windows are
+        // planned without a device (plan-only handles generate and compile their module too) and uploaded by to_device.
+        std::vector<int64_t> hQ, hX, hS, hF;
+        std::vector<int32_t> hR, hT, hE;
+        int64_t xbuf_doubles = 0, nparts = 0;
+        // output ranges: window j covers entries [o + j*W, min(o + (j+1)*W, end)) of every space (one space unless block-owned)
+        struct Space { int64_t o, end, W; };
+        std::vector<Space> spaces;
+        bool planned = false;              // products: the plan exists (host); ok = its kernels are loaded as well
+        std::string why;                   // why the fast path was not taken (exa_compress_info / exa_product_info)
+    } wj, wh, wp[2];                       // compressed Jacobian / Hessian; J'v / Hv (WK_JTPROD, WK_HPROD)
     hipModule_t wmodule = nullptr;
+    // owner-computes products: third module (generated at model build when every scatter target is range-affine)
+    WindowSpec pspec;
+    std::string psource, phsaco_path;
+    hipModule_t pmodule = nullptr;
     // permuted-store path of exa_cjac / exa_chess for matrices the windows do not fit (exa_c*p, see WindowSpec)
     struct Scatter { bool ok = false; hipFunction_t f = nullptr; DevBuf pos; } sj, sh;
     // ... and its merged-slot form for the Hessian (exa_chessm): the merged slot space has its own sorted lists
@@ -142,10 +155,11 @@ struct Handle {
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
             cj.release(); ch.release(); cbuf.release();
-            for (Window *w : {&wj, &wh}) { w->Q.release(); w->R.release(); w->X.release(); w->T.release(); w->E.release(); w->xbuf.release(); w->S.release(); w->F.release(); w->part.release(); }
+            for (Window *w : {&wj, &wh, &wp[0], &wp[1]}) { w->Q.release(); w->R.release(); w->X.release(); w->T.release(); w->E.release(); w->xbuf.release(); w->S.release(); w->F.release(); w->part.release(); }
             sj.pos.release(); sh.pos.release(); chm.release(); dM.release();
             gbyvar.release(); gbuf.release(); gone.release();
             if (wmodule) (void)hipModuleUnload(wmodule);
+            if (pmodule) (void)hipModuleUnload(pmodule);
             pjrows.release(); pjcols.release(); phrows.release(); phcols.release();
             jbycol.release(); hbyrow.release(); hbycol.release();
             for (auto &b : dcols) b.release();
@@ -161,6 +175,7 @@ struct Handle {
 std::vector<std::unique_ptr<Handle>> g_models;   // id = index + 1
 
 Handle *get(int id) {
+    g_err.clear();          // exa_last_error() describes the LAST failed call: every entry point comes through here first
     std::lock_guard<std::mutex> lk(g_mu);
     if (id < 1 || id > (int)g_models.size()) return nullptr;
     return g_models[id - 1].get();
@@ -765,6 +780,580 @@ void do_struct(Handle &h, bool hess, bool wide, void *rows, void *cols) {
     launch(h, f, h.grid[hess ? CB_HSTRUCT : CB_JSTRUCT], kBlock, a);
 }
 
+// ---- windowed compressed evaluation (SURVEY §8f.3; kernels: exa_codegen.cpp generate_window_module) -----------------
+// Decides, per matrix, whether the sorted structure is regular enough for the fast path, and prepares its tables:
+//   * every slot s of every active pattern sits at compressed entry a_s + b_s*I for all points but a few at the ends
+//     (fit at the middle point, checked for every point on the device); at most kBlock such end points in total — they are
+//     evaluated by the tail kernel exa_c*x;
+//   * the slots of a pattern are split into PASSES: one per stride b_s and per cluster of targets within 48 points (the
+//     x[i] and u[i] blocks of a discretised ODE lie millions of entries apart); slots with b_s = 0 (an entry every point
+//     adds to) go to the shared-entry kernel exa_c*s instead; at most 24 passes, at most 6 evaluations per point;
+//   * window size and kernel shape (one chunk per pass / chunk loops) from the strides, see below.
+// Anything else (data-indexed targets, stepped ranges of different lengths meeting in the same columns) keeps the gather.
+// Knobs: EXAHIP_CWINDOW=0 gather only (the reference's scheme, bit for bit); EXAHIP_VERBOSE=1 prints the pass table;
+// EXAHIP_KEEP_SOURCE=1 keeps the generated source next to the cached code object.
+// Products (wk = WK_JTPROD / WK_HPROD): the same plan over the dense output vector — entry = 0-based variable, the maps
+// a_s + b_s*I come from the index expressions (product_items), nothing is fitted or checked on the device, and the data
+// points are ALL points of every pattern whatever the shard (a rank of a sharded model owns a range of WINDOWS and
+// evaluates whatever touches them: owner computes).  Host-only: also planned for exa_plan_only handles.
+Handle::Window &window_of(Handle &h, int wk) { return wk == WK_CJAC ? h.wj : wk == WK_CHESS ? h.wh : h.wp[wk - WK_JTPROD]; }
+bool window_plan(Handle &h, int wk, const int32_t *cmap, WindowMatrix &wm) {
+    const Model &m = *h.m;
+    const ParamLayout &L = h.gen.layout;
+    const bool hess = wk == WK_CHESS, product = wk >= WK_JTPROD;
+    std::vector<WindowPat> &pats = wm.pats;
+    std::vector<WindowShared> &shared = wm.shared;
+    bool &single = wm.single;
+    int &nspaces = wm.nspaces, &zs = wm.zs;
+    Handle::Window &w = window_of(h, wk);
+    const int64_t ncomp = product ? m.nvar : (hess ? h.ch.cnnz : h.cj.cnnz);
+    const auto &act = L.active[wk == WK_CJAC ? CB_JAC : wk == WK_CHESS ? CB_HESS : wk == WK_JTPROD ? CB_JTPROD : CB_HPROD];
+    auto no = [&](const std::string &why) { w.why = why; return false; };
+    if (act.empty() || ncomp == 0) return no("empty");
+    if (product && ncomp > 0x7fffffffLL) return no("more than 2^31 variables");
+    std::vector<int64_t> Q;
+    int64_t bmax = 0, spread_max = 0, npts = 0, passes_pts = 0;
+    int smax = 1;
+    std::map<int, std::pair<std::vector<int64_t>, std::vector<int64_t>>> items;     // products: per pattern the static (a, b)
+    for (int k : act) {
+        if (product) {
+            auto &ab = items[k];
+            if (!product_items(m, L, wk, k, ab.first, ab.second)) return no("pattern " + std::to_string(k) + ": a target is reached through a data column");
+            smax = std::max(smax, (int)ab.first.size());
+        } else smax = std::max(smax, hess ? m.pats[k].o2step : m.pats[k].o1step);
+    }
+    struct Exc { int k; int64_t I; };
+    std::vector<Exc> exc;
+    struct Sh { int k; int64_t e_lo, e_hi; std::vector<int64_t> target; };
+    std::vector<Sh> shs;
+    for (size_t j = 0; j < act.size(); j++) {
+        const int k = act[j];
+        const Pattern &p = m.pats[k];
+        const int S = product ? (int)items[k].first.size() : (hess ? p.o2step : p.o1step);
+        if (S == 0) continue;
+        // This process's data points of the pattern are [lo, hi) (all of them unless sharded) and slot s of point I sits at
+        // o + S * I of the COO it writes — also for the packed local slice of a shard, whose offset word already holds
+        // local_offset - S * lo (fill_params).  Everything below is in ABSOLUTE point indices, which is what the window
+        // kernels evaluate.  (Products: every point of the pattern, see above.)
+        const auto &pl = L.pat[k];
+        const int64_t lo = product ? 0 : h.P[pl.lo], hi = product ? p.n : h.P[pl.hi], n = hi - lo, o = product ? 0 : h.P[hess ? pl.o2 : pl.o1];
+        if (n <= 0) continue;
+        const int64_t mid = lo + (n >= 2 ? std::min(n / 2, n - 2) : 0);
+        std::vector<int64_t> a((size_t)S), bs((size_t)S), aloc((size_t)S);
+        int64_t cnt = 0, e_lo = 0, e_hi = n;
+        if (product) { a = items[k].first; bs = items[k].second; }
+        else {
+            std::vector<int32_t> two((size_t)2 * S);
+            HIPCHK(hipMemcpy(two.data(), cmap + o + (int64_t)S * mid, 4 * (size_t)S * (n >= 2 ? 2 : 1), hipMemcpyDeviceToHost));
+            for (int s = 0; s < S; s++) {
+                bs[s] = n >= 2 ? (int64_t)two[S + s] - two[s] : 1;
+                a[s] = (int64_t)two[s] - bs[s] * mid;
+                aloc[s] = a[s] + bs[s] * lo;            // the same map in the local index I - lo (what the check kernel walks)
+            }
+            affine_exceptions(cmap, o + (int64_t)S * lo, S, n, aloc.data(), bs.data(), mid - lo, &cnt, &e_lo, &e_hi, h.stream);
+        }
+        if (n <= 8) { e_lo = n; e_hi = n; }       // a handful of points (boundary conditions): all of them go to the tail kernel
+        if (e_lo + (n - e_hi) > kBlock) return no("pattern " + std::to_string(k) + ": " + std::to_string(cnt) + " points off the regular structure");
+        e_lo += lo; e_hi += lo;
+        for (int64_t I = lo; I < e_lo; I++) exc.push_back({k, I});
+        for (int64_t I = e_hi; I < hi; I++) exc.push_back({k, I});
+        if (e_hi <= e_lo) continue;     // every point of the pattern is irregular (tiny pattern): exa_c*x does it all
+        npts += e_hi - e_lo;
+        // stride classes
+        std::vector<int64_t> strides;
+        for (int s = 0; s < S; s++) if (std::find(strides.begin(), strides.end(), bs[s]) == strides.end()) strides.push_back(bs[s]);
+        if (strides.size() > 8) return no("pattern " + std::to_string(k) + ": slots advance with " + std::to_string(strides.size()) + " different strides");
+        for (int64_t b : strides) {
+            if (b == 0) {
+                // entries every point adds to: per-workgroup sums + fold
+                WindowShared q;
+                Sh sh{k, e_lo, e_hi, {}};
+                q.k = k;
+                for (int s = 0; s < S; s++) {
+                    if (bs[s] != 0) continue;
+                    size_t g = 0;
+                    for (; g < sh.target.size(); g++) if (sh.target[g] == a[s]) break;
+                    if (g == sh.target.size()) { sh.target.push_back(a[s]); q.groups.emplace_back(); }
+                    q.groups[g].push_back(s);
+                }
+                shared.push_back(std::move(q));
+                shs.push_back(std::move(sh));
+                passes_pts += e_hi - e_lo;
+                continue;
+            }
+            // distinct targets of this stride, ascending; targets more than 64 points apart (another block of
+            // variables: x[i] and u[i] of a discretised ODE) form separate passes, each re-evaluating the points for
+            // its own slots only (the compiler drops what those slots do not need)
+            std::vector<int64_t> av;
+            for (int s = 0; s < S; s++) if (bs[s] == b && std::find(av.begin(), av.end(), a[s]) == av.end()) av.push_back(a[s]);
+            std::sort(av.begin(), av.end());
+            const int64_t ab = b < 0 ? -b : b;
+            for (size_t c0 = 0; c0 < av.size();) {
+                size_t c1 = c0 + 1;
+                while (c1 < av.size() && (av[c1] - av[c0]) / ab <= 48) c1++;
+                WindowPat wp;
+                wp.k = k;
+                wp.qbase = (int)Q.size();
+                wp.group.assign(S, -1);
+                std::vector<int64_t> ga;      // groups in slot order (the order the values are added in)
+                for (int s = 0; s < S; s++) {
+                    if (bs[s] != b || a[s] < av[c0] || a[s] > av[c1 - 1]) continue;
+                    int g = -1;
+                    for (size_t q = 0; q < ga.size(); q++) if (ga[q] == a[s]) g = (int)q;
+                    if (g < 0) { g = (int)ga.size(); ga.push_back(a[s]); }
+                    wp.group[s] = g;
+                }
+                wp.phase.assign(ga.size(), 0);
+                for (size_t g = 0; g < ga.size(); g++) {
+                    int ph = 0;
+                    for (bool again = true; again;) {
+                        again = false;
+                        for (size_t q = 0; q < g; q++)
+                            if (wp.phase[q] == ph && (ga[g] - ga[q]) % ab == 0) { ph++; again = true; break; }
+                    }
+                    wp.phase[g] = ph;
+                }
+                const int64_t amin = av[c0], amax = av[c1 - 1];
+                spread_max = std::max(spread_max, (amax - amin) / ab + 1);
+                bmax = std::max(bmax, ab);
+                passes_pts += e_hi - e_lo;
+                Q.push_back(b); Q.push_back(e_lo); Q.push_back(e_hi); Q.push_back(amin); Q.push_back(amax);
+                for (int64_t v : ga) Q.push_back(v);
+                pats.push_back(std::move(wp));
+                c0 = c1;
+            }
+        }
+    }
+    if ((int64_t)exc.size() > kBlock) return no(std::to_string(exc.size()) + " irregular end points");
+    if (pats.empty()) return no("no regular pattern");
+    if (pats.size() > 24 || (double)passes_pts > 6.0 * (double)npts)
+        return no(std::to_string(pats.size()) + " passes over " + std::to_string((double)passes_pts / std::max<double>(1.0, (double)npts)) + "x the points");
+    // ---- block-owned variant (WindowSpec): the passes fall into several far-apart output ranges (SPACES: the column
+    // blocks of a model laid out as separate variable arrays).  Workgroup j owns window j of every space — n points'
+    // worth of each — so a pattern is evaluated once per point, not once per pass (rocket chess: 1.84x the VALU
+    // instructions of the uncompressed sweep with one window space).  Needs: positive strides, one stride per space,
+    // every pattern's points of a block within one chunk.
+    nspaces = 0; zs = 0;
+    std::vector<int32_t> Rb;
+    int64_t Wtot = 0, nblocks = 0;
+    {
+        bool ok = pats.size() >= 2;
+        struct Sp { int64_t lo, hi, b, W = 0, off = 0, o = 0, end = 0; };
+        std::vector<Sp> sp;
+        std::vector<size_t> order(pats.size());
+        auto out_lo = [&](size_t q) { const int64_t *t = &Q[pats[q].qbase]; return t[3] + t[0] * t[1]; };
+        auto out_hi = [&](size_t q) { const int64_t *t = &Q[pats[q].qbase]; return t[4] + t[0] * (t[2] - 1) + 1; };
+        for (size_t q = 0; q < pats.size() && ok; q++) { order[q] = q; if (Q[pats[q].qbase] <= 0) ok = false; }
+        if (ok) {
+            std::sort(order.begin(), order.end(), [&](size_t a, size_t c) { return out_lo(a) < out_lo(c); });
+            for (size_t q : order) {
+                const int64_t b = Q[pats[q].qbase];
+                if (!sp.empty() && out_lo(q) < sp.back().hi) {
+                    if (sp.back().b != b) { ok = false; break; }
+                    sp.back().hi = std::max(sp.back().hi, out_hi(q));
+                } else sp.push_back({out_lo(q), out_hi(q), b});
+                pats[q].space = (int)sp.size() - 1;
+            }
+        }
+        ok = ok && sp.size() >= 2 && sp.size() <= 16;
+        int64_t n = 0;
+        if (ok) {
+            int64_t sumb = 0;
+            for (const auto &q : sp) sumb += q.b;
+            // 6144 doubles of LDS per workgroup (3072 / 4096 / 5120 / 6144 / 7680 measured on the rocket: profiles/NOTES.md)
+            n = std::min<int64_t>(kBlock - 2 * spread_max - 2, 6144 / sumb) / 16 * 16;
+            ok = n >= 64;
+        }
+        std::vector<int> pk;
+        if (ok) {
+            for (size_t q = 0; q < sp.size(); q++) {
+                sp[q].W = sp[q].b * n; sp[q].off = Wtot; Wtot += sp[q].W;
+                sp[q].o = q == 0 ? 0 : sp[q].lo;
+            }
+            for (size_t q = 0; q < sp.size(); q++) {
+                sp[q].end = q + 1 < sp.size() ? sp[q + 1].o : ncomp;
+                nblocks = std::max(nblocks, (sp[q].end - sp[q].o + sp[q].W - 1) / sp[q].W);
+            }
+            for (const auto &wp : pats) if (std::find(pk.begin(), pk.end(), wp.k) == pk.end()) pk.push_back(wp.k);
+            ok = nblocks * (int64_t)pk.size() * 2 < (int64_t)1 << 28;
+        }
+        if (ok) {
+            auto fdiv = [](int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; };
+            auto cdiv = [&](int64_t a, int64_t b) { return -fdiv(-a, b); };
+            Rb.assign((size_t)nblocks * pk.size() * 2, 0);
+            for (int64_t j = 0; j < nblocks && ok; j++)
+                for (size_t u = 0; u < pk.size() && ok; u++) {
+                    int64_t lo = INT64_MAX, hi = INT64_MIN;
+                    for (const auto &wp : pats) {
+                        if (wp.k != pk[u]) continue;
+                        const Sp &q = sp[wp.space];
+                        const int64_t c0 = q.o + j * q.W, c1 = std::min(c0 + q.W, q.end) - 1;
+                        if (c1 < c0) continue;
+                        const int64_t *t = &Q[wp.qbase];
+                        int64_t l = std::max(cdiv(c0 - t[4], t[0]), t[1]), hh = std::min(fdiv(c1 - t[3], t[0]) + 1, t[2]);
+                        if (hh <= l) continue;
+                        lo = std::min(lo, l); hi = std::max(hi, hh);
+                    }
+                    if (hi <= lo) { lo = 0; hi = 0; }
+                    if (hi - lo > kBlock) ok = false;
+                    Rb[(j * pk.size() + u) * 2] = (int32_t)lo; Rb[(j * pk.size() + u) * 2 + 1] = (int32_t)hi;
+                }
+        }
+        if (ok) {
+            nspaces = (int)sp.size();
+            zs = (int)Q.size();
+            w.spaces.clear();
+            for (const auto &q : sp) { Q.push_back(q.o); Q.push_back(q.end); Q.push_back(q.W); Q.push_back(q.off); w.spaces.push_back({q.o, q.end, q.W}); }
+            if (verbose())
+                for (size_t q = 0; q < sp.size(); q++)
+                    fprintf(stderr, "[exahip]   space %zu: entries [%ld,%ld) stride %ld window %ld\n", q, (long)sp[q].o, (long)sp[q].end, (long)sp[q].b, (long)sp[q].W);
+        } else {
+            for (auto &wp : pats) wp.space = 0;
+            Rb.clear();
+        }
+    }
+    // Window size.  If every pass advances with the same stride, W = what kBlock points produce (less the straddling
+    // points): every pass of every window is one chunk and the straight-line kernel applies (LV 1e7 chess: 0.097 ms
+    // against 0.112 with chunk loops at any W).  With mixed strides the small-stride passes need several chunks per
+    // window anyway, and large windows win (rocket 1e6 chess, W = 1008 / 2272 / 3024 / 4080: 0.334 / 0.175 / 0.145 /
+    // 0.122 ms; cjac 0.090 / 0.056 / 0.054 / 0.057): W = 4080 (32 KB of LDS, 5 workgroups per CU) unless that leaves
+    // fewer than ~8 windows per CU.
+    int64_t bmin = bmax;
+    for (const auto &wp : pats) bmin = std::min<int64_t>(bmin, std::llabs(Q[wp.qbase]));
+    int64_t W = std::min<int64_t>((kBlock - spread_max - 1) * bmax, 4096) / 16 * 16;
+    single = W >= 16 && W / bmin + spread_max + 1 <= kBlock;
+    if (bmax == 1 && bmin == 1 && nspaces == 0) {
+        // every pass advances one entry per point: the PLANES form (below) needs no swizzled window, so W is only rounded to
+        // whole 64-byte lines of the output: W + spread - 1 points fill the 256 lanes
+        bool unit = true;
+        for (const auto &wp : pats) unit = unit && Q[wp.qbase] == 1;
+        if (unit && kBlock - spread_max + 1 >= 16) { W = (kBlock - spread_max + 1) / 8 * 8; single = true; }
+    }
+    if (!single) {
+        const int64_t fill = ncomp / 2048 / 16 * 16;
+        W = std::max<int64_t>(std::min<int64_t>(4080, fill), std::min<int64_t>(W, 1024));
+    }
+    if (nspaces > 0) { W = Wtot; single = true; }
+    if (W < 16) return no("window too small");
+    const int64_t nwin = nspaces > 0 ? nblocks : (ncomp + W - 1) / W;
+    // work amplification: points evaluated (whole chunks of kBlock) over points present
+    double work = 0.0;
+    for (const auto &wp : pats) {
+        const int64_t ab = std::llabs(Q[wp.qbase]);
+        const int64_t n = Q[wp.qbase + 2] - Q[wp.qbase + 1];
+        const double per = (double)W / (double)ab + (double)spread_max;
+        const double wins = std::min<double>((double)nwin, (double)n * (double)ab / (double)W + 1.0);
+        work += wins * std::ceil(per / kBlock) * kBlock;
+    }
+    if (nspaces == 0 && work > 2.0 * (double)passes_pts + 4096.0 * pats.size())
+        return no("windows would evaluate " + std::to_string(work / std::max<double>(1.0, (double)passes_pts)) + "x the points");
+    // irregular points: targets straight from the slot map, grouped by distinct target
+    w.nx = (int)exc.size();
+    w.smax = smax;
+    if (w.nx) {
+        std::vector<int64_t> X;
+        std::vector<int32_t> tgt((size_t)w.nx * smax, -1);
+        for (int t = 0; t < w.nx; t++) {
+            const Pattern &p = m.pats[exc[t].k];
+            X.push_back(exc[t].k); X.push_back(exc[t].I);
+            if (product) {
+                const auto &ab = items[exc[t].k];
+                for (size_t s = 0; s < ab.first.size(); s++) tgt[(size_t)t * smax + s] = (int32_t)(ab.first[s] + ab.second[s] * exc[t].I);
+                continue;
+            }
+            const int S = hess ? p.o2step : p.o1step;
+            const int64_t o = h.P[hess ? L.pat[exc[t].k].o2 : L.pat[exc[t].k].o1];
+            HIPCHK(hipMemcpy(tgt.data() + (size_t)t * smax, cmap + o + (int64_t)S * exc[t].I, 4 * (size_t)S, hipMemcpyDeviceToHost));
+        }
+        std::map<int32_t, std::vector<int32_t>> by;
+        for (size_t e = 0; e < tgt.size(); e++) if (tgt[e] >= 0) by[tgt[e]].push_back((int32_t)e);
+        std::vector<int32_t> T{(int32_t)by.size()}, E;
+        for (auto &kv : by) {
+            T.push_back(kv.first); T.push_back((int32_t)E.size());
+            E.insert(E.end(), kv.second.begin(), kv.second.end());
+            T.push_back((int32_t)E.size());
+        }
+        w.hX = X; w.hT = T; w.hE = E; w.xbuf_doubles = (int64_t)tgt.size();
+    }
+    // shared entries: workgroup map, partial-sum layout, fold list
+    w.ns_blocks = 0;
+    w.hF.assign(1, 0);                 // F[0] = 0 groups unless filled below
+    w.hS.clear(); w.nparts = 0;
+    if (!shs.empty()) {
+        std::vector<int64_t> St, F{0};
+        int64_t blocks = 0, parts = 0;
+        for (const auto &sh : shs) {
+            const int64_t per = (int64_t)kBlock * kSharedTiles, nt = (sh.e_hi - sh.e_lo + per - 1) / per;
+            St.push_back(sh.e_lo); St.push_back(sh.e_hi); St.push_back(blocks); St.push_back(parts);
+            for (size_t g = 0; g < sh.target.size(); g++) { F.push_back(parts + (int64_t)g * nt); F.push_back(nt); F.push_back(sh.target[g]); F[0]++; }
+            blocks += nt;
+            parts += nt * (int64_t)sh.target.size();
+        }
+        St.push_back(0); St.push_back(0); St.push_back(blocks); St.push_back(parts);     // sentinel
+        w.ns_blocks = blocks;
+        w.hS = St; w.hF = F; w.nparts = parts;
+    }
+    w.hQ = Q;
+    // R[window][pass] = [lo, hi): the regular points with a slot of that pass inside the window
+    if (nspaces > 0) {
+        w.hR = Rb;
+    } else {
+        auto fdiv = [](int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; };   // b > 0
+        auto cdiv = [&](int64_t a, int64_t b) { return -fdiv(-a, b); };
+        const size_t np = pats.size();
+        std::vector<int32_t> R((size_t)nwin * np * 2);
+        for (int64_t j = 0; j < nwin; j++) {
+            const int64_t c0 = j * W, c1 = c0 + W - 1;
+            for (size_t q = 0; q < np; q++) {
+                const int64_t *t = &Q[pats[q].qbase];
+                const int64_t b = t[0], amin = t[3], amax = t[4];
+                int64_t lo, hi;
+                if (b > 0) { lo = cdiv(c0 - amax, b); hi = fdiv(c1 - amin, b) + 1; }
+                else { lo = cdiv(amin - c1, -b); hi = fdiv(amax - c0, -b) + 1; }
+                lo = std::max(lo, t[1]); hi = std::min(hi, t[2]);
+                if (hi < lo) hi = lo;
+                R[(j * np + q) * 2] = (int32_t)lo; R[(j * np + q) * 2 + 1] = (int32_t)hi;
+            }
+        }
+        w.hR.swap(R);
+        w.spaces.assign(1, {0, ncomp, W});
+    }
+    w.W = (int)W;
+    w.nwin = nwin;
+    {
+        // PLANES form (WindowMatrix::planes): one-chunk kernels whose passes all advance by one entry per data point
+        size_t groups = 0;
+        bool unit = single;
+        for (const auto &wp : pats) { groups += wp.phase.size(); unit = unit && Q[wp.qbase] == 1; }
+        wm.planes = unit && groups > 0 && groups * kBlock * 8 <= 65536;
+        w.lds_bytes = wm.planes ? (int)(groups * kBlock * 8) : (int)(8 * W);
+    }
+    w.why = (nspaces > 0 ? "block-owned windows, " + std::to_string(nspaces) + " spaces" : (single ? "one chunk per pass" : "chunk loops")) + (wm.planes ? ", planes" : "");
+    if (verbose()) {
+        fprintf(stderr, "[exahip] windowed %s (%s): W=%ld windows=%ld passes=%zu shared-entry workgroups=%ld irregular points=%d\n", wk == WK_CHESS ? "hess" : wk == WK_CJAC ? "jac" : wk == WK_JTPROD ? "jtprod" : "hprod", nspaces > 0 ? "block-owned, one evaluation per point" : (single ? "one chunk per pass" : "chunk loops"), (long)W,
+                (long)nwin, pats.size(), (long)w.ns_blocks, w.nx);
+        for (size_t q = 0; q < pats.size(); q++) {
+            const int64_t *t = &Q[pats[q].qbase];
+            fprintf(stderr, "[exahip]   pass %zu: pattern %d  b=%ld  points [%ld,%ld)  targets %ld..%ld  groups=%zu\n", q, pats[q].k, (long)t[0], (long)t[1], (long)t[2],
+                    (long)t[3], (long)t[4], pats[q].phase.size());
+        }
+    }
+    return true;
+}
+// device copies of a planned window's tables (the host copies are dropped: R alone is 8 B per window and pass)
+void window_upload(Handle::Window &w) {
+    auto up = [](DevBuf &b, const void *src, size_t bytes) { b.ensure(std::max<size_t>(bytes, 8)); if (bytes) HIPCHK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice)); };
+    up(w.Q, w.hQ.data(), 8 * w.hQ.size()); up(w.R, w.hR.data(), 4 * w.hR.size());
+    up(w.X, w.hX.data(), 8 * w.hX.size()); up(w.T, w.hT.data(), 4 * w.hT.size()); up(w.E, w.hE.data(), 4 * w.hE.size());
+    up(w.S, w.hS.data(), 8 * w.hS.size()); up(w.F, w.hF.data(), 8 * w.hF.size());
+    w.xbuf.ensure(8 * (size_t)std::max<int64_t>(w.xbuf_doubles, 1)); w.part.ensure(8 * (size_t)std::max<int64_t>(w.nparts, 1));
+    for (auto *v : {&w.hQ, &w.hX, &w.hS, &w.hF}) std::vector<int64_t>().swap(*v);
+    for (auto *v : {&w.hR, &w.hT, &w.hE}) std::vector<int32_t>().swap(*v);
+}
+
+// Owner-computes products (exa_jtprodw / exa_hprodw): planned on the host at model build — also for exa_plan_only handles, so
+// that exa_compile / exahip.pack build the module ahead of time — whenever every scatter target of J'v / Hv is affine in
+// a range column.  EXAHIP_PRODUCT_WINDOW=0 keeps the atomics / the sorted gather.
+void plan_products(Handle &h) {
+    h.pspec = WindowSpec();
+    h.psource.clear();
+    const char *env = getenv("EXAHIP_PRODUCT_WINDOW");
+    bool any = false;
+    for (int wk : {WK_JTPROD, WK_HPROD}) {
+        Handle::Window &w = window_of(h, wk);
+        w.ok = w.planned = false; w.why.clear(); w.nx = 0; w.ns_blocks = 0; w.nwin = 0;
+        if (env && atoi(env) == 0) { w.why = "disabled (EXAHIP_PRODUCT_WINDOW=0)"; continue; }
+        w.planned = window_plan(h, wk, nullptr, h.pspec.mat[wk]);
+        if (!w.planned) h.pspec.mat[wk] = WindowMatrix();
+        any = any || w.planned;
+    }
+    if (any) h.psource = generate_window_module(*h.m, h.gen.layout, h.pspec);
+}
+// loads the product module and uploads the tables; a module that cannot be built leaves the products on their other paths
+void load_products(Handle &h) {
+    if (h.psource.empty()) return;
+    try {
+        CodeObject co = get_code_object(h.psource, true);
+        h.phsaco_path = co.path; h.build_ms += co.build_ms;
+        HIPCHK(hipModuleLoadData(&h.pmodule, co.image.data()));
+        auto fn = [&](const std::string &name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.pmodule, name.c_str())); return f; };
+        for (int wk : {WK_JTPROD, WK_HPROD}) {
+            Handle::Window &w = window_of(h, wk);
+            if (!w.planned) continue;
+            const std::string nm = wk == WK_JTPROD ? "exa_jtprod" : "exa_hprod";
+            w.fw = fn(nm + "w"); w.fx = fn(nm + "x");
+            if (w.ns_blocks) w.fs = fn(nm + "s");
+            window_upload(w);
+            w.ok = true;
+        }
+    } catch (const std::exception &e) {
+        std::string msg = e.what();
+        if (msg.size() > 300) msg.resize(300);
+        for (int wk : {WK_JTPROD, WK_HPROD}) { Handle::Window &w = window_of(h, wk); w.ok = false; w.why = "the window kernels could not be built (" + msg + ")"; }
+        if (h.pmodule) { (void)hipModuleUnload(h.pmodule); h.pmodule = nullptr; }
+    }
+}
+
+void window_setup(Handle &h) {
+    // exa_compress may be called again (e.g. with another EXAHIP_CWINDOW): start from scratch
+    for (Handle::Window *w : {&h.wj, &h.wh}) { w->ok = false; w->why.clear(); w->nx = 0; w->ns_blocks = 0; w->nwin = 0; }
+    h.sj.ok = h.sh.ok = false; h.sj.f = h.sh.f = nullptr;
+    h.merged = false; h.f_chessm = h.f_hstructm = nullptr; h.chm.release();
+    if (h.wmodule) { (void)hipModuleUnload(h.wmodule); h.wmodule = nullptr; }
+    const char *env = getenv("EXAHIP_CWINDOW");
+    if (env && atoi(env) == 0) { h.wj.why = h.wh.why = "disabled (EXAHIP_CWINDOW=0)"; return; }
+    h.sj.ok = h.sh.ok = false;
+    const bool plan_windows = true;                 // (a shard plans the windows of its local slice: absolute point indices throughout)
+    const Model &m = *h.m;
+    if (std::max(h.lnnzj, h.lnnzh) > 0x7fffffffLL) { h.wj.why = h.wh.why = "nnz exceeds int32"; return; }
+    WindowSpec spec;
+    DevBuf cmap;
+    cmap.ensure(4 * (size_t)std::max<int64_t>(std::max(h.lnnzj, h.lnnzh), 1));
+    bool okj = false, okh = false;
+    if (plan_windows) try {
+        build_slot_map(h.cj, (int32_t *)cmap.p, h.stream);
+        HIPCHK(hipStreamSynchronize(h.stream));
+        okj = window_plan(h, WK_CJAC, (const int32_t *)cmap.p, spec.mat[WK_CJAC]);
+        if (!okj) spec.mat[WK_CJAC] = WindowMatrix();
+        else window_upload(h.wj);
+        build_slot_map(h.ch, (int32_t *)cmap.p, h.stream);
+        HIPCHK(hipStreamSynchronize(h.stream));
+        okh = window_plan(h, WK_CHESS, (const int32_t *)cmap.p, spec.mat[WK_CHESS]);
+        if (!okh) spec.mat[WK_CHESS] = WindowMatrix();
+        else window_upload(h.wh);
+    } catch (...) { cmap.release(); throw; }
+    cmap.release();
+    // what the windows do not cover goes through the permuted store when it can: 32-bit positions, no entry with more
+    // than 512 duplicates (those are summed cooperatively through the gather lists)
+    h.sj.ok = h.sh.ok = false;
+    const char *se = getenv("EXAHIP_CSCATTER");
+    const bool scatter_on = !(se && atoi(se) == 0);
+    spec.jac_scatter = scatter_on && !okj && h.cj.nnz > 0 && h.cj.nlong == 0;
+    spec.hess_scatter = scatter_on && !okh && h.ch.nnz > 0 && h.ch.nlong == 0;
+    // Hessian: merged slots when the fused groups collapse enough of them (ACOPF: 5.7 M slots -> 1.9 M)
+    std::vector<int64_t> M;
+    if (spec.hess_scatter) {
+        const ParamLayout &L = h.gen.layout;
+        const std::vector<int> sm = merged_hess_slots(m, L);
+        int64_t nm = 0;
+        for (size_t g = 0; g < L.groups[CB_HESS].size(); g++) {
+            const auto &pp = L.pat[L.groups[CB_HESS][g].front()];
+            M.push_back(nm);
+            nm += (int64_t)sm[g] * (h.P[pp.hi] - h.P[pp.lo]);
+        }
+        if (nm > 0 && nm < 0xffffffffLL && (double)nm <= 0.8 * (double)h.ch.nnz) { spec.hess_merged = true; h.nmerged = nm; }
+    }
+    if (!okj && !okh && !spec.jac_scatter && !spec.hess_scatter) return;
+    const std::string src = generate_window_module(m, h.gen.layout, spec);
+    std::vector<char> image;
+    // the gather path needs no second module: a host without hipcc (a packed library's consumer) or a failed compilation
+    // must not take exa_compress down with it
+    try {
+        image = get_code_object(src, true).image;
+        HIPCHK(hipModuleLoadData(&h.wmodule, image.data()));
+        auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
+        if (okj) { h.wj.fw = fn("exa_cjacw"); h.wj.fx = fn("exa_cjacx"); if (h.wj.ns_blocks) h.wj.fs = fn("exa_cjacs"); }
+        if (okh) { h.wh.fw = fn("exa_chessw"); h.wh.fx = fn("exa_chessx"); if (h.wh.ns_blocks) h.wh.fs = fn("exa_chesss"); }
+        if (spec.jac_scatter) h.sj.f = fn("exa_cjacp");
+        if (spec.hess_scatter) h.sh.f = fn("exa_chessp");
+        if (spec.hess_merged) { h.f_chessm = fn("exa_chessm"); h.f_hstructm = fn("exa_hstructm"); }
+    } catch (const std::exception &e) {
+        std::string msg = e.what();
+        if (msg.size() > 300) msg.resize(300);
+        h.wj.why = h.wh.why = "the windowed kernels could not be built (" + msg + ")";
+        if (h.wmodule) { (void)hipModuleUnload(h.wmodule); h.wmodule = nullptr; }
+        return;
+    }
+    // a matrix on the windowed sweep never gathers: its sorted permutation (4 B per uncompressed slot: 3.6 GB for LV 1e8)
+    // and pointer list can go
+    if (okj) { h.cj.release_gather(); h.wj.ok = true; }
+    if (okh) { h.ch.release_gather(); h.wh.ok = true; }
+    if (spec.hess_merged && h.f_chessm) {
+        // structure of the merged slot space -> its own sorted lists; it must describe the same matrix as the slots'
+        DevBuf r, c;
+        try {
+            h.dM.ensure(8 * M.size());
+            HIPCHK(hipMemcpy(h.dM.p, M.data(), 8 * M.size(), hipMemcpyHostToDevice));
+            r.ensure(8 * (size_t)h.nmerged); c.ensure(8 * (size_t)h.nmerged);
+            const void *P = h.dP.p, *Mp = h.dM.p;
+            void *rp = r.p, *cp = c.p;
+            void *a[] = {&P, &rp, &cp, &Mp};
+            launch(h, h.f_hstructm, h.grid[CB_HESS], kBlock, a);
+            build_compressed(h.chm, (const int64_t *)r.p, (const int64_t *)c.p, h.nmerged, std::max<int64_t>(m.nvar, 1), std::max<int64_t>(m.nvar, 1), h.stream);
+            HIPCHK(hipStreamSynchronize(h.stream));
+        } catch (...) { r.release(); c.release(); throw; }
+        r.release(); c.release();
+        if (h.chm.cnnz == h.ch.cnnz && h.chm.nlong == 0) {
+            h.sh.pos.ensure(4 * (size_t)h.nmerged);
+            build_positions(h.chm, (uint32_t *)h.sh.pos.p, h.stream);
+            HIPCHK(hipStreamSynchronize(h.stream));
+            h.merged = true;
+            h.sh.ok = true;
+            h.wh.why = "merged slots (" + std::to_string(h.nmerged) + " for " + std::to_string(h.ch.nnz) + "), permuted store + sequential sums";
+            h.ch.release_gather();
+        } else h.chm.release();
+    }
+    for (int hess = 0; hess < 2; hess++) {
+        Handle::Scatter &sc = hess ? h.sh : h.sj;
+        CompressedCOO &cc = hess ? h.ch : h.cj;
+        if (hess && h.merged) continue;
+        if (!(hess ? spec.hess_scatter : spec.jac_scatter) || !sc.f) continue;
+        sc.pos.ensure(4 * (size_t)cc.nnz);
+        build_positions(cc, (uint32_t *)sc.pos.p, h.stream);
+        HIPCHK(hipStreamSynchronize(h.stream));
+        sc.ok = true;
+        (hess ? h.wh : h.wj).why = cc.cnnz == cc.nnz ? "permuted store (no duplicates: the sweep writes the compressed entries directly)"
+                                                      : "permuted store + sequential sums of the sorted duplicates";
+    }
+}
+void do_scatter(Handle &h, bool hess, const double *x, const double *y, double sigma, double *vals) {
+    Handle::Scatter &sc = hess ? h.sh : h.sj;
+    const CompressedCOO &cc = hess ? h.ch : h.cj;
+    const void *P = h.dP.p, *th = h.dtheta.p, *pos = sc.pos.p;
+    if (hess && h.merged) {
+        const bool direct = h.chm.cnnz == h.chm.nnz;
+        double *out = direct ? vals : (double *)h.cbuf.p;
+        const void *Mp = h.dM.p;
+        void *a[] = {&P, &x, &y, &th, &out, &sigma, &pos, &Mp};
+        launch(h, h.f_chessm, h.grid[CB_HESS], kBlock, a);
+        if (!direct) compress_sorted(h.chm, out, vals, h.stream);
+        return;
+    }
+    const bool direct = cc.cnnz == cc.nnz;          // a permutation: the sorted order IS the compressed array
+    double *out = direct ? vals : (double *)h.cbuf.p;
+    if (hess) { void *a[] = {&P, &x, &y, &th, &out, &sigma, &pos}; launch(h, sc.f, h.grid[CB_HESS], kBlock, a); }
+    else { void *a[] = {&P, &x, &th, &out, &pos}; launch(h, sc.f, h.grid[CB_JAC], kBlock, a); }
+    if (!direct) compress_sorted(cc, out, vals, h.stream);
+}
+
+// wk: which window kernel set (WKind); v: the vector of a product (null for the compressed COO).  [w0, w1): the windows
+// this launch evaluates — all of them, or the ones a rank of an owner-sharded product owns.
+void do_window(Handle &h, int wk, const double *x, const double *y, const double *v, double sigma, double *vals, int64_t w0 = 0, int64_t w1 = -1) {
+    Handle::Window &w = window_of(h, wk);
+    const void *P = h.dP.p, *Q = w.Q.p, *R = w.R.p, *th = h.dtheta.p;
+    int64_t ncomp = wk == WK_CHESS ? h.ch.cnnz : wk == WK_CJAC ? h.cj.cnnz : h.m->nvar;
+    int W = w.W;
+    void *part = w.part.p;
+    const int64_t ns = w.ns_blocks;
+    if (w1 < 0) w1 = w.nwin;
+    if (ns) {
+        const void *S = w.S.p;
+        void *a1[] = {&P, &S, &x, &y, &th, &v, &part, &sigma};
+        HIPCHK(hipModuleLaunchKernel(w.fs, (unsigned)ns, 1, 1, kBlock, 1, 1, 0, h.stream, a1, nullptr));
+    }
+    void *a[] = {&P, &Q, &R, &x, &y, &th, &v, &vals, &sigma, &ncomp, &W, &w0};
+    if (w1 > w0) HIPCHK(hipModuleLaunchKernel(w.fw, (unsigned)(w1 - w0), 1, 1, kBlock, 1, 1, (unsigned)w.lds_bytes, h.stream, a, nullptr));
+    if (w.nx || ns) {
+        // tail: the irregular end points, then the fold of the shared-entry partial sums (one workgroup)
+        const void *X = w.X.p, *T = w.T.p, *E = w.E.p, *F = w.F.p;
+        void *xbuf = w.xbuf.p;
+        int nx = w.nx;
+        void *a2[] = {&P, &X, &T, &E, &x, &y, &th, &v, &xbuf, &vals, &sigma, &nx, &part, &F};
+        HIPCHK(hipModuleLaunchKernel(w.fx, 1, 1, 1, 1024, 1, 1, 0, h.stream, a2, nullptr));     // 1024 threads: the fold is one workgroup's loop
+    }
+}
+
+
 // The HIP "current device" is per host thread; a model lives on the device that was current in exa_create.  A call from
 // a thread whose current device is another one (a Julia task that migrated, a worker thread that never called
 // hipSetDevice) would allocate its scratch buffers on the wrong GPU: every device call runs with the model's device
@@ -815,7 +1404,8 @@ int create(const exa_model_desc_t *desc, int *id_out, bool device) {
         auto h = std::make_unique<Handle>();
         h->m = plan_model(desc);
         h->gen = generate_module(*h->m);
-        if (device) to_device(*h);
+        plan_products(*h);
+        if (device) { to_device(*h); load_products(*h); }
         else fill_params(*h);
         *id_out = put(std::move(h));
         return 0;
@@ -867,6 +1457,7 @@ int exa_compile(int id) {
     return guard(id, false, [&](Handle &h) {
         CodeObject co = get_code_object(h.gen.source, false);
         h.hsaco_path = co.path; h.build_how = co.how; h.build_ms = co.build_ms;
+        if (!h.psource.empty()) { CodeObject pc = get_code_object(h.psource, false); h.phsaco_path = pc.path; h.build_ms += pc.build_ms; }
     });
 }
 const char *exa_code_object_path(int id) {
@@ -1074,22 +1665,83 @@ static bool sorted_possible(Handle &h, bool hess) {
     const int64_t nnz = hess ? h.lnnzh : h.lnnzj;
     return (h.world == 1 || h.coo_local) && nnz > 0;
 }
+// Owner-computes windows: possible when the model's targets are range-affine (plan_products) and the module is loaded; a
+// SHARDED model takes them only when nothing is left to the tail kernel (no tiny patterns, no entry every point adds to):
+// those belong to all ranks at once.
+static bool window_possible(Handle &h, bool hess) {
+    const Handle::Window &w = h.wp[hess ? 1 : 0];
+    return w.ok && (h.world == 1 || (w.nx == 0 && w.ns_blocks == 0));
+}
 static int resolve_mode(Handle &h, bool hess) {
     int &mode = hess ? h.hp_mode : h.jt_mode;
     if (mode < 0) {
-        int v = 0;
-        mode = tune_lookup(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), &v) && v == 1 && sorted_possible(h, hess) ? 1 : 0;
+        int v = -1;
+        const bool tuned = tune_lookup(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 2;
+        if (tuned && ((v == 1 && sorted_possible(h, hess)) || (v == 2 && window_possible(h, hess)) || v == 0)) mode = v;
+        // undecided and never tuned: the windows, unless some entry is added to by EVERY data point (a literal index: the
+        // rocket's step length) — that costs a second evaluation pass (exa_*s), which the atomics of the sweep do not pay
+        else mode = window_possible(h, hess) && h.wp[hess ? 1 : 0].ns_blocks == 0 ? 2 : 0;
     }
+    if (mode == 2 && !window_possible(h, hess)) return 0;
     if (mode == 1 && !sorted_possible(h, hess)) return 0;      // sharded at global positions: nothing to sort locally
     if (mode == 1) prod_setup(h, hess);                          // no-op once the lists exist
     return mode;
 }
+// Windows [w0, w1) a rank of a sharded model owns, and the pieces of the output they cover (owner computes: complete
+// values, nothing to sum).  pieces: (offset, count, owner rank) for EVERY rank — what an all-gather-v needs.
+static void owned_windows(const Handle &h, const Handle::Window &w, int rank, int64_t *w0, int64_t *w1) {
+    *w0 = (int64_t)((__int128)w.nwin * rank / h.world);
+    *w1 = (int64_t)((__int128)w.nwin * (rank + 1) / h.world);
+}
+struct Piece { int64_t off, count; int root; };
+static std::vector<Piece> window_pieces(const Handle &h, const Handle::Window &w) {
+    std::vector<Piece> out;
+    for (int r = 0; r < h.world; r++) {
+        int64_t w0, w1;
+        owned_windows(h, w, r, &w0, &w1);
+        for (const auto &sp : w.spaces) {
+            const int64_t a = std::min(sp.o + w0 * sp.W, sp.end), b = std::min(sp.o + w1 * sp.W, sp.end);
+            if (b > a) out.push_back({a, b - a, r});
+        }
+    }
+    return out;
+}
+// Makes a vector whole whose pieces are complete on their owners (in place): RCCL — one grouped set of broadcasts; a host
+// reducer (exa_comm_hook) only knows how to sum, so the other ranks' pieces are zeroed and the covering range summed.
+static void allgatherv(Handle &h, double *buf, const std::vector<Piece> &pieces) {
+    if (!h.reduce || h.world == 1 || pieces.empty()) return;
+    if (h.nccl) {
+        std::vector<int64_t> off, cnt; std::vector<int> root;
+        for (const Piece &q : pieces) { off.push_back(q.off); cnt.push_back(q.count); root.push_back(q.root); }
+        rccl_allgatherv_f64(h.nccl, buf, off.data(), cnt.data(), root.data(), (int)pieces.size(), h.stream);
+    } else if (h.hook) {
+        int64_t lo = INT64_MAX, hi = 0;
+        for (const Piece &q : pieces) {
+            if (q.root != h.rank) HIPCHK(hipMemsetAsync(buf + q.off, 0, 8 * (size_t)q.count, h.stream));
+            lo = std::min(lo, q.off); hi = std::max(hi, q.off + q.count);
+        }
+        const int rc = h.hook(h.hook_ctx, buf + lo, hi - lo, (void *)h.stream);
+        if (rc != 0) throw std::runtime_error("the host's all-reduce hook returned status " + std::to_string(rc));
+    }
+}
+static void run_product_window(Handle &h, bool hess, const double *x, const double *y, const double *v, double w, double *out) {
+    Handle::Window &win = h.wp[hess ? 1 : 0];
+    if (h.world == 1) { do_window(h, hess ? WK_HPROD : WK_JTPROD, x, y, v, w, out); return; }
+    int64_t w0, w1;
+    owned_windows(h, win, h.rank, &w0, &w1);
+    do_window(h, hess ? WK_HPROD : WK_JTPROD, x, y, v, w, out, w0, w1);
+    allgatherv(h, out, window_pieces(h, win));
+}
 static void run_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
-    if (resolve_mode(h, false) == 1) do_jtprod_sorted(h, x, v, Jtv); else do_jtprod(h, x, v, Jtv);
+    const int mode = resolve_mode(h, false);
+    if (mode == 2) { run_product_window(h, false, x, nullptr, v, 0.0, Jtv); return; }
+    if (mode == 1) do_jtprod_sorted(h, x, v, Jtv); else do_jtprod(h, x, v, Jtv);
     allreduce(h, Jtv, h.m->nvar);
 }
 static void run_hprod(Handle &h, const double *x, const double *y, const double *v, double w, double *Hv) {
-    if (resolve_mode(h, true) == 1) do_hprod_sorted(h, x, y, v, w, Hv); else do_hprod(h, x, y, v, w, Hv);
+    const int mode = resolve_mode(h, true);
+    if (mode == 2) { run_product_window(h, true, x, y, v, w, Hv); return; }
+    if (mode == 1) do_hprod_sorted(h, x, y, v, w, Hv); else do_hprod(h, x, y, v, w, Hv);
     allreduce(h, Hv, h.m->nvar);
 }
 int exa_jtprod(int id, const double *x, const double *v, double *Jtv) {
@@ -1103,15 +1755,31 @@ int exa_hprod(int id, const double *x, const double *y, const double *v, double 
         run_hprod(h, x, y, v, w, Hv);
     });
 }
-/* 0 = atomics inside the sweep, 1 = COO + sorted gather, -1 = undecided (default): the decision exa_tune persisted for
- * this module / device / sizes if there is one, else 0 */
+/* 0 = atomics inside the sweep, 1 = COO + sorted gather, 2 = owner-computes windows, -1 = undecided (default): the decision
+ * exa_tune persisted for this module / device / sizes if there is one, else the windows where the model has them, else 0 */
 int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode) {
-    if (jtprod_mode < -1 || jtprod_mode > 1 || hprod_mode < -1 || hprod_mode > 1) return 1;
+    if (jtprod_mode < -1 || jtprod_mode > 2 || hprod_mode < -1 || hprod_mode > 2) return 1;
     return guard(id, true, [&](Handle &h) {
+        if (jtprod_mode == 2 && !window_possible(h, false)) throw BadInput("J'v has no owner-computes windows on this model: " + h.wp[0].why);
+        if (hprod_mode == 2 && !window_possible(h, true)) throw BadInput("Hv has no owner-computes windows on this model: " + h.wp[1].why);
         if (jtprod_mode == 1) prod_setup(h, false);      // refuses a sharded model at global positions (status 1)
         if (hprod_mode == 1) prod_setup(h, true);
         h.jt_mode = jtprod_mode; h.hp_mode = hprod_mode;
     });
+}
+/* What exa_jtprod (hess = 0) / exa_hprod (hess = 1) run: 0 atomics, 1 sorted gather, 2 owner-computes windows (resolved as a
+ * call would resolve it, without building anything); buf <- the kernel shape of the windows or why the model has none. */
+int exa_product_info(int id, int hess, char *buf, int cap) {
+    Handle *h = get(id);
+    if (!h) return -1;
+    const Handle::Window &w = h->wp[hess ? 1 : 0];
+    if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", w.why.c_str());
+    const int mode = hess ? h->hp_mode : h->jt_mode;
+    if (mode >= 0) return mode == 2 && !window_possible(*h, hess != 0) ? 0 : mode;
+    int v = -1;
+    if (h->on_device && tune_lookup(source_key(h->gen.source), tune_signature(*h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 2 &&
+        (v != 2 || window_possible(*h, hess != 0)) && (v != 1 || sorted_possible(*h, hess != 0))) return v;
+    return (h->on_device ? window_possible(*h, hess != 0) : w.planned) && w.ns_blocks == 0 ? 2 : 0;
 }
 /* grad!: 0 = gathered (affine patterns) + FP64 atomics (data-indexed ones), 1 = gradient COO + sorted gather (the reference's
  * scheme: deterministic, and immune to many data points sharing a few variables), -1 = undecided: the persisted exa_tune
@@ -1129,8 +1797,9 @@ int exa_set_deterministic(int id, int on) {
     return guard(id, true, [&](Handle &h) {
         if (on) {
             if (grad_sorted_possible(h)) { grad_setup(h); h.grad_mode = 1; }
-            if (sorted_possible(h, false)) { prod_setup(h, false); h.jt_mode = 1; }
-            if (sorted_possible(h, true)) { prod_setup(h, true); h.hp_mode = 1; }
+            // (the owner-computes windows are deterministic too: a fixed order of additions, no atomics)
+            if (window_possible(h, false)) h.jt_mode = 2; else if (sorted_possible(h, false)) { prod_setup(h, false); h.jt_mode = 1; }
+            if (window_possible(h, true)) h.hp_mode = 2; else if (sorted_possible(h, true)) { prod_setup(h, true); h.hp_mode = 1; }
         } else { h.grad_mode = -1; h.jt_mode = -1; h.hp_mode = -1; }
     });
 }
@@ -1263,489 +1932,6 @@ int exa_hess_structure_host(int id, int32_t *r, int32_t *c) { return struct_host
 int exa_jac_structure64_host(int id, int64_t *r, int64_t *c) { return struct_host(id, false, true, r, c); }
 int exa_hess_structure64_host(int id, int64_t *r, int64_t *c) { return struct_host(id, true, true, r, c); }
 
-// ---- windowed compressed evaluation (SURVEY §8f.3; kernels: exa_codegen.cpp generate_window_module) -----------------
-// Decides, per matrix, whether the sorted structure is regular enough for the fast path, and prepares its tables:
-//   * every slot s of every active pattern sits at compressed entry a_s + b_s*I for all points but a few at the ends
-//     (fit at the middle point, checked for every point on the device); at most kBlock such end points in total — they are
-//     evaluated by the tail kernel exa_c*x;
-//   * the slots of a pattern are split into PASSES: one per stride b_s and per cluster of targets within 48 points (the
-//     x[i] and u[i] blocks of a discretised ODE lie millions of entries apart); slots with b_s = 0 (an entry every point
-//     adds to) go to the shared-entry kernel exa_c*s instead; at most 24 passes, at most 6 evaluations per point;
-//   * window size and kernel shape (one chunk per pass / chunk loops) from the strides, see below.
-// Anything else (data-indexed targets, stepped ranges of different lengths meeting in the same columns) keeps the gather.
-// Knobs: EXAHIP_CWINDOW=0 gather only (the reference's scheme, bit for bit); EXAHIP_VERBOSE=1 prints the pass table;
-// EXAHIP_KEEP_SOURCE=1 keeps the generated source next to the cached code object.
-bool window_plan(Handle &h, bool hess, const int32_t *cmap, std::vector<WindowPat> &pats, std::vector<WindowShared> &shared, bool &single,
-                 int &nspaces, int &zs) {
-    const Model &m = *h.m;
-    const ParamLayout &L = h.gen.layout;
-    Handle::Window &w = hess ? h.wh : h.wj;
-    const CompressedCOO &cc = hess ? h.ch : h.cj;
-    const auto &act = L.active[hess ? CB_HESS : CB_JAC];
-    auto no = [&](const std::string &why) { w.why = why; return false; };
-    if (act.empty() || cc.cnnz == 0) return no("empty");
-    std::vector<int64_t> Q;
-    int64_t bmax = 0, spread_max = 0, npts = 0, passes_pts = 0;
-    int smax = 1;
-    for (int k : act) smax = std::max(smax, hess ? m.pats[k].o2step : m.pats[k].o1step);
-    struct Exc { int k; int64_t I; };
-    std::vector<Exc> exc;
-    struct Sh { int k; int64_t e_lo, e_hi; std::vector<int64_t> target; };
-    std::vector<Sh> shs;
-    for (size_t j = 0; j < act.size(); j++) {
-        const int k = act[j];
-        const Pattern &p = m.pats[k];
-        const int S = hess ? p.o2step : p.o1step;
-        // This process's data points of the pattern are [lo, hi) (all of them unless sharded) and slot s of point I sits at
-        // o + S * I of the COO it writes — also for the packed local slice of a shard, whose offset word already holds
-        // local_offset - S * lo (fill_params).  Everything below is in ABSOLUTE point indices, which is what the window
-        // kernels evaluate.
-        const auto &pl = L.pat[k];
-        const int64_t lo = h.P[pl.lo], hi = h.P[pl.hi], n = hi - lo, o = h.P[hess ? pl.o2 : pl.o1];
-        if (n <= 0) continue;
-        const int64_t mid = lo + (n >= 2 ? std::min(n / 2, n - 2) : 0);
-        std::vector<int32_t> two((size_t)2 * S);
-        HIPCHK(hipMemcpy(two.data(), cmap + o + (int64_t)S * mid, 4 * (size_t)S * (n >= 2 ? 2 : 1), hipMemcpyDeviceToHost));
-        std::vector<int64_t> a((size_t)S), bs((size_t)S), aloc((size_t)S);
-        for (int s = 0; s < S; s++) {
-            bs[s] = n >= 2 ? (int64_t)two[S + s] - two[s] : 1;
-            a[s] = (int64_t)two[s] - bs[s] * mid;
-            aloc[s] = a[s] + bs[s] * lo;            // the same map in the local index I - lo (what the check kernel walks)
-        }
-        int64_t cnt = 0, e_lo = 0, e_hi = n;
-        affine_exceptions(cmap, o + (int64_t)S * lo, S, n, aloc.data(), bs.data(), mid - lo, &cnt, &e_lo, &e_hi, h.stream);
-        if (n <= 8) { e_lo = n; e_hi = n; }       // a handful of points (boundary conditions): all of them go to the tail kernel
-        if (e_lo + (n - e_hi) > kBlock) return no("pattern " + std::to_string(k) + ": " + std::to_string(cnt) + " points off the regular structure");
-        e_lo += lo; e_hi += lo;
-        for (int64_t I = lo; I < e_lo; I++) exc.push_back({k, I});
-        for (int64_t I = e_hi; I < hi; I++) exc.push_back({k, I});
-        if (e_hi <= e_lo) continue;     // every point of the pattern is irregular (tiny pattern): exa_c*x does it all
-        npts += e_hi - e_lo;
-        // stride classes
-        std::vector<int64_t> strides;
-        for (int s = 0; s < S; s++) if (std::find(strides.begin(), strides.end(), bs[s]) == strides.end()) strides.push_back(bs[s]);
-        if (strides.size() > 8) return no("pattern " + std::to_string(k) + ": slots advance with " + std::to_string(strides.size()) + " different strides");
-        for (int64_t b : strides) {
-            if (b == 0) {
-                // entries every point adds to: per-workgroup sums + fold
-                WindowShared q;
-                Sh sh{k, e_lo, e_hi, {}};
-                q.k = k;
-                for (int s = 0; s < S; s++) {
-                    if (bs[s] != 0) continue;
-                    size_t g = 0;
-                    for (; g < sh.target.size(); g++) if (sh.target[g] == a[s]) break;
-                    if (g == sh.target.size()) { sh.target.push_back(a[s]); q.groups.emplace_back(); }
-                    q.groups[g].push_back(s);
-                }
-                shared.push_back(std::move(q));
-                shs.push_back(std::move(sh));
-                passes_pts += e_hi - e_lo;
-                continue;
-            }
-            // distinct targets of this stride, ascending; targets more than 64 points apart (another block of
-            // variables: x[i] and u[i] of a discretised ODE) form separate passes, each re-evaluating the points for
-            // its own slots only (the compiler drops what those slots do not need)
-            std::vector<int64_t> av;
-            for (int s = 0; s < S; s++) if (bs[s] == b && std::find(av.begin(), av.end(), a[s]) == av.end()) av.push_back(a[s]);
-            std::sort(av.begin(), av.end());
-            const int64_t ab = b < 0 ? -b : b;
-            for (size_t c0 = 0; c0 < av.size();) {
-                size_t c1 = c0 + 1;
-                while (c1 < av.size() && (av[c1] - av[c0]) / ab <= 48) c1++;
-                WindowPat wp;
-                wp.k = k;
-                wp.qbase = (int)Q.size();
-                wp.group.assign(S, -1);
-                std::vector<int64_t> ga;      // groups in slot order (the order the values are added in)
-                for (int s = 0; s < S; s++) {
-                    if (bs[s] != b || a[s] < av[c0] || a[s] > av[c1 - 1]) continue;
-                    int g = -1;
-                    for (size_t q = 0; q < ga.size(); q++) if (ga[q] == a[s]) g = (int)q;
-                    if (g < 0) { g = (int)ga.size(); ga.push_back(a[s]); }
-                    wp.group[s] = g;
-                }
-                wp.phase.assign(ga.size(), 0);
-                for (size_t g = 0; g < ga.size(); g++) {
-                    int ph = 0;
-                    for (bool again = true; again;) {
-                        again = false;
-                        for (size_t q = 0; q < g; q++)
-                            if (wp.phase[q] == ph && (ga[g] - ga[q]) % ab == 0) { ph++; again = true; break; }
-                    }
-                    wp.phase[g] = ph;
-                }
-                const int64_t amin = av[c0], amax = av[c1 - 1];
-                spread_max = std::max(spread_max, (amax - amin) / ab + 1);
-                bmax = std::max(bmax, ab);
-                passes_pts += e_hi - e_lo;
-                Q.push_back(b); Q.push_back(e_lo); Q.push_back(e_hi); Q.push_back(amin); Q.push_back(amax);
-                for (int64_t v : ga) Q.push_back(v);
-                pats.push_back(std::move(wp));
-                c0 = c1;
-            }
-        }
-    }
-    if ((int64_t)exc.size() > kBlock) return no(std::to_string(exc.size()) + " irregular end points");
-    if (pats.empty()) return no("no regular pattern");
-    if (pats.size() > 24 || (double)passes_pts > 6.0 * (double)npts)
-        return no(std::to_string(pats.size()) + " passes over " + std::to_string((double)passes_pts / std::max<double>(1.0, (double)npts)) + "x the points");
-    // ---- block-owned variant (WindowSpec): the passes fall into several far-apart output ranges (SPACES: the column
-    // blocks of a model laid out as separate variable arrays).  Workgroup j owns window j of every space — n points'
-    // worth of each — so a pattern is evaluated once per point, not once per pass (rocket chess: 1.84x the VALU
-    // instructions of the uncompressed sweep with one window space).  Needs: positive strides, one stride per space,
-    // every pattern's points of a block within one chunk.
-    nspaces = 0; zs = 0;
-    std::vector<int32_t> Rb;
-    int64_t Wtot = 0, nblocks = 0;
-    {
-        bool ok = pats.size() >= 2;
-        struct Sp { int64_t lo, hi, b, W = 0, off = 0, o = 0, end = 0; };
-        std::vector<Sp> sp;
-        std::vector<size_t> order(pats.size());
-        auto out_lo = [&](size_t q) { const int64_t *t = &Q[pats[q].qbase]; return t[3] + t[0] * t[1]; };
-        auto out_hi = [&](size_t q) { const int64_t *t = &Q[pats[q].qbase]; return t[4] + t[0] * (t[2] - 1) + 1; };
-        for (size_t q = 0; q < pats.size() && ok; q++) { order[q] = q; if (Q[pats[q].qbase] <= 0) ok = false; }
-        if (ok) {
-            std::sort(order.begin(), order.end(), [&](size_t a, size_t c) { return out_lo(a) < out_lo(c); });
-            for (size_t q : order) {
-                const int64_t b = Q[pats[q].qbase];
-                if (!sp.empty() && out_lo(q) < sp.back().hi) {
-                    if (sp.back().b != b) { ok = false; break; }
-                    sp.back().hi = std::max(sp.back().hi, out_hi(q));
-                } else sp.push_back({out_lo(q), out_hi(q), b});
-                pats[q].space = (int)sp.size() - 1;
-            }
-        }
-        ok = ok && sp.size() >= 2 && sp.size() <= 16;
-        int64_t n = 0;
-        if (ok) {
-            int64_t sumb = 0;
-            for (const auto &q : sp) sumb += q.b;
-            // 6144 doubles of LDS per workgroup (3072 / 4096 / 5120 / 6144 / 7680 measured on the rocket: profiles/NOTES.md)
-            n = std::min<int64_t>(kBlock - 2 * spread_max - 2, 6144 / sumb) / 16 * 16;
-            ok = n >= 64;
-        }
-        std::vector<int> pk;
-        if (ok) {
-            for (size_t q = 0; q < sp.size(); q++) {
-                sp[q].W = sp[q].b * n; sp[q].off = Wtot; Wtot += sp[q].W;
-                sp[q].o = q == 0 ? 0 : sp[q].lo;
-            }
-            for (size_t q = 0; q < sp.size(); q++) {
-                sp[q].end = q + 1 < sp.size() ? sp[q + 1].o : cc.cnnz;
-                nblocks = std::max(nblocks, (sp[q].end - sp[q].o + sp[q].W - 1) / sp[q].W);
-            }
-            for (const auto &wp : pats) if (std::find(pk.begin(), pk.end(), wp.k) == pk.end()) pk.push_back(wp.k);
-            ok = nblocks * (int64_t)pk.size() * 2 < (int64_t)1 << 28;
-        }
-        if (ok) {
-            auto fdiv = [](int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; };
-            auto cdiv = [&](int64_t a, int64_t b) { return -fdiv(-a, b); };
-            Rb.assign((size_t)nblocks * pk.size() * 2, 0);
-            for (int64_t j = 0; j < nblocks && ok; j++)
-                for (size_t u = 0; u < pk.size() && ok; u++) {
-                    int64_t lo = INT64_MAX, hi = INT64_MIN;
-                    for (const auto &wp : pats) {
-                        if (wp.k != pk[u]) continue;
-                        const Sp &q = sp[wp.space];
-                        const int64_t c0 = q.o + j * q.W, c1 = std::min(c0 + q.W, q.end) - 1;
-                        if (c1 < c0) continue;
-                        const int64_t *t = &Q[wp.qbase];
-                        int64_t l = std::max(cdiv(c0 - t[4], t[0]), t[1]), hh = std::min(fdiv(c1 - t[3], t[0]) + 1, t[2]);
-                        if (hh <= l) continue;
-                        lo = std::min(lo, l); hi = std::max(hi, hh);
-                    }
-                    if (hi <= lo) { lo = 0; hi = 0; }
-                    if (hi - lo > kBlock) ok = false;
-                    Rb[(j * pk.size() + u) * 2] = (int32_t)lo; Rb[(j * pk.size() + u) * 2 + 1] = (int32_t)hi;
-                }
-        }
-        if (ok) {
-            nspaces = (int)sp.size();
-            zs = (int)Q.size();
-            for (const auto &q : sp) { Q.push_back(q.o); Q.push_back(q.end); Q.push_back(q.W); Q.push_back(q.off); }
-            if (verbose())
-                for (size_t q = 0; q < sp.size(); q++)
-                    fprintf(stderr, "[exahip]   space %zu: entries [%ld,%ld) stride %ld window %ld\n", q, (long)sp[q].o, (long)sp[q].end, (long)sp[q].b, (long)sp[q].W);
-        } else {
-            for (auto &wp : pats) wp.space = 0;
-            Rb.clear();
-        }
-    }
-    // Window size.  If every pass advances with the same stride, W = what kBlock points produce (less the straddling
-    // points): every pass of every window is one chunk and the straight-line kernel applies (LV 1e7 chess: 0.097 ms
-    // against 0.112 with chunk loops at any W).  With mixed strides the small-stride passes need several chunks per
-    // window anyway, and large windows win (rocket 1e6 chess, W = 1008 / 2272 / 3024 / 4080: 0.334 / 0.175 / 0.145 /
-    // 0.122 ms; cjac 0.090 / 0.056 / 0.054 / 0.057): W = 4080 (32 KB of LDS, 5 workgroups per CU) unless that leaves
-    // fewer than ~8 windows per CU.
-    int64_t bmin = bmax;
-    for (const auto &wp : pats) bmin = std::min<int64_t>(bmin, std::llabs(Q[wp.qbase]));
-    int64_t W = std::min<int64_t>((kBlock - spread_max - 1) * bmax, 4096) / 16 * 16;
-    single = W >= 16 && W / bmin + spread_max + 1 <= kBlock;
-    if (!single) {
-        const int64_t fill = cc.cnnz / 2048 / 16 * 16;
-        W = std::max<int64_t>(std::min<int64_t>(4080, fill), std::min<int64_t>(W, 1024));
-    }
-    if (nspaces > 0) { W = Wtot; single = true; }
-    if (W < 16) return no("window too small");
-    const int64_t nwin = nspaces > 0 ? nblocks : (cc.cnnz + W - 1) / W;
-    // work amplification: points evaluated (whole chunks of kBlock) over points present
-    double work = 0.0;
-    for (const auto &wp : pats) {
-        const int64_t ab = std::llabs(Q[wp.qbase]);
-        const int64_t n = Q[wp.qbase + 2] - Q[wp.qbase + 1];
-        const double per = (double)W / (double)ab + (double)spread_max;
-        const double wins = std::min<double>((double)nwin, (double)n * (double)ab / (double)W + 1.0);
-        work += wins * std::ceil(per / kBlock) * kBlock;
-    }
-    if (nspaces == 0 && work > 2.0 * (double)passes_pts + 4096.0 * pats.size())
-        return no("windows would evaluate " + std::to_string(work / std::max<double>(1.0, (double)passes_pts)) + "x the points");
-    // irregular points: targets straight from the slot map, grouped by distinct target
-    w.nx = (int)exc.size();
-    w.smax = smax;
-    if (w.nx) {
-        std::vector<int64_t> X;
-        std::vector<int32_t> tgt((size_t)w.nx * smax, -1);
-        for (int t = 0; t < w.nx; t++) {
-            const Pattern &p = m.pats[exc[t].k];
-            const int S = hess ? p.o2step : p.o1step;
-            const int64_t o = h.P[hess ? L.pat[exc[t].k].o2 : L.pat[exc[t].k].o1];
-            X.push_back(exc[t].k); X.push_back(exc[t].I);
-            HIPCHK(hipMemcpy(tgt.data() + (size_t)t * smax, cmap + o + (int64_t)S * exc[t].I, 4 * (size_t)S, hipMemcpyDeviceToHost));
-        }
-        std::map<int32_t, std::vector<int32_t>> by;
-        for (size_t e = 0; e < tgt.size(); e++) if (tgt[e] >= 0) by[tgt[e]].push_back((int32_t)e);
-        std::vector<int32_t> T{(int32_t)by.size()}, E;
-        for (auto &kv : by) {
-            T.push_back(kv.first); T.push_back((int32_t)E.size());
-            E.insert(E.end(), kv.second.begin(), kv.second.end());
-            T.push_back((int32_t)E.size());
-        }
-        w.X.ensure(8 * X.size()); w.T.ensure(4 * T.size()); w.E.ensure(4 * std::max<size_t>(E.size(), 1)); w.xbuf.ensure(8 * tgt.size());
-        HIPCHK(hipMemcpy(w.X.p, X.data(), 8 * X.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(w.T.p, T.data(), 4 * T.size(), hipMemcpyHostToDevice));
-        if (!E.empty()) HIPCHK(hipMemcpy(w.E.p, E.data(), 4 * E.size(), hipMemcpyHostToDevice));
-    }
-    // shared entries: workgroup map, partial-sum layout, fold list
-    w.ns_blocks = 0;
-    {
-        const int64_t zero = 0;        // F[0] = 0 groups unless filled below
-        w.F.ensure(8);
-        HIPCHK(hipMemcpy(w.F.p, &zero, 8, hipMemcpyHostToDevice));
-    }
-    if (!shs.empty()) {
-        std::vector<int64_t> St, F{0};
-        int64_t blocks = 0, parts = 0;
-        for (const auto &sh : shs) {
-            const int64_t per = (int64_t)kBlock * kSharedTiles, nt = (sh.e_hi - sh.e_lo + per - 1) / per;
-            St.push_back(sh.e_lo); St.push_back(sh.e_hi); St.push_back(blocks); St.push_back(parts);
-            for (size_t g = 0; g < sh.target.size(); g++) { F.push_back(parts + (int64_t)g * nt); F.push_back(nt); F.push_back(sh.target[g]); F[0]++; }
-            blocks += nt;
-            parts += nt * (int64_t)sh.target.size();
-        }
-        St.push_back(0); St.push_back(0); St.push_back(blocks); St.push_back(parts);     // sentinel
-        w.ns_blocks = blocks;
-        w.S.ensure(8 * St.size()); w.F.ensure(8 * F.size()); w.part.ensure(8 * (size_t)std::max<int64_t>(parts, 1));
-        HIPCHK(hipMemcpy(w.S.p, St.data(), 8 * St.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(w.F.p, F.data(), 8 * F.size(), hipMemcpyHostToDevice));
-    }
-    w.Q.ensure(8 * Q.size());
-    HIPCHK(hipMemcpy(w.Q.p, Q.data(), 8 * Q.size(), hipMemcpyHostToDevice));
-    // R[window][pass] = [lo, hi): the regular points with a slot of that pass inside the window
-    if (nspaces > 0) {
-        w.R.ensure(4 * Rb.size());
-        HIPCHK(hipMemcpy(w.R.p, Rb.data(), 4 * Rb.size(), hipMemcpyHostToDevice));
-    } else {
-        auto fdiv = [](int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; };   // b > 0
-        auto cdiv = [&](int64_t a, int64_t b) { return -fdiv(-a, b); };
-        const size_t np = pats.size();
-        std::vector<int32_t> R((size_t)nwin * np * 2);
-        for (int64_t j = 0; j < nwin; j++) {
-            const int64_t c0 = j * W, c1 = c0 + W - 1;
-            for (size_t q = 0; q < np; q++) {
-                const int64_t *t = &Q[pats[q].qbase];
-                const int64_t b = t[0], amin = t[3], amax = t[4];
-                int64_t lo, hi;
-                if (b > 0) { lo = cdiv(c0 - amax, b); hi = fdiv(c1 - amin, b) + 1; }
-                else { lo = cdiv(amin - c1, -b); hi = fdiv(amax - c0, -b) + 1; }
-                lo = std::max(lo, t[1]); hi = std::min(hi, t[2]);
-                if (hi < lo) hi = lo;
-                R[(j * np + q) * 2] = (int32_t)lo; R[(j * np + q) * 2 + 1] = (int32_t)hi;
-            }
-        }
-        w.R.ensure(4 * R.size());
-        HIPCHK(hipMemcpy(w.R.p, R.data(), 4 * R.size(), hipMemcpyHostToDevice));
-    }
-    w.W = (int)W;
-    w.nwin = nwin;
-    w.why = nspaces > 0 ? "block-owned windows, " + std::to_string(nspaces) + " spaces" : (single ? "one chunk per pass" : "chunk loops");
-    if (verbose()) {
-        fprintf(stderr, "[exahip] windowed %s (%s): W=%ld windows=%ld passes=%zu shared-entry workgroups=%ld irregular points=%d\n", hess ? "hess" : "jac", nspaces > 0 ? "block-owned, one evaluation per point" : (single ? "one chunk per pass" : "chunk loops"), (long)W,
-                (long)nwin, pats.size(), (long)w.ns_blocks, w.nx);
-        for (size_t q = 0; q < pats.size(); q++) {
-            const int64_t *t = &Q[pats[q].qbase];
-            fprintf(stderr, "[exahip]   pass %zu: pattern %d  b=%ld  points [%ld,%ld)  targets %ld..%ld  groups=%zu\n", q, pats[q].k, (long)t[0], (long)t[1], (long)t[2],
-                    (long)t[3], (long)t[4], pats[q].phase.size());
-        }
-    }
-    return true;
-}
-
-void window_setup(Handle &h) {
-    // exa_compress may be called again (e.g. with another EXAHIP_CWINDOW): start from scratch
-    for (Handle::Window *w : {&h.wj, &h.wh}) { w->ok = false; w->why.clear(); w->nx = 0; w->ns_blocks = 0; w->nwin = 0; }
-    h.sj.ok = h.sh.ok = false; h.sj.f = h.sh.f = nullptr;
-    h.merged = false; h.f_chessm = h.f_hstructm = nullptr; h.chm.release();
-    if (h.wmodule) { (void)hipModuleUnload(h.wmodule); h.wmodule = nullptr; }
-    const char *env = getenv("EXAHIP_CWINDOW");
-    if (env && atoi(env) == 0) { h.wj.why = h.wh.why = "disabled (EXAHIP_CWINDOW=0)"; return; }
-    h.sj.ok = h.sh.ok = false;
-    const bool plan_windows = true;                 // (a shard plans the windows of its local slice: absolute point indices throughout)
-    const Model &m = *h.m;
-    if (std::max(h.lnnzj, h.lnnzh) > 0x7fffffffLL) { h.wj.why = h.wh.why = "nnz exceeds int32"; return; }
-    WindowSpec spec;
-    DevBuf cmap;
-    cmap.ensure(4 * (size_t)std::max<int64_t>(std::max(h.lnnzj, h.lnnzh), 1));
-    bool okj = false, okh = false;
-    if (plan_windows) try {
-        build_slot_map(h.cj, (int32_t *)cmap.p, h.stream);
-        HIPCHK(hipStreamSynchronize(h.stream));
-        okj = window_plan(h, false, (const int32_t *)cmap.p, spec.jac, spec.jac_shared, spec.jac_single, spec.jac_nspaces, spec.jac_zs);
-        if (!okj) { spec.jac.clear(); spec.jac_shared.clear(); }
-        build_slot_map(h.ch, (int32_t *)cmap.p, h.stream);
-        HIPCHK(hipStreamSynchronize(h.stream));
-        okh = window_plan(h, true, (const int32_t *)cmap.p, spec.hess, spec.hess_shared, spec.hess_single, spec.hess_nspaces, spec.hess_zs);
-        if (!okh) { spec.hess.clear(); spec.hess_shared.clear(); }
-    } catch (...) { cmap.release(); throw; }
-    cmap.release();
-    // what the windows do not cover goes through the permuted store when it can: 32-bit positions, no entry with more
-    // than 512 duplicates (those are summed cooperatively through the gather lists)
-    h.sj.ok = h.sh.ok = false;
-    const char *se = getenv("EXAHIP_CSCATTER");
-    const bool scatter_on = !(se && atoi(se) == 0);
-    spec.jac_scatter = scatter_on && !okj && h.cj.nnz > 0 && h.cj.nlong == 0;
-    spec.hess_scatter = scatter_on && !okh && h.ch.nnz > 0 && h.ch.nlong == 0;
-    // Hessian: merged slots when the fused groups collapse enough of them (ACOPF: 5.7 M slots -> 1.9 M)
-    std::vector<int64_t> M;
-    if (spec.hess_scatter) {
-        const ParamLayout &L = h.gen.layout;
-        const std::vector<int> sm = merged_hess_slots(m, L);
-        int64_t nm = 0;
-        for (size_t g = 0; g < L.groups[CB_HESS].size(); g++) {
-            const auto &pp = L.pat[L.groups[CB_HESS][g].front()];
-            M.push_back(nm);
-            nm += (int64_t)sm[g] * (h.P[pp.hi] - h.P[pp.lo]);
-        }
-        if (nm > 0 && nm < 0xffffffffLL && (double)nm <= 0.8 * (double)h.ch.nnz) { spec.hess_merged = true; h.nmerged = nm; }
-    }
-    if (!okj && !okh && !spec.jac_scatter && !spec.hess_scatter) return;
-    const std::string src = generate_window_module(m, h.gen.layout, spec);
-    std::vector<char> image;
-    // the gather path needs no second module: a host without hipcc (a packed library's consumer) or a failed compilation
-    // must not take exa_compress down with it
-    try {
-        image = get_code_object(src, true).image;
-        HIPCHK(hipModuleLoadData(&h.wmodule, image.data()));
-        auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
-        if (okj) { h.wj.fw = fn("exa_cjacw"); h.wj.fx = fn("exa_cjacx"); if (h.wj.ns_blocks) h.wj.fs = fn("exa_cjacs"); }
-        if (okh) { h.wh.fw = fn("exa_chessw"); h.wh.fx = fn("exa_chessx"); if (h.wh.ns_blocks) h.wh.fs = fn("exa_chesss"); }
-        if (spec.jac_scatter) h.sj.f = fn("exa_cjacp");
-        if (spec.hess_scatter) h.sh.f = fn("exa_chessp");
-        if (spec.hess_merged) { h.f_chessm = fn("exa_chessm"); h.f_hstructm = fn("exa_hstructm"); }
-    } catch (const std::exception &e) {
-        std::string msg = e.what();
-        if (msg.size() > 300) msg.resize(300);
-        h.wj.why = h.wh.why = "the windowed kernels could not be built (" + msg + ")";
-        if (h.wmodule) { (void)hipModuleUnload(h.wmodule); h.wmodule = nullptr; }
-        return;
-    }
-    // a matrix on the windowed sweep never gathers: its sorted permutation (4 B per uncompressed slot: 3.6 GB for LV 1e8)
-    // and pointer list can go
-    if (okj) { h.cj.release_gather(); h.wj.ok = true; }
-    if (okh) { h.ch.release_gather(); h.wh.ok = true; }
-    if (spec.hess_merged && h.f_chessm) {
-        // structure of the merged slot space -> its own sorted lists; it must describe the same matrix as the slots'
-        DevBuf r, c;
-        try {
-            h.dM.ensure(8 * M.size());
-            HIPCHK(hipMemcpy(h.dM.p, M.data(), 8 * M.size(), hipMemcpyHostToDevice));
-            r.ensure(8 * (size_t)h.nmerged); c.ensure(8 * (size_t)h.nmerged);
-            const void *P = h.dP.p, *Mp = h.dM.p;
-            void *rp = r.p, *cp = c.p;
-            void *a[] = {&P, &rp, &cp, &Mp};
-            launch(h, h.f_hstructm, h.grid[CB_HESS], kBlock, a);
-            build_compressed(h.chm, (const int64_t *)r.p, (const int64_t *)c.p, h.nmerged, std::max<int64_t>(m.nvar, 1), std::max<int64_t>(m.nvar, 1), h.stream);
-            HIPCHK(hipStreamSynchronize(h.stream));
-        } catch (...) { r.release(); c.release(); throw; }
-        r.release(); c.release();
-        if (h.chm.cnnz == h.ch.cnnz && h.chm.nlong == 0) {
-            h.sh.pos.ensure(4 * (size_t)h.nmerged);
-            build_positions(h.chm, (uint32_t *)h.sh.pos.p, h.stream);
-            HIPCHK(hipStreamSynchronize(h.stream));
-            h.merged = true;
-            h.sh.ok = true;
-            h.wh.why = "merged slots (" + std::to_string(h.nmerged) + " for " + std::to_string(h.ch.nnz) + "), permuted store + sequential sums";
-            h.ch.release_gather();
-        } else h.chm.release();
-    }
-    for (int hess = 0; hess < 2; hess++) {
-        Handle::Scatter &sc = hess ? h.sh : h.sj;
-        CompressedCOO &cc = hess ? h.ch : h.cj;
-        if (hess && h.merged) continue;
-        if (!(hess ? spec.hess_scatter : spec.jac_scatter) || !sc.f) continue;
-        sc.pos.ensure(4 * (size_t)cc.nnz);
-        build_positions(cc, (uint32_t *)sc.pos.p, h.stream);
-        HIPCHK(hipStreamSynchronize(h.stream));
-        sc.ok = true;
-        (hess ? h.wh : h.wj).why = cc.cnnz == cc.nnz ? "permuted store (no duplicates: the sweep writes the compressed entries directly)"
-                                                      : "permuted store + sequential sums of the sorted duplicates";
-    }
-}
-void do_scatter(Handle &h, bool hess, const double *x, const double *y, double sigma, double *vals) {
-    Handle::Scatter &sc = hess ? h.sh : h.sj;
-    const CompressedCOO &cc = hess ? h.ch : h.cj;
-    const void *P = h.dP.p, *th = h.dtheta.p, *pos = sc.pos.p;
-    if (hess && h.merged) {
-        const bool direct = h.chm.cnnz == h.chm.nnz;
-        double *out = direct ? vals : (double *)h.cbuf.p;
-        const void *Mp = h.dM.p;
-        void *a[] = {&P, &x, &y, &th, &out, &sigma, &pos, &Mp};
-        launch(h, h.f_chessm, h.grid[CB_HESS], kBlock, a);
-        if (!direct) compress_sorted(h.chm, out, vals, h.stream);
-        return;
-    }
-    const bool direct = cc.cnnz == cc.nnz;          // a permutation: the sorted order IS the compressed array
-    double *out = direct ? vals : (double *)h.cbuf.p;
-    if (hess) { void *a[] = {&P, &x, &y, &th, &out, &sigma, &pos}; launch(h, sc.f, h.grid[CB_HESS], kBlock, a); }
-    else { void *a[] = {&P, &x, &th, &out, &pos}; launch(h, sc.f, h.grid[CB_JAC], kBlock, a); }
-    if (!direct) compress_sorted(cc, out, vals, h.stream);
-}
-
-void do_window(Handle &h, bool hess, const double *x, const double *y, double sigma, double *vals) {
-    Handle::Window &w = hess ? h.wh : h.wj;
-    const void *P = h.dP.p, *Q = w.Q.p, *R = w.R.p, *th = h.dtheta.p;
-    int64_t ncomp = hess ? h.ch.cnnz : h.cj.cnnz;
-    int W = w.W;
-    void *part = w.part.p;
-    const int64_t ns = w.ns_blocks;
-    if (ns) {
-        const void *S = w.S.p;
-        void *a1[] = {&P, &S, &x, &y, &th, &part, &sigma};
-        HIPCHK(hipModuleLaunchKernel(w.fs, (unsigned)ns, 1, 1, kBlock, 1, 1, 0, h.stream, a1, nullptr));
-    }
-    void *a[] = {&P, &Q, &R, &x, &y, &th, &vals, &sigma, &ncomp, &W};
-    HIPCHK(hipModuleLaunchKernel(w.fw, (unsigned)w.nwin, 1, 1, kBlock, 1, 1, (unsigned)(8 * W), h.stream, a, nullptr));
-    if (w.nx || ns) {
-        // tail: the irregular end points, then the fold of the shared-entry partial sums (one workgroup)
-        const void *X = w.X.p, *T = w.T.p, *E = w.E.p, *F = w.F.p;
-        void *xbuf = w.xbuf.p;
-        int nx = w.nx;
-        void *a2[] = {&P, &X, &T, &E, &x, &y, &th, &xbuf, &vals, &sigma, &nx, &part, &F};
-        HIPCHK(hipModuleLaunchKernel(w.fx, 1, 1, 1, 1024, 1, 1, 0, h.stream, a2, nullptr));     // 1024 threads: the fold is one workgroup's loop
-    }
-}
-
 // ---- compressed COO (CompressedNLPModel, src/utils.jl:425-579) ---------------------------------------------
 int exa_compress(int id) {
     return guard(id, true, [&](Handle &h) {
@@ -1811,7 +1997,7 @@ int exa_cjac(int id, const double *x, double *vals) {
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) {
         if (!h.compressed) throw BadInput("exa_compress has not been called");
-        if (h.wj.ok) { do_window(h, false, x, nullptr, 0.0, vals); return; }
+        if (h.wj.ok) { do_window(h, WK_CJAC, x, nullptr, nullptr, 0.0, vals); return; }
         if (h.sj.ok) { do_scatter(h, false, x, nullptr, 0.0, vals); return; }
         do_jac(h, x, (double *)h.cbuf.p);
         compress_values(h.cj, (const double *)h.cbuf.p, vals, h.stream);
@@ -1821,7 +2007,7 @@ int exa_chess(int id, const double *x, const double *y, double w, double *vals) 
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) {
         if (!h.compressed) throw BadInput("exa_compress has not been called");
-        if (h.wh.ok) { do_window(h, true, x, y, w, vals); return; }
+        if (h.wh.ok) { do_window(h, WK_CHESS, x, y, nullptr, w, vals); return; }
         if (h.sh.ok) { do_scatter(h, true, x, y, w, vals); return; }
         do_hess(h, x, y, w, (double *)h.cbuf.p);
         compress_values(h.ch, (const double *)h.cbuf.p, vals, h.stream);
@@ -1925,6 +2111,14 @@ int exa_tune(int id, int what, const double *x, const double *y) {
                     if (hess) best = pick_faster(h, [&] { do_hprod(h, x, y, x, sigma, g); }, [&] { do_hprod_sorted(h, x, y, x, sigma, g); });
                     else best = pick_faster(h, [&] { do_jtprod(h, x, y, g); }, [&] { do_jtprod_sorted(h, x, y, g); });
                     if (best == 0) drop_sorted(h, hess != 0);
+                }
+                if (window_possible(h, hess != 0)) {
+                    // the owner-computes windows against the winner so far
+                    const int other = best;
+                    auto base = [&] { if (hess) { if (other) do_hprod_sorted(h, x, y, x, sigma, g); else do_hprod(h, x, y, x, sigma, g); }
+                                      else { if (other) do_jtprod_sorted(h, x, y, g); else do_jtprod(h, x, y, g); } };
+                    auto wnd = [&] { if (hess) run_product_window(h, true, x, y, x, sigma, g); else run_product_window(h, false, x, nullptr, y, 0.0, g); };
+                    if (pick_faster(h, base, wnd) == 1) { best = 2; if (other == 1) drop_sorted(h, hess != 0); }
                 }
                 mode = best;
                 tune_store(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), best);

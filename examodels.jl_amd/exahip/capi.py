@@ -26,7 +26,7 @@ SYMBOLS = [
     "exa_chess_structure64", "exa_cjac_csc", "exa_chess_csc", "exa_cjac", "exa_chess",
     "exa_build_info", "exa_tune", "exa_comm_unique_id", "exa_comm_init", "exa_comm_attach", "exa_comm_hook", "exa_comm_free",
     "exa_comm_info", "exa_set_reduce", "exa_allreduce", "exa_set_coo_local", "exa_local_nnzj64", "exa_local_nnzh64",
-    "exa_coo_slices", "exa_shard_var_range", "exa_hess_variant",
+    "exa_coo_slices", "exa_shard_var_range", "exa_hess_variant", "exa_product_info",
 ]
 # ... and include/exahip_recipe.h
 RECIPE_SYMBOLS = [
@@ -134,6 +134,7 @@ def lib():
     L.exa_coo_slices.argtypes = [i32, i32, vp]
     L.exa_shard_var_range.argtypes = [i32, vp, vp]
     L.exa_hess_variant.argtypes = [i32]
+    L.exa_product_info.argtypes = [i32, i32, ctypes.c_char_p, i32]
     # include/exahip_recipe.h
     cp, sz = ctypes.c_char_p, ctypes.c_size_t
     L.exa_recipe_load.argtypes = [vp, sz]
@@ -167,5 +168,7 @@ class ExaHipError(RuntimeError):
 def check(status, what):
     if status == 0:
         return
-    msg = lib().exa_last_error().decode(errors="replace") if status == 2 else "bad id or argument"
+    msg = lib().exa_last_error().decode(errors="replace")
+    if status != 2:
+        msg = "bad id or argument" + (": " + msg if msg else "")
     raise ExaHipError(f"{what}: status {status}: {msg}")

@@ -506,7 +506,8 @@ class ExaModel:
         return out
 
     def set_product_mode(self, jtprod=-1, hprod=-1):
-        """0 atomics in the sweep, 1 COO + sorted gather, -1 undecided (default): what tune() persisted, else atomics."""
+        """0 atomics in the sweep, 1 COO + sorted gather, 2 owner-computes windows (range-affine models), -1 undecided
+        (default): what tune() persisted, else the windows where the model has them, else atomics."""
         capi.check(self._L.exa_set_product_mode(self.id, int(jtprod), int(hprod)), "exa_set_product_mode")
 
     def set_grad_mode(self, mode=-1):
@@ -521,6 +522,13 @@ class ExaModel:
         a = ctypes.c_int(0)
         capi.check(self._L.exa_get_grad_mode(self.id, ctypes.addressof(a)), "exa_get_grad_mode")
         return a.value
+
+    def product_info(self, which):
+        """(mode, text) for which = "jtprod" | "hprod": the implementation a call would run now (0 atomics, 1 sorted gather,
+        2 owner-computes windows) and the kernel shape of the windows / why the model has none (exa_product_info)."""
+        buf = ctypes.create_string_buffer(512)
+        mode = self._L.exa_product_info(self.id, 1 if which == "hprod" else 0, buf, 512)
+        return mode, buf.value.decode()
 
     def product_mode(self):
         a, b = ctypes.c_int(0), ctypes.c_int(0)

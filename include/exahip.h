@@ -51,7 +51,7 @@
 extern "C" {
 #endif
 
-#define EXAHIP_ABI_VERSION 2
+#define EXAHIP_ABI_VERSION 3
 
 int         exa_abi_version(void);
 const char *exa_last_error(void);                       /* thread-local text of the last status-2 failure */
@@ -175,12 +175,21 @@ int exa_hess(int id, const double *x, const double *y, double obj_weight, double
 int exa_jprod (int id, const double *x, const double *v, double *Jv);             /* Jv [ncon]  = J(x) v,   v [nvar] */
 int exa_jtprod(int id, const double *x, const double *v, double *Jtv);            /* Jtv [nvar] = J(x)' v,  v [ncon] */
 int exa_hprod (int id, const double *x, const double *y, const double *v, double obj_weight, double *Hv);  /* Hv [nvar] */
-/* exa_jtprod / exa_hprod have two implementations: FP64 atomics inside the sweep, or COO + gather through build-time
- * sorted lists (the reference's prod helper, KA ext :56-178, :482-511; deterministic).  mode: 0 atomics, 1 sorted gather,
- * -1 (default) undecided: the decision exa_tune measured and persisted for this module / device / sizes ("chosen by
- * measured contention") if there is one, else atomics.  The mode is fixed before a call; a callback never measures. */
+/* exa_jtprod / exa_hprod have three implementations.  mode 0: FP64 atomics inside the sweep (zero-fill + atomics; order of
+ * additions varies).  mode 1: COO + gather through build-time sorted lists (the reference's prod helper, KA ext :56-178,
+ * :482-511; deterministic).  mode 2: OWNER-COMPUTES WINDOWS — models whose every scatter target is (range value) * literal +
+ * literal (stencil models: LV, discretised ODEs): a workgroup owns a window of consecutive variables, evaluates the data
+ * points that touch it (the few straddling two windows twice), adds their contributions in LDS in a fixed order and streams
+ * the window out with plain coalesced stores — no zero-fill, no atomics, bit-reproducible; a sharded model owns a range of
+ * windows per rank (complete values, all-gather-v instead of all-reduce).  -1 (default) undecided: the decision exa_tune
+ * measured and persisted for this module / device / sizes ("chosen by measured contention") if there is one, else mode 2
+ * where the model has windows, else 0.  The mode is fixed before a call; a callback never measures. */
 int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode);
 int exa_get_product_mode(int id, int *jtprod_mode, int *hprod_mode);
+/* What exa_jtprod (hess = 0) / exa_hprod (hess = 1) would run now: 0 | 1 | 2 as above, -1 bad id; buf <- the kernel shape of the
+ * owner-computes windows ("one chunk per pass" | "chunk loops" | "block-owned windows, K spaces") or why the model has none.
+ * Works on exa_plan_only handles too (the plan is host-only; EXAHIP_PRODUCT_WINDOW=0 disables it). */
+int exa_product_info(int id, int hess, char *buf, int cap);
 /* exa_grad likewise: 0 = affine-indexed objective patterns gathered per variable + data-indexed ones added with FP64
  * atomics, 1 = the reference's scheme (KA ext :310-336: gradient COO of ExaCore.nnzg slots, (variable, slot) lists sorted
  * once, every variable's slots added in slot order — deterministic; a variable shared by millions of data points is

@@ -1,0 +1,145 @@
+"""-m gpu: owner-computes windows for J'v / Hv (exa_jtprodw / exa_hprodw; reference: jtprod_nln! / hprod!, KA ext :389-511,
+which zero-fill and accumulate through sorted lists).  A workgroup owns a window of consecutive variables and adds the
+contributions of the data points that touch it in LDS, in a fixed order: no zero-fill, no atomics, bit-reproducible, and a
+sharded model owns a range of windows per rank."""
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from zoo import ZOO, point
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+RTOL = 1e-10
+
+
+def relerr(a, ref):
+    a, ref = np.asarray(a), np.asarray(ref)
+    scale = np.maximum(np.abs(ref), 1e-3 * max(1.0, np.max(np.abs(ref)))) if ref.size else 1.0
+    return float(np.max(np.abs(a - ref) / scale)) if ref.size else 0.0
+
+
+def _models():
+    from exahip import models
+    cases = {n: ZOO[n] for n in ("lv3", "lv20", "lv1000", "rocket50", "stepped", "cops_chain", "cops_elec")}
+    cases["lv70001"] = lambda: models.luksan_vlcek_model(70_001)          # many windows, ragged last one
+    cases["lv_objfirst_5000"] = lambda: models.luksan_vlcek_model(5000, obj_first=True)
+    cases["rocket3000"] = lambda: models.rocket_model(3000)               # block-owned windows + an entry every point adds to
+    return cases
+
+
+@pytest.mark.parametrize("name", sorted(_models()))
+def test_window_products_equal_the_oracle_and_are_bit_reproducible(libs, name):
+    import torch
+    from exahip import ExaModel, capi
+    import oracle
+    m = ExaModel(_models()[name]())
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=12)
+    v = np.random.default_rng(5).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(6).standard_normal(m.meta.ncon)
+    dev = torch.device("cuda:0")
+    xd, yd, vd, wd = (torch.from_numpy(a).to(dev) for a in (x, y, v, w))
+    for which, call, ref in (("jtprod", lambda out: m.jtprod(xd, wd, out=out), o.jtprod(x, w)),
+                             ("hprod", lambda out: m.hprod(xd, yd, vd, sigma, out=out), o.hprod(x, y, v, sigma))):
+        mode, text = m.product_info(which)
+        try:
+            m.set_product_mode(2 if which == "jtprod" else -1, 2 if which == "hprod" else -1)
+        except capi.ExaHipError:
+            # no windows: a handful of points (everything would go to the tail kernel), or targets through a data column
+            assert (name == "cops_elec" and which == "hprod" and "data column" in text) or (name == "lv3" and text == "no regular pattern"), (name, which, text)
+            continue
+        assert text.startswith(("one chunk per pass", "chunk loops", "block-owned windows")), text
+        # undecided models take the windows by default unless an entry is shared by every data point (rocket: the step length)
+        assert mode == (0 if name.startswith("rocket") else 2), (name, which, mode, text)
+        outs = []
+        for _ in range(3):
+            out = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)   # fully overwritten: no zero-fill needed
+            call(out)
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy())
+        assert relerr(outs[0], ref) <= RTOL, (name, which)
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])         # fixed order of additions
+        # the other two implementations agree
+        jm, hm = (0, -1) if which == "jtprod" else (-1, 0)
+        m.set_product_mode(jm, hm)
+        out = torch.empty(m.meta.nvar, dtype=torch.float64, device=dev)
+        call(out)
+        assert relerr(out.cpu().numpy(), outs[0]) <= RTOL
+        m.set_product_mode(-1, -1)
+
+
+def test_a_model_with_data_indexed_targets_has_no_windows(libs):
+    from exahip import ExaModel, capi
+    m = ExaModel(ZOO["acopf30"]())
+    assert m.product_info("jtprod")[0] == 0 and "data column" in m.product_info("jtprod")[1]
+    with pytest.raises(capi.ExaHipError, match="no owner-computes windows"):
+        m.set_product_mode(2, 2)
+
+
+def test_the_window_knob_switches_them_off(libs, monkeypatch):
+    from exahip import ExaModel
+    monkeypatch.setenv("EXAHIP_PRODUCT_WINDOW", "0")
+    m = ExaModel(ZOO["lv20"]())
+    assert m.product_info("hprod") == (0, "disabled (EXAHIP_PRODUCT_WINDOW=0)")
+    import oracle
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=1)
+    v = np.ones(m.meta.nvar)
+    assert relerr(m.hprod(x, y, v, sigma), o.hprod(x, y, v, sigma)) <= RTOL
+
+
+@pytest.mark.parametrize("name", ["lv1000", "lv70001", "stepped"])
+def test_a_sharded_model_owns_ranges_of_windows(libs, name):
+    """Owner computes: rank r evaluates the windows [nwin*r/G, nwin*(r+1)/G) — complete values for the variables it owns,
+    from whatever data points touch them — and writes nothing else.  Without a communicator the pieces of G ranks written
+    into one buffer are the whole product; nothing needs a sum."""
+    import torch
+    from exahip import ExaModel
+    import oracle
+    m = ExaModel(_models()[name]())
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=2)
+    v = np.random.default_rng(5).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(6).standard_normal(m.meta.ncon)
+    dev = torch.device("cuda:0")
+    xd, yd, vd, wd = (torch.from_numpy(a).to(dev) for a in (x, y, v, w))
+    G = 3
+    jt = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)
+    hv = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)
+    written = np.zeros(m.meta.nvar, dtype=int)
+    try:
+        for r in range(G):
+            m.set_shard(r, G)
+            assert m.product_info("hprod")[0] == 2
+            before = torch.isnan(hv).cpu().numpy()
+            m.jtprod(xd, wd, out=jt)
+            m.hprod(xd, yd, vd, sigma, out=hv)
+            torch.cuda.synchronize()
+            written += (before & ~torch.isnan(hv).cpu().numpy()).astype(int)
+    finally:
+        m.set_shard(0, 1)
+    assert written.min() == 1 and written.max() == 1                  # every variable written by exactly one rank
+    assert relerr(jt.cpu().numpy(), o.jtprod(x, w)) <= RTOL
+    assert relerr(hv.cpu().numpy(), o.hprod(x, y, v, sigma)) <= RTOL
+
+
+def test_full_size_lv_windows_against_the_atomics(libs):
+    """BASELINE config 2 size: LV N = 1e7, J'v and Hv by windows == by atomics (1e-10), twice the same bits."""
+    import torch
+    from exahip import ExaModel, models
+    N = 10_000_000
+    m = ExaModel(models.luksan_vlcek_model(N))
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(m.meta.x0 + 0.1 * np.random.default_rng(0).uniform(-1, 1, N)).to(dev)
+    y = torch.from_numpy(np.random.default_rng(1).standard_normal(N - 2)).to(dev)
+    v = torch.from_numpy(np.random.default_rng(2).standard_normal(N)).to(dev)
+    assert m.product_info("jtprod")[0] == 2 and m.product_info("hprod")[0] == 2
+    a1, b1 = m.jtprod(x, y).clone(), m.hprod(x, y, v, 0.5).clone()
+    a2, b2 = m.jtprod(x, y), m.hprod(x, y, v, 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+    m.set_product_mode(0, 0)
+    a0, b0 = m.jtprod(x, y), m.hprod(x, y, v, 0.5)
+    for got, ref in ((a1, a0), (b1, b0)):
+        scale = torch.clamp(ref.abs(), min=1e-3 * float(ref.abs().max()))
+        assert float(((got - ref).abs() / scale).max()) <= RTOL
