@@ -45,7 +45,7 @@ def test_library_exports_every_declared_symbol(libs):
     for s in recipe:
         assert hasattr(L, s), f"libexahip.so does not export {s}"
     assert sorted(capi.RECIPE_SYMBOLS) == recipe, "capi.RECIPE_SYMBOLS and include/exahip_recipe.h disagree"
-    assert L.exa_abi_version() == 2
+    assert L.exa_abi_version() == 3
 
 
 def test_bad_ids_and_arguments_return_status_1(libs):
