@@ -19,7 +19,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
     L.pat.resize(np);
     for (int k = 0; k < np; k++) {
         auto &pp = L.pat[k];
-        pp.lo = w++; pp.hi = w++; pp.o0 = w++; pp.o1 = w++; pp.o2 = w++; pp.oa = w++; pp.ob = w++;
+        pp.lo = w++; pp.hi = w++; pp.o0 = w++; pp.o1 = w++; pp.o2 = w++; pp.oa = w++; pp.ob = w++; pp.qlo = w++; pp.qhi = w++;
         for (size_t c = 0; c < m.pats[k].cols.size(); c++) {
             const Column &col = m.pats[k].cols[c];
             pp.col.push_back(col.alias_pat >= 0 ? L.pat[col.alias_pat].col[col.alias_col] : w++);      // one word per DISTINCT column
@@ -198,13 +198,16 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
     scatter_lds(CB_GRAD);
     gen_dispatch(os, L, CB_GRAD, "grad", "P, x, th, out", ", lds");
     os << "}\n";
-    // grad!, gather part: one thread per variable; also provides the zero of untouched variables (no memset)
+    // grad!, gather part: one thread per variable of [v_begin, v_end); also provides the zero of untouched variables (no
+    // memset).  The value is COMPLETE — every data point of every gathered pattern that touches the variable, whatever the
+    // shard — for the variables [own_lo, own_hi) this rank owns, and zero elsewhere: owner computes.  A sharded model whose
+    // objective patterns are all gathered launches it over its own variables only and needs no collective at all.
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_grad_pull(const long* __restrict__ P, const double* __restrict__ x, "
-          "const double* __restrict__ th, double* __restrict__ out, long nvar) {\n"
-          "    const long v0 = (long)blockIdx.x * (EXA_BLOCK * EXA_PULL_PPT) + threadIdx.x;\n    double g[EXA_PULL_PPT];\n"
-          "#pragma unroll\n    for (int u = 0; u < EXA_PULL_PPT; u++) {\n        const long v_ = v0 + u * EXA_BLOCK, v = v_ < nvar ? v_ : nvar - 1;\n        g[u] = 0.0;\n";
+          "const double* __restrict__ th, double* __restrict__ out, long v_begin, long v_end, long own_lo, long own_hi) {\n"
+          "    const long v0 = v_begin + (long)blockIdx.x * (EXA_BLOCK * EXA_PULL_PPT) + threadIdx.x;\n    double g[EXA_PULL_PPT];\n"
+          "#pragma unroll\n    for (int u = 0; u < EXA_PULL_PPT; u++) {\n        const long v_ = v0 + u * EXA_BLOCK, v = v_ < v_end ? v_ : v_end - 1;\n        g[u] = 0.0;\n";
     for (int k : L.pull) os << "        g[u] += p" << k << "_pull(P, x, th, v + 1);\n";
-    os << "    }\n#pragma unroll\n    for (int u = 0; u < EXA_PULL_PPT; u++) { const long v = v0 + u * EXA_BLOCK; if (v < nvar) out[v] = g[u]; }\n}\n";
+    os << "    }\n#pragma unroll\n    for (int u = 0; u < EXA_PULL_PPT; u++) { const long v = v0 + u * EXA_BLOCK; if (v < v_end) out[v] = v >= own_lo && v < own_hi ? g[u] : 0.0; }\n}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_cons(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out, double* __restrict__ aug) {\n";
     {

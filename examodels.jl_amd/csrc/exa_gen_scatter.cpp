@@ -187,6 +187,23 @@ bool pull_ok(const Pattern &p, std::vector<Affine> &slots) {
     return true;
 }
 
+}  // namespace gen
+void pull_point_range(const Pattern &p, int64_t v_lo, int64_t v_hi, int64_t *jlo, int64_t *jhi) {
+    std::vector<gen::Affine> slots;
+    *jlo = 0; *jhi = 0;
+    if (!gen::pull_ok(p, slots) || v_hi < v_lo) return;
+    auto fdiv = [](int64_t a, int64_t b) { int64_t q = a / b; return (a % b != 0 && a < 0) ? q - 1 : q; };   // b > 0
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    for (const gen::Affine &s : slots) {
+        const Column &c = p.cols[s.col];
+        // variable = c.start + c.step * J + s.c  (s.a == 1, c.step >= 1)
+        lo = std::min(lo, -fdiv(-(v_lo - s.c - c.start), c.step));
+        hi = std::max(hi, fdiv(v_hi - s.c - c.start, c.step) + 1);
+    }
+    lo = std::max<int64_t>(lo, 0); hi = std::min(hi, p.n);
+    if (hi > lo) { *jlo = lo; *jhi = hi; }
+}
+namespace gen {
 void gen_pull_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
     const Pattern &p = m.pats[pi];
     std::vector<Affine> slots;
@@ -195,7 +212,9 @@ void gen_pull_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, long v) {\n    double g = 0.0;\n";
     // every slot is evaluated unconditionally at an index clamped into the shard and its contribution selected
     // afterwards: no data-dependent branch, so a thread handling several variables has all its loads in flight at once
-    os << "    const long lo_ = " << Body(m, pi, L).P(L.pat[pi].lo) << ", hi_ = " << Body(m, pi, L).P(L.pat[pi].hi) << ";\n"
+    // (the points of the WHOLE pattern that touch this rank's variables, not the shard's own points: the variable's owner
+    // evaluates whatever touches it; clamped indices stay inside that range, i.e. inside the stretch of x the rank holds)
+    os << "    const long lo_ = " << Body(m, pi, L).P(L.pat[pi].qlo) << ", hi_ = " << Body(m, pi, L).P(L.pat[pi].qhi) << ";\n"
        << "    if (lo_ >= hi_) return 0.0;\n";
     for (int s = 0; s < p.o1step; s++) {
         Body b(m, pi, L);

@@ -94,6 +94,9 @@ struct ParamLayout {
     // word indices into the int64 parameter table P that every kernel receives
     struct Pat {
         int lo = -1, hi = -1, o0 = -1, o1 = -1, o2 = -1, oa = -1;
+        // gathered objective patterns (exa_grad_pull, owner computes): the data points [qlo, qhi) of the WHOLE pattern that
+        // touch a variable this rank owns — all of them unless sharded (lo / hi are the shard's own data points)
+        int qlo = -1, qhi = -1;
         int ob = -1;            // OBJ patterns: first slot of this pattern's workgroups among the fused sweep's objective partials
         std::vector<int> col;   // per column: device pointer (I64/F64) or range start (RANGE)
     };
@@ -132,7 +135,9 @@ constexpr int kBlock = 256;
 // exa_gen.hpp); the generator turns it on by itself for huge bodies, the runtime asks for it when a scatter kernel of the
 // compiled module turns out to spill registers.
 Generated generate_module(const Model &m, bool loopfree_scatter = false);
-bool pattern_var_range(const Pattern &p, int64_t lo, int64_t hi, int64_t *vmin, int64_t *vmax);   // exa_gen_module.cpp
+bool pattern_var_range(const Pattern &p, int64_t lo, int64_t hi, int64_t *vmin, int64_t *vmax);
+// data points [jlo, jhi) of a gathered objective pattern with a first-order slot on one of the 1-based variables [v_lo, v_hi]
+void pull_point_range(const Pattern &p, int64_t v_lo, int64_t v_hi, int64_t *jlo, int64_t *jhi);       // exa_gen_scatter.cpp   // exa_gen_module.cpp
 
 // Windowed compressed-COO kernels (exa_cjac / exa_chess fast path).  One pattern of such a kernel: every
 // slot s of data point I lands on compressed entry a_s + b * I; slots with the same a_s are added in registers (group),

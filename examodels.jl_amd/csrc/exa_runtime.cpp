@@ -196,6 +196,10 @@ std::string tune_signature(const Handle &h, const std::string &what) {
     return what + ":" + sha256_hex(t).substr(0, 16);
 }
 
+struct Handle;
+// variables rank r of a sharded model owns (owner-computes grad!): [own_var_lo(r), own_var_lo(r + 1))
+int64_t own_var_lo(const Handle &h, int r) { return (int64_t)((__int128)h.m->nvar * r / h.world); }
+
 // ---- parameter table -------------------------------------------------------------------------------------
 void fill_params(Handle &h) {
     const Model &m = *h.m;
@@ -212,6 +216,13 @@ void fill_params(Handle &h) {
         const auto &pp = L.pat[k];
         const int64_t lo = (int64_t)((__int128)p.n * h.rank / h.world), hi = (int64_t)((__int128)p.n * (h.rank + 1) / h.world);
         h.P[pp.lo] = lo; h.P[pp.hi] = hi; h.P[pp.o0] = p.o0; h.P[pp.o1] = p.o1; h.P[pp.o2] = p.o2; h.P[pp.oa] = p.oa;
+        // gathered objective patterns: the points of the whole pattern that touch the variables this rank owns
+        h.P[pp.qlo] = 0; h.P[pp.qhi] = p.n;
+        if (h.world > 1 && std::find(L.pull.begin(), L.pull.end(), (int)k) != L.pull.end()) {
+            int64_t jlo = 0, jhi = 0;
+            pull_point_range(p, own_var_lo(h, h.rank) + 1, own_var_lo(h, h.rank + 1), &jlo, &jhi);
+            h.P[pp.qlo] = jlo; h.P[pp.qhi] = jhi;
+        }
         h.lo1[k] = l1; h.lo2[k] = l2;
         if (local) {
             if (p.kind != EXA_PAT_OBJ) { h.P[pp.o1] = l1 - (int64_t)p.o1step * lo; l1 += (int64_t)p.o1step * (hi - lo); }
@@ -547,6 +558,72 @@ void allreduce(Handle &h, double *buf, int64_t count) {
     }
 }
 
+// Windows [w0, w1) a rank of a sharded model owns, and the pieces of the output they cover (owner computes: complete
+// values, nothing to sum).  pieces: (offset, count, owner rank) for EVERY rank — what an all-gather-v needs.
+void owned_windows(const Handle &h, const Handle::Window &w, int rank, int64_t *w0, int64_t *w1) {
+    *w0 = (int64_t)((__int128)w.nwin * rank / h.world);
+    *w1 = (int64_t)((__int128)w.nwin * (rank + 1) / h.world);
+}
+struct Piece { int64_t off, count; int root; };
+std::vector<Piece> window_pieces(const Handle &h, const Handle::Window &w) {
+    std::vector<Piece> out;
+    for (int r = 0; r < h.world; r++) {
+        int64_t w0, w1;
+        owned_windows(h, w, r, &w0, &w1);
+        for (const auto &sp : w.spaces) {
+            const int64_t a = std::min(sp.o + w0 * sp.W, sp.end), b = std::min(sp.o + w1 * sp.W, sp.end);
+            if (b > a) out.push_back({a, b - a, r});
+        }
+    }
+    return out;
+}
+// Makes a vector whole whose pieces are complete on their owners (in place): RCCL — one grouped set of broadcasts; a host
+// reducer (exa_comm_hook) only knows how to sum, so the other ranks' pieces are zeroed and the covering range summed.
+void allgatherv(Handle &h, double *buf, const std::vector<Piece> &pieces, bool force = false) {
+    if ((!h.reduce && !force) || h.world == 1 || pieces.empty()) return;
+    if (h.nccl) {
+        std::vector<int64_t> off, cnt; std::vector<int> root;
+        for (const Piece &q : pieces) { off.push_back(q.off); cnt.push_back(q.count); root.push_back(q.root); }
+        rccl_allgatherv_f64(h.nccl, buf, off.data(), cnt.data(), root.data(), (int)pieces.size(), h.stream);
+    } else if (h.hook) {
+        int64_t lo = INT64_MAX, hi = 0;
+        for (const Piece &q : pieces) {
+            if (q.root != h.rank) HIPCHK(hipMemsetAsync(buf + q.off, 0, 8 * (size_t)q.count, h.stream));
+            lo = std::min(lo, q.off); hi = std::max(hi, q.off + q.count);
+        }
+        const int rc = h.hook(h.hook_ctx, buf + lo, hi - lo, (void *)h.stream);
+        if (rc != 0) throw std::runtime_error("the host's all-reduce hook returned status " + std::to_string(rc));
+    }
+}
+std::vector<Piece> var_pieces(const Handle &h) {
+    std::vector<Piece> out;
+    for (int r = 0; r < h.world; r++) out.push_back({own_var_lo(h, r), own_var_lo(h, r + 1) - own_var_lo(h, r), r});
+    return out;
+}
+// constraint rows the ranks own: the base rows of their data points, pattern by pattern
+std::vector<Piece> row_pieces(const Handle &h) {
+    std::vector<Piece> out;
+    for (int r = 0; r < h.world; r++)
+        for (const Pattern &p : h.m->pats) {
+            if (p.kind != EXA_PAT_CON || p.n <= 0) continue;
+            const int64_t lo = (int64_t)((__int128)p.n * r / h.world), hi = (int64_t)((__int128)p.n * (r + 1) / h.world);
+            if (hi > lo) out.push_back({p.o0 + lo, hi - lo, r});
+        }
+    return out;
+}
+// slots of the Jacobian / Hessian COO the ranks own (global positions)
+std::vector<Piece> coo_pieces(const Handle &h, bool hess) {
+    std::vector<Piece> out;
+    for (int r = 0; r < h.world; r++)
+        for (const Pattern &p : h.m->pats) {
+            const int64_t step = hess ? p.o2step : (p.kind != EXA_PAT_OBJ ? p.o1step : 0);
+            if (step <= 0 || p.n <= 0) continue;
+            const int64_t lo = (int64_t)((__int128)p.n * r / h.world), hi = (int64_t)((__int128)p.n * (r + 1) / h.world);
+            if (hi > lo) out.push_back({(hess ? p.o2 : p.o1) + step * lo, step * (hi - lo), r});
+        }
+    return out;
+}
+
 // ---- callbacks (device pointers, asynchronous) ------------------------------------------------------------
 void do_obj(Handle &h, const double *x, double *out_dev) {
     const void *P = h.dP.p, *th = h.dtheta.p;
@@ -559,20 +636,30 @@ void do_obj(Handle &h, const double *x, double *out_dev) {
     launch(h, h.f_red, 1, 1024, a2);
     allreduce(h, out_dev, 1);
 }
+// grad!.  Gathered (range-affine) objective patterns are evaluated per VARIABLE, so a sharded model shards them by variable
+// range: rank r computes complete values for the variables [nvar*r/G, nvar*(r+1)/G) from whatever data points touch them
+// (it needs the halo of x, exa_shard_var_range) — a disjoint slice, no zero-fill, no collective; all-gather-v only to
+// make the vector whole on every rank.  Patterns that scatter through a data index add the partial sums of the shard's
+// own data points on top (the gathered part then holds zeros outside the owned slice) and the vector is all-reduced.
 void do_grad(Handle &h, const double *x, double *g) {
     const void *P = h.dP.p, *th = h.dtheta.p;
-    int64_t nvar = h.m->nvar;
-    if (!h.gen.layout.pull.empty()) {
+    const int64_t nvar = h.m->nvar;
+    const bool scatter = !h.gen.layout.active[CB_GRAD].empty(), pull = !h.gen.layout.pull.empty();     // (the MODEL's patterns, not this shard's)
+    const bool owner = pull && !scatter;
+    if (pull) {
         // gathered patterns: plain coalesced store of every g[v] (zero where nothing contributes)
-        void *a0[] = {&P, &x, &th, &g, &nvar};
+        int64_t own_lo = h.world > 1 ? own_var_lo(h, h.rank) : 0, own_hi = h.world > 1 ? own_var_lo(h, h.rank + 1) : nvar;
+        int64_t vb = owner ? own_lo : 0, ve = owner ? own_hi : nvar;
+        void *a0[] = {&P, &x, &th, &g, &vb, &ve, &own_lo, &own_hi};
         const int64_t per = (int64_t)kBlock * h.gen.layout.pull_ppt;
-        launch(h, h.f_gradpull, (nvar + per - 1) / per, kBlock, a0);
+        launch(h, h.f_gradpull, (ve - vb + per - 1) / per, kBlock, a0);
     } else {
         HIPCHK(hipMemsetAsync(g, 0, sizeof(double) * (size_t)nvar, h.stream));
     }
     void *a[] = {&P, &x, &th, &g};
     launch(h, h.f_grad, h.grid[CB_GRAD], kBlock, a);   // scattered patterns: FP64 hardware atomics on top
-    allreduce(h, g, nvar);
+    if (owner) allgatherv(h, g, var_pieces(h));
+    else if (scatter || pull) allreduce(h, g, nvar);
 }
 // grad! by sorted gather: exa_gradv writes the gradient COO, every variable's slots are added in slot order (long lists
 // cooperatively).  Lists are built at the first use; a sharded model keeps the atomics (its ranks write disjoint parts of
@@ -619,27 +706,34 @@ static void run_grad(Handle &h, const double *x, double *g) {
     if (resolve_grad_mode(h) == 1) { do_grad_sorted(h, x, g); allreduce(h, g, h.m->nvar); }
     else do_grad(h, x, g);
 }
+// cons_nln!.  A base row belongs to one data point, so a sharded model's ranks own disjoint row slices; with exa_cons1 the
+// thread of a row evaluates the row's augmentation terms itself, from whatever data points they come — owner computes: every
+// rank's rows are COMPLETE, nothing is zero-filled, nothing is summed (all-gather-v only to make c whole on every rank).  Only
+// the two-stage path (rows collecting > 512 terms) still forms partial sums over the shard's terms and all-reduces c.
+bool rows_owner_complete(const Handle &h) { return h.m->nconaug == 0 || h.cons1; }
 void do_cons(Handle &h, const double *x, double *c) {
     if (h.m->ncon == 0) return;
     void *buf = h.daugbuf.p;
-    if (h.world > 1) {
+    const bool owner = rows_owner_complete(h);
+    if (h.world > 1 && !owner) {
         HIPCHK(hipMemsetAsync(c, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
         if (h.m->nconaug) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
     }
     const void *P = h.dP.p, *th = h.dtheta.p;
-    if (h.cons1 && h.world == 1) {
+    if (h.cons1) {
         // ONE launch: every base row's thread evaluates the row's augmentation terms itself (exa_cons1)
         const void *ptr = h.daugcsr.p, *src = h.daugsrc.p, *coef = h.daugcoef.p;
         void *a1[] = {&P, &x, &th, &c, &ptr, &src, &coef};
         launch(h, h.f_cons1, h.grid[CB_CONS1], kBlock, a1);
-        allreduce(h, c, h.m->ncon);
+        allgatherv(h, c, row_pieces(h));
         return;
     }
     // base rows (plain stores into c) and augmentation terms (into the value buffer, coalesced)
     void *a[] = {&P, &x, &th, &c, &buf};
     launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a);
     if (h.m->nconaug) aug_gather(h, buf, c);       // then one deterministic gather per target row
-    allreduce(h, c, h.m->ncon);
+    if (owner) allgatherv(h, c, row_pieces(h));
+    else allreduce(h, c, h.m->ncon);
 }
 void do_jac(Handle &h, const double *x, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
@@ -661,13 +755,15 @@ void do_hess(Handle &h, const double *x, const double *y, double sigma, double *
 void do_fused(Handle &h, const double *x, const double *y, double sigma, double *obj_dev, double *c, double *jv, double *hv) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *part = h.dpart.p, *buf = h.daugbuf.p;
-    if (h.world > 1) {
+    // linear augmentation terms are added inside the sweep through the row lists of exa_cons1 when those exist: the rows a
+    // rank owns are then complete (as in do_cons); otherwise partial sums over the shard's terms + all-reduce
+    const bool inline_aug = h.cons1 && h.m->aug_linear && h.m->nconaug > 0;
+    const bool owner = h.m->nconaug == 0 || inline_aug;
+    if (h.world > 1 && !owner) {
         if (h.m->ncon) HIPCHK(hipMemsetAsync(c, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
         if (h.m->nconaug) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
     }
     int64_t n = h.grid[CB_FUSED];
-    // linear augmentation terms are added inside the sweep through the row lists of exa_cons1 when those exist
-    const bool inline_aug = h.cons1 && h.world == 1 && h.m->aug_linear && h.m->nconaug > 0;
     const void *ap = inline_aug ? h.daugcsr.p : nullptr, *as = inline_aug ? h.daugsrc.p : nullptr, *ac = inline_aug ? h.daugcoef.p : nullptr;
     void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma, &ap, &as, &ac};
     launch(h, h.f_fused, n, kBlock, a);
@@ -676,29 +772,32 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
     else HIPCHK(hipMemsetAsync(obj_dev, 0, sizeof(double), h.stream));
     if (h.m->nconaug && !inline_aug) aug_gather(h, buf, c);
     allreduce(h, obj_dev, 1);
-    if (h.m->ncon) allreduce(h, c, h.m->ncon);
+    if (h.m->ncon) { if (owner) allgatherv(h, c, row_pieces(h)); else allreduce(h, c, h.m->ncon); }
 }
 // matrix-free products (jprod_nln! / jtprod_nln! / hprod!, nlp.jl:1882-1978)
 void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
     if (h.m->ncon == 0) return;
     void *buf = h.daugbuf.p;
-    if (h.world > 1) {
+    const bool one = h.f_jprod1 && (h.cons1 || h.m->nconaug == 0);      // rows complete on their owner, as in do_cons
+    const bool owner = one || h.m->nconaug == 0;
+    if (h.world > 1 && !owner) {
         HIPCHK(hipMemsetAsync(Jv, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
         if (h.m->nconaug) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
     }
     const void *P = h.dP.p, *th = h.dtheta.p;
-    if (h.f_jprod1 && h.world == 1 && (h.cons1 || h.m->nconaug == 0)) {
+    if (one) {
         // ONE launch (fused groups; augmentation terms c * x[k] contribute c * v[k] straight from the row lists)
         const void *ptr = h.daugcsr.p, *src = h.daugsrc.p, *coef = h.daugcoef.p;
         void *a1[] = {&P, &x, &th, &v, &Jv, &ptr, &src, &coef};
         launch(h, h.f_jprod1, h.grid[CB_CONS1], kBlock, a1);
-        allreduce(h, Jv, h.m->ncon);
+        allgatherv(h, Jv, row_pieces(h));
         return;
     }
     void *a[] = {&P, &x, &th, &v, &Jv, &buf};
     launch(h, h.f_jprod, h.grid[CB_JPROD], kBlock, a);
     if (h.m->nconaug) aug_gather(h, buf, Jv);
-    allreduce(h, Jv, h.m->ncon);
+    if (owner) allgatherv(h, Jv, row_pieces(h));
+    else allreduce(h, Jv, h.m->ncon);
 }
 void do_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
     HIPCHK(hipMemsetAsync(Jtv, 0, sizeof(double) * (size_t)h.m->nvar, h.stream));
@@ -1148,7 +1247,7 @@ void window_upload(Handle::Window &w) {
     up(w.S, w.hS.data(), 8 * w.hS.size()); up(w.F, w.hF.data(), 8 * w.hF.size());
     w.xbuf.ensure(8 * (size_t)std::max<int64_t>(w.xbuf_doubles, 1)); w.part.ensure(8 * (size_t)std::max<int64_t>(w.nparts, 1));
     for (auto *v : {&w.hQ, &w.hX, &w.hS, &w.hF}) std::vector<int64_t>().swap(*v);
-    for (auto *v : {&w.hR, &w.hT, &w.hE}) std::vector<int32_t>().swap(*v);
+    for (auto *v : {&w.hT, &w.hE}) std::vector<int32_t>().swap(*v);      // (hR stays: exa_shard_var_range reads the owned windows' point ranges)
 }
 
 // Owner-computes products (exa_jtprodw / exa_hprodw): planned on the host at model build — also for exa_plan_only handles, so
@@ -1389,6 +1488,9 @@ int guard(int id, bool need_device, F &&f) {
     }
 }
 
+// host-pointer variants of a sharded model: entries this rank does not own come back as zeros (owner pieces + zeros add
+// up across ranks like partial sums do)
+void zero_if_sharded(Handle &h, void *p, size_t bytes) { if (h.world > 1 && bytes) HIPCHK(hipMemsetAsync(p, 0, bytes, h.stream)); }
 void h2d(Handle &h, DevBuf &b, const void *src, size_t bytes) {
     b.ensure(bytes);
     if (bytes) HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, h.stream));
@@ -1687,43 +1789,6 @@ static int resolve_mode(Handle &h, bool hess) {
     if (mode == 1) prod_setup(h, hess);                          // no-op once the lists exist
     return mode;
 }
-// Windows [w0, w1) a rank of a sharded model owns, and the pieces of the output they cover (owner computes: complete
-// values, nothing to sum).  pieces: (offset, count, owner rank) for EVERY rank — what an all-gather-v needs.
-static void owned_windows(const Handle &h, const Handle::Window &w, int rank, int64_t *w0, int64_t *w1) {
-    *w0 = (int64_t)((__int128)w.nwin * rank / h.world);
-    *w1 = (int64_t)((__int128)w.nwin * (rank + 1) / h.world);
-}
-struct Piece { int64_t off, count; int root; };
-static std::vector<Piece> window_pieces(const Handle &h, const Handle::Window &w) {
-    std::vector<Piece> out;
-    for (int r = 0; r < h.world; r++) {
-        int64_t w0, w1;
-        owned_windows(h, w, r, &w0, &w1);
-        for (const auto &sp : w.spaces) {
-            const int64_t a = std::min(sp.o + w0 * sp.W, sp.end), b = std::min(sp.o + w1 * sp.W, sp.end);
-            if (b > a) out.push_back({a, b - a, r});
-        }
-    }
-    return out;
-}
-// Makes a vector whole whose pieces are complete on their owners (in place): RCCL — one grouped set of broadcasts; a host
-// reducer (exa_comm_hook) only knows how to sum, so the other ranks' pieces are zeroed and the covering range summed.
-static void allgatherv(Handle &h, double *buf, const std::vector<Piece> &pieces) {
-    if (!h.reduce || h.world == 1 || pieces.empty()) return;
-    if (h.nccl) {
-        std::vector<int64_t> off, cnt; std::vector<int> root;
-        for (const Piece &q : pieces) { off.push_back(q.off); cnt.push_back(q.count); root.push_back(q.root); }
-        rccl_allgatherv_f64(h.nccl, buf, off.data(), cnt.data(), root.data(), (int)pieces.size(), h.stream);
-    } else if (h.hook) {
-        int64_t lo = INT64_MAX, hi = 0;
-        for (const Piece &q : pieces) {
-            if (q.root != h.rank) HIPCHK(hipMemsetAsync(buf + q.off, 0, 8 * (size_t)q.count, h.stream));
-            lo = std::min(lo, q.off); hi = std::max(hi, q.off + q.count);
-        }
-        const int rc = h.hook(h.hook_ctx, buf + lo, hi - lo, (void *)h.stream);
-        if (rc != 0) throw std::runtime_error("the host's all-reduce hook returned status " + std::to_string(rc));
-    }
-}
 static void run_product_window(Handle &h, bool hess, const double *x, const double *y, const double *v, double w, double *out) {
     Handle::Window &win = h.wp[hess ? 1 : 0];
     if (h.world == 1) { do_window(h, hess ? WK_HPROD : WK_JTPROD, x, y, v, w, out); return; }
@@ -1839,6 +1904,7 @@ int exa_grad_host(int id, const double *x, double *g) {
         const size_t n = 8 * (size_t)h.m->nvar;
         h2d(h, h.sx, x, n);
         h.sout.ensure(n);
+        zero_if_sharded(h, h.sout.p, n);
         run_grad(h, (const double *)h.sx.p, (double *)h.sout.p);
         d2h(h, g, h.sout.p, n);
     });
@@ -1850,6 +1916,7 @@ int exa_cons_host(int id, const double *x, double *c) {
         if (!n) return;
         h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
         h.sout.ensure(n);
+        zero_if_sharded(h, h.sout.p, n);
         do_cons(h, (const double *)h.sx.p, (double *)h.sout.p);
         d2h(h, c, h.sout.p, n);
     });
@@ -1886,6 +1953,7 @@ int exa_jprod_host(int id, const double *x, const double *v, double *Jv) {
         h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
         h2d(h, h.sv, v, 8 * (size_t)h.m->nvar);
         h.sout.ensure(n);
+        zero_if_sharded(h, h.sout.p, n);
         do_jprod(h, (const double *)h.sx.p, (const double *)h.sv.p, (double *)h.sout.p);
         d2h(h, Jv, h.sout.p, n);
     });
@@ -1898,6 +1966,7 @@ int exa_jtprod_host(int id, const double *x, const double *v, double *Jtv) {
         if (h.m->ncon) { if (!v) throw std::runtime_error("null input"); h2d(h, h.sv, v, 8 * (size_t)h.m->ncon); }
         else h.sv.ensure(8);
         h.sout.ensure(n);
+        zero_if_sharded(h, h.sout.p, n);
         run_jtprod(h, (const double *)h.sx.p, (const double *)h.sv.p, (double *)h.sout.p);
         d2h(h, Jtv, h.sout.p, n);
     });
@@ -1911,6 +1980,7 @@ int exa_hprod_host(int id, const double *x, const double *y, const double *v, do
         if (h.m->ncon) { if (!y) throw std::runtime_error("null multipliers"); h2d(h, h.sy, y, 8 * (size_t)h.m->ncon); }
         else h.sy.ensure(8);
         h.sout.ensure(n);
+        zero_if_sharded(h, h.sout.p, n);
         run_hprod(h, (const double *)h.sx.p, (const double *)h.sy.p, (const double *)h.sv.p, w, (double *)h.sout.p);
         d2h(h, Hv, h.sout.p, n);
     });
@@ -2231,20 +2301,101 @@ int exa_shard_var_range(int id, int64_t *lo_out, int64_t *hi_out) {
     Handle *h = get(id);
     if (!h || !lo_out || !hi_out) return 1;
     const Model &m = *h->m;
+    const ParamLayout &L = h->gen.layout;
     int64_t vmin = INT64_MAX, vmax = INT64_MIN;
-    for (const Pattern &p : m.pats) {
-        const int64_t lo = (int64_t)((__int128)p.n * h->rank / h->world), hi = (int64_t)((__int128)p.n * (h->rank + 1) / h->world);
+    bool anywhere = false;
+    auto add = [&](const Pattern &p, int64_t lo, int64_t hi) {
+        if (hi <= lo || anywhere) return;
+        int64_t a = 0, b = 0;
+        if (!pattern_var_range(p, lo, hi, &a, &b)) { anywhere = true; return; }      // data-indexed: anywhere
+        if (a <= b) { vmin = std::min(vmin, a); vmax = std::max(vmax, b); }
+    };
+    for (size_t k = 0; k < m.pats.size(); k++) {
+        const Pattern &p = m.pats[k];
         if (p.n <= 0) continue;
+        const int64_t lo = (int64_t)((__int128)p.n * h->rank / h->world), hi = (int64_t)((__int128)p.n * (h->rank + 1) / h->world);
         // a shard holding nothing of a pattern still re-reads one point of it (the branch-free loads of the chained
         // kernels clamp there): the last point before the shard, or point 0
         const int64_t lo_ = hi > lo ? lo : (hi > 0 ? hi - 1 : 0), hi_ = hi > lo ? hi : lo_ + 1;
-        int64_t a = 0, b = 0;
-        if (!pattern_var_range(p, lo_, hi_, &a, &b)) { vmin = 1; vmax = m.nvar; break; }     // data-indexed: anywhere
-        if (a <= b) { vmin = std::min(vmin, a); vmax = std::max(vmax, b); }
+        add(p, lo_, hi_);
+        if (h->world == 1) continue;
+        // owner-computes callbacks reach beyond the shard's own data points:
+        //   cons_nln! / jprod in one launch: a row's owner evaluates the row's augmentation terms wherever they come from;
+        if (p.kind == EXA_PAT_CONAUG && (h->cons1 || !h->on_device)) add(p, 0, p.n);
+        //   grad!: the points of a gathered objective pattern that touch the variables this rank owns;
+        if (std::find(L.pull.begin(), L.pull.end(), (int)k) != L.pull.end()) add(p, h->P[L.pat[k].qlo], h->P[L.pat[k].qhi]);
     }
+    //   J'v / Hv by windows: the points that touch the windows this rank owns
+    for (int wk : {WK_JTPROD, WK_HPROD}) {
+        const Handle::Window &w = h->wp[wk - WK_JTPROD];
+        if (h->world == 1 || !w.planned || w.nx || w.ns_blocks || w.hR.empty()) continue;
+        int64_t w0, w1;
+        owned_windows(*h, w, h->rank, &w0, &w1);
+        const WindowMatrix &wm = h->pspec.mat[wk];
+        std::vector<int> pk;            // R is [window][pass] (one space) or [block][pattern] (block-owned)
+        for (const auto &wp : wm.pats) if (wm.nspaces == 0 || std::find(pk.begin(), pk.end(), wp.k) == pk.end()) pk.push_back(wp.k);
+        for (size_t q = 0; q < pk.size(); q++) {
+            int64_t lo = INT64_MAX, hi = INT64_MIN;
+            for (int64_t j = w0; j < w1; j++) {
+                const int32_t a = w.hR[(j * pk.size() + q) * 2], b = w.hR[(j * pk.size() + q) * 2 + 1];
+                if (b > a) { lo = std::min<int64_t>(lo, a); hi = std::max<int64_t>(hi, b); }
+            }
+            if (hi > lo) add(m.pats[pk[q]], lo, hi);
+        }
+    }
+    if (anywhere) { *lo_out = 0; *hi_out = m.nvar; return 0; }
     if (vmin > vmax) { *lo_out = 0; *hi_out = 0; return 0; }
     *lo_out = vmin - 1; *hi_out = vmax;       // 0-based [lo, hi)
     return 0;
 }
-
+/* How a sharded model's rank leaves the output of callback `which` when nothing completes it (no communicator, or
+ * exa_set_reduce(id, 0)): 1 = OWNER PIECES — complete values in disjoint pieces (rows of its data points, variables / windows
+ * it owns), nothing else written, an all-gather makes the vector whole; 0 = PARTIAL SUMS over the whole vector, an
+ * all-reduce(sum) completes it.  which: 0 obj, 1 grad, 2 cons, 5 jprod, 6 jtprod, 7 hprod (3 jac / 4 hess: always pieces).
+ * -1 bad id / argument. */
+int exa_shard_layout(int id, int which) {
+    Handle *hh = get(id);
+    if (!hh) return -1;
+    Handle &h = *hh;
+    switch (which) {
+    case 0: return 0;
+    case 1: return h.gen.layout.active[CB_GRAD].empty() && !h.gen.layout.pull.empty() ? 1 : 0;
+    case 2: return rows_owner_complete(h) || !h.on_device ? 1 : 0;
+    case 3: case 4: return 1;
+    case 5: return (h.m->nconaug == 0 || (h.m->aug_linear && (h.cons1 || !h.on_device))) ? 1 : 0;
+    case 6: case 7: {
+        const bool hess = which == 7;
+        const int mode = hess ? h.hp_mode : h.jt_mode;
+        const Handle::Window &w = h.wp[hess ? 1 : 0];
+        const bool can = (h.on_device ? w.ok : w.planned) && w.nx == 0 && w.ns_blocks == 0;
+        return can && (mode == 2 || mode < 0) ? 1 : 0;
+    }
+    }
+    return -1;
+}
+/* Makes a sharded Jacobian (hess = 0) / Hessian (hess = 1) COO vector whole on every rank: all-gather-v of the ranks' slot
+ * ranges (a piece travels once; nothing is zero-filled or summed — an all-reduce of zero-padded vectors would move world x
+ * the data).  `local`: what this rank's exa_jac / exa_hess wrote — the packed local slice (exa_set_coo_local) or
+ * the global-length vector with this rank's slots in place; `global` [nnzj | nnzh]: receives everything (may equal `local`
+ * when that is the global-length vector).  Needs a communicator; world 1: a device copy. */
+int exa_allgather_coo(int id, int hess, const double *local, double *global) {
+    if (!local || !global) return 1;
+    return guard(id, true, [&](Handle &h) {
+        const Model &m = *h.m;
+        if (h.world > 1 && !h.nccl && !h.hook) throw BadInput("the model has no communicator");
+        const bool packed = h.coo_local && h.world > 1;
+        if (h.world == 1 || packed || local != global) {
+            for (size_t k = 0; k < m.pats.size(); k++) {
+                const Pattern &p = m.pats[k];
+                const int64_t step = hess ? p.o2step : (p.kind != EXA_PAT_OBJ ? p.o1step : 0);
+                if (step <= 0 || p.n <= 0) continue;
+                const int64_t lo = (int64_t)((__int128)p.n * h.rank / h.world), hi = (int64_t)((__int128)p.n * (h.rank + 1) / h.world);
+                const int64_t g0 = (hess ? p.o2 : p.o1) + step * lo, l0 = packed ? (hess ? h.lo2[k] : h.lo1[k]) : g0;
+                if (hi > lo && local + l0 != global + g0)
+                    HIPCHK(hipMemcpyAsync(global + g0, local + l0, 8 * (size_t)(step * (hi - lo)), hipMemcpyDeviceToDevice, h.stream));
+            }
+        }
+        allgatherv(h, global, coo_pieces(h, hess != 0), true);
+    });
+}
 }  // extern "C"

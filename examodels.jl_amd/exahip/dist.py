@@ -2,8 +2,11 @@
 
 The reference has no multi-device path; this is new.  What needs communication and what does not:
   * jac_coord / hess_coord / structures: COO slots are private to a data point, so each rank fills a DISJOINT slice
-    of the global vector (or, with `coo_local`, a packed slice-sized buffer) — no collective.
-  * obj (1 double), grad / jtprod / hprod (nvar), cons / jprod (ncon): all_reduce(SUM).
+    of the global vector (or, with `coo_local`, a packed slice-sized buffer) — no collective (exa_allgather_coo for a
+    consumer that wants the whole vector);
+  * cons / jprod (rows), grad of range-affine objectives (variables), jtprod / hprod by windows: sharded by OWNER — ranks
+    hold complete disjoint pieces, all-gather-v makes them whole;
+  * obj (1 double), grad with data-indexed patterns, jtprod / hprod by atomics (nvar): all_reduce(SUM).
 The collectives live BEHIND THE C ABI (include/exahip.h, exa_comm_*): libexahip enqueues `ncclAllReduce` on the model's
 stream right after the kernels, so a Julia host gets the same multi-GPU path.  This module only distributes the
 ncclUniqueId (through torch.distributed, whatever its backend) and, where there is no RCCL — the gloo CPU/one-GPU test
@@ -123,10 +126,18 @@ class ShardedEvaluator:
     def hess_coord(self, x, y, obj_weight=1.0, out=None):
         return self.model.hess_coord(x, y, obj_weight, out=out)
 
-    def gather_coo(self, buf):
-        """Make a sharded COO vector (global positions) whole on every rank.  `buf` must have been ZERO-filled before
-        the sharded evaluation wrote into it; disjoint slices + zeros => all_reduce(SUM) is a gather.  Moves ~world x the
-        bytes of the evaluation itself: offered, not the headline."""
+    def gather_coo(self, buf, hess=True):
+        """Make a sharded Hessian (hess=True) / Jacobian (hess=False) COO vector whole on every rank.  In the library:
+        exa_allgather_coo, an all-gather-v of the ranks' slot ranges (each piece travels once).  The host fallback (the CPU
+        oracle path) needs `buf` ZERO-filled before the sharded evaluation wrote into it: disjoint slices + zeros =>
+        all_reduce(SUM) is a gather (moves ~world x the data)."""
+        t = _as_tensor(buf)
+        if self.in_library and t.is_cuda:
+            return self.model.allgather_coo(t, hess=hess)
+        return self._allreduce(t)
+
+    def sum_buffer(self, buf):
+        """all_reduce(SUM) of any device / host buffer of the caller's (exa_allreduce in the library)."""
         t = _as_tensor(buf)
         if self.in_library and t.is_cuda:
             return self.model.allreduce(t)

@@ -229,6 +229,7 @@ class ExaModel:
         self.meta = Meta(load_vectors, nvar=nvar, ncon=ncon, nnzj=L.exa_nnzj64(self.id), nnzh=L.exa_nnzh64(self.id),
                          nnzg=L.exa_nnzg64(self.id), minimize=self._minimize)
         self._stream = None
+        self._coo_local = False
 
     def describe(self):
         """Pattern-table view (exa_model_desc_t) of a model planned without a device — what a recipe became."""
@@ -352,7 +353,28 @@ class ExaModel:
         capi.check(self._L.exa_allreduce(self.id, t.data_ptr(), t.numel()), "exa_allreduce")
         return t
 
+    def allgather_coo(self, local, hess=True, out=None):
+        """exa_allgather_coo: the sharded Jacobian / Hessian COO vector whole on every rank (all-gather-v of the slot ranges).
+        `local`: this rank's exa_jac / exa_hess output (packed local slice, or global-length with its slots in place)."""
+        import torch
+        self._use_torch_stream(local)
+        n = self.meta.nnzh if hess else self.meta.nnzj
+        if out is None:
+            out = local if local.numel() == n and not self._coo_local else torch.empty(n, dtype=torch.float64, device=local.device)
+        capi.check(self._L.exa_allgather_coo(self.id, 1 if hess else 0, local.data_ptr(), out.data_ptr()), "exa_allgather_coo")
+        return out
+
+    def shard_layout(self, which):
+        """"pieces" (complete values in disjoint pieces: all-gather completes) or "partial" (partial sums: all-reduce completes)
+        — how a rank of a sharded model leaves the output of `which` (obj grad cons jac hess jprod jtprod hprod) on its own."""
+        k = {"obj": 0, "grad": 1, "cons": 2, "jac": 3, "hess": 4, "jprod": 5, "jtprod": 6, "hprod": 7}[which]
+        r = self._L.exa_shard_layout(self.id, k)
+        if r < 0:
+            raise capi.ExaHipError("exa_shard_layout")
+        return "pieces" if r == 1 else "partial"
+
     def set_coo_local(self, on=True):
+        self._coo_local = bool(on)
         capi.check(self._L.exa_set_coo_local(self.id, 1 if on else 0), "exa_set_coo_local")
 
     @property

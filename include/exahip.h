@@ -113,19 +113,32 @@ const char *exa_kernel_source(int id);
  * exa_compress and the structure calls synchronise and cannot be captured. */
 int exa_set_stream(int id, void *hip_stream);
 /* Shard every pattern's iterator: this process evaluates data points [floor(n*rank/world), floor(n*(rank+1)/world))
- * of every pattern.  COO outputs (jac/hess/structures) are written at their GLOBAL slot
- * positions, so ranks fill disjoint slices of one global vector; obj/grad/cons hold this rank's partial
- * sums (base constraint rows outside the shard are written as 0) and are completed by an allreduce(sum)
- * in the host layer.  rank=0, world=1 restores the unsharded model. */
+ * of every pattern.  What a rank then writes (without a communicator, or with exa_set_reduce(id, 0)):
+ *   jac / hess / structures   its data points' COO slots at their GLOBAL positions (or packed, exa_set_coo_local): disjoint;
+ *   cons, jprod               the base rows of its data points, COMPLETE (the row's owner evaluates the row's augmentation
+ *                             terms itself) — other rows are not touched.  Only models with rows collecting > 512 terms
+ *                             fall back to partial sums over the whole vector;
+ *   grad                      objective patterns gathered per variable (range-affine): the variables
+ *                             [floor(nvar*rank/world), floor(nvar*(rank+1)/world)), COMPLETE, nothing else touched;
+ *                             with a pattern that scatters through a data index: partial sums over the whole vector;
+ *   jtprod, hprod             owner-computes windows (exa_set_product_mode 2): the windows the rank owns, COMPLETE;
+ *                             otherwise partial sums over the whole vector;
+ *   obj                       a partial sum.
+ * rank=0, world=1 restores the unsharded model. */
 int exa_set_shard(int id, int rank, int world);
 
 /* ---- multi-GPU behind the ABI: one process per GPU, collectives on the model's stream -----------------
  * What the reference accumulates on one device — obj (KA ext :253-271), grad! (:310-336), cons_nln! with its
- * augmentation rows (:273-308) and the products — is a SUM over data points, so a sharded model needs
- * all-reduce(sum) of: 1 double (obj), nvar doubles (grad, jtprod, hprod), ncon doubles (cons, jprod).  With a
- * communicator attached, exa_obj / exa_obj_async / exa_grad / exa_cons / exa_jprod / exa_jtprod / exa_hprod /
- * exa_eval_fused (and their *_host variants) enqueue that all-reduce right after the kernels and every rank receives the
- * complete result.  jac_coord! / hess_coord! / the structures need NO collective: COO slots are private to a data point.
+ * augmentation rows (:273-308) and the products — is a SUM over data points.  Here most of it is sharded by OWNER instead
+ * (see exa_set_shard): ranks hold complete, disjoint pieces, and with a communicator attached the callbacks make every
+ * vector whole on every rank by the cheapest collective that does it, enqueued right after the kernels:
+ *   obj                              all-reduce(sum) of 1 double;
+ *   cons, jprod (rows owned)         all-gather-v of the row slices (no zero-fill, nothing summed, each piece travels once);
+ *   grad (variables owned)           all-gather-v of the variable slices;   grad with data-indexed patterns: all-reduce(nvar);
+ *   jtprod / hprod                   windows: all-gather-v of the owned windows;  atomics / sorted gather: all-reduce(nvar);
+ *   jac_coord! / hess_coord! / structures   NO collective: COO slots are private to a data point (exa_allgather_coo makes
+ *                                    a sharded COO vector whole where a consumer wants that).
+ * exa_set_reduce(id, 0) keeps the communicator but leaves the pieces / partial sums as they are.
  *
  *   exa_comm_unique_id   rank 0 obtains an ncclUniqueId (128 bytes) and the host distributes it (MPI.bcast, a file, ...);
  *   exa_comm_init        every rank: ncclCommInitRank on the process's current HIP device (collective) + exa_set_shard;
@@ -147,6 +160,18 @@ int exa_comm_free(int id);
 int exa_comm_info(int id, int *rank, int *world, int *kind);      /* kind: 0 none, 1 RCCL, 2 host reducer */
 int exa_set_reduce(int id, int on);
 int exa_allreduce(int id, double *device_buffer, int64_t count);
+/* How a rank of a sharded model leaves the output of callback `which` when nothing completes it (no communicator, or
+ * exa_set_reduce(id, 0)): 1 = OWNER PIECES (complete values in disjoint pieces, nothing else written: an all-gather makes
+ * the vector whole), 0 = PARTIAL SUMS over the whole vector (an all-reduce(sum) completes it), -1 bad id / argument.
+ * which: 0 obj, 1 grad, 2 cons, 3 jac, 4 hess, 5 jprod, 6 jtprod, 7 hprod. */
+int exa_shard_layout(int id, int which);
+/* A sharded Jacobian (hess = 0) / Hessian (hess = 1) COO vector made whole on every rank: all-gather-v of the ranks' slot
+ * ranges (a piece travels once; an all-reduce of zero-padded vectors would move world x the data).  `local` = what this
+ * rank's exa_jac / exa_hess wrote: the packed local slice (exa_set_coo_local) or the global-length vector with the rank's
+ * slots in place; `global` [nnzj | nnzh] receives everything and may be `local` itself in the second case.  DEVICE pointers,
+ * asynchronous on the model's stream.  Replaces a hess_coord! whose contract is the full vector on the caller's device
+ * (src/nlp.jl:1906-1940) for consumers that are not sharded themselves. */
+int exa_allgather_coo(int id, int hess, const double *local, double *global);
 /* Local-slice COO.  By default a sharded rank writes its Jacobian / Hessian / structure slots at their GLOBAL positions
  * (the caller's buffers have nnzj / nnzh entries, the rank fills its disjoint part).  With exa_set_coo_local(id, 1) the
  * rank's slots are PACKED: pattern after pattern, each pattern's data points [lo, hi) in order — buffers of

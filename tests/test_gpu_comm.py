@@ -72,12 +72,27 @@ def test_host_reducer_hook_is_called_for_every_reducing_callback(libs):
     m.comm_hook(0, 1, lambda ptr, count, stream: seen.append(count) or 0)
     nv, nc = m.meta.nvar, m.meta.ncon
     m.obj(xd); m.grad(xd); m.cons(xd); m.jprod(xd, vd); m.jtprod(xd, wd); m.hprod(xd, yd, vd, s)
-    assert seen == [1, nv, nc, nc, nv, nv]
+    # obj: 1 double; grad (the generator costs reach pg through a data column), J'v, Hv (atomics): partial sums of nvar.
+    # cons / jprod: NOTHING is summed — a row's owner evaluates the row's augmentation terms itself (exa_cons1); ranks hold
+    # complete row slices (made whole by all-gather-v, which a one-rank model does not need)
+    assert seen == [1, nv, nv, nv]
     seen.clear()
     m.jac_coord(xd); m.hess_coord(xd, yd, s); m.jac_structure(); m.hess_structure()
     assert seen == []                                 # COO outputs need no collective
     m.eval_fused(xd, yd, s)
-    assert seen == [1, nc]
+    assert seen == [1]
+    # a stencil model (every index range-affine) is sharded by OWNER throughout: grad by variable range, cons by row, the
+    # products by window — only obj is a sum
+    lv = ExaModel(ZOO["lv1000"]())
+    xl = torch.from_numpy(np.asarray(lv.meta.x0) + 0.01).to(dev)
+    yl, vl = torch.ones(lv.meta.ncon, dtype=torch.float64, device=dev), torch.ones(lv.meta.nvar, dtype=torch.float64, device=dev)
+    seen.clear()
+    lv.comm_hook(0, 1, lambda ptr, count, stream: seen.append(count) or 0)
+    lv.grad(xl); lv.cons(xl); lv.jprod(xl, vl); lv.jtprod(xl, yl); lv.hprod(xl, yl, vl, s); lv.hess_coord(xl, yl, s)
+    assert seen == []
+    lv.obj(xl)
+    assert seen == [1]
+    seen.clear()
     # a failing reducer is a status-2 error, not a crash
     from exahip import capi
     m.comm_free()
@@ -164,7 +179,7 @@ def test_eight_shards_from_resident_slices_reproduce_the_model(libs):
         m.set_shard(rank, world)
         m.set_coo_local(True)
         vlo, vhi, ylo, yhi = resident_ranges(m, rank, world)
-        assert vhi - vlo <= N // world + 4 and yhi - ylo <= N // world + 1
+        assert vhi - vlo <= N // world + 4 + 2 * 256 and yhi - ylo <= N // world + 1       # + the windows an owner-computes product reaches
         xs = torch.from_numpy(x[vlo:vhi].copy()).to(dev)
         ys = torch.from_numpy(y[ylo:yhi].copy()).to(dev)
         n = m.local_nnzh
@@ -213,3 +228,8 @@ def test_bench_launch_path_with_two_ranks(libs):
     assert d["config"]["resident_per_gpu_bytes"] < 0.51 * 8 * (9 + 1 + 1) * 400000 + 4096
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["higher_is_better"] is True
     assert d["collectives"].get("transport") == "hook" and d["collectives"]["grad_plus_allreduce_ms"] > 0, d["collectives"]
+    assert d["collectives"]["coo_allgather_ms"] > 0 and d["collectives"]["coo_allgather_bytes"] == 8 * d["config"]["nnzh"]
+    assert "all-gather-v" in d["collectives"]["grad_collective"]             # LV: grad! is sharded by variable owner
+    # the same workload on one GPU, measured in the same run by rank 0: what a scaling ratio has to be computed against
+    assert d["scale_base"]["n_gpus"] == 1 and d["scale_base"]["value"] > 0 and d["speedup_vs_scale_base"] > 0
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["value"] > 0

@@ -46,7 +46,7 @@ def _worker(rank, world, port, q):
             whole = ev.gather_coo(h).cpu().numpy()
             j = torch.zeros(m.meta.nnzj, dtype=torch.float64, device=dev)
             ev.jac_coord(xd, out=j)
-            jw = ev.gather_coo(j).cpu().numpy()
+            jw = ev.gather_coo(j, hess=False).cpu().numpy()
             H, J = o.hess_coord(x, y, s), o.jac_coord(x)
             ok = (abs(f - o.obj(x)) <= 1e-10 * max(1, abs(o.obj(x))) and np.allclose(g, o.grad(x), rtol=1e-10, atol=1e-12)
                   and np.allclose(c, o.cons(x), rtol=1e-10, atol=1e-12) and np.allclose(whole, H, rtol=1e-10, atol=1e-12)
@@ -83,7 +83,7 @@ def _worker(rank, world, port, q):
             cv = cm.hess_coord(xd, yd, s)
             dense = torch.zeros(m.meta.nvar * m.meta.nvar, dtype=torch.float64, device=dev)
             dense.index_add_(0, (cr - 1) * m.meta.nvar + (cc - 1), cv)
-            dense = ev.gather_coo(dense).cpu().numpy().reshape(m.meta.nvar, m.meta.nvar)
+            dense = ev.sum_buffer(dense).cpu().numpy().reshape(m.meta.nvar, m.meta.nvar)
             Hd = np.zeros((m.meta.nvar, m.meta.nvar))
             np.add.at(Hd, (Hr - 1, Hc - 1), H)
             ok = ok and np.allclose(dense, Hd, rtol=1e-10, atol=1e-11) and cm.meta.nnzh <= m.local_nnzh

@@ -62,7 +62,7 @@ def test_all_entry_points(built, name):
 
 @pytest.mark.parametrize("name", ["empty_iterators", "n257", "no_objective"])
 def test_sharded_edge_models(built, name):
-    """three ranks' partial results of a tiny model (some shards are empty) add up to the unsharded evaluation"""
+    """three ranks' results of a tiny model (some shards are empty) — owner pieces written into one buffer, partial sums added up — are the unsharded evaluation"""
     import torch
     m, o = built[name]
     dev = torch.device("cuda:0")
@@ -70,6 +70,11 @@ def test_sharded_edge_models(built, name):
     y = np.linspace(-1, 1, m.meta.ncon)
     xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
     acc_h = np.zeros(m.meta.nnzh)
+    # cons / grad: "pieces" (complete values in disjoint pieces, the rest untouched: all ranks write into ONE buffer) or
+    # "partial" (partial sums over the whole vector: added up) — exa_shard_layout
+    lay_c, lay_g = m.shard_layout("cons"), m.shard_layout("grad")
+    c_buf = torch.full((max(1, m.meta.ncon),), float("nan"), dtype=torch.float64, device=dev)
+    g_buf = torch.full((max(1, m.meta.nvar),), float("nan"), dtype=torch.float64, device=dev)
     acc_c = np.zeros(m.meta.ncon)
     acc_g = np.zeros(m.meta.nvar)
     f = 0.0
@@ -78,11 +83,22 @@ def test_sharded_edge_models(built, name):
             m.set_shard(r, 3)
             h = torch.zeros(m.meta.nnzh, dtype=torch.float64, device=dev)
             acc_h += m.hess_coord(xd, yd, 0.5, out=h).cpu().numpy()
-            acc_c += m.cons(xd).cpu().numpy()
-            acc_g += m.grad(xd).cpu().numpy()
+            if lay_c == "pieces":
+                m.cons(xd, out=c_buf)
+            else:
+                acc_c += m.cons(xd).cpu().numpy()
+            if lay_g == "pieces":
+                m.grad(xd, out=g_buf)
+            else:
+                acc_g += m.grad(xd).cpu().numpy()
             f += m.obj(xd)
     finally:
         m.set_shard(0, 1)
+    torch.cuda.synchronize()
+    if lay_c == "pieces":
+        acc_c = c_buf.cpu().numpy()[:m.meta.ncon]
+    if lay_g == "pieces":
+        acc_g = g_buf.cpu().numpy()[:m.meta.nvar]
     np.testing.assert_allclose(acc_h, o.hess_coord(x, y, 0.5), **TOL)
     np.testing.assert_allclose(acc_c, o.cons(x), **TOL)
     np.testing.assert_allclose(acc_g, o.grad(x), **TOL)

@@ -116,7 +116,7 @@ def test_set_value_takes_effect_without_rebuild(built):
 
 def test_sharded_outputs_tile_the_global_coo(built):
     """with the iterator sharded G ways, the ranks' COO slices are disjoint and their union is the
-    unsharded result; obj/grad/cons partials sum to the unsharded result."""
+    unsharded result; cons rows / grad variables are owner pieces (written into one buffer), obj partial sums."""
     import torch
     m, o = built["lv1000"]
     x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=3)
@@ -125,8 +125,9 @@ def test_sharded_outputs_tile_the_global_coo(built):
     G = 4
     acc_h = np.full(m.meta.nnzh, np.nan)
     acc_j = np.full(m.meta.nnzj, np.nan)
-    g = np.zeros(m.meta.nvar)
-    c = np.zeros(m.meta.ncon)
+    from conftest import RankReplay
+    rr = RankReplay(m, [("grad", m.meta.nvar), ("cons", m.meta.ncon)], dev)
+    assert rr.layout == {"grad": "pieces", "cons": "pieces"}        # LV: every index is range-affine
     f = 0.0
     try:
         for r in range(G):
@@ -142,15 +143,15 @@ def test_sharded_outputs_tile_the_global_coo(built):
             pj = pj.cpu().numpy()
             assert not np.any(~np.isnan(pj) & ~np.isnan(acc_j)), "shards overlap"
             acc_j[~np.isnan(pj)] = pj[~np.isnan(pj)]
-            g += m.grad(xd).cpu().numpy()
-            c += m.cons(xd).cpu().numpy()
+            rr.add("grad", lambda out: m.grad(xd, out=out))
+            rr.add("cons", lambda out: m.cons(xd, out=out))
             f += m.obj(xd)
     finally:
         m.set_shard(0, 1)
     assert not np.any(np.isnan(acc_h)) and relerr(acc_h, o.hess_coord(x, y, sigma)) <= RTOL
     assert not np.any(np.isnan(acc_j)) and relerr(acc_j, o.jac_coord(x)) <= RTOL
-    assert relerr(g, o.grad(x)) <= RTOL
-    assert relerr(c, o.cons(x)) <= RTOL
+    assert relerr(rr.result("grad"), o.grad(x)) <= RTOL
+    assert relerr(rr.result("cons"), o.cons(x)) <= RTOL
     assert abs(f - o.obj(x)) <= RTOL * max(1.0, abs(o.obj(x)))
 
 

@@ -56,15 +56,20 @@ def test_products_device_pointers_and_sharding(libs):
     dev = torch.device("cuda:0")
     xd, yd, vd, wd = (torch.from_numpy(a).to(dev) for a in (x, y, v, w))
     G = 3
-    jv, jtv, hv = np.zeros(m.meta.ncon), np.zeros(m.meta.nvar), np.zeros(m.meta.nvar)
+    jtv, hv = np.zeros(m.meta.nvar), np.zeros(m.meta.nvar)
+    # J v: a rank writes the rows of its own data points, complete (the row's owner adds the augmentation terms itself),
+    # and nothing else — all ranks into one buffer; J'v / Hv of this data-indexed model: partial sums, added up
+    assert m.shard_layout("jprod") == "pieces" and m.shard_layout("jtprod") == "partial" and m.shard_layout("hprod") == "partial"
+    jvd = torch.full((m.meta.ncon,), float("nan"), dtype=torch.float64, device=dev)
     try:
         for r in range(G):
             m.set_shard(r, G)
-            jv += m.jprod(xd, vd).cpu().numpy()
+            m.jprod(xd, vd, out=jvd)
             jtv += m.jtprod(xd, wd).cpu().numpy()
             hv += m.hprod(xd, yd, vd, sigma).cpu().numpy()
     finally:
         m.set_shard(0, 1)
+    jv = jvd.cpu().numpy()
     assert relerr(jv, o.jprod(x, v)) <= RTOL
     assert relerr(jtv, o.jtprod(x, w)) <= RTOL
     assert relerr(hv, o.hprod(x, y, v, sigma)) <= RTOL

@@ -68,7 +68,8 @@ if os.environ.get("CHECK_ALL"):
         got[((ccol - 1) * nrow + (cr - 1)).cpu().numpy()] = np.where(np.isfinite(cv), cv, 0.0)
         errs += [rel(got, dense)]
 if os.environ.get("SHARDS"):
-    # the same model cut into SHARDS shards (one after the other on this GPU): partial sums of obj / grad! / cons_nln! /
+    # the same model cut into SHARDS shards (one after the other on this GPU; host-pointer entry points: entries a rank does
+    # not own come back as zeros, so owner pieces add up like partial sums): obj / grad! / cons_nln! /
     # products add up to the oracle's, the COO slices written at their global positions tile the unsharded COO
     W = int(os.environ["SHARDS"])
     m.set_product_mode(0, 0)
