@@ -254,7 +254,7 @@ void gen_cons_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
        << "(const long* __restrict__ P, double* __restrict__ c, double* __restrict__ aug, long tid, double v) {\n"
        << "    const long I = " << b.P(L.pat[pi].lo) << " + tid;\n    if (I >= " << b.P(L.pat[pi].hi) << ") return;\n";
     if (b.p.kind == EXA_PAT_CONAUG) os << "    aug[" << b.P(L.pat[pi].oa) << " + I] = v;\n";
-    else os << "    c[" << b.P(L.pat[pi].o0) << " + I] = v;\n";
+    else os << "    __builtin_nontemporal_store(v, &c[" << b.P(L.pat[pi].o0) << " + I]);\n";
     os << "}\n";
 }
 
@@ -352,7 +352,8 @@ void gen_fused_group_fn(std::ostringstream &os, const Model &m, const ParamLayou
     os << "static __device__ __forceinline__ double g" << gi << "_fused"
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, const double* __restrict__ th, "
           "double* __restrict__ cout, double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma, "
-          "long tid, double* lds, const long* __restrict__ augptr, const long* __restrict__ augsrc, const double* __restrict__ augcoef) {\n";
+          "long tid, double* lds, const long* __restrict__ augptr, const long* __restrict__ augsrc, const double* __restrict__ augcoef, "
+          "double* __restrict__ gout) {\n";
     {
         Body b0(m, grp.front(), L);
         os << "    const long I0 = " << b0.P(L.pat[grp.front()].lo) << " + tid;\n    const long hi = " << b0.P(L.pat[grp.front()].hi) << ";\n"
@@ -369,7 +370,10 @@ void gen_fused_group_fn(std::ostringstream &os, const Model &m, const ParamLayou
         if (p.ad[p.ad_root].kind == AD_CONST) value = E.tod(b.cval(p.root));
         const bool isobj = p.kind == EXA_PAT_OBJ;
         GenAlg a1(b, p.comp1, p.o1step);
-        if (!isobj && p.o1step > 0) grpass(p, p.ad_root, a1, Emitter::litf(1.0));
+        // (objective patterns: their first partials are grad! — added to gout when the caller wants all five callbacks from
+        // this one sweep, exa_eval_all; gathered patterns are left to exa_grad_pull, which needs no atomics)
+        const bool ingrad = isobj && p.o1step > 0 && std::find(L.pull.begin(), L.pull.end(), pk) == L.pull.end();
+        if ((!isobj || ingrad) && p.o1step > 0) grpass(p, p.ad_root, a1, Emitter::litf(1.0));
         Val adj = isobj ? E.raw("sigma", false) : E.raw("y[" + b.row0() + "]", false);
         GenAlg a2(b, p.comp2, p.o2step);
         if (p.o2step > 0) hrpass0(p, p.ad_root, a2, adj, zero_seed(b));
@@ -390,8 +394,10 @@ void gen_fused_group_fn(std::ostringstream &os, const Model &m, const ParamLayou
                   "                const double c0 = augcoef[j], c1 = augcoef[j + 1], c2 = augcoef[j + 2], c3 = augcoef[j + 3];\n"
                   "                const double x0 = x[i0], x1 = x[i1], x2 = x[i2], x3 = x[i3];\n"
                   "                v += __dmul_rn(c0, x0); v += __dmul_rn(c1, x1); v += __dmul_rn(c2, x2); v += __dmul_rn(c3, x3);\n            }\n"
-                  "            for (; j < je; j++) v += __dmul_rn(augcoef[j], x[augsrc[j]]);\n        }\n        cout[r_] = v;\n    }\n";
-        else os << "    if (I0 < hi) " << (p.kind == EXA_PAT_CONAUG ? "augout" : "cout") << "[" << rowtxt << "] = " << E.sd(value) << ";\n";
+                  "            for (; j < je; j++) v += __dmul_rn(augcoef[j], x[augsrc[j]]);\n        }\n        __builtin_nontemporal_store(v, &cout[r_]);\n    }\n";
+        // (base rows: non-temporal — 8 B per row that nothing of this evaluation reads again must not push x / y out of the MALL)
+        else if (p.kind == EXA_PAT_CONAUG) os << "    if (I0 < hi) augout[" << rowtxt << "] = " << E.sd(value) << ";\n";
+        else os << "    if (I0 < hi) __builtin_nontemporal_store(" << E.sd(value) << ", &cout[" << rowtxt << "]);\n";
         const std::string tag = "_" + std::to_string(pk);
         if (!isobj && p.o1step > 0) {
             std::vector<std::string> vals;
@@ -402,6 +408,23 @@ void gen_fused_group_fn(std::ostringstream &os, const Model &m, const ParamLayou
             std::vector<std::string> vals;
             for (int s = 0; s < p.o2step; s++) vals.push_back(E.sd(a2.acc[s]));
             emit_coo_stores(os, b, L.pat[pk].o2, p.o2step, vals, use_tile(p.o2step), "hout", "h" + tag);
+        }
+        if (ingrad) {
+            // contributions of one point to the same variable first, then one add per distinct variable: a literal index
+            // (the same variable for every point) by wavefront reduction, a data index with lanes of one target peeled,
+            // anything else lane by lane; the whole wavefront is here (tail lanes are clamped, act = false)
+            Scatter sc(b);
+            for (int sl = 0; sl < p.o1step; sl++) sc.add(b, p.slotvar1[sl], a1.acc[sl]);
+            sc.merge();
+            for (; emitted < E.lines.size(); emitted++) os << "    " << E.lines[emitted] << "\n";
+            os << "    if (gout) {\n        const bool act = I0 < hi;\n";
+            for (const Scatter::Item &it : sc.items) {
+                const std::string idx = E.s(E.sub(it.vidx, Emitter::liti(1)));
+                if (it.vidx.is_lit()) os << "        exa_wave_atomic_add(&gout[" << idx << "], act ? " << E.sd(it.val) << " : 0.0);\n";
+                else if (!affine(*it.p, it.ir).ok) os << "        exa_scatter_add1(gout, " << idx << ", " << E.sd(it.val) << ", act);\n";
+                else os << "        if (act) exa_atomic_add(&gout[" << idx << "], " << E.sd(it.val) << ");\n";
+            }
+            os << "    }\n";
         }
         if (isobj) ret = "(I0 < hi ? " + E.sd(value) + " : 0.0)";
     }

@@ -207,7 +207,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
           "    const long v0 = v_begin + (long)blockIdx.x * (EXA_BLOCK * EXA_PULL_PPT) + threadIdx.x;\n    double g[EXA_PULL_PPT];\n"
           "#pragma unroll\n    for (int u = 0; u < EXA_PULL_PPT; u++) {\n        const long v_ = v0 + u * EXA_BLOCK, v = v_ < v_end ? v_ : v_end - 1;\n        g[u] = 0.0;\n";
     for (int k : L.pull) os << "        g[u] += p" << k << "_pull(P, x, th, v + 1);\n";
-    os << "    }\n#pragma unroll\n    for (int u = 0; u < EXA_PULL_PPT; u++) { const long v = v0 + u * EXA_BLOCK; if (v < v_end) out[v] = v >= own_lo && v < own_hi ? g[u] : 0.0; }\n}\n";
+    os << "    }\n#pragma unroll\n    for (int u = 0; u < EXA_PULL_PPT; u++) { const long v = v0 + u * EXA_BLOCK; if (v < v_end) __builtin_nontemporal_store(v >= own_lo && v < own_hi ? g[u] : 0.0, &out[v]); }\n}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_cons(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out, double* __restrict__ aug) {\n";
     {
@@ -258,7 +258,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
                 const auto &pp = L.pat[pk];
                 bool target = false;
                 for (int a : augs) target = target || m.pats[a].base == pk;
-                if (!target) { os << "        out[P[" << pp.o0 << "] + I] = " << E.sd(vals[q]) << ";\n"; continue; }
+                if (!target) { os << "        __builtin_nontemporal_store(" << E.sd(vals[q]) << ", &out[P[" << pp.o0 << "] + I]);\n"; continue; }
                 os << "        {\n        double v = " << E.sd(vals[q]) << ";\n        const long r_ = P[" << pp.o0 << "] + I;\n";
                 if (m.aug_linear) {
                     os << "        long j = augptr[r_];\n        const long je = augptr[r_ + 1];\n"
@@ -280,7 +280,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
                     }
                     os << "        }\n";
                 }
-                os << "        out[r_] = v;\n        }\n";
+                os << "        __builtin_nontemporal_store(v, &out[r_]);\n        }\n";
             }
             os << "    }\n";
         }
@@ -326,7 +326,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
                 const int pk = grp[q];
                 bool target = false;
                 for (int a : augs) target = target || m.pats[a].base == pk;
-                if (!target) { os << "        out[P[" << L.pat[pk].o0 << "] + I] = " << E.sd(sums[q]) << ";\n"; continue; }
+                if (!target) { os << "        __builtin_nontemporal_store(" << E.sd(sums[q]) << ", &out[P[" << L.pat[pk].o0 << "] + I]);\n"; continue; }
                 os << "        {\n        double s_ = " << E.sd(sums[q]) << ";\n        const long r_ = P[" << L.pat[pk].o0 << "] + I;\n"
                       "        long j = augptr[r_];\n        const long je = augptr[r_ + 1];\n"
                       "        for (; j + 4 <= je; j += 4) {\n"
@@ -334,7 +334,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
                       "            const double c0 = augcoef[j], c1 = augcoef[j + 1], c2 = augcoef[j + 2], c3 = augcoef[j + 3];\n"
                       "            const double v0 = v[i0], v1 = v[i1], v2 = v[i2], v3 = v[i3];\n"
                       "            s_ += __dmul_rn(c0, v0); s_ += __dmul_rn(c1, v1); s_ += __dmul_rn(c2, v2); s_ += __dmul_rn(c3, v3);\n        }\n"
-                      "        for (; j < je; j++) s_ += __dmul_rn(augcoef[j], v[augsrc[j]]);\n        out[r_] = s_;\n        }\n";
+                      "        for (; j < je; j++) s_ += __dmul_rn(augcoef[j], v[augsrc[j]]);\n        __builtin_nontemporal_store(s_, &out[r_]);\n        }\n";
             }
             os << "    }\n";
         }
@@ -372,25 +372,37 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
             if (p.kind != EXA_PAT_OBJ && use_tile(p.o1step)) mx = std::max(mx, tile_doubles(p.o1step));
             if (use_tile(p.o2step)) mx = std::max(mx, tile_doubles(p.o2step));
         }
+        // bmap: null = the block map of exa_eval_fused (P[blk]); exa_eval_all passes a map that holds ONE MORE unit after the
+        // fused groups — the tiles of the gathered gradient (the body of exa_grad_pull: one thread per variable of
+        // [v_begin, v_end), complete for [own_lo, own_hi), zero elsewhere) — so that grad! rides in the same launch; in the
+        // interleaved block order a gradient tile runs right after the tiles that have just pulled its stretch of x into L2
         os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_fused(const long* __restrict__ P, const double* __restrict__ x, "
               "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ part, double* __restrict__ cout, "
               "double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma, "
-              "const long* __restrict__ augptr, const long* __restrict__ augsrc, const double* __restrict__ augcoef) {\n";
+              "const long* __restrict__ augptr, const long* __restrict__ augsrc, const double* __restrict__ augcoef, double* __restrict__ gout, "
+              "const long* __restrict__ bmap, long v_begin, long v_end, long own_lo, long own_hi) {\n";
         if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all + (threadIdx.x >> 6) * " << mx << ";\n";
         else os << "    double* lds = nullptr;\n";
         // only the workgroups of OBJECTIVE patterns have something to add to obj: they write one partial sum each, at a
         // compact index (pattern's first slot + tile), so the reduction reads 1/3 of the workgroup count on LV
         os << "    const long b = blockIdx.x;\n"
-           << "    const long e_ = ((const long*)P[" << L.blk[CB_FUSED] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
+           << "    const long e_ = (bmap ? bmap : (const long*)P[" << L.blk[CB_FUSED] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
               "    const long tile_ = e_ & ((1L << 40) - 1);\n    const long tid0 = tile_ * EXA_BLOCK + threadIdx.x;\n";
         const auto &grps = L.groups[CB_FUSED];
         for (size_t k = 0; k < grps.size(); k++) {
             os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") { const double v = g" << k
-               << "_fused(P, x, y, th, cout, augout, jout, hout, sigma, tid0, lds, augptr, augsrc, augcoef);";
+               << "_fused(P, x, y, th, cout, augout, jout, hout, sigma, tid0, lds, augptr, augsrc, augcoef, gout);";
             if (m.pats[grps[k].front()].kind == EXA_PAT_OBJ)
                 os << " const double s = exa_block_sum(v); if (threadIdx.x == 0) part[P[" << L.pat[grps[k].front()].ob << "] + tile_] = s;";
             else os << " (void)v;";
             os << " }\n";
+        }
+        if (!L.pull.empty()) {
+            os << "    " << (grps.empty() ? "" : "else ") << "if (ps_ == " << grps.size() << ") {\n"
+                  "        const long v0 = v_begin + tile_ * (EXA_BLOCK * EXA_PULL_PPT) + threadIdx.x;\n        double g[EXA_PULL_PPT];\n"
+                  "#pragma unroll\n        for (int u = 0; u < EXA_PULL_PPT; u++) {\n            const long v_ = v0 + u * EXA_BLOCK, v = v_ < v_end ? v_ : v_end - 1;\n            g[u] = 0.0;\n";
+            for (int k : L.pull) os << "            g[u] += p" << k << "_pull(P, x, th, v + 1);\n";
+            os << "        }\n#pragma unroll\n        for (int u = 0; u < EXA_PULL_PPT; u++) { const long v = v0 + u * EXA_BLOCK; if (v < v_end) __builtin_nontemporal_store(v >= own_lo && v < own_hi ? g[u] : 0.0, &gout[v]); }\n    }\n";
         }
         os << "}\n";
     }

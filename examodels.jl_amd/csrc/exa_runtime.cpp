@@ -88,6 +88,8 @@ struct Handle {
     DevBuf dP, dtheta, dpart, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
     int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation
     DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] units one after the other, [1] interleaved in runs of 128
+    DevBuf dmapg[2];                        // exa_eval_all: the fused sweep's units + the gathered-gradient tiles (same two orders)
+    int64_t gridg = 0;
     int order[CB_COUNT] = {0};              // which map is active
     int norders[CB_COUNT] = {1};            // how many maps exist: exa_tune measures all of them
     int hess_variant = 0;                   // hess_coord! kernel: 0 exa_hess (one tile per workgroup), 1 exa_hessc (chained, grouped, pipelined)
@@ -154,6 +156,7 @@ struct Handle {
             daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); dobj.release();
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
+            dmapg[0].release(); dmapg[1].release();
             cj.release(); ch.release(); cbuf.release();
             for (Window *w : {&wj, &wh, &wp[0], &wp[1]}) { w->Q.release(); w->R.release(); w->X.release(); w->T.release(); w->E.release(); w->xbuf.release(); w->S.release(); w->F.release(); w->part.release(); }
             sj.pos.release(); sh.pos.release(); chm.release(); dM.release();
@@ -288,7 +291,10 @@ void fill_params(Handle &h) {
             }
             h.fused_nobj = nobj;
         }
-        auto build = [&](int64_t run_len) {
+        auto build_units = [](const std::vector<int64_t> &nb, int64_t run_len) {
+            const size_t na = nb.size();
+            int64_t total = 0;
+            for (int64_t v : nb) total += v;
             std::vector<int64_t> map, done(na, 0);
             map.reserve((size_t)total + 1);
             while ((int64_t)map.size() < total) {
@@ -302,6 +308,24 @@ void fill_params(Handle &h) {
             }
             return map;
         };
+        auto build = [&](int64_t run_len) { return build_units(nb, run_len); };
+        if (cb == CB_FUSED) {
+            // exa_eval_all: the same units + the tiles of the gathered gradient as one more unit (see exa_fused)
+            h.gridg = 0;
+            if (h.on_device && !L.pull.empty()) {
+                const bool owner = L.active[CB_GRAD].empty();
+                const int64_t vb = owner && h.world > 1 ? own_var_lo(h, h.rank) : 0, ve = owner && h.world > 1 ? own_var_lo(h, h.rank + 1) : m.nvar;
+                const int64_t per = (int64_t)kBlock * L.pull_ppt;
+                std::vector<int64_t> nbg = nb;
+                nbg.push_back((ve - vb + per - 1) / per);
+                h.gridg = total + nbg.back();
+                for (int k = 0; k < 2; k++) {
+                    std::vector<int64_t> mp = build_units(nbg, k ? 128 : 0);
+                    h.dmapg[k].ensure(sizeof(int64_t) * std::max<size_t>(mp.size(), 1));
+                    if (!mp.empty()) HIPCHK(hipMemcpy(h.dmapg[k].p, mp.data(), sizeof(int64_t) * mp.size(), hipMemcpyHostToDevice));
+                }
+            }
+        }
         const bool tunable = cb == CB_HESS || cb == CB_HESSC || cb == CB_JAC || cb == CB_FUSED || cb == CB_CONS;
         if (cb == CB_HESS) h.hess_stream_bytes = out_bytes + 8.0 * (double)(m.nvar + m.ncon) / h.world;
         const bool two = h.on_device && total > 0 && na > 1 && tunable && out_bytes >= 128e6;
@@ -752,7 +776,10 @@ void do_hess(Handle &h, const double *x, const double *y, double sigma, double *
     launch(h, h.f_hess, h.grid[CB_HESS], kBlock, a);
 }
 // fused obj + cons_nln! + jac_coord! + hess_coord! at one x
-void do_fused(Handle &h, const double *x, const double *y, double sigma, double *obj_dev, double *c, double *jv, double *hv) {
+// gout: null, or the gradient vector the objective patterns that are NOT gathered per variable add their first partials
+// to (exa_eval_all; the caller has zero-filled it or run exa_grad_pull into it)
+void do_fused(Handle &h, const double *x, const double *y, double sigma, double *obj_dev, double *c, double *jv, double *hv, double *gout = nullptr,
+              bool with_pull = false) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *part = h.dpart.p, *buf = h.daugbuf.p;
     // linear augmentation terms are added inside the sweep through the row lists of exa_cons1 when those exist: the rows a
@@ -765,7 +792,17 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
     }
     int64_t n = h.grid[CB_FUSED];
     const void *ap = inline_aug ? h.daugcsr.p : nullptr, *as = inline_aug ? h.daugsrc.p : nullptr, *ac = inline_aug ? h.daugcoef.p : nullptr;
-    void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma, &ap, &as, &ac};
+    // with_pull: the gathered gradient's tiles ride in this launch as one more unit of the block map (exa_eval_all)
+    const void *bmap = nullptr;
+    int64_t vb = 0, ve = 0, own_lo = 0, own_hi = 0;
+    if (with_pull && h.gridg > 0) {
+        const bool owner = h.gen.layout.active[CB_GRAD].empty();
+        own_lo = h.world > 1 ? own_var_lo(h, h.rank) : 0; own_hi = h.world > 1 ? own_var_lo(h, h.rank + 1) : h.m->nvar;
+        vb = owner ? own_lo : 0; ve = owner ? own_hi : h.m->nvar;
+        bmap = h.dmapg[h.order[CB_FUSED] ? 1 : 0].p;
+        n = h.gridg;
+    }
+    void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma, &ap, &as, &ac, &gout, &bmap, &vb, &ve, &own_lo, &own_hi};
     launch(h, h.f_fused, n, kBlock, a);
     int64_t nobj = h.fused_nobj;
     if (n > 0 && nobj > 0) { void *a2[] = {&part, &nobj, &obj_dev}; launch(h, h.f_red, 1, 1024, a2); }
@@ -773,6 +810,39 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
     if (h.m->nconaug && !inline_aug) aug_gather(h, buf, c);
     allreduce(h, obj_dev, 1);
     if (h.m->ncon) { if (owner) allgatherv(h, c, row_pieces(h)); else allreduce(h, c, h.m->ncon); }
+}
+// All five callbacks of a solver iteration at one x (the call pattern of
+// test/NLPModelsIpoptLite.jl/src/NLPModelsIpoptLite.jl:28-40): obj, grad!, cons_nln!, jac_coord!, hess_coord!.  The fused
+// sweep's objective patterns hold their first partials already: those that scatter through a data index add them to g
+// inside the sweep (no exa_grad launch, no second evaluation); range-affine ones are gathered per variable by exa_grad_pull
+// BEFORE the sweep (it also provides the zeros; x is then warm in the MALL for the sweep, whose 1.2 GB of output would
+// otherwise evict it before a grad! that ran afterwards).
+void do_eval_all(Handle &h, const double *x, const double *y, double sigma, double *obj_dev, double *g, double *c, double *jv, double *hv) {
+    const ParamLayout &L = h.gen.layout;
+    const int64_t nvar = h.m->nvar;
+    const bool scatter = !L.active[CB_GRAD].empty(), pull = !L.pull.empty();
+    if (h.grad_mode == 1 && grad_sorted_possible(h)) {       // deterministic grad! requested: the sorted gather, separately
+        grad_setup(h);
+        do_grad_sorted(h, x, g);
+        do_fused(h, x, y, sigma, obj_dev, c, jv, hv);
+        return;
+    }
+    const bool owner = pull && !scatter;
+    if (pull && scatter) {
+        // both kinds of objective pattern: the gathered part first (it provides the zeros the atomics of the sweep add to)
+        const void *P = h.dP.p, *th = h.dtheta.p;
+        int64_t own_lo = h.world > 1 ? own_var_lo(h, h.rank) : 0, own_hi = h.world > 1 ? own_var_lo(h, h.rank + 1) : nvar;
+        int64_t vb = 0, ve = nvar;
+        void *a0[] = {&P, &x, &th, &g, &vb, &ve, &own_lo, &own_hi};
+        const int64_t per = (int64_t)kBlock * L.pull_ppt;
+        launch(h, h.f_gradpull, (ve - vb + per - 1) / per, kBlock, a0);
+    } else if (!pull) {
+        HIPCHK(hipMemsetAsync(g, 0, sizeof(double) * (size_t)nvar, h.stream));
+    }
+    // (only gathered patterns: their tiles ride inside the sweep's launch)
+    do_fused(h, x, y, sigma, obj_dev, c, jv, hv, g, /*with_pull=*/pull && !scatter);
+    if (owner) allgatherv(h, g, var_pieces(h));
+    else if (scatter || pull) allreduce(h, g, nvar);
 }
 // matrix-free products (jprod_nln! / jtprod_nln! / hprod!, nlp.jl:1882-1978)
 void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
@@ -1754,6 +1824,13 @@ int exa_eval_fused(int id, const double *x, const double *y, double w, double *o
     return guard(id, true, [&](Handle &h) {
         if ((h.m->ncon && (!c || !y)) || (h.m->nnzj && !jvals) || (h.m->nnzh && !hvals)) throw BadInput("null output");
         do_fused(h, x, y, w, obj_dev, c, jvals, hvals);
+    });
+}
+int exa_eval_all(int id, const double *x, const double *y, double w, double *obj_dev, double *g, double *c, double *jvals, double *hvals) {
+    if (!x || !obj_dev || !g) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if ((h.m->ncon && (!c || !y)) || (h.m->nnzj && !jvals) || (h.m->nnzh && !hvals)) throw BadInput("null output");
+        do_eval_all(h, x, y, w, obj_dev, g, c, jvals, hvals);
     });
 }
 int exa_jprod(int id, const double *x, const double *v, double *Jv) {

@@ -22,7 +22,7 @@ SYMBOLS = [
     "exa_hess", "exa_jprod", "exa_jtprod", "exa_hprod", "exa_jprod_host", "exa_jtprod_host", "exa_hprod_host", "exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",
     "exa_obj_host", "exa_grad_host", "exa_cons_host", "exa_jac_host", "exa_hess_host", "exa_jac_structure_host",
     "exa_hess_structure_host", "exa_jac_structure64_host", "exa_hess_structure64_host", "exa_time_callback", "exa_sync", "exa_block_order",
-    "exa_eval_fused", "exa_set_product_mode", "exa_get_product_mode", "exa_set_grad_mode", "exa_get_grad_mode", "exa_set_deterministic", "exa_compress", "exa_compress_info", "exa_cnnzj64", "exa_cnnzh64", "exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64",
+    "exa_eval_fused", "exa_eval_all", "exa_set_product_mode", "exa_get_product_mode", "exa_set_grad_mode", "exa_get_grad_mode", "exa_set_deterministic", "exa_compress", "exa_compress_info", "exa_cnnzj64", "exa_cnnzh64", "exa_cjac_structure", "exa_chess_structure", "exa_cjac_structure64",
     "exa_chess_structure64", "exa_cjac_csc", "exa_chess_csc", "exa_cjac", "exa_chess",
     "exa_build_info", "exa_tune", "exa_comm_unique_id", "exa_comm_init", "exa_comm_attach", "exa_comm_hook", "exa_comm_free",
     "exa_comm_info", "exa_set_reduce", "exa_allreduce", "exa_set_coo_local", "exa_local_nnzj64", "exa_local_nnzh64",
@@ -104,6 +104,7 @@ def lib():
     L.exa_sync.argtypes = [i32]
     L.exa_block_order.argtypes = [i32, i32]
     L.exa_eval_fused.argtypes = [i32, vp, vp, dbl, vp, vp, vp, vp]
+    L.exa_eval_all.argtypes = [i32, vp, vp, dbl, vp, vp, vp, vp, vp]
     L.exa_set_product_mode.argtypes = [i32, i32, i32]
     L.exa_get_product_mode.argtypes = [i32, vp, vp]
     L.exa_set_grad_mode.argtypes = [i32, i32]

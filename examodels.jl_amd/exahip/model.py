@@ -502,6 +502,21 @@ class ExaModel:
                                           jac.data_ptr(), hess.data_ptr()), "exa_eval_fused")
         return f, c, jac, hess
 
+    def eval_all(self, x, y, obj_weight=1.0, g=None, c=None, jac=None, hess=None, obj_out=None):
+        """obj + grad + cons + jac_coord + hess_coord at one x (exa_eval_all): the evaluation set of a solver iteration.
+        Device tensors only; returns (obj as a 1-element device tensor, g, c, jac, hess); nothing synchronises."""
+        import torch
+        self._use_torch_stream(x)
+        dev = x.device
+        f = torch.empty(1, dtype=torch.float64, device=dev) if obj_out is None else obj_out
+        g = torch.empty(self.meta.nvar, dtype=torch.float64, device=dev) if g is None else g
+        c = torch.empty(self.meta.ncon, dtype=torch.float64, device=dev) if c is None else c
+        jac = torch.empty(self.local_nnzj, dtype=torch.float64, device=dev) if jac is None else jac
+        hess = torch.empty(self.local_nnzh, dtype=torch.float64, device=dev) if hess is None else hess
+        capi.check(self._L.exa_eval_all(self.id, x.data_ptr(), y.data_ptr(), float(obj_weight), f.data_ptr(), g.data_ptr(), c.data_ptr(),
+                                        jac.data_ptr(), hess.data_ptr()), "exa_eval_all")
+        return f, g, c, jac, hess
+
     # ---- matrix-free products: jprod_nln! / jtprod_nln! / hprod! (nlp.jl:1882-1978) -----------------------------
     def _prod(self, name, x, v, nv, n_out, out, y=None, w=1.0):
         if _is_torch(x):

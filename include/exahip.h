@@ -250,6 +250,13 @@ int exa_hess_structure64_host(int id, int64_t *rows, int64_t *cols);
  * are by-products of it, src/graph.jl:416-447): one launch instead of four, transcendental work done once.
  * All DEVICE pointers; *obj_dev receives the objective value on the device (no synchronisation). */
 int exa_eval_fused(int id, const double *x, const double *y, double obj_weight, double *obj_dev, double *c, double *jvals, double *hvals);
+/* ... and grad! with them: all FIVE callbacks of a solver iteration at one x (the call pattern of
+ * test/NLPModelsIpoptLite.jl/src/NLPModelsIpoptLite.jl:28-40).  The objective patterns of the sweep hold their first partials
+ * already: patterns that scatter through a data index add them to g inside the sweep (no second evaluation, no exa_grad
+ * launch); range-affine ones are gathered per variable by exa_grad_pull, launched BEFORE the sweep so that x is still warm
+ * in the 256 MB MALL when the sweep reads it.  g [nvar] is fully overwritten.  Results equal the separate callbacks
+ * (bitwise, except the atomically added part of g).  With exa_set_grad_mode(1) the gradient comes from the sorted gather. */
+int exa_eval_all(int id, const double *x, const double *y, double obj_weight, double *obj_dev, double *g, double *c, double *jvals, double *hvals);
 
 /* ---- compressed COO: duplicate (row,col) entries summed (CompressedNLPModel, src/utils.jl:425-579; KA ext :1290-1319) --- */
 /* One-off set-up on the device: sorts the (col,row) pairs of both structures (stable), builds ptr/perm.  Entries come

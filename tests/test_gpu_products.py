@@ -117,6 +117,40 @@ def test_fused_sweep_equals_separate_callbacks(libs, name):
     assert relerr(h.cpu().numpy(), o.hess_coord(x, y, sigma)) <= RTOL
 
 
+@pytest.mark.parametrize("name", list(ZOO))
+def test_eval_all_equals_the_five_separate_callbacks(libs, name):
+    """exa_eval_all (the evaluation set of NLPModelsIpoptLite.jl:28-40): obj, grad!, cons, jac_coord, hess_coord
+    from one sweep (+ the gathered gradient kernel) == the separate callbacks — bitwise, except the part of g that objective
+    patterns add atomically inside the sweep — and == the oracle.  Outputs are poisoned first: fully overwritten."""
+    import torch
+    from exahip import ExaModel
+    import oracle
+    m = ExaModel(ZOO[name]())
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=23)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    nan = float("nan")
+    bufs = [torch.full((max(1, k),), nan, dtype=torch.float64, device=dev) for k in (m.meta.nvar, m.meta.ncon, m.meta.nnzj, m.meta.nnzh)]
+    f, g, c, j, h = m.eval_all(xd, yd, sigma, g=bufs[0], c=bufs[1], jac=bufs[2], hess=bufs[3])
+    torch.cuda.synchronize()
+    fo = o.obj(x)
+    assert abs(f.item() - fo) <= RTOL * max(1.0, abs(fo))
+    for got, ref, sep in ((g, o.grad(x), m.grad(xd)), (c, o.cons(x), m.cons(xd)), (j, o.jac_coord(x), m.jac_coord(xd)),
+                          (h, o.hess_coord(x, y, sigma), m.hess_coord(xd, yd, sigma))):
+        n = ref.size
+        assert relerr(got.cpu().numpy()[:n], ref) <= RTOL
+        if got is g and m.shard_layout("grad") == "pieces":           # gathered gradient: the same function, the same bits
+            assert torch.equal(got[:n], sep[:n])
+        else:       # (atomic adds in any order; the sweep and the separate kernels contract their FMAs differently)
+            assert relerr(got.cpu().numpy()[:n], sep.cpu().numpy()[:n]) <= 1e-12
+    # deterministic gradient requested: eval_all takes the sorted gather for it
+    m.set_grad_mode(1)
+    f2, g2, *_ = m.eval_all(xd, yd, sigma)
+    assert relerr(g2.cpu().numpy(), o.grad(x)) <= RTOL and torch.equal(g2, m.grad(xd))
+    m.set_grad_mode(-1)
+
+
 @pytest.mark.parametrize("name", ["lv20", "acopf30", "rocket50", "mixed", "cops_elec"])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_both_product_implementations(libs, name, mode):

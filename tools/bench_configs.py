@@ -88,6 +88,9 @@ def run(name, core, reps=50):
         m.eval_fused(x, y, 0.5, c=c, jac=j, hess=h, obj_out=fo)
         m.grad(x, out=bufs["grad"])
 
+    def evaluate_all():
+        m.eval_all(x, y, 0.5, g=bufs["grad"], c=c, jac=j, hess=h, obj_out=fo)
+
     def timed(fn, n=50):
         best = 1e9
         for _ in range(3):
@@ -108,7 +111,7 @@ def run(name, core, reps=50):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         evaluate()
-    out["iteration_set_fused_plus_grad"] = {"eager_ms": timed(evaluate), "hip_graph_ms": timed(graph.replay)}
+    out["iteration_set_fused_plus_grad"] = {"eager_ms": timed(evaluate), "hip_graph_ms": timed(graph.replay), "eval_all_ms": timed(evaluate_all)}
     # duplicate-summed COO (CompressedNLPModel): one-off set-up (device radix sorts) and the per-evaluation cost
     import time
     from exahip import CompressedExaModel
