@@ -419,17 +419,89 @@ CodeObject get_code_object(const std::string &source, bool memory_only_ok) {
     return co;
 }
 
-// ---- persisted tuning decisions: <cache>/<source key>.tune, lines "<signature> <value>" ---------------------------
-bool tune_lookup(const std::string &key, const std::string &signature, int *value) {
+// ---- notes about a module: <cache>/<source key>.note, or handed over in memory (exa_cache_note) ----------------------------
+// One fact so far: "loopfree" — the scatter kernels of this module spill registers when compiled with loops around their
+// bodies, so the model's module is the one generated WITHOUT them (another source, another key).  The decision is taken
+// once, where the module is compiled (exa_compile, exahip.pack, or the first device build), from the code object's own
+// metadata; every later build — plan-only or device, this process or another, a packed library's consumer — starts from
+// the note and generates the final module at once: no second compile, and no compiler needed by a consumer.
+std::map<std::string, std::string> g_notes;
+std::string note_lookup(const std::string &key) {
+    {
+        std::lock_guard<std::mutex> lk(g_pre_mu);
+        auto it = g_notes.find(key);
+        if (it != g_notes.end()) return it->second;
+    }
     for (const std::string &d : read_dirs()) {
         std::vector<char> txt;
-        if (!read_regular_file(d + "/" + key + ".tune", txt)) continue;
-        std::istringstream ss(std::string(txt.begin(), txt.end()));
-        std::string sig;
-        int v, found = 0;
-        while (ss >> sig >> v) if (sig == signature) { *value = v; found = 1; }    // the last line for a signature wins
-        if (found) return true;
+        if (read_regular_file(d + "/" + key + ".note", txt)) {
+            std::string t(txt.begin(), txt.end());
+            while (!t.empty() && (t.back() == '\n' || t.back() == ' ')) t.pop_back();
+            return t;
+        }
     }
+    return "";
+}
+void note_store(const std::string &key, const std::string &note, bool persist) {
+    { std::lock_guard<std::mutex> lk(g_pre_mu); g_notes[key] = note; }
+    if (!persist) return;
+    const std::string d = writable_cache_dir();
+    if (d.empty()) return;
+    try { write_atomically(d + "/" + key + ".note", note.data(), note.size()); } catch (const std::exception &) {}
+}
+
+// ---- resources of a kernel, read from the code object's AMDGPU metadata (msgpack in an ELF note) -----------------------------
+// The kernel's map holds its keys in sorted order: .agpr_count ... .name ... .private_segment_fixed_size ... .vgpr_count,
+// .vgpr_spill_count.  Enough of msgpack is understood here to read the unsigned integers that follow those keys.
+bool kernel_resources(const std::vector<char> &image, const std::string &kernel, int *vgpr, int *agpr, int *scratch, int *vgpr_spill) {
+    const std::string img(image.begin(), image.end());
+    auto mstr = [](const std::string &t) { return std::string(1, (char)(0xa0 | t.size())) + t; };      // fixstr (< 32 bytes)
+    auto uint_at = [&](size_t p, long *out) {
+        if (p >= img.size()) return false;
+        const unsigned char c = (unsigned char)img[p];
+        if (c <= 0x7f) { *out = c; return true; }
+        auto be = [&](int n) { long v = 0; for (int i = 1; i <= n; i++) v = (v << 8) | (unsigned char)img[p + i]; return v; };
+        if (c == 0xcc && p + 1 < img.size()) { *out = be(1); return true; }
+        if (c == 0xcd && p + 2 < img.size()) { *out = be(2); return true; }
+        if (c == 0xce && p + 4 < img.size()) { *out = be(4); return true; }
+        return false;
+    };
+    const std::string name_kv = mstr(".name") + (kernel.size() < 32 ? mstr(kernel) : std::string(1, (char)0xd9) + std::string(1, (char)kernel.size()) + kernel);
+    const size_t at = img.find(name_kv);
+    if (at == std::string::npos) return false;
+    auto after = [&](const std::string &key, long *out) {      // first occurrence behind .name: the same kernel's map
+        const size_t p = img.find(mstr(key), at);
+        return p != std::string::npos && uint_at(p + 1 + key.size(), out);
+    };
+    auto before = [&](const std::string &key, long *out) {
+        const size_t p = img.rfind(mstr(key), at);
+        return p != std::string::npos && uint_at(p + 1 + key.size(), out);
+    };
+    long v = 0, a = 0, sc = 0, sp = 0;
+    if (!after(".private_segment_fixed_size", &sc) || !after(".vgpr_count", &v)) return false;
+    (void)before(".agpr_count", &a);
+    (void)after(".vgpr_spill_count", &sp);
+    *vgpr = (int)v; *agpr = (int)a; *scratch = (int)sc; *vgpr_spill = (int)sp;
+    return true;
+}
+
+// ---- persisted tuning decisions: <cache>/<source key>.tune, lines "<signature> <value>" ---------------------------
+static bool tune_lookup_in(const std::string &d, const std::string &key, const std::string &signature, int *value) {
+    std::vector<char> txt;
+    if (!read_regular_file(d + "/" + key + ".tune", txt)) return false;
+    std::istringstream ss(std::string(txt.begin(), txt.end()));
+    std::string sig;
+    int v, found = 0;
+    while (ss >> sig >> v) if (sig == signature) { *value = v; found = 1; }    // the last line for a signature wins
+    return found != 0;
+}
+// The directory decisions are WRITTEN to is read first: a newer exa_tune result there is not shadowed by an older line in
+// a read-only <install>/kernel_cache that comes earlier in read_dirs().
+bool tune_lookup(const std::string &key, const std::string &signature, int *value) {
+    const std::string w = writable_cache_dir();
+    if (!w.empty() && tune_lookup_in(w, key, signature, value)) return true;
+    for (const std::string &d : read_dirs())
+        if (d != w && tune_lookup_in(d, key, signature, value)) return true;
     return false;
 }
 void tune_store(const std::string &key, const std::string &signature, int value) {
@@ -440,7 +512,7 @@ void tune_store(const std::string &key, const std::string &signature, int value)
     // at the same moment, and a read-modify-write would keep only the last writer's.  The directory is a trusted one
     // (writable_cache_dir); the last line for a signature wins when the file is read.
     int cur = 0;
-    if (tune_lookup(key, signature, &cur) && cur == value) return;      // nothing new: the file does not grow with every exa_tune
+    if (tune_lookup_in(d, key, signature, &cur) && cur == value) return;      // nothing new IN THE FILE BEING WRITTEN: it does not grow with every exa_tune
     const std::string line = signature + " " + std::to_string(value) + "\n";
     const int fd = open(p.c_str(), O_WRONLY | O_CREAT | O_APPEND | O_NOFOLLOW | O_CLOEXEC, 0644);
     if (fd < 0) return;                                     // tuning is an optimisation

@@ -23,6 +23,11 @@ struct CodeObject {
 CodeObject get_code_object(const std::string &source, bool memory_only_ok);
 bool cache_add(const std::string &name, const void *blob, size_t len);
 std::string writable_cache_dir();     // "" when there is none
+// facts about a module that travel with it (exa_build.cpp "notes"): "" when there is none
+std::string note_lookup(const std::string &key);
+void note_store(const std::string &key, const std::string &note, bool persist);
+// registers, scratch bytes per lane and spilled VGPRs of a kernel, from the code object's metadata; false = not found
+bool kernel_resources(const std::vector<char> &image, const std::string &kernel, int *vgpr, int *agpr, int *scratch, int *vgpr_spill);
 
 bool tune_lookup(const std::string &key, const std::string &signature, int *value);
 void tune_store(const std::string &key, const std::string &signature, int value);

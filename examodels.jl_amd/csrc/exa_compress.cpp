@@ -416,6 +416,8 @@ void build_sorted_index(SortedIndex &s, const int64_t *keys1, int64_t nnz, int64
     if (hm[0] > (unsigned long long)kMaxLong) throw std::runtime_error("too many long groups for the sorted products");
     s.nlong = (int64_t)hm[0]; s.maxlen = (int64_t)hm[1];
     if (s.nlong) {
+        // (the per-chunk partial sums of the long groups are allocated HERE, at set-up: a callback never allocates)
+        HIPCHK_C(hipMalloc(&s.partial, 8 * (size_t)s.nlong * (size_t)((s.maxlen + kChunk - 1) / kChunk)));
         HIPCHK_C(hipMalloc(&s.long_rows, 4 * (size_t)s.nlong));
         HIPCHK_C(hipMemcpyAsync(s.long_rows, list.p, 4 * (size_t)s.nlong, hipMemcpyDeviceToDevice, stream));
         HIPCHK_C(hipStreamSynchronize(stream));
@@ -445,7 +447,6 @@ void spmv_gather(const SortedIndex &s, const double *vals, const int64_t *other,
         }
         if (s.nlong) {
             const unsigned chunks = (unsigned)((s.maxlen + kChunk - 1) / kChunk);
-            if (!s.partial) HIPCHK_C(hipMalloc(&const_cast<SortedIndex &>(s).partial, 8 * (size_t)s.nlong * chunks));
             hipLaunchKernelGGL(k_spmv_long2, dim3((unsigned)s.nlong, chunks), dim3(256), 0, stream, (const uint32_t *)s.long_rows,
                                (const int64_t *)s.ptr, (const uint32_t *)s.perm, (const uint32_t *)s.oth, vals, v, (double *)s.partial);
             hipLaunchKernelGGL(k_spmv_fold, dim3(grid_for(s.nlong)), dim3(256), 0, stream, (const uint32_t *)s.long_rows, (const double *)s.partial,

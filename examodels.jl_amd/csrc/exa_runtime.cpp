@@ -130,7 +130,8 @@ struct Handle {
     // ... and its merged-slot form for the Hessian (exa_chessm): the merged slot space has its own sorted lists
     bool merged = false;
     int device = -1;            // the HIP device that was current in exa_create (DeviceScope)
-    bool loopfree_scatter = false;     // the module was generated a second time without loops in the scatter kernels (to_device)
+    bool loopfree_scatter = false;     // the module is the one generated without loops in the scatter kernels (module_for)
+    std::string first_key;             // ... and this is the key of the module with loops it replaces (its "loopfree" note)
     // grad! by sorted gather (the reference's scheme, deterministic): gradient COO + (variable, slot) lists, built on demand
     hipFunction_t f_gradv = nullptr, f_gstruct = nullptr;
     SortedIndex gbyvar;
@@ -152,6 +153,11 @@ struct Handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     ~Handle() {
+        // (every other entry point runs with the model's device current, DeviceScope; so must the teardown: hipFree /
+        // hipModuleUnload / ncclCommDestroy of a model created on GPU 1 from a thread whose current device is GPU 0)
+        int prev = -1;
+        const bool switched = on_device && device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device && hipSetDevice(device) == hipSuccess;
+        if (on_device) (void)hipStreamSynchronize(stream);
         if (on_device) {
             daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); dobj.release();
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
@@ -172,6 +178,7 @@ struct Handle {
             if (module) (void)hipModuleUnload(module);
         }
         if (nccl && nccl_owned) { try { rccl_comm_destroy(nccl); } catch (...) {} }
+        if (switched) (void)hipSetDevice(prev);
     }
 };
 
@@ -371,13 +378,46 @@ void fill_params(Handle &h) {
     }
 }
 
+// The model's first module, compiled or fetched.  A scatter kernel that SPILLS registers (bodies of hundreds to thousands
+// of SSA values) must not carry wavefront-level state across its body: with spills in play (scratch, or AGPRs used as spill
+// space) the per-lane accumulators of shared targets (summed by a butterfly after a 16-tile loop) and the peeling loop of
+// exa_scatter_add have returned wrong sums on random depth-6 models (tests/test_random_expressions.py).  The generator
+// avoids the loops for bodies it can see are huge (kHugeBody); here the COMPILED kernels are asked — their registers and
+// scratch are in the code object's metadata, no device needed — and a module whose scatter kernels spill is generated again
+// without loops.  The decision is recorded as a note of the first module's key (note_store), so plan-only handles,
+// exa_compile, exahip.pack, later processes and a packed library's consumer all arrive at the SAME final module directly.
+bool scatter_kernels_spill(const CodeObject &co) {
+    bool spills = false;
+    for (const char *name : {"exa_grad", "exa_jtprod", "exa_hprod"}) {
+        int v = 0, a = 0, sc = 0, sp = 0;
+        if (!kernel_resources(co.image, name, &v, &a, &sc, &sp)) continue;
+        // (AGPRs in a kernel without MFMA are spill space: the 256 architectural VGPRs are exhausted)
+        if (sc > 0 || a > 0 || sp > 0) spills = true;
+        if (verbose()) fprintf(stderr, "[exahip] %s: %d VGPRs, %d AGPRs, %d bytes of scratch per lane, %d spilled\n", name, v, a, sc, sp);
+    }
+    return spills;
+}
+CodeObject module_for(Handle &h, bool memory_only_ok) {
+    CodeObject co = get_code_object(h.gen.source, memory_only_ok);
+    if (!h.loopfree_scatter && scatter_kernels_spill(co)) {
+        h.first_key = co.key;
+        note_store(co.key, "loopfree", true);
+        h.loopfree_scatter = true;
+        h.gen = generate_module(*h.m, true);
+        CodeObject c2 = get_code_object(h.gen.source, memory_only_ok);
+        c2.build_ms += co.build_ms;
+        return c2;
+    }
+    return co;
+}
+
 void to_device(Handle &h) {
     Model &m = *h.m;
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
         throw HipError("no HIP device available (libexahip has no CPU fallback): " + std::string(hipGetErrorString(e)));
-    CodeObject co = get_code_object(h.gen.source, true);
+    CodeObject co = module_for(h, true);
     std::vector<char> &image = co.image;
     h.hsaco_path = co.path; h.build_how = co.how; h.build_ms = co.build_ms;
     {
@@ -390,32 +430,6 @@ void to_device(Handle &h) {
     h.on_device = true;   // from here on the destructor releases whatever was acquired
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
-    // A scatter kernel that SPILLS registers (bodies of hundreds to thousands of SSA values) must not carry
-    // wavefront-level state across its body: with spills in play (scratch, or AGPRs used as spill space), the per-lane
-    // accumulators of shared targets (summed by a butterfly after a 16-tile loop) and the peeling loop of exa_scatter_add
-    // have returned wrong, NaN or garbage sums — depending on what the spill space held before (random depth-6 models of
-    // tests/test_random_expressions.py, with the hiprtc of ROCm 7.0 and, less often, the hipcc of 7.2; never with the
-    // wavefront operations off).  The generator avoids the loops for bodies it can see are huge; here the compiled
-    // kernels are asked, and a module whose scatter kernels spill is generated again without them.
-    if (!h.loopfree_scatter) {
-        bool spills = false;
-        for (const char *name : {"exa_grad", "exa_jtprod", "exa_hprod"}) {
-            // (more than 256 registers = the 256 VGPRs are exhausted and values are parked in AGPRs: spilling all the same)
-            int local = 0, regs = 0;
-            if (hipFuncGetAttribute(&local, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn(name)) == hipSuccess && local > 0) spills = true;
-            if (hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn(name)) == hipSuccess && regs > 256) spills = true;
-            if (verbose()) fprintf(stderr, "[exahip] %s: %d bytes of scratch per lane, %d registers\n", name, local, regs);
-        }
-        if (spills) {
-            (void)hipModuleUnload(h.module);
-            h.module = nullptr;
-            h.loopfree_scatter = true;
-            h.gen = generate_module(m, true);
-            co = get_code_object(h.gen.source, true);
-            h.hsaco_path = co.path; h.build_how = co.how; h.build_ms += co.build_ms;
-            HIPCHK(hipModuleLoadData(&h.module, co.image.data()));
-        }
-    }
     h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
     h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull");
     h.f_auglong = fn("exa_aug_long"); h.f_augfold = fn("exa_aug_fold");
@@ -717,13 +731,20 @@ void do_grad_sorted(Handle &h, const double *x, double *g) {
     launch(h, h.f_gradv, h.grid[CB_OBJ], kBlock, a);
     spmv_gather(h.gbyvar, (const double *)h.gbuf.p, nullptr, nullptr, nullptr, false, (const double *)h.gone.p, g, false, h.stream);
 }
+// A callback never allocates, sorts or synchronises: the sorted lists a persisted / explicit decision needs are built
+// eagerly (eager_setup at model build and after a reshard; exa_set_*_mode; exa_tune).  Should a call still find them
+// missing while its stream is being CAPTURED (hipStreamBeginCapture), it runs the implementation that needs none.
+bool capturing(const Handle &h) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(h.stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 static int resolve_grad_mode(Handle &h) {
     if (h.grad_mode < 0) {
         int v = 0;
         h.grad_mode = tune_lookup(source_key(h.gen.source), tune_signature(h, "grad"), &v) && v == 1 ? 1 : 0;
     }
     if (h.grad_mode == 1 && !grad_sorted_possible(h)) return 0;
-    if (h.grad_mode == 1) grad_setup(h);
+    if (h.grad_mode == 1 && !h.grad_ready) { if (capturing(h)) return 0; grad_setup(h); }
     return h.grad_mode;
 }
 static void run_grad(Handle &h, const double *x, double *g) {
@@ -1570,14 +1591,20 @@ void d2h(Handle &h, void *dst, const void *src, size_t bytes) {
     HIPCHK(hipStreamSynchronize(h.stream));
 }
 
+void (*g_eager_setup)(Handle &) = nullptr;      // eager_setup (defined with the mode logic further down)
 int create(const exa_model_desc_t *desc, int *id_out, bool device) {
     if (!desc || !id_out) return 1;
     try {
         auto h = std::make_unique<Handle>();
         h->m = plan_model(desc);
         h->gen = generate_module(*h->m);
+        if (note_lookup(source_key(h->gen.source)) == "loopfree" && h->gen.source.find("// scatter kernels without loops") == std::string::npos) {       // decided where this module was first compiled
+            h->first_key = source_key(h->gen.source);
+            h->loopfree_scatter = true;
+            h->gen = generate_module(*h->m, true);
+        }
         plan_products(*h);
-        if (device) { to_device(*h); load_products(*h); }
+        if (device) { to_device(*h); load_products(*h); if (g_eager_setup) g_eager_setup(*h); }
         else fill_params(*h);
         *id_out = put(std::move(h));
         return 0;
@@ -1618,6 +1645,30 @@ int exa_cache_add(const char *name, const void *code_object, size_t len) {
     if (!name || !code_object || len == 0) return 1;
     return cache_add(name, code_object, len) ? 0 : 1;     // refuses anything that is not an AMDGPU code object
 }
+int exa_cache_note(const char *name, const char *note) {
+    if (!name || !note || !*name) return 1;
+    note_store(name, note, false);
+    return 0;
+}
+/* code objects of a compiled model (exa_compile / a device model): k = 0 the model's module, 1 the owner-computes product
+ * windows (when the model has them).  name <- the module's name (what exa_cache_add takes), path <- its file. */
+int exa_code_object_count(int id) { Handle *h = get(id); return h ? (h->psource.empty() ? 1 : 2) : -1; }
+int exa_code_object(int id, int k, char *name, int ncap, char *path, int pcap) {
+    Handle *h = get(id);
+    if (!h || k < 0 || k > 1 || (k == 1 && h->psource.empty())) return 1;
+    if (name && ncap > 0) snprintf(name, (size_t)ncap, "%s", source_key(k == 0 ? h->gen.source : h->psource).c_str());
+    if (path && pcap > 0) snprintf(path, (size_t)pcap, "%s", (k == 0 ? h->hsaco_path : h->phsaco_path).c_str());
+    return 0;
+}
+/* "" or the name of the module WITH loops this model's module replaces: a packed library hands exa_cache_note(that name,
+ * "loopfree") over with the code object, so that its consumer generates the final module at once */
+const char *exa_module_alias(int id) {
+    Handle *h = get(id);
+    if (!h) return nullptr;
+    static thread_local std::string name;
+    name = h->first_key;
+    return name.c_str();
+}
 const char *exa_module_name(int id) {
     Handle *h = get(id);
     if (!h) return nullptr;
@@ -1627,7 +1678,7 @@ const char *exa_module_name(int id) {
 }
 int exa_compile(int id) {
     return guard(id, false, [&](Handle &h) {
-        CodeObject co = get_code_object(h.gen.source, false);
+        CodeObject co = module_for(h, false);
         h.hsaco_path = co.path; h.build_how = co.how; h.build_ms = co.build_ms;
         if (!h.psource.empty()) { CodeObject pc = get_code_object(h.psource, false); h.phsaco_path = pc.path; h.build_ms += pc.build_ms; }
     });
@@ -1703,6 +1754,7 @@ static void reshard(Handle &h, int rank, int world, bool coo_local) {
             for (Handle::Window *w : {&h.wj, &h.wh}) { w->ok = false; w->why.clear(); }
             h.sj.ok = h.sh.ok = false;
         }
+        if (g_eager_setup) g_eager_setup(h);
     }
 }
 int exa_set_stream(int id, void *s) { return guard(id, true, [&](Handle &h) { h.stream = (hipStream_t)s; }); }
@@ -1863,9 +1915,19 @@ static int resolve_mode(Handle &h, bool hess) {
     }
     if (mode == 2 && !window_possible(h, hess)) return 0;
     if (mode == 1 && !sorted_possible(h, hess)) return 0;      // sharded at global positions: nothing to sort locally
-    if (mode == 1) prod_setup(h, hess);                          // no-op once the lists exist
+    if (mode == 1 && !(hess ? h.prod_ready_h : h.prod_ready_j)) { if (capturing(h)) return 0; prod_setup(h, hess); }
     return mode;
 }
+// what the persisted decisions need, built at model build / reshard instead of inside the first callback
+static void eager_setup(Handle &h) {
+    if (!h.on_device) return;
+    const int g = h.grad_mode, jt = h.jt_mode, hp = h.hp_mode;
+    (void)resolve_grad_mode(h);
+    (void)resolve_mode(h, false);
+    (void)resolve_mode(h, true);
+    h.grad_mode = g; h.jt_mode = jt; h.hp_mode = hp;          // (still "undecided" for exa_get_*_mode until a call resolves them)
+}
+static const bool g_eager_registered = (g_eager_setup = eager_setup, true);
 static void run_product_window(Handle &h, bool hess, const double *x, const double *y, const double *v, double w, double *out) {
     Handle::Window &win = h.wp[hess ? 1 : 0];
     if (h.world == 1) { do_window(h, hess ? WK_HPROD : WK_JTPROD, x, y, v, w, out); return; }
@@ -2306,8 +2368,11 @@ int exa_comm_init(int id, int rank, int world, const void *unique_id128) {
     if (!unique_id128 || world < 1 || rank < 0 || rank >= world) return 1;
     return guard(id, true, [&](Handle &h) {
         if (h.nccl || h.hook) throw BadInput("the model already has a communicator (exa_comm_free first)");
-        reshard(h, rank, world, h.coo_local);
-        h.nccl = rccl_comm_init(rank, world, unique_id128);       // collective over all ranks; on the current HIP device
+        // the communicator first: if it cannot be created (librccl missing, init failure) the model stays as it was — not
+        // sharded without a communicator, returning partial results
+        void *comm = rccl_comm_init(rank, world, unique_id128);    // collective over all ranks; on the current HIP device
+        try { reshard(h, rank, world, h.coo_local); } catch (...) { try { rccl_comm_destroy(comm); } catch (...) {} throw; }
+        h.nccl = comm;
         h.nccl_owned = true;
     });
 }

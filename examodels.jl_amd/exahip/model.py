@@ -293,6 +293,16 @@ class ExaModel:
         capi.check(self._L.exa_compile(self.id), "exa_compile")
         return self._L.exa_code_object_path(self.id).decode()
 
+    def code_objects(self):
+        """[(module name, code object bytes)] of a compiled model: its module and, where it has them, the product windows'."""
+        out = []
+        for k in range(self._L.exa_code_object_count(self.id)):
+            name, path = ctypes.create_string_buffer(128), ctypes.create_string_buffer(4096)
+            capi.check(self._L.exa_code_object(self.id, k, name, 128, path, 4096), "exa_code_object")
+            with open(path.value.decode(), "rb") as fh:
+                out.append((name.value.decode(), fh.read()))
+        return out
+
     def build_info(self):
         """(how, build_ms): how the module was obtained — "preloaded" | "disk" | "hiprtc" | "hipcc" — and the compiler's time."""
         buf, ms = ctypes.create_string_buffer(32), ctypes.c_double(0.0)

@@ -24,13 +24,15 @@
  * uninitialised memory, cf. benchmark/runbenchmark.jl:88-92).  Evaluation never errors on the values
  * of x (NaN/Inf propagate).
  *
- * Pointers: the unsuffixed callbacks take DEVICE pointers (what Julia passes as pointer(::ROCArray))
- * and are asynchronous on the model's stream (exa_set_stream; default the null stream) FROM THE FIRST CALL — no callback
- * ever measures, tunes or synchronises (exa_tune is the explicit, blocking set-up step for that) — except exa_obj
- * whose `out` is a HOST double and therefore synchronises.  The *_host variants take host pointers,
- * stage through device scratch owned by the model, and synchronise (the role of WrapperNLPModel,
- * src/utils.jl:159-208).  One call in flight per model id (reference callbacks share scratch too,
- * KA ext :21-31); distinct ids are independent.
+ * Pointers: the unsuffixed callbacks take DEVICE pointers (what Julia passes as pointer(::ROCArray)) and are asynchronous on
+ * the model's stream (exa_set_stream; default the null stream): a callback never measures, tunes, sorts or synchronises —
+ * exa_tune is the explicit, blocking set-up step for measuring; the sorted lists a persisted or explicit decision needs
+ * (exa_set_product_mode / exa_set_grad_mode / exa_set_deterministic) are built at model build, at those calls and at
+ * exa_set_shard, never inside a callback; the only allocation a callback may make is the scratch of its FIRST call
+ * (run every callback once before capturing a graph) — except exa_obj whose `out` is a HOST double and therefore
+ * synchronises.  The *_host variants take host pointers, stage through device scratch owned by the model, and synchronise
+ * (the role of WrapperNLPModel, src/utils.jl:159-208); on a sharded model they return zeros where the rank owns nothing.
+ * One call in flight per model id (reference callbacks share scratch too, KA ext :21-31); distinct ids are independent.
  *
  * There is NO CPU fallback: if no HIP device or the kernel module cannot be built, exa_new_from_table
  * fails with status 2.
@@ -76,6 +78,17 @@ const char *exa_module_name(int id);
  * like a compile_library product of ExaModelsCompiler (ExaModelsCompiler.jl:108-222).  Status 1 for anything that is
  * not an AMDGPU ELF code object (or a clang offload bundle of one). */
 int exa_cache_add(const char *name, const void *code_object, size_t len);
+/* A fact that travels with a module.  One so far: note "loopfree" for the name of a module whose scatter kernels were found
+ * to spill registers where it was compiled (the model's module is then the one generated without loops around their bodies,
+ * under another name): a later build that finds the note generates the final module at once.  exa_module_alias(id) is the
+ * name to attach it to ("" when the model's module replaces nothing). */
+int exa_cache_note(const char *name, const char *note);
+const char *exa_module_alias(int id);
+/* The code objects of a compiled model (after exa_compile, or a device model): k = 0 the model's module, k = 1 the module of
+ * the owner-computes product windows when the model has them (exa_product_info).  name <- what exa_cache_add takes,
+ * path <- the file.  exahip.pack embeds all of them. */
+int exa_code_object_count(int id);
+int exa_code_object(int id, int k, char *name, int ncap, char *path, int pcap);
 /* How the module of a device model was obtained: how <- "preloaded" | "disk" | "hiprtc" | "hipcc", *build_ms <- the
  * compiler's time (0 unless it ran).  The reference pays this at the first call of every callback (Julia's JIT). */
 int exa_build_info(int id, char *how, int cap, double *build_ms);

@@ -367,16 +367,27 @@ class CompiledHess:
     def __init__(self, ir, o):
         self.src = emit_source(ir, o)
         self.nnzh = o.nnzh
-        d = os.path.join(tempfile.gettempdir(), f"exaoracle_compiled_{os.getuid()}")
+        # a PRIVATE directory, verified before anything in it is loaded: $EXAHIP_CACHE_DIR or ~/.cache/exaoracle (0700, owned
+        # by this user, not a symlink) — never a predictable path under /tmp
+        base = os.environ.get("EXAHIP_CACHE_DIR") or os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "exaoracle")
+        d = os.path.join(base, "compiled_oracle")
         os.makedirs(d, mode=0o700, exist_ok=True)
-        tag = hashlib.sha256(self.src.encode()).hexdigest()[:24]
+        st = os.lstat(d)
+        import stat
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            raise RuntimeError(f"{d} is not a private directory of this user: refusing to load shared objects from it")
+        # -march=native like Julia's JIT (which targets the host CPU); -ffp-contract=off: no FMA contraction, like the reference
+        flags = ["-O2", "-march=native", "-fPIC", "-shared", "-std=gnu11", "-ffp-contract=off", "-fopenmp", "-w"]
+        tag = hashlib.sha256((self.src + " ".join(flags)).encode()).hexdigest()[:24]
         so = os.path.join(d, tag + ".so")
         if not os.path.exists(so):
-            csrc = os.path.join(d, tag + ".c")
-            with open(csrc, "w") as fh:
+            fd, csrc = tempfile.mkstemp(suffix=".c", dir=d)
+            with os.fdopen(fd, "w") as fh:
                 fh.write(self.src)
-            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-ffp-contract=off", "-fopenmp", "-w", "-o", so + ".tmp", csrc, "-lm"])
-            os.replace(so + ".tmp", so)
+            tmp = csrc[:-2] + ".so"
+            subprocess.check_call(["gcc"] + flags + ["-o", tmp, csrc, "-lm"])
+            os.replace(tmp, so)
+            os.unlink(csrc)
         self.lib = ctypes.CDLL(so)
         vp = ctypes.c_void_p
         self.lib.set_col.argtypes = [ctypes.c_int, ctypes.c_int, vp]

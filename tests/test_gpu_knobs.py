@@ -1,0 +1,89 @@
+"""-m gpu: every environment knob that changes the generated code or the path taken has a parity test (DESIGN.md §10 lists
+them: knob -> test).  The knobs covered elsewhere: EXAHIP_STRICT_IEEE / EXAHIP_SYM_TRIG (test_gpu_special_values.py),
+EXAHIP_HESS_VARIANT / EXAHIP_LDS_MAX (test_gpu_parity.py), EXAHIP_CWINDOW / EXAHIP_CSCATTER (test_gpu_compressed.py),
+EXAHIP_PRODUCT_WINDOW (test_gpu_product_windows.py), EXAHIP_COMPILER / EXAHIP_HIPCC / EXAHIP_HIPCC_FLAGS / EXAHIP_CACHE_DIR
+(test_plan_and_abi.py, test_gpu_comm.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import has_gpu
+from zoo import ZOO, point
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
+
+
+def _everything(m, x, y, s, v, w):
+    import torch
+    dev = torch.device("cuda:0")
+    xd, yd, vd, wd = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (x, y, v, w))
+    f, g, c, j, h = m.eval_all(xd, yd, s)
+    out = {"obj": m.obj(xd), "grad": m.grad(xd), "cons": m.cons(xd), "jac": m.jac_coord(xd), "hess": m.hess_coord(xd, yd, s),
+           "jprod": m.jprod(xd, vd), "jtprod": m.jtprod(xd, wd), "hprod": m.hprod(xd, yd, vd, s), "all_c": c, "all_j": j, "all_h": h}
+    torch.cuda.synchronize()
+    return {k: (t.cpu().numpy().copy() if hasattr(t, "cpu") else t) for k, t in out.items()}
+
+
+@pytest.mark.parametrize("name", ["acopf30", "rocket50", "lv1000", "mixed"])
+def test_group_knob_ungrouped_kernels_give_the_same_bits(libs, name, monkeypatch):
+    """EXAHIP_GROUP=0: every pattern evaluated on its own (no fused groups, no chained groups).  Grouping shares loads and
+    sincos evaluations, it changes no formula: outputs agree to the last bits (not always bit for bit — the compiler contracts
+    multiply-adds differently in a larger body; the scattered products also merge same-target contributions in registers)."""
+    from exahip import ExaModel
+    import oracle
+    m1 = ExaModel(ZOO[name]())
+    monkeypatch.setenv("EXAHIP_GROUP", "0")
+    m0 = ExaModel(ZOO[name]())
+    assert m0._L.exa_module_name(m0.id) != m1._L.exa_module_name(m1.id) or name in ("lv1000", "mixed")       # another module where groups exist
+    o = oracle.OracleModel(m1.ir)
+    x, y, s = point(m1.meta.x0, m1.meta.ncon, seed=9)
+    v = np.random.default_rng(5).standard_normal(m1.meta.nvar)
+    w = np.random.default_rng(6).standard_normal(max(1, m1.meta.ncon))[:m1.meta.ncon]
+    a, b = _everything(m1, x, y, s, v, w), _everything(m0, x, y, s, v, w)
+    for k in ("cons", "jac", "hess", "jprod", "all_c", "all_j", "all_h", "grad", "jtprod", "hprod"):
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-12, atol=1e-13, err_msg=k)
+    np.testing.assert_allclose(b["hess"], o.hess_coord(x, y, s), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(b["hprod"], o.hprod(x, y, v, s), rtol=1e-10, atol=1e-11)
+
+
+@pytest.mark.parametrize("name", ["acopf30", "lv1000"])
+def test_fast_trig_knob_ocml_sincos_gives_the_oracle_values_too(libs, name, monkeypatch):
+    """EXAHIP_FAST_TRIG=0: ocml's sincos (0.7 ulp) instead of the lean FP64 one (1.3 ulp): both within the 1e-10 bar."""
+    from exahip import ExaModel
+    import oracle
+    monkeypatch.setenv("EXAHIP_FAST_TRIG", "0")
+    m = ExaModel(ZOO[name]())
+    assert "exa_sincos(t" not in m.kernel_source().split("extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_obj")[1]
+    o = oracle.OracleModel(m.ir)
+    x, y, s = point(m.meta.x0, m.meta.ncon, seed=10)
+    v = np.random.default_rng(5).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(6).standard_normal(m.meta.ncon)
+    a = _everything(m, x, y, s, v, w)
+    for k, ref in (("grad", o.grad(x)), ("cons", o.cons(x)), ("jac", o.jac_coord(x)), ("hess", o.hess_coord(x, y, s)),
+                   ("jtprod", o.jtprod(x, w)), ("hprod", o.hprod(x, y, v, s))):
+        np.testing.assert_allclose(a[k], ref, rtol=1e-10, atol=1e-11)
+
+
+def test_keep_source_and_verbose_knobs_change_nothing_but_leave_evidence(libs, tmp_path, monkeypatch, capfd):
+    """EXAHIP_KEEP_SOURCE=1 writes the generated .hip next to the cached code object (both modules of the model);
+    EXAHIP_VERBOSE=1 prints one line per decision on stderr.  Neither changes a module's name or a result."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "from exahip import ExaModel, models\n"
+            "m = ExaModel(models.luksan_vlcek_model(3000))\n"
+            "import numpy as np\n"
+            "print(m._L.exa_module_name(m.id).decode(), float(np.sum(m.hprod(m.meta.x0, np.ones(m.meta.ncon), np.ones(m.meta.nvar), 0.5))))\n"
+            % (os.path.join(root, "examodels.jl_amd"), os.path.join(root, "tests")))
+    outs = []
+    for env in ({}, {"EXAHIP_KEEP_SOURCE": "1", "EXAHIP_VERBOSE": "1"}):
+        d = tmp_path / ("b" if env else "a")
+        d.mkdir()
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, EXAHIP_CACHE_DIR=str(d), **env), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append((r.stdout.strip().splitlines()[-1], r.stderr, sorted(os.listdir(d))))
+    assert outs[0][0] == outs[1][0]                                      # same module, same numbers
+    assert not any(f.endswith(".hip") for f in outs[0][2]) and sum(f.endswith(".hip") for f in outs[1][2]) == 2
+    assert "[exahip]" not in outs[0][1] and "[exahip] windowed hprod" in outs[1][1]

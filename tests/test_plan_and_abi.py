@@ -369,3 +369,36 @@ def test_julia_shim_ccall_signatures_match_the_header():
         assert jl_class(ret) == c_class(cret + " x"), (name, ret, cret)
         for ja, ca in zip(jargs, cargs):
             assert jl_class(ja) == c_class(ca), (name, ja, ca)
+
+
+def test_loopfree_note_makes_every_build_arrive_at_the_same_module(libs):
+    """the decision "this module's scatter kernels spill: generate them without loops" is taken where the module
+    is compiled (from the code object's metadata, exa_build.cpp kernel_resources) and recorded as a NOTE of the first
+    module's name; a build that finds the note — plan-only or device, a packed library's consumer (exa_cache_note) —
+    generates the final module at once, under the same name, without a second compile."""
+    from exahip import ExaModel, capi, models
+    L = capi.lib()
+    core = models.rocket_model(77)
+    a = ExaModel(core, device=False)
+    first = L.exa_module_name(a.id).decode()
+    assert L.exa_module_alias(a.id).decode() == "" and "scatter kernels without loops" not in a.kernel_source()
+    assert L.exa_cache_note(first.encode(), b"loopfree") == 0          # what a packed library does at load
+    b = ExaModel(models.rocket_model(77), device=False)
+    final = L.exa_module_name(b.id).decode()
+    assert final != first and L.exa_module_alias(b.id).decode() == first
+    assert "scatter kernels without loops" in b.kernel_source()
+    c = ExaModel(models.rocket_model(77), device=False)
+    assert L.exa_module_name(c.id).decode() == final                    # deterministic: the same final module every time
+    assert L.exa_cache_note(first.encode(), b"") == 0                   # (leave no note behind for the other tests)
+
+
+def test_kernel_resources_are_read_from_the_code_object(libs):
+    """exa_compile of a small model: its module and the product-window module are both reported (exa_code_object), and a
+    model whose scatter kernels fit the register file keeps its first module (no alias)."""
+    from exahip import ExaModel, capi, models
+    m = ExaModel(models.luksan_vlcek_model(50), device=False)
+    m.compile()
+    objs = m.code_objects()
+    assert len(objs) == 2 and all(name.startswith("exa_") and blob[:4] == b"\x7fELF" or blob[:24] == b"__CLANG_OFFLOAD_BUNDLE__" for name, blob in objs)
+    assert objs[0][0] == capi.lib().exa_module_name(m.id).decode() and capi.lib().exa_module_alias(m.id).decode() == ""
+    assert b"exa_hprodw" in objs[1][1] and b"exa_jtprodw" in objs[1][1]
