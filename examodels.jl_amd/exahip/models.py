@@ -123,10 +123,15 @@ def rocket_model(nh):
 # ---------------------------------------------------------------------------------------------------------------
 # AC optimal power flow — BASELINE.json config 4
 # ---------------------------------------------------------------------------------------------------------------
-def synthetic_power_data(nbus, nbr, ngen, seed=0):
+def synthetic_power_data(nbus, nbr, ngen, seed=0, topology="random"):
     """Synthetic ACOPF data with the field layout of test/NLPTest/power.jl:31-93 (the PGLIB case files and the
-    ExaPowerIO artifact are not available offline — SURVEY §8d config 4).  Topology: a spanning chain plus
-    random extra branches (connected graph, mean degree 2*nbr/nbus)."""
+    ExaPowerIO artifact are not available offline — SURVEY §8d config 4).
+    topology "random": a spanning chain plus extra branches between uniformly random buses, listed in random order —
+    every gather of a bus variable lands on its own cache line (the worst case for the branch-indexed patterns).
+    topology "bus":    what a PGLIB / MATPOWER case file looks like — branches LISTED BY FROM-BUS, ends close in the
+    numbering (buses of one area are numbered together): a spanning chain, extra branches to a bus a geometrically
+    distributed distance away (mean 12, 90 %), a few long ties between areas (10 %); degree distribution as in
+    transmission cases (mean 2*nbr/nbus ~ 3.2, most buses 2-4, hubs up to ~10)."""
     r = np.random.default_rng(seed)
     f_bus = np.empty(nbr, dtype=np.int64)
     t_bus = np.empty(nbr, dtype=np.int64)
@@ -134,14 +139,30 @@ def synthetic_power_data(nbus, nbr, ngen, seed=0):
     f_bus[:nchain] = np.arange(1, nchain + 1)
     t_bus[:nchain] = np.arange(2, nchain + 2)
     extra = nbr - nchain
-    if extra > 0:
-        f = r.integers(1, nbus + 1, size=extra)
-        t = r.integers(1, nbus, size=extra)
-        t = np.where(t >= f, t + 1, t)          # t != f
-        f_bus[nchain:] = f
-        t_bus[nchain:] = t
-    perm = r.permutation(nbr)
-    f_bus, t_bus = f_bus[perm], t_bus[perm]
+    if topology == "bus":
+        if extra > 0:
+            f = r.integers(1, nbus + 1, size=extra)
+            near = r.geometric(1.0 / 12.0, size=extra) + 1                   # 2, 3, ...: the chain already joins neighbours
+            far = r.integers(1, nbus, size=extra)
+            d = np.where(r.uniform(size=extra) < 0.9, near, far)
+            t = f + d * np.where(r.uniform(size=extra) < 0.5, 1, -1)
+            t = (t - 1) % nbus + 1                                             # (the numbering wraps around)
+            t = np.where(t == f, np.where(f < nbus, f + 1, f - 1), t)
+            f_bus[nchain:] = np.minimum(f, t)
+            t_bus[nchain:] = np.maximum(f, t)
+        order = np.lexsort((t_bus, f_bus))                                     # listed by from-bus, like a case file
+        f_bus, t_bus = f_bus[order], t_bus[order]
+    elif topology == "random":
+        if extra > 0:
+            f = r.integers(1, nbus + 1, size=extra)
+            t = r.integers(1, nbus, size=extra)
+            t = np.where(t >= f, t + 1, t)          # t != f
+            f_bus[nchain:] = f
+            t_bus[nchain:] = t
+        perm = r.permutation(nbr)
+        f_bus, t_bus = f_bus[perm], t_bus[perm]
+    else:
+        raise ValueError("topology must be 'random' or 'bus'")
     bidx = np.arange(1, nbr + 1)
     # arcs: k = 1..nbr "from" side, nbr+1..2nbr "to" side (ref[:arcs] = arcs_from ++ arcs_to)
     arc_i = np.arange(1, 2 * nbr + 1)

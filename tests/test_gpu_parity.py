@@ -257,3 +257,22 @@ def test_chained_hess_kernel_is_the_same_function(libs, monkeypatch, name):
         for g0, l0, cnt in m.coo_slices(True):
             assert relerr(loc[l0:l0 + cnt], H[g0:g0 + cnt]) <= RTOL
     assert relerr(whole, H) <= RTOL
+
+
+def test_bus_ordered_acopf_topology_matches_the_oracle(libs):
+    """models.synthetic_power_data(topology="bus"): branches listed by from-bus, ends close in the numbering (the layout of
+    a PGLIB case file) — the same 15-pattern model (test/NLPTest/power.jl:112-213), only the data differ."""
+    from exahip import ExaModel, models
+    import oracle
+    data = models.synthetic_power_data(300, 480, 40, seed=4, topology="bus")
+    f = data["branch"].cols["f_bus"]
+    assert np.all(np.diff(f) >= 0) and np.all(data["branch"].cols["t_bus"] != f)
+    m = ExaModel(models.ac_power_model(data))
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(models.acopf_start(models.ac_power_model(data)), m.meta.ncon, seed=6)
+    v = np.random.default_rng(2).standard_normal(m.meta.nvar)
+    assert relerr(m.cons(x), o.cons(x)) <= RTOL and relerr(m.grad(x), o.grad(x)) <= RTOL
+    assert relerr(m.jac_coord(x), o.jac_coord(x)) <= RTOL and relerr(m.hess_coord(x, y, sigma), o.hess_coord(x, y, sigma)) <= RTOL
+    assert relerr(m.hprod(x, y, v, sigma), o.hprod(x, y, v, sigma)) <= RTOL
+    for a, b in zip(m.jac_structure() + m.hess_structure(), o.jac_structure() + o.hess_structure()):
+        assert np.array_equal(a, b)
