@@ -75,3 +75,44 @@ def test_hip_path_reproduces_the_fixtures(libs, name):
     close(m.jprod(x, a["u"]), a["jprod"], "jprod")
     close(m.jtprod(x, a["v"]), a["jtprod"], "jtprod")
     close(m.hprod(x, y, a["u"], s), a["hprod"], "hprod")
+
+
+# ---- fixtures written by the REAL reference (tools/reference_check.jl --dump tests/golden/zoo_fixtures_reference) ---------------
+REF_DIR = os.path.join(HERE, "golden", "zoo_fixtures_reference")
+REF_NAMES = sorted(f[:-5] for f in os.listdir(REF_DIR) if f.endswith(".json")) if os.path.isdir(REF_DIR) else []
+
+
+def _load_ref(name):
+    import json
+    with open(os.path.join(REF_DIR, name + ".json")) as fh:
+        man = json.load(fh)
+    raw = open(os.path.join(REF_DIR, name + ".bin"), "rb").read()
+    return man["scalars"], {k: np.frombuffer(raw, dtype="<" + dt, count=n, offset=off) for k, (dt, n, off) in man["arrays"].items()}
+
+
+def test_reference_check_kit_rebuilds_every_fixture_model():
+    """tools/reference_check.jl states, with the reference's own macros, every model the fixtures hold (static check: no
+    Julia in the build container), and knows the --dump mode that turns its outputs into committed fixtures."""
+    jl = open(os.path.join(os.path.dirname(HERE), "tools", "reference_check.jl")).read()
+    import re
+    listed = set(re.findall(r'\("(\w+)", a ->', jl))
+    assert listed == set(NAMES), (sorted(set(NAMES) - listed), sorted(listed - set(NAMES)))
+    assert "--dump" in jl and "zoo_fixtures_reference" in jl and "function dump_fixture" in jl
+
+
+@pytest.mark.skipif(not REF_NAMES, reason="no reference-generated fixtures committed yet (needs a machine with Julia: tools/reference_check.jl --dump)")
+@pytest.mark.parametrize("name", REF_NAMES or ["-"])
+def test_oracle_equals_what_the_reference_computed(libs, name):
+    """Structure == and values 1e-10 against a Julia process's outputs: the Hessian slot order pinned by the reference itself."""
+    import oracle
+    sc, a = _load_ref(name)
+    o = oracle.OracleModel(fx.models()[name]().to_ir())
+    x, y, s = a["x"], a["y"], sc["sigma"]
+    jr, jc = o.jac_structure()
+    hr, hc = o.hess_structure()
+    assert np.array_equal(jr, a["jac_rows"]) and np.array_equal(jc, a["jac_cols"])
+    assert np.array_equal(hr, a["hess_rows"]) and np.array_equal(hc, a["hess_cols"])
+    assert abs(o.obj(x) - sc["obj"]) <= RTOL * max(1.0, abs(sc["obj"]))
+    for got, key in ((o.cons(x), "cons"), (o.grad(x), "grad"), (o.jac_coord(x), "jac_vals"), (o.hess_coord(x, y, s), "hess_vals"),
+                     (o.jprod(x, a["u"]), "jprod"), (o.jtprod(x, a["v"]), "jtprod"), (o.hprod(x, y, a["u"], s), "hprod")):
+        close(got, a[key], key)

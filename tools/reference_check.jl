@@ -1,7 +1,13 @@
 # reference_check.jl — compares the REAL reference (ExaModels.jl v0.12, backend = nothing) with the golden fixtures this
 # repository's oracle and HIP path are tested against (tests/golden/zoo_fixtures/, tests/test_golden_zoo.py).
 #
-#     julia --project=<env with ExaModels 0.12 and NLPModels> tools/reference_check.jl [fixture dir]
+#     julia --project=<env with ExaModels 0.12 and NLPModels> tools/reference_check.jl [fixture dir] [--dump OUTDIR]
+#
+# --dump OUTDIR additionally writes, for every model, a fixture in the SAME format whose inputs (x, y, sigma, u, v, the ACOPF
+# tables) are the committed fixture's and whose outputs — structures and values of all callbacks — are the REFERENCE's:
+# commit that directory as tests/golden/zoo_fixtures_reference/ and tests/test_golden_zoo.py checks the oracle and the HIP
+# path against what a Julia process computed (structure ==, values 1e-10): "parity unpinned on the Hessian slot order"
+# becomes a committed fact.
 #
 # It cannot run in the build container (no Julia there); it is the one command that, on any machine with Julia, turns
 # "the COO slot order is pinned by two independent re-readings of src/hessian.jl" into "a Julia process agrees with every
@@ -12,11 +18,16 @@
 # Models: the Luksan-Vlcek family (test/NLPTest/luksan.jl, benchmark/runbenchmark.jl:163-169, N = 3 ... 1e4 = BASELINE
 # config 1), the 2-D split variant with a tuple-target augmentation, the ACOPF of test/NLPTest/power.jl on the synthetic
 # 30-bus tables stored in the fixture, the Goddard rocket as this repository states it, trivialmax, and the 2-D
-# augmentation model of test/NLPTest/conaug_test.jl:200-213.
+# augmentation model of test/NLPTest/conaug_test.jl:200-213, the two COPS models of benchmark/runbenchmark.jl:239-282 (hanging
+# chain, electrons on a sphere) and this repository's two feature models (`mixed`: parameters with an offset index range,
+# table iterators with Int and Float columns, a 1-D augmentation, literal and data exponents; `stepped`: StepRange iterators,
+# exa_sum / exa_prod, Constant algebra, a parameterised power) — 15 of the 15 fixture models.
 using ExaModels, NLPModels, Printf
 import JSON   # any JSON reader will do; JSON.jl is what ExaModels' own test environment has
 
-const DIR = length(ARGS) >= 1 ? ARGS[1] : joinpath(@__DIR__, "..", "tests", "golden", "zoo_fixtures")
+const DUMP = (k = findfirst(==("--dump"), ARGS); k === nothing ? nothing : ARGS[k+1])
+const POS = [a for (i, a) in enumerate(ARGS) if a != "--dump" && (i == 1 || ARGS[i-1] != "--dump")]
+const DIR = length(POS) >= 1 ? POS[1] : joinpath(@__DIR__, "..", "tests", "golden", "zoo_fixtures")
 
 function load_fixture(name)
     man = JSON.parsefile(joinpath(DIR, name * ".json"))
@@ -133,13 +144,78 @@ function acopf_model(a)                            # test/NLPTest/power.jl:112-2
     return ExaModel(w; prod = true)
 end
 
+function cops_chain_model(n)                       # benchmark/runbenchmark.jl:239-264, operand for operand
+    nh = max(2, div(n - 4, 4))
+    L = 4; a = 1; b = 3
+    tmin = b > a ? 1/4 : 3/4
+    tf = 1.0; h = tf / nh
+    c = ExaCore(concrete = Val(true))
+    @add_var(c, u,  nh+1; start = [4*abs(b-a)*(k/nh - tmin) for k in 1:nh+1])
+    @add_var(c, x1, nh+1; start = [4*abs(b-a)*k/nh*(1/2*k/nh - tmin) + a for k in 1:nh+1])
+    @add_var(c, x2, nh+1; start = [(4*abs(b-a)*k/nh*(1/2*k/nh - tmin) + a) * (4*abs(b-a)*(k/nh - tmin)) for k in 1:nh+1])
+    @add_var(c, x3, nh+1; start = [4*abs(b-a)*(k/nh - tmin) for k in 1:nh+1])
+    @add_obj(c, x2[nh+1])
+    @add_con(c, c1, x1[j+1] - x1[j] - 1/2*h*(u[j] + u[j+1]) for j in 1:nh)
+    @add_con(c, c2, x1[1] - a)
+    @add_con(c, c3, x1[nh+1] - b)
+    @add_con(c, c4, x2[1])
+    @add_con(c, c5, x3[1])
+    @add_con(c, c6, x3[nh+1] - L)
+    @add_con(c, c7, x2[j+1] - x2[j] - 1/2*h*(x1[j]*sqrt(1+u[j]^2) + x1[j+1]*sqrt(1+u[j+1]^2)) for j in 1:nh)
+    @add_con(c, c8, x3[j+1] - x3[j] - 1/2*h*(sqrt(1+u[j]^2) + sqrt(1+u[j+1]^2)) for j in 1:nh)
+    return ExaModel(c; prod = true)
+end
+
+function cops_elec_model(np)                       # benchmark/runbenchmark.jl:267-282 (the start point is not compared: x comes from the fixture)
+    itr = [(i, j) for i in 1:np-1 for j in i+1:np]
+    core = ExaCore(concrete = Val(true))
+    @add_var(core, x, 1:np; start = zeros(np))
+    @add_var(core, y, 1:np; start = zeros(np))
+    @add_var(core, z, 1:np; start = ones(np))
+    @add_obj(core, 1 / sqrt((x[i]-x[j])^2 + (y[i]-y[j])^2 + (z[i]-z[j])^2) for (i, j) in itr)
+    @add_con(core, c1, x[i]^2 + y[i]^2 + z[i]^2 - 1 for i = 1:np)
+    return ExaModel(core; prod = true)
+end
+
+function mixed_model()                             # tests/zoo.py mixed_model, statement for statement
+    c = ExaCore(concrete = Val(true))
+    @add_var(c, x, 12; start = collect(range(0.5, 1.5; length = 12)))
+    @add_var(c, z, 0:5; start = fill(0.7, 6))
+    c, th = add_par(c, 2:4; value = [10.0, 20.0, 30.0])
+    tab = [(i = i, j = j, w = w, e = e) for (i, j, w, e) in zip([1, 3, 5, 7], [2, 4, 6, 8], [0.5, 1.5, -2.0, 3.0], [2, 3, 4, 5])]
+    @add_obj(c, d.w * (x[d.i] - x[d.j])^2 + sin(x[d.i] * x[d.j]) for d in tab)
+    @add_obj(c, exp(-z[i]) * z[i]^3 + th[2] * z[i] for i = 0:5)
+    @add_con(c, g1, th[j] * x[1] * x[j] + log(x[j+1]) for j = 2:4)
+    @add_con(c, g, x[d.i] / x[d.j] - d.w * sqrt(x[d.j]) + x[d.i]^d.e for d in tab; lcon = fill(-1.0, 4), ucon = fill(1.0, 4))
+    @add_con!(c, g, k => tanh(x[k] * x[k+4]) - 3 * x[k+8] for k = 1:4)
+    @add_con(c, g3, z[i] * z[i-1] - cos(z[i] - x[12]) + 2.0^z[i] for i = 1:5)
+    return ExaModel(c; prod = true)
+end
+
+function stepped_model()                           # tests/zoo.py stepped_model: StepRange iterators, exa_sum / exa_prod, Constant
+    N = 50
+    c = ExaCore(concrete = Val(true))
+    @add_var(c, x, N; start = collect(range(0.4, 1.6; length = N)))
+    c, th = add_par(c, 2; value = [1.5, 0.25])
+    @add_obj(c, (x[i] - x[i+1])^2 + Constant(1) * x[i] * Constant(0) + th[1] * x[i+1] for i = 1:2:(N-1))
+    @add_obj(c, exa_sum(x[i+k]^2 for k in 0:2) * 0.5 for i = 2:3:(N-2))
+    @add_con(c, s1, exa_prod(1 + x[i+k] for k in 0:2) - x[i]^th[2] + Constant(2)^x[i+1] for i = 3:3:(N-2))
+    @add_con(c, s2, (x[i] + (-x[i-1]) + 2 * x[i-2]) / (1 + x[i]^2) for i = N:-4:3)
+    return ExaModel(c; prod = true)
+end
+
 const MODELS = [
     ("lv3", a -> lv_model(3)), ("lv20", a -> lv_model(20)), ("lv20_objfirst", a -> lv_model(20; obj_first = true)),
     ("lv1000", a -> lv_model(1000)), ("lv10000", a -> lv_model(10_000)),
     ("lv_split_20x1", a -> lv_split_model(20, 1)), ("lv_split_20x2", a -> lv_split_model(20, 2)),
     ("trivialmax", a -> trivialmax_model(6)), ("conaug2d", a -> conaug2d_model()),
     ("rocket50", a -> rocket_model(50)), ("acopf30", a -> acopf_model(a)),
+    ("cops_chain", a -> cops_chain_model(200)), ("cops_elec", a -> cops_elec_model(25)),
+    ("mixed", a -> mixed_model()), ("stepped", a -> stepped_model()),
 ]
+# `stepped`: tests/zoo.py builds exa_sum / exa_prod as the reference's SumNode / ProdNode over the literal offsets 0:2 and the last
+# constraint's sum from a list — if the first run shows a structure mismatch on this model only, compare that row's
+# statement with tests/zoo.py:stepped_model before suspecting the evaluator.
 
 relerr(a, ref) = isempty(ref) ? 0.0 : maximum(abs.(a .- ref) ./ max.(abs.(ref), 1e-3 * max(1.0, maximum(abs.(ref)))))
 
@@ -165,7 +241,41 @@ function check(name, build)
     say("jprod", relerr(NLPModels.jprod(m, x, u), a["jprod"]) <= 1e-10)
     say("jtprod", relerr(NLPModels.jtprod(m, x, v), a["jtprod"]) <= 1e-10)
     say("hprod", relerr(NLPModels.hprod(m, x, y, u; obj_weight = s), a["hprod"]) <= 1e-10)
+    if DUMP !== nothing
+        out = Pair{String,Any}["x" => x, "y" => y, "u" => u, "v" => v,
+            "cons" => NLPModels.cons(m, x), "grad" => NLPModels.grad(m, x),
+            "jac_rows" => Int32.(jr), "jac_cols" => Int32.(jc), "jac_vals" => jv,
+            "hess_rows" => Int32.(hr), "hess_cols" => Int32.(hc), "hess_vals" => hv,
+            "jprod" => NLPModels.jprod(m, x, u), "jtprod" => NLPModels.jtprod(m, x, v), "hprod" => NLPModels.hprod(m, x, y, u; obj_weight = s)]
+        for (k, val) in a                      # the model's data tables travel along unchanged
+            startswith(k, "data_") && push!(out, k => val)
+        end
+        scal = Dict("nvar" => m.meta.nvar, "ncon" => m.meta.ncon, "nnzj" => m.meta.nnzj, "nnzh" => m.meta.nnzh, "sigma" => s,
+                    "obj" => NLPModels.obj(m, x), "minimize" => m.meta.minimize, "generated_by" => "tools/reference_check.jl --dump (ExaModels.jl, backend = nothing)")
+        dump_fixture(DUMP, name, scal, out)
+    end
     return ok
+end
+
+# the format of tests/golden/make_zoo_fixtures.py: <name>.bin = the arrays back to back (little endian), <name>.json = scalars +
+# {array name: [dtype, count, byte offset]}
+function dump_fixture(dir, name, scalars, arrays)
+    mkpath(dir)
+    man = Dict{String,Any}("scalars" => scalars, "arrays" => Dict{String,Any}())
+    off = 0
+    open(joinpath(dir, name * ".bin"), "w") do io
+        for (k, val) in arrays
+            v = val isa AbstractVector ? collect(val) : [val]
+            dt = eltype(v) == Float64 ? "f8" : eltype(v) == Int32 ? "i4" : "i8"
+            v = dt == "i8" ? Int64.(v) : v
+            write(io, htol.(v))
+            man["arrays"][k] = Any[dt, length(v), off]
+            off += sizeof(v)
+        end
+    end
+    open(joinpath(dir, name * ".json"), "w") do io
+        JSON.print(io, man, 1)
+    end
 end
 
 function main()
