@@ -1911,7 +1911,9 @@ static int resolve_mode(Handle &h, bool hess) {
         if (tuned && ((v == 1 && sorted_possible(h, hess)) || (v == 2 && window_possible(h, hess)) || v == 0)) mode = v;
         // undecided and never tuned: the windows, unless some entry is added to by EVERY data point (a literal index: the
         // rocket's step length) — that costs a second evaluation pass (exa_*s), which the atomics of the sweep do not pay
-        else mode = window_possible(h, hess) && h.wp[hess ? 1 : 0].ns_blocks == 0 ? 2 : 0;
+        // (measured on the rocket, nh = 1e6: J'v by windows 0.045 against 0.062 ms — its first-order body is cheap enough to
+        // evaluate twice —, Hv 0.079 against 0.070; exa_tune measures the model at hand)
+        else mode = window_possible(h, hess) && (h.wp[hess ? 1 : 0].ns_blocks == 0 || !hess) ? 2 : 0;
     }
     if (mode == 2 && !window_possible(h, hess)) return 0;
     if (mode == 1 && !sorted_possible(h, hess)) return 0;      // sharded at global positions: nothing to sort locally
@@ -1983,7 +1985,7 @@ int exa_product_info(int id, int hess, char *buf, int cap) {
     int v = -1;
     if (h->on_device && tune_lookup(source_key(h->gen.source), tune_signature(*h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 2 &&
         (v != 2 || window_possible(*h, hess != 0)) && (v != 1 || sorted_possible(*h, hess != 0))) return v;
-    return (h->on_device ? window_possible(*h, hess != 0) : w.planned) && w.ns_blocks == 0 ? 2 : 0;
+    return (h->on_device ? window_possible(*h, hess != 0) : w.planned) && (w.ns_blocks == 0 || !hess) ? 2 : 0;
 }
 /* grad!: 0 = gathered (affine patterns) + FP64 atomics (data-indexed ones), 1 = gradient COO + sorted gather (the reference's
  * scheme: deterministic, and immune to many data points sharing a few variables), -1 = undecided: the persisted exa_tune

@@ -50,7 +50,7 @@ def test_window_products_equal_the_oracle_and_are_bit_reproducible(libs, name):
             continue
         assert text.startswith(("one chunk per pass", "chunk loops", "block-owned windows")), text
         # undecided models take the windows by default unless an entry is shared by every data point (rocket: the step length)
-        assert mode == (0 if name.startswith("rocket") else 2), (name, which, mode, text)
+        assert mode == (0 if name.startswith("rocket") and which == "hprod" else 2), (name, which, mode, text)
         outs = []
         for _ in range(3):
             out = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)   # fully overwritten: no zero-fill needed
