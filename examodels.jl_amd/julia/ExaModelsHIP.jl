@@ -203,6 +203,24 @@ function coo_slices(m; hess::Bool = true)          # rows of (first global slot,
     return permutedims(reshape(out[1:3np], 3, np))
 end
 
+# a sharded Jacobian (hess = false) / Hessian COO vector whole on every rank: all-gather-v of the ranks' slot ranges
+function allgather_coo!(m, dest::AbstractVector, loc::AbstractVector; hess::Bool = true)
+    chk(ccall((:exa_allgather_coo, LIB), Cint, (Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, hess, pointer(loc), pointer(dest)), "exa_allgather_coo"); dest
+end
+# :pieces (complete values in disjoint pieces: an all-gather completes) or :partial (partial sums: an all-reduce completes):
+# how this rank leaves the output of callback `which` (0 obj 1 grad 2 cons 3 jac 4 hess 5 jprod 6 jtprod 7 hprod) on its own
+shard_layout(m, which::Integer) = ccall((:exa_shard_layout, LIB), Cint, (Cint, Cint), m.ext.id, which) == 1 ? :pieces : :partial
+# jtprod / hprod implementation: 0 atomics in the sweep, 1 COO + sorted gather, 2 owner-computes windows, -1 undecided
+product_mode!(m, jtprod::Integer, hprod::Integer) = chk(ccall((:exa_set_product_mode, LIB), Cint, (Cint, Cint, Cint), m.ext.id, jtprod, hprod), "exa_set_product_mode")
+# all five callbacks of a solver iteration from one sweep (NLPModelsIpoptLite.jl:28-40); returns the objective as a 1-element device array
+function eval_all!(m, x::AbstractVector, y::AbstractVector, g::AbstractVector, c::AbstractVector, jac::AbstractVector, hess::AbstractVector; obj_weight = one(eltype(x)))
+    usestream(m)
+    f = ROCArray{Float64}(undef, 1)
+    chk(ccall((:exa_eval_all, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}),
+              m.ext.id, pointer(x), pointer(y), Float64(obj_weight), pointer(f), pointer(g), pointer(c), pointer(jac), pointer(hess)), "exa_eval_all")
+    return f
+end
+
 # ---- the seven callbacks (device pointers; asynchronous on the task's stream except obj) ------------------------
 const HM{T,VT} = AbstractExaModel{T,VT,E} where {E<:HIPExtension}
 chk(st, what) = st == 0 || error("$what: status $st: " * unsafe_string(ccall((:exa_last_error, LIB), Cstring, ())))
