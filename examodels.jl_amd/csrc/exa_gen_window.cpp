@@ -148,9 +148,31 @@ static void emit_plane_gather(std::ostringstream &os, const std::vector<WindowPa
     }
 }
 
+// shared-entry sums formed inside a one-chunk window kernel (WindowShared::attach): `own` = the point's first target of the
+// attached pass lies in this workgroup's window (c0 / Wexpr: first entry and length of that window), so every regular point is
+// counted by exactly one workgroup; one block sum per group, written to this window's partial
+static void emit_shared_in(std::ostringstream &os, const WindowMatrix &wm, const std::string &widx, std::function<std::string(int)> c0,
+                           std::function<std::string(int)> Wexpr, std::function<std::string(int)> Ivar, std::function<std::string(int)> act,
+                           std::function<std::string(int)> vals) {
+    for (const WindowShared &sh : wm.shared_in) {
+        const WindowPat &wp = wm.pats[sh.attach];
+        size_t g0 = 0;
+        for (size_t g = 0; g < wp.phase.size(); g++) if (wp.phase[g] < wp.phase[g0]) g0 = g;
+        os << "    {\n        const long e_ = Q[" << wp.qbase + 5 + g0 << "] + Q[" << wp.qbase << "] * " << Ivar(sh.attach) << " - (" << c0(sh.attach) << ");\n"
+           << "        const bool own_ = " << act(sh.attach) << " && (unsigned long)e_ < (unsigned long)(" << Wexpr(sh.attach) << ");\n";
+        for (size_t g = 0; g < sh.groups.size(); g++) {
+            std::string sum;
+            for (int sl : sh.groups[g]) sum += (sum.empty() ? "" : " + ") + (vals(sh.attach) + "[" + std::to_string(sl) + "]");
+            os << "        { const double s_ = exa_block_sum(own_ ? " << sum << " : 0.0); if (threadIdx.x == 0) part[Q[" << sh.qs << "] + " << g << " * Q[" << sh.qs + 1
+               << "] + " << widx << "] = s_; __syncthreads(); }\n";
+        }
+        os << "    }\n";
+    }
+}
+
 static const char *kWindowArgs = "(const long* __restrict__ P, const long* __restrict__ Q, const int* __restrict__ R, const double* __restrict__ x, "
                                  "const double* __restrict__ y, const double* __restrict__ th, const double* __restrict__ v, double* __restrict__ cout, "
-                                 "double sigma, long ncomp, int W, long wb) {\n";
+                                 "double sigma, long ncomp, int W, long wb, double* __restrict__ part) {\n";
 
 static void gen_window_kernels(std::ostringstream &os, const std::vector<int> &S, const WindowMatrix &wm, int wk) {
     const KindNames &kn = kKind[wk];
@@ -179,6 +201,8 @@ static void gen_window_kernels(std::ostringstream &os, const std::vector<int> &S
         for (int j = 0; j < np; j++)
             os << "        const bool act" << j << " = lo" << j << " + threadIdx.x < hi" << j << ";\n        const long I" << j << " = act" << j << " ? lo" << j
                << " + threadIdx.x : 0;\n        double v" << j << "[" << std::max(1, S[pats[j].k]) << "];\n        " << fn_name(pats[j].k, kn.fv) << "(P, x, y, th, v, sigma, I" << j << ", v" << j << ");\n";
+        emit_shared_in(os, wm, "wi_", [&](int) { return std::string("c0"); }, [&](int) { return std::string("W"); }, [&](int j) { return "I" + std::to_string(j); },
+                       [&](int j) { return "act" + std::to_string(j); }, [&](int j) { return "v" + std::to_string(j); });
         emit_planes(os, S, pats, [&](int j) { return "lo" + std::to_string(j); }, [&](int j) { return "hi" + std::to_string(j); },
                     [&](int j) { return "v" + std::to_string(j); });
         os << "        const long e_ = c0 + threadIdx.x;\n        double acc_ = 0.0;\n";
@@ -192,6 +216,8 @@ static void gen_window_kernels(std::ostringstream &os, const std::vector<int> &S
         for (int j = 0; j < np; j++)
             os << "        const bool act" << j << " = lo" << j << " + threadIdx.x < hi" << j << ";\n        const long I" << j << " = act" << j << " ? lo" << j
                << " + threadIdx.x : 0;\n        double v" << j << "[" << std::max(1, S[pats[j].k]) << "];\n        " << fn_name(pats[j].k, kn.fv) << "(P, x, y, th, v, sigma, I" << j << ", v" << j << ");\n";
+        emit_shared_in(os, wm, "wi_", [&](int) { return std::string("c0"); }, [&](int) { return std::string("W"); }, [&](int j) { return "I" + std::to_string(j); },
+                       [&](int j) { return "act" + std::to_string(j); }, [&](int j) { return "v" + std::to_string(j); });
         for (int j = 0; j < np; j++)
             os << "        __syncthreads();\n        w" << j << "_" << kn.fa << "(Q, I" << j << ", act" << j << ", c0, W, win, v" << j << ");\n";
     } else {
@@ -230,6 +256,13 @@ static void gen_window_kernel_blocks(std::ostringstream &os, const std::vector<i
         os << "    const bool act" << q << " = r_[" << 2 * q << "] + (long)threadIdx.x < r_[" << 2 * q + 1 << "];\n    const long I" << q << " = act" << q
            << " ? r_[" << 2 * q << "] + (long)threadIdx.x : 0;\n    double v" << q << "[" << std::max(1, S[pk[q]]) << "];\n    " << fn_name(pk[q], kn.fv) << "(P, x, y, th, v, sigma, I" << q
            << ", v" << q << ");\n";
+    {
+        auto qof_ = [&](int j) { return (size_t)(std::find(pk.begin(), pk.end(), pats[j].k) - pk.begin()); };
+        auto zof_ = [&](int j) { return wm.zs + 4 * pats[j].space; };
+        emit_shared_in(os, wm, "j_", [&](int j) { return "Q[" + std::to_string(zof_(j)) + "] + j_ * Q[" + std::to_string(zof_(j) + 2) + "]"; },
+                       [&](int j) { return "Q[" + std::to_string(zof_(j) + 2) + "]"; }, [&](int j) { return "I" + std::to_string(qof_(j)); },
+                       [&](int j) { return "act" + std::to_string(qof_(j)); }, [&](int j) { return "v" + std::to_string(qof_(j)); });
+    }
     if (wm.planes) {
         auto qof = [&](int j) { return (size_t)(std::find(pk.begin(), pk.end(), pats[j].k) - pk.begin()); };
         auto lo = [&](int j) { return "(long)r_[" + std::to_string(2 * qof(j)) + "]"; };

@@ -150,9 +150,13 @@ struct WindowPat {             // one (pattern, stride class) pass
     int space = 0;              // block-owned variant: which output space (column block) the pass writes to
 };
 constexpr int kSharedTiles = 8;   // chunks of kBlock points per workgroup of the shared-entry kernel (exa_c*s)
-struct WindowShared {          // slots of a pattern that land on ONE compressed entry for every data point (b = 0):
-    int k = 0;                  // summed per workgroup (exa_c*s), folded in a fixed order by the tail kernel (exa_c*x)
+struct WindowShared {          // slots of a pattern that land on ONE entry for every data point (b = 0: a literal index):
+    int k = 0;                  // summed per workgroup, folded in a fixed order by the tail kernel (exa_*x)
     std::vector<std::vector<int>> groups;   // slots of each such entry
+    // attach >= 0: the sums are formed INSIDE the window kernel, by the pass `attach` of the same pattern (every regular
+    // point belongs to exactly one window: the one that holds the first target of that pass) — one partial per window and
+    // group at part[Q[qs] + g * Q[qs + 1] + window]; attach < 0: by the kernel of their own (exa_*s: one more evaluation pass)
+    int attach = -1, qs = 0;
 };
 // What a window kernel produces.  CJAC / CHESS: the compressed (duplicate-summed) COO arrays of exa_cjac / exa_chess — entry
 // = position in the (col, row)-sorted structure, fitted to a_s + b*I on the device at exa_compress.  JTPROD / HPROD: the
@@ -162,7 +166,8 @@ struct WindowShared {          // slots of a pattern that land on ONE compressed
 enum WKind { WK_CJAC = 0, WK_CHESS = 1, WK_JTPROD = 2, WK_HPROD = 3, WK_COUNT = 4 };
 struct WindowMatrix {
     std::vector<WindowPat> pats;
-    std::vector<WindowShared> shared;
+    std::vector<WindowShared> shared;        // summed by exa_*s
+    std::vector<WindowShared> shared_in;     // summed inside the window kernel (one-chunk kernels)
     // every pass of every window fits one chunk of kBlock points: straight-line kernel (all passes' loads first, then
     // the additions), compiled for 8 waves per SIMD; otherwise chunk loops, no occupancy hint (it made them spill)
     bool single = false;

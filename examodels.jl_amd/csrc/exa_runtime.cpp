@@ -118,6 +118,7 @@ struct Handle {
         struct Space { int64_t o, end, W; };
         std::vector<Space> spaces;
         bool planned = false;              // products: the plan exists (host); ok = its kernels are loaded as well
+        bool has_shared = false;           // some entry is added to by every data point (partial sums + fold: not owner-shardable)
         std::string why;                   // why the fast path was not taken (exa_compress_info / exa_product_info)
     } wj, wh, wp[2];                       // compressed Jacobian / Hessian; J'v / Hv (WK_JTPROD, WK_HPROD)
     hipModule_t wmodule = nullptr;
@@ -1269,17 +1270,36 @@ bool window_plan(Handle &h, int wk, const int32_t *cmap, WindowMatrix &wm) {
     w.ns_blocks = 0;
     w.hF.assign(1, 0);                 // F[0] = 0 groups unless filled below
     w.hS.clear(); w.nparts = 0;
+    w.has_shared = !shs.empty();
     if (!shs.empty()) {
         std::vector<int64_t> St, F{0};
         int64_t blocks = 0, parts = 0;
-        for (const auto &sh : shs) {
+        std::vector<WindowShared> own_kernel, in_kernel;
+        for (size_t i = 0; i < shs.size(); i++) {
+            const auto &sh = shs[i];
+            // one-chunk kernels: a pattern that has a pass in the windows sums its all-points entries INSIDE the window
+            // kernel (one partial per window: every regular point belongs to exactly one) — no second evaluation pass
+            int attach = -1;
+            if (single) for (size_t q = 0; q < pats.size() && attach < 0; q++) if (pats[q].k == sh.k) attach = (int)q;
+            if (attach >= 0) {
+                WindowShared r = shared[i];
+                r.attach = attach; r.qs = (int)Q.size();
+                Q.push_back(parts); Q.push_back(nwin);
+                for (size_t g = 0; g < sh.target.size(); g++) { F.push_back(parts + (int64_t)g * nwin); F.push_back(nwin); F.push_back(sh.target[g]); F[0]++; }
+                parts += nwin * (int64_t)sh.target.size();
+                in_kernel.push_back(std::move(r));
+                continue;
+            }
             const int64_t per = (int64_t)kBlock * kSharedTiles, nt = (sh.e_hi - sh.e_lo + per - 1) / per;
             St.push_back(sh.e_lo); St.push_back(sh.e_hi); St.push_back(blocks); St.push_back(parts);
             for (size_t g = 0; g < sh.target.size(); g++) { F.push_back(parts + (int64_t)g * nt); F.push_back(nt); F.push_back(sh.target[g]); F[0]++; }
             blocks += nt;
             parts += nt * (int64_t)sh.target.size();
+            own_kernel.push_back(shared[i]);
         }
         St.push_back(0); St.push_back(0); St.push_back(blocks); St.push_back(parts);     // sentinel
+        shared.swap(own_kernel);
+        wm.shared_in.swap(in_kernel);
         w.ns_blocks = blocks;
         w.hS = St; w.hF = F; w.nparts = parts;
     }
@@ -1351,7 +1371,7 @@ void plan_products(Handle &h) {
     bool any = false;
     for (int wk : {WK_JTPROD, WK_HPROD}) {
         Handle::Window &w = window_of(h, wk);
-        w.ok = w.planned = false; w.why.clear(); w.nx = 0; w.ns_blocks = 0; w.nwin = 0;
+        w.ok = w.planned = false; w.has_shared = false; w.why.clear(); w.nx = 0; w.ns_blocks = 0; w.nwin = 0;
         if (env && atoi(env) == 0) { w.why = "disabled (EXAHIP_PRODUCT_WINDOW=0)"; continue; }
         w.planned = window_plan(h, wk, nullptr, h.pspec.mat[wk]);
         if (!w.planned) h.pspec.mat[wk] = WindowMatrix();
@@ -1386,7 +1406,7 @@ void load_products(Handle &h) {
 
 void window_setup(Handle &h) {
     // exa_compress may be called again (e.g. with another EXAHIP_CWINDOW): start from scratch
-    for (Handle::Window *w : {&h.wj, &h.wh}) { w->ok = false; w->why.clear(); w->nx = 0; w->ns_blocks = 0; w->nwin = 0; }
+    for (Handle::Window *w : {&h.wj, &h.wh}) { w->ok = false; w->has_shared = false; w->why.clear(); w->nx = 0; w->ns_blocks = 0; w->nwin = 0; }
     h.sj.ok = h.sh.ok = false; h.sj.f = h.sh.f = nullptr;
     h.merged = false; h.f_chessm = h.f_hstructm = nullptr; h.chm.release();
     if (h.wmodule) { (void)hipModuleUnload(h.wmodule); h.wmodule = nullptr; }
@@ -1531,9 +1551,9 @@ void do_window(Handle &h, int wk, const double *x, const double *y, const double
         void *a1[] = {&P, &S, &x, &y, &th, &v, &part, &sigma};
         HIPCHK(hipModuleLaunchKernel(w.fs, (unsigned)ns, 1, 1, kBlock, 1, 1, 0, h.stream, a1, nullptr));
     }
-    void *a[] = {&P, &Q, &R, &x, &y, &th, &v, &vals, &sigma, &ncomp, &W, &w0};
+    void *a[] = {&P, &Q, &R, &x, &y, &th, &v, &vals, &sigma, &ncomp, &W, &w0, &part};
     if (w1 > w0) HIPCHK(hipModuleLaunchKernel(w.fw, (unsigned)(w1 - w0), 1, 1, kBlock, 1, 1, (unsigned)w.lds_bytes, h.stream, a, nullptr));
-    if (w.nx || ns) {
+    if (w.nx || w.has_shared) {
         // tail: the irregular end points, then the fold of the shared-entry partial sums (one workgroup)
         const void *X = w.X.p, *T = w.T.p, *E = w.E.p, *F = w.F.p;
         void *xbuf = w.xbuf.p;
@@ -1901,7 +1921,7 @@ static bool sorted_possible(Handle &h, bool hess) {
 // those belong to all ranks at once.
 static bool window_possible(Handle &h, bool hess) {
     const Handle::Window &w = h.wp[hess ? 1 : 0];
-    return w.ok && (h.world == 1 || (w.nx == 0 && w.ns_blocks == 0));
+    return w.ok && (h.world == 1 || (w.nx == 0 && !w.has_shared));
 }
 static int resolve_mode(Handle &h, bool hess) {
     int &mode = hess ? h.hp_mode : h.jt_mode;
@@ -1909,11 +1929,10 @@ static int resolve_mode(Handle &h, bool hess) {
         int v = -1;
         const bool tuned = tune_lookup(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 2;
         if (tuned && ((v == 1 && sorted_possible(h, hess)) || (v == 2 && window_possible(h, hess)) || v == 0)) mode = v;
-        // undecided and never tuned: the windows, unless some entry is added to by EVERY data point (a literal index: the
-        // rocket's step length) — that costs a second evaluation pass (exa_*s), which the atomics of the sweep do not pay
-        // (measured on the rocket, nh = 1e6: J'v by windows 0.045 against 0.062 ms — its first-order body is cheap enough to
-        // evaluate twice —, Hv 0.079 against 0.070; exa_tune measures the model at hand)
-        else mode = window_possible(h, hess) && (h.wp[hess ? 1 : 0].ns_blocks == 0 || !hess) ? 2 : 0;
+        // undecided and never tuned: the windows where the model has them (rocket nh = 1e6: J'v 0.040 against 0.060 ms for the
+        // atomics, Hv 0.053 against 0.067 — with the all-points entry summed inside the window kernel; as a separate
+        // evaluation pass it was 0.079)
+        else mode = window_possible(h, hess) ? 2 : 0;
     }
     if (mode == 2 && !window_possible(h, hess)) return 0;
     if (mode == 1 && !sorted_possible(h, hess)) return 0;      // sharded at global positions: nothing to sort locally
@@ -1985,7 +2004,7 @@ int exa_product_info(int id, int hess, char *buf, int cap) {
     int v = -1;
     if (h->on_device && tune_lookup(source_key(h->gen.source), tune_signature(*h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 2 &&
         (v != 2 || window_possible(*h, hess != 0)) && (v != 1 || sorted_possible(*h, hess != 0))) return v;
-    return (h->on_device ? window_possible(*h, hess != 0) : w.planned) && (w.ns_blocks == 0 || !hess) ? 2 : 0;
+    return (h->on_device ? window_possible(*h, hess != 0) : w.planned) ? 2 : 0;
 }
 /* grad!: 0 = gathered (affine patterns) + FP64 atomics (data-indexed ones), 1 = gradient COO + sorted gather (the reference's
  * scheme: deterministic, and immune to many data points sharing a few variables), -1 = undecided: the persisted exa_tune
@@ -2472,7 +2491,7 @@ int exa_shard_var_range(int id, int64_t *lo_out, int64_t *hi_out) {
     //   J'v / Hv by windows: the points that touch the windows this rank owns
     for (int wk : {WK_JTPROD, WK_HPROD}) {
         const Handle::Window &w = h->wp[wk - WK_JTPROD];
-        if (h->world == 1 || !w.planned || w.nx || w.ns_blocks || w.hR.empty()) continue;
+        if (h->world == 1 || !w.planned || w.nx || w.has_shared || w.hR.empty()) continue;
         int64_t w0, w1;
         owned_windows(*h, w, h->rank, &w0, &w1);
         const WindowMatrix &wm = h->pspec.mat[wk];
@@ -2511,7 +2530,7 @@ int exa_shard_layout(int id, int which) {
         const bool hess = which == 7;
         const int mode = hess ? h.hp_mode : h.jt_mode;
         const Handle::Window &w = h.wp[hess ? 1 : 0];
-        const bool can = (h.on_device ? w.ok : w.planned) && w.nx == 0 && w.ns_blocks == 0;
+        const bool can = (h.on_device ? w.ok : w.planned) && w.nx == 0 && !w.has_shared;
         return can && (mode == 2 || mode < 0) ? 1 : 0;
     }
     }

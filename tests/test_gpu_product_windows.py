@@ -49,8 +49,9 @@ def test_window_products_equal_the_oracle_and_are_bit_reproducible(libs, name):
             assert (name == "cops_elec" and which == "hprod" and "data column" in text) or (name == "lv3" and text == "no regular pattern"), (name, which, text)
             continue
         assert text.startswith(("one chunk per pass", "chunk loops", "block-owned windows")), text
-        # undecided models take the windows by default unless an entry is shared by every data point (rocket: the step length)
-        assert mode == (0 if name.startswith("rocket") and which == "hprod" else 2), (name, which, mode, text)
+        # undecided models take the windows by default (an entry every data point adds to — the rocket's step length — is
+        # summed per window inside the window kernel and folded in window order by the tail kernel)
+        assert mode == 2, (name, which, mode, text)
         outs = []
         for _ in range(3):
             out = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)   # fully overwritten: no zero-fill needed
