@@ -185,7 +185,9 @@ static void gen_window_kernels(std::ostringstream &os, const std::vector<int> &S
     // chunk loops did spill under it (LV, two chunks per window: 0.118 -> 0.375 ms)
     int slots = 0;
     for (const auto &wp : pats) slots += S[wp.k];
-    const int waves = !wm.single ? 0 : (slots <= 16 ? 8 : (slots <= 40 ? 6 : 0));
+    // (products: every pass's values are live until the planes are written — the 6-wave hint made a 12-pass kernel spill 820 B
+    // per lane)
+    const int waves = !wm.single ? 0 : (slots <= 16 ? 8 : (slots <= 40 && wk <= WK_CHESS ? 6 : 0));
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) ";
     if (waves > 0) os << "__attribute__((amdgpu_waves_per_eu(" << waves << "))) ";
     os << "exa_" << kn.nm << "w" << kWindowArgs << "    extern __shared__ double win[];\n";

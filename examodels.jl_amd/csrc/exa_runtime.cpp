@@ -125,6 +125,7 @@ struct Handle {
     // owner-computes products: third module (generated at model build when every scatter target is range-affine)
     WindowSpec pspec;
     std::string psource, phsaco_path;
+    bool no_attach = false, no_attach_c = false;   // all-points entries by the kernel of their own, never inside a window kernel (products / compressed COO)
     hipModule_t pmodule = nullptr;
     // permuted-store path of exa_cjac / exa_chess for matrices the windows do not fit (exa_c*p, see WindowSpec)
     struct Scatter { bool ok = false; hipFunction_t f = nullptr; DevBuf pos; } sj, sh;
@@ -1280,7 +1281,7 @@ bool window_plan(Handle &h, int wk, const int32_t *cmap, WindowMatrix &wm) {
             // one-chunk kernels: a pattern that has a pass in the windows sums its all-points entries INSIDE the window
             // kernel (one partial per window: every regular point belongs to exactly one) — no second evaluation pass
             int attach = -1;
-            if (single) for (size_t q = 0; q < pats.size() && attach < 0; q++) if (pats[q].k == sh.k) attach = (int)q;
+            if (single && !(product ? h.no_attach : h.no_attach_c)) for (size_t q = 0; q < pats.size() && attach < 0; q++) if (pats[q].k == sh.k) attach = (int)q;
             if (attach >= 0) {
                 WindowShared r = shared[i];
                 r.attach = attach; r.qs = (int)Q.size();
@@ -1379,11 +1380,51 @@ void plan_products(Handle &h) {
     }
     if (any) h.psource = generate_window_module(*h.m, h.gen.layout, h.pspec);
 }
+// A window module, compiled or fetched — and ASKED: a kernel that sums across lanes (exa_block_sum: the all-points entries
+// summed inside a window kernel, or by exa_*s) must not spill registers.  With scratch in play such kernels have returned
+// wrong, run-to-run different sums (tools/window_sweep.py 227 1 blocks: a 12-pass Hv window kernel under a 6-wave occupancy
+// hint, 820 B of scratch per lane; the same finding as for the scatter kernels, module_for).  The registers and scratch of
+// every kernel are in the code object's metadata.  spills(kind) -> true when a cross-lane kernel of that kind spills.
+bool window_kernels_spill(const CodeObject &co, const WindowSpec &spec, int wk) {
+    static const char *nm[WK_COUNT] = {"exa_cjac", "exa_chess", "exa_jtprod", "exa_hprod"};
+    const WindowMatrix &wm = spec.mat[wk];
+    if (wm.pats.empty()) return false;
+    bool bad = false;
+    for (const char *sfx : {"w", "s"}) {
+        if ((sfx[0] == 'w' && wm.shared_in.empty()) || (sfx[0] == 's' && wm.shared.empty())) continue;
+        int v = 0, a = 0, sc = 0, sp = 0;
+        const std::string name = std::string(nm[wk]) + sfx;
+        if (!kernel_resources(co.image, name, &v, &a, &sc, &sp)) continue;
+        if (sc > 0 || sp > 0) bad = true;
+        if (verbose()) fprintf(stderr, "[exahip] %s: %d VGPRs, %d bytes of scratch per lane, %d spilled%s\n", name.c_str(), v, sc, sp, sc > 0 || sp > 0 ? "  <- sums across lanes: not with spills" : "");
+    }
+    return bad;
+}
+// the product module: first with the all-points entries summed inside the window kernels; if such a kernel spills, planned
+// again with those sums in their own kernel; a kind whose exa_*s still spills gives its windows up
+CodeObject product_module_for(Handle &h, bool memory_only_ok) {
+    for (int attempt = 0;; attempt++) {
+        CodeObject co = get_code_object(h.psource, memory_only_ok);
+        bool bad = false;
+        for (int wk : {WK_JTPROD, WK_HPROD}) bad = bad || window_kernels_spill(co, h.pspec, wk);
+        if (!bad) return co;
+        if (attempt == 0 && !h.no_attach) { h.no_attach = true; plan_products(h); if (h.psource.empty()) return CodeObject(); continue; }
+        bool any = false;
+        for (int wk : {WK_JTPROD, WK_HPROD}) {
+            Handle::Window &w = window_of(h, wk);
+            if (window_kernels_spill(co, h.pspec, wk)) { w.planned = false; w.why = "the window kernels spill registers around a sum across lanes"; h.pspec.mat[wk] = WindowMatrix(); }
+            any = any || w.planned;
+        }
+        h.psource = any ? generate_window_module(*h.m, h.gen.layout, h.pspec) : std::string();
+        if (h.psource.empty()) return CodeObject();
+    }
+}
 // loads the product module and uploads the tables; a module that cannot be built leaves the products on their other paths
 void load_products(Handle &h) {
     if (h.psource.empty()) return;
     try {
-        CodeObject co = get_code_object(h.psource, true);
+        CodeObject co = product_module_for(h, true);
+        if (h.psource.empty()) return;
         h.phsaco_path = co.path; h.build_ms += co.build_ms;
         HIPCHK(hipModuleLoadData(&h.pmodule, co.image.data()));
         auto fn = [&](const std::string &name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.pmodule, name.c_str())); return f; };
@@ -1459,7 +1500,10 @@ void window_setup(Handle &h) {
     // the gather path needs no second module: a host without hipcc (a packed library's consumer) or a failed compilation
     // must not take exa_compress down with it
     try {
-        image = get_code_object(src, true).image;
+        CodeObject wco = get_code_object(src, true);
+        for (int wk : {WK_CJAC, WK_CHESS})
+            if (window_kernels_spill(wco, spec, wk)) throw std::runtime_error(std::string(wk == WK_CJAC ? "exa_cjac" : "exa_chess") + ": a window kernel that sums across lanes spills registers");
+        image = wco.image;
         HIPCHK(hipModuleLoadData(&h.wmodule, image.data()));
         auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
         if (okj) { h.wj.fw = fn("exa_cjacw"); h.wj.fx = fn("exa_cjacx"); if (h.wj.ns_blocks) h.wj.fs = fn("exa_cjacs"); }
@@ -1700,7 +1744,7 @@ int exa_compile(int id) {
     return guard(id, false, [&](Handle &h) {
         CodeObject co = module_for(h, false);
         h.hsaco_path = co.path; h.build_how = co.how; h.build_ms = co.build_ms;
-        if (!h.psource.empty()) { CodeObject pc = get_code_object(h.psource, false); h.phsaco_path = pc.path; h.build_ms += pc.build_ms; }
+        if (!h.psource.empty()) { CodeObject pc = product_module_for(h, false); h.phsaco_path = pc.path; h.build_ms += pc.build_ms; }
     });
 }
 const char *exa_code_object_path(int id) {
@@ -2183,6 +2227,10 @@ int exa_compress(int id) {
         } catch (...) { r.release(); c.release(); throw; }
         r.release(); c.release();
         window_setup(h);
+        if (!h.no_attach_c && (h.wj.why.find("spills registers") != std::string::npos || h.wh.why.find("spills registers") != std::string::npos)) {
+            h.no_attach_c = true;          // once more with the all-points entries summed by the kernel of their own
+            window_setup(h);
+        }
         if (!(h.wj.ok || nnzj == 0) || !(h.wh.ok || nnzh == 0)) h.cbuf.ensure(8 * (size_t)mx);
         h.compressed = true;
     });

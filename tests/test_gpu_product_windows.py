@@ -144,3 +144,34 @@ def test_full_size_lv_windows_against_the_atomics(libs):
     for got, ref in ((a1, a0), (b1, b0)):
         scale = torch.clamp(ref.abs(), min=1e-3 * float(ref.abs().max()))
         assert float(((got - ref).abs() / scale).max()) <= RTOL
+
+
+@pytest.mark.parametrize("seed,flavour", [(8, ""), (14, ""), (205, "blocks"), (208, "blocks"), (227, "blocks")])
+def test_random_range_models_through_the_windows(libs, seed, flavour):
+    """Random trees over range iterators (tests/randexpr.py; tools/window_sweep.py ran 200 seeds): chunk loops, one-chunk
+    kernels, block-owned windows, literal-index targets summed inside the window kernel.  Seed 227 is the regression of a
+    real fault: its 12-pass Hv kernel, compiled under a 6-wave occupancy hint, spilled 820 B per lane around the block sums
+    of its all-points entries and returned wrong, run-to-run different values (the hint is gone for the products, and a
+    window kernel that sums across lanes is checked for spills after compilation, exa_runtime.cpp window_kernels_spill)."""
+    import torch
+    import randexpr
+    from exahip import ExaModel, capi
+    import oracle
+    m = ExaModel(randexpr.build_range_model(seed, npts=1000, unit=flavour == "blocks", blocks=flavour == "blocks"))
+    o = oracle.OracleModel(m.ir)
+    x = m.meta.x0 + 0.05 * np.random.default_rng(seed).uniform(-1, 1, m.meta.nvar)
+    y = np.random.default_rng(seed + 1).standard_normal(m.meta.ncon)
+    v = np.random.default_rng(seed + 2).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(seed + 3).standard_normal(m.meta.ncon)
+    dev = torch.device("cuda:0")
+    xd, yd, vd, wd = (torch.from_numpy(a).to(dev) for a in (x, y, v, w))
+    m.set_product_mode(2, 2)
+    for call, ref in ((lambda out: m.jtprod(xd, wd, out=out), o.jtprod(x, w)), (lambda out: m.hprod(xd, yd, vd, 0.7, out=out), o.hprod(x, y, v, 0.7))):
+        outs = []
+        for _ in range(3):
+            out = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)
+            call(out)
+            torch.cuda.synchronize()
+            outs.append(out.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        assert relerr(outs[0], ref) <= 1e-9
