@@ -92,6 +92,16 @@ def test_deep_random_patterns_on_hip(libs, seed, monkeypatch):
     assert relerr(m.hess_coord(x, y, 0.7), o.hess_coord(x, y, 0.7)) <= tol
     assert relerr(m.jac_coord(x), o.jac_coord(x)) <= tol
     assert relerr(m.cons(x), o.cons(x)) <= tol
+    # all five from one sweep: the objective patterns add their first partials inside the (spilling) fused kernel with
+    # wavefront-level adds — the same kind of code as the scatter kernels above
+    import torch
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    for _ in range(3):
+        f, g, c, j, h = m.eval_all(xd, yd, 0.7)
+        torch.cuda.synchronize()
+        assert abs(f.item() - o.obj(x)) <= tol * max(1.0, abs(o.obj(x)))
+        assert relerr(g.cpu().numpy(), o.grad(x)) <= tol and relerr(h.cpu().numpy(), o.hess_coord(x, y, 0.7)) <= tol
+        assert relerr(c.cpu().numpy(), o.cons(x)) <= tol and relerr(j.cpu().numpy(), o.jac_coord(x)) <= tol
 
 
 @pytest.mark.gpu
