@@ -39,6 +39,7 @@ for p in (os.path.join(ROOT, "examodels.jl_amd"), os.path.join(ROOT, "oracle")):
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+HESS_KERNELS = ("exa_hess", "exa_hesscl", "exa_hessc")       # by exa_hess_variant
 CONFIGS = {
     2: "LuksanVlcek N=1e7, hess_coord!",
     3: "Goddard rocket (COPS-3) nh=1e6, hess_coord!",
@@ -255,7 +256,7 @@ def traffic_for(m, config, per_gpu_points):
         return None
     with open(path) as fh:
         t = json.load(fh)
-    kernel = "exa_hessc" if m._L.exa_hess_variant(m.id) == 1 else "exa_hess"
+    kernel = HESS_KERNELS[m._L.exa_hess_variant(m.id)]
     if t.get("module") != m._L.exa_module_name(m.id).decode() or t.get("points") != per_gpu_points or t.get("kernel") != kernel:
         return None
     return t.get("hbm_bytes_per_launch")
@@ -488,9 +489,9 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
         "evals_per_s": steps / elapsed,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_for(m, config, per_gpu if world > 1 else points),
-                     "kernel": "exa_hessc" if L.exa_hess_variant(m.id) == 1 else "exa_hess", "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     "kernel": HESS_KERNELS[L.exa_hess_variant(m.id)], "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "block_order": {0: "sequential", 1: "interleaved-128"}.get(L.exa_block_order(m.id, 4), "n/a")},
-        "build": {"module": how, "module_name": L.exa_module_name(m.id).decode(), "hess_kernel": "exa_hessc" if L.exa_hess_variant(m.id) == 1 else "exa_hess",
+        "build": {"module": how, "module_name": L.exa_module_name(m.id).decode(), "hess_kernel": HESS_KERNELS[L.exa_hess_variant(m.id)],
                   "compile_ms": compile_ms, "model_build_s": build_s, "first_hess_call_ms": first_call_ms,
                   "tune_ms": tune_ms,
                   "note": "first_hess_call_ms = host time of the first exa_hess + its completion (asynchronous launch, no measuring inside)"},

@@ -171,6 +171,8 @@ std::string prelude_text(const ParamLayout &L);   // kPrelude with its @TAGS@ fi
 // ---------------------------------------------------------------------------------------------------
 // per-pattern body generator
 // ---------------------------------------------------------------------------------------------------
+struct Affine { bool ok = false; int col = -1; int64_t a = 0, c = 0; };      // index expression == a * (RANGE column) + c ?
+Affine affine(const Pattern &p, int k);                                        // exa_gen_scatter.cpp
 struct FV { Val x, y1, y2, h11, h12, h22, vidx; };
 
 struct Body {
@@ -183,6 +185,10 @@ struct Body {
                                 // common subexpressions of co-indexed patterns are emitted once)
     std::vector<FV> fv;
     std::map<int, Val> cmemo;   // IR node -> value of constant subtree
+    // x loads whose index is (unit-step range column) + literal: SSA name of the loaded value -> (column, literal); and
+    // whether some x load is NOT of that form (staged chained kernels, ParamLayout::stage)
+    std::map<std::string, std::pair<int, int64_t>> xoff;
+    bool xother = false;
 
     Body(const Model &mm, int pidx, const ParamLayout &ll, Emitter *shared = nullptr)
         : m(mm), p(mm.pats[pidx]), pi(pidx), L(ll), e(shared ? *shared : own_) { fv.resize(p.ad.size()); }
@@ -262,7 +268,12 @@ struct Body {
         case AD_CONST: if (!structure) v.x = cval(t.ir); return;
         case AD_VAR:
             v.vidx = cval(t.ir);
-            if (!structure) v.x = var_load(v.vidx);
+            if (!structure) {
+                v.x = var_load(v.vidx);
+                const Affine f = affine(p, t.ir);
+                if (f.ok && f.col >= 0 && f.a == 1 && p.cols[f.col].step == 1 && v.x.k == Val::SF) xoff[e.s(v.x)] = {f.col, f.c};
+                else xother = true;
+            }
             return;
         case AD_UN: {
             forward(t.l, order, structure);
@@ -375,10 +386,9 @@ int merged_slot_count(const Model &m, const ParamLayout &L, const std::vector<in
 void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const std::string &call_prefix, const std::string &call_args,
                   const std::string &tail_args = "");
 void gen_dispatch_chained(std::ostringstream &os, const ParamLayout &L, int cb, const char *name, bool hess);
+void gen_dispatch_chained_staged(std::ostringstream &os, const Model &m, const ParamLayout &L);
+bool pattern_stage(const Model &m, int pi, const ParamLayout &L, ParamLayout::Stage *out);      // ParamLayout::stage of one pattern
 
-// ---- index expression == a * (RANGE column) + c ? (exa_gen_scatter.cpp) ----------------------------------------------
-struct Affine { bool ok = false; int col = -1; int64_t a = 0, c = 0; };
-Affine affine(const Pattern &p, int k);
 
 // ---- scattered `out[idx-1] += val` (grad of data-indexed patterns, J'v, Hv) ------------------------------------
 // Three mechanisms, picked per target at generation time:

@@ -25,14 +25,20 @@ static bool is_memory_read(const std::string &expr) {
         if (expr.compare(0, strlen(pre), pre) == 0) return true;
     return false;
 }
-Split split_body(const Emitter &e) {
+// staged != null: x loads listed there (name -> literal offset from the pattern's smallest one) are NOT loaded: the
+// evaluation stage reads them from the wavefront's staged stretch, xs[xd + offset]
+static Split split_body_staged(const Emitter &e, const std::map<std::string, int64_t> *staged);
+Split split_body(const Emitter &e) { return split_body_staged(e, nullptr); }
+static Split split_body_staged(const Emitter &e, const std::map<std::string, int64_t> *staged) {
     Split sp;
     size_t d = 0;
     for (size_t li = 0; li < e.lines.size(); li++) {
         const std::string &line = e.lines[li];
         if (d < e.defs.size() && e.defs[d].line == (int)li) {
             const Emitter::Def &df = e.defs[d++];
-            if (is_memory_read(df.expr)) {
+            if (staged && df.expr.compare(0, 2, "x[") == 0 && staged->count(df.name)) {
+                sp.eval.push_back("const double " + df.name + " = xs[xd + " + std::to_string(staged->at(df.name)) + "];");
+            } else if (is_memory_read(df.expr)) {
                 sp.load.push_back(line);
                 if (df.is_int) {
                     sp.load.push_back("ik[" + std::to_string(sp.nik) + "] = " + df.name + ";");
@@ -293,6 +299,45 @@ void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     std::vector<std::string> vals;
     for (int s = 0; s < p.o2step; s++) vals.push_back(b.e.sd(a.acc[s]));
     if (L.chain[CB_HESSC] > 0) emit_two_stage(os, b, L, pi, CB_HESSC, "hessc", true, tile, L.pat[pi].o2, p.o2step, vals);
+    if (L.chain[CB_HESSC] > 0 && L.staged) {
+        // the staged pair (exa_hesscl): pK_hessclL loads what is NOT x (multipliers, table columns, parameters), pK_hessclE
+        // takes its x operands from the staged stretch
+        std::map<std::string, int64_t> off;
+        for (const auto &kv : b.xoff) off[kv.first] = kv.second.second - L.stage[pi].cmin;
+        const Split sp = split_body_staged(b.e, &off);
+        g_handover[{CB_COUNT, pi}] = {sp.nin, sp.nik};
+        os << "static __device__ __forceinline__ void " << fn_name(pi, "hesscl") << "L(const long* __restrict__ P, const double* __restrict__ y, "
+           << "const double* __restrict__ th, long tid, double* in, long* ik) {\n"
+           << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n"
+           << "    const long I = I0 < hi ? I0 : (hi > 0 ? hi - 1 : 0);\n";
+        for (const auto &l : sp.load) os << "    " << l << "\n";
+        os << "    (void)I;\n}\n";
+        os << "static __device__ __forceinline__ void " << fn_name(pi, "hesscl") << "E(const long* __restrict__ P, const double* in, const long* ik, "
+           << "const double* xs, int xd, double* __restrict__ out, double* __restrict__ sink, double sigma, long tid, double* lds) {\n"
+           << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n"
+           << "    const int lane = threadIdx.x & 63;\n    const long I = I0 < hi ? I0 : (hi > 0 ? hi - 1 : 0);\n";
+        for (const auto &l : sp.eval) os << "    " << l << "\n";
+        emit_coo_stores(os, b, L.pat[pi].o2, p.o2step, vals, tile, "out", "", true);
+        os << "}\n";
+    }
+}
+
+// ParamLayout::stage of pattern pi: every x index of its second-order body is (ONE unit-step range column) + literal
+bool pattern_stage(const Model &m, int pi, const ParamLayout &L, ParamLayout::Stage *out) {
+    Body b(m, pi, L);
+    const Pattern &p = b.p;
+    b.forward(p.ad_root, 2, false);
+    if (b.xother || b.xoff.empty()) return false;
+    int col = -1;
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    for (const auto &kv : b.xoff) {
+        if (col >= 0 && kv.second.first != col) return false;
+        col = kv.second.first;
+        lo = std::min(lo, kv.second.second); hi = std::max(hi, kv.second.second);
+    }
+    if (hi - lo > kStageHalo) return false;
+    out->word = L.pat[pi].col[col]; out->cmin = lo; out->cmax = hi;
+    return true;
 }
 
 // jac_coord! / hess_coord! (exa_jac / exa_hess): one device function per FUSED GROUP — the patterns of exactly the same
@@ -540,6 +585,70 @@ void gen_dispatch_chained(std::ostringstream &os, const ParamLayout &L, int cb, 
         os << "\n#pragma unroll\n            for (int q = 0; q < " << std::max(1, h0.first) << "; q++) { asm volatile(\"\" : \"+v\"(in" << first << "n[q])); in" << first << "[q] = in" << first << "n[q]; }\n"
            << "#pragma unroll\n            for (int q = 0; q < " << std::max(1, h0.second) << "; q++) { asm volatile(\"\" : \"+v\"(ik" << first << "n[q])); ik" << first << "[q] = ik" << first << "n[q]; }\n        }\n    }\n";
     }
+}
+
+// exa_hesscl: the chained dispatch with the x operands staged through LDS (ParamLayout::stage).  Per wavefront and tile the
+// stretch [B + 64 w + 256 t, + 64 + halo) of x — B = the smallest of the patterns' stretch bases — is loaded once (one 8-byte
+// load per lane + a halo load by `halo_` lanes; the next tile's, like the other loads, BEFORE the current tile is evaluated),
+// written to the wavefront's LDS stretch at the top of the iteration, and every pattern of the group reads its operands from
+// there at lane + (its base - B) + literal.
+void gen_dispatch_chained_staged(std::ostringstream &os, const Model &m, const ParamLayout &L) {
+    const int cb = CB_HESSC, T = L.chain[cb];
+    const auto &groups = L.groups[cb];
+    auto ld = [&](int pk, const std::string &tid, const std::string &sfx) {
+        os << "p" << pk << "_hessclL(P, y, th, " << tid << ", in" << pk << sfx << ", ik" << pk << sfx << ");";
+    };
+    auto ev = [&](int pk, const std::string &tid) {
+        os << "p" << pk << "_hessclE(P, in" << pk << ", ik" << pk << ", xs, lane + d" << pk << "_, out, sink, sigma, " << tid << ", lds);";
+    };
+    os << "    const long e_ = ((const long*)P[" << L.blk[cb] << "])[blockIdx.x];\n    const int gs_ = (int)(e_ >> 40);\n"
+       << "    const long t0_ = (e_ & ((1L << 40) - 1)) * " << T << ";\n    const int lane = threadIdx.x & 63;\n";
+    for (size_t g = 0; g < groups.size(); g++) {
+        const auto &grp = groups[g];
+        const int first = grp.front();
+        os << "    " << (g ? "else " : "") << "if (gs_ == " << g << ") {\n        const long tend_ = t0_ + " << T << " < P[" << L.gtiles[cb][g] << "] ? t0_ + " << T
+           << " : P[" << L.gtiles[cb][g] << "];\n";
+        // stretch geometry (scalars): base of every pattern, the common base, the patterns' distances from it, the halo, the
+        // last variable any point of the group reads (loads beyond it are clamped onto it)
+        for (int pk : grp)
+            os << "        const long B" << pk << "_ = P[" << L.stage[pk].word << "] + P[" << L.pat[pk].lo << "] + (" << L.stage[pk].cmin << "L) - 1L;\n";
+        os << "        long B_ = B" << first << "_;\n";
+        for (int pk : grp) os << "        B_ = B" << pk << "_ < B_ ? B" << pk << "_ : B_;\n";
+        os << "        int halo_ = 0;\n        long xlast_ = 0;\n";
+        for (int pk : grp)
+            os << "        const int d" << pk << "_ = (int)(B" << pk << "_ - B_);\n        halo_ = d" << pk << "_ + " << (L.stage[pk].cmax - L.stage[pk].cmin) << " > halo_ ? d" << pk << "_ + "
+               << (L.stage[pk].cmax - L.stage[pk].cmin) << " : halo_;\n        { const long l_ = P[" << L.stage[pk].word << "] + P[" << L.pat[pk].hi << "] - 1L + (" << L.stage[pk].cmax
+               << "L) - 1L; xlast_ = l_ > xlast_ ? l_ : xlast_; }\n";
+        for (int pk : grp) {
+            const auto ho = g_handover[{CB_COUNT, pk}];
+            os << "        double in" << pk << "[" << std::max(1, ho.first) << "]; long ik" << pk << "[" << std::max(1, ho.second) << "];\n";
+        }
+        const auto h0 = g_handover[{CB_COUNT, first}];
+        os << "        double in" << first << "n[" << std::max(1, h0.first) << "]; long ik" << first << "n[" << std::max(1, h0.second) << "];\n"
+           << "        double g0_, g1_;\n";
+        auto G = [&](const std::string &t) {
+            os << "        { const long a_ = B_ + (" << t << ") * EXA_BLOCK + (threadIdx.x & ~63); long a0_ = a_ + lane; a0_ = a0_ < xlast_ ? a0_ : xlast_; "
+                  "long a1_ = a_ + 64 + lane; a1_ = a1_ < xlast_ ? a1_ : xlast_; g0_ = x[a0_]; g1_ = x[lane < halo_ ? a1_ : a0_]; }\n";
+        };
+        G("t0_");
+        os << "        "; ld(first, "t0_ * EXA_BLOCK + threadIdx.x", "");
+        os << "\n        asm volatile(\"\" : \"+v\"(g0_)); asm volatile(\"\" : \"+v\"(g1_));\n"
+           << "#pragma unroll\n        for (int q = 0; q < " << std::max(1, h0.first) << "; q++) asm volatile(\"\" : \"+v\"(in" << first << "[q]));\n"
+           << "#pragma unroll\n        for (int q = 0; q < " << std::max(1, h0.second) << "; q++) asm volatile(\"\" : \"+v\"(ik" << first << "[q]));\n"
+           << "#pragma unroll 1\n        for (long t = t0_; t < tend_; t++) {\n            const long tid = t * EXA_BLOCK + threadIdx.x;\n"
+           << "            __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier();\n"
+           << "            xs[lane] = g0_;\n            if (lane < halo_) xs[64 + lane] = g1_;\n"
+           << "            __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n";
+        for (size_t j = 1; j < grp.size(); j++) { os << "            "; ld(grp[j], "tid", ""); os << "\n"; }
+        os << "    ";
+        G("t + 1 < tend_ ? t + 1 : t");
+        os << "            "; ld(first, "(t + 1 < tend_ ? t + 1 : t) * EXA_BLOCK + threadIdx.x", "n"); os << "\n";
+        for (size_t j = 0; j < grp.size(); j++) { os << "            "; ev(grp[j], "tid"); os << "\n"; }
+        os << "            asm volatile(\"\" : \"+v\"(g0_)); asm volatile(\"\" : \"+v\"(g1_));\n"
+           << "#pragma unroll\n            for (int q = 0; q < " << std::max(1, h0.first) << "; q++) { asm volatile(\"\" : \"+v\"(in" << first << "n[q])); in" << first << "[q] = in" << first << "n[q]; }\n"
+           << "#pragma unroll\n            for (int q = 0; q < " << std::max(1, h0.second) << "; q++) { asm volatile(\"\" : \"+v\"(ik" << first << "n[q])); ik" << first << "[q] = ik" << first << "n[q]; }\n        }\n    }\n";
+    }
+    (void)m;
 }
 
 }  // namespace gen

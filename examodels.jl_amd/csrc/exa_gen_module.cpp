@@ -92,6 +92,13 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
         }
     }
 
+    // exa_hesscl (ParamLayout::stage): only when EVERY pattern of EVERY chained group qualifies
+    L.stage.assign(np, ParamLayout::Stage());
+    L.staged = L.chain[CB_HESSC] > 0 && !L.groups[CB_HESSC].empty();
+    if (L.staged)
+        for (const auto &grp : L.groups[CB_HESSC])
+            for (int k : grp) L.staged = L.staged && pattern_stage(m, k, L, &L.stage[k]);
+    if (!L.staged) L.stage.assign(np, ParamLayout::Stage());
     // streaming value kernels keep more loads in flight per wavefront with several points per thread (measured)
     // (measured, LV 1e7: obj 0.037 -> 0.020 ms with 8 points per thread; 2 - 16 points per thread moved cons / jac / hess by
     // +-2 %, profiles/NOTES.md)
@@ -362,6 +369,14 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
               "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma, double* __restrict__ sink) {\n";
         lds_decl(CB_HESS, true);
         gen_dispatch_chained(os, L, CB_HESSC, "hessc", true);
+        os << "}\n";
+    }
+    if (L.chain[CB_HESSC] > 0 && L.staged) {
+        os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hesscl(const long* __restrict__ P, const double* __restrict__ x, "
+              "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma, double* __restrict__ sink) {\n";
+        lds_decl(CB_HESS, true);
+        os << "    __shared__ double xs_all[(EXA_BLOCK / 64) * " << 64 + kStageHalo << "];\n    double* xs = xs_all + (threadIdx.x >> 6) * " << 64 + kStageHalo << ";\n";
+        gen_dispatch_chained_staged(os, m, L);
         os << "}\n";
     }
     // fused cons + jac + hess (+ objective partial sums)

@@ -116,6 +116,16 @@ struct ParamLayout {
     // share vmcnt in order, so loads issued after a tile's stores would wait for those stores to drain).
     // chain = 0: one (pattern, tile) per workgroup, the plain dispatch.  gtiles = P word with each group's tile count.
     int chain[CB_COUNT];
+    // exa_hesscl — exa_hessc with the inputs STAGED THROUGH LDS: generated when every x index of every pattern of every chained
+    // group is (unit-step range value) + literal.  A wavefront's 64 points of a tile then read one stretch of x: one coalesced
+    // 8-byte load per lane + a halo load by a few lanes, written to LDS, from which every pattern of the group takes its
+    // stencil operands (ds_read) — instead of two or three overlapping wide loads per pattern.  stage[k] = {word of the range
+    // column, smallest and largest literal offset} of pattern k (word < 0: not staged).  The patterns' stretches start at
+    // B_k = P[word] + P[lo] + cmin - 1; the kernel stages [min B_k, +64 + kStageHalo): the runtime launches it only when all
+    // stretches fit (exa_runtime.cpp stage_fits), else exa_hessc.
+    struct Stage { int word = -1; int64_t cmin = 0, cmax = 0; };
+    std::vector<Stage> stage;
+    bool staged = false;
     std::vector<std::vector<int>> groups[CB_COUNT];
     std::vector<int> gtiles[CB_COUNT];
     int nwords = 0;
@@ -149,6 +159,7 @@ struct WindowPat {             // one (pattern, stride class) pass
     int qbase = 0;              // first word of this pass's table in Q: b, e_lo, e_hi, amin, amax, a[group]...
     int space = 0;              // block-owned variant: which output space (column block) the pass writes to
 };
+constexpr int kStageHalo = 16;     // doubles of halo a wavefront stages beyond its 64 points (exa_hesscl)
 constexpr int kSharedTiles = 8;   // chunks of kBlock points per workgroup of the shared-entry kernel (exa_c*s)
 struct WindowShared {          // slots of a pattern that land on ONE entry for every data point (b = 0: a literal index):
     int k = 0;                  // summed per workgroup, folded in a fixed order by the tail kernel (exa_*x)

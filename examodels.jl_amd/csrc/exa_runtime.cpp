@@ -78,7 +78,7 @@ struct Handle {
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
     hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
-                  f_hess = nullptr, f_hessc = nullptr, f_cons1 = nullptr, f_jprod1 = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
+                  f_hess = nullptr, f_hessc = nullptr, f_hesscl = nullptr, f_cons1 = nullptr, f_jprod1 = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
     DevBuf daugcoef;
@@ -92,7 +92,9 @@ struct Handle {
     int64_t gridg = 0;
     int order[CB_COUNT] = {0};              // which map is active
     int norders[CB_COUNT] = {1};            // how many maps exist: exa_tune measures all of them
-    int hess_variant = 0;                   // hess_coord! kernel: 0 exa_hess (one tile per workgroup), 1 exa_hessc (chained, grouped, pipelined)
+    int hess_variant = 0;                   // hess_coord! kernel: 0 exa_hess (one tile per workgroup), 1 chained, grouped, pipelined: exa_hesscl
+                                            // (x staged through LDS) where this shard's stretches fit, else exa_hessc; 2 exa_hessc always
+    bool stage_ok = false;                  // exa_hesscl's stretch geometry holds for this shard (fill_params)
     double hess_stream_bytes = 0.0;         // HBM bytes one hess_coord! of this shard streams (outputs + x + y)
     int64_t fused_nobj = 0;                 // objective partial sums written by exa_fused
     std::vector<DevBuf> dcols;              // flattened over patterns
@@ -369,10 +371,23 @@ void fill_params(Handle &h) {
     if (L.chain[CB_HESSC] > 0) {
         const char *ce = getenv("EXAHIP_HESS_VARIANT");
         int pv = 0;
-        if (ce) h.hess_variant = atoi(ce) != 0;
-        else if (tune_lookup(source_key(h.gen.source), tune_signature(h, "hessvariant"), &pv)) h.hess_variant = pv != 0;
+        if (ce) h.hess_variant = std::min(2, std::max(0, atoi(ce)));
+        else if (tune_lookup(source_key(h.gen.source), tune_signature(h, "hessvariant"), &pv)) h.hess_variant = std::min(2, std::max(0, pv));
         else h.hess_variant = h.hess_stream_bytes >= 1.5e9;
     }
+    // exa_hesscl stages, per wavefront and tile, ONE stretch of 64 + kStageHalo variables for all patterns of a group: the
+    // patterns' first variables (of THIS shard's first points) must lie within the halo of each other
+    h.stage_ok = L.staged;
+    if (L.staged)
+        for (const auto &grp : L.groups[CB_HESSC]) {
+            int64_t bmin = INT64_MAX;
+            for (int k : grp) {
+                if (h.P[L.pat[k].hi] <= h.P[L.pat[k].lo]) h.stage_ok = false;
+                bmin = std::min(bmin, h.P[L.stage[k].word] + h.P[L.pat[k].lo] + L.stage[k].cmin);
+            }
+            for (int k : grp)
+                if (h.P[L.stage[k].word] + h.P[L.pat[k].lo] + L.stage[k].cmax - bmin > kStageHalo) h.stage_ok = false;
+        }
     if (h.on_device) {
         h.dP.ensure(sizeof(int64_t) * h.P.size());
         HIPCHK(hipMemcpy(h.dP.p, h.P.data(), sizeof(int64_t) * h.P.size(), hipMemcpyHostToDevice));
@@ -438,6 +453,7 @@ void to_device(Handle &h) {
     h.f_fused = fn("exa_fused");
     h.f_jprod = fn("exa_jprod"); h.f_jtprod = fn("exa_jtprod"); h.f_hprod = fn("exa_hprod"); h.f_jac = fn("exa_jac"); h.f_hess = fn("exa_hess");
     if (h.gen.layout.chain[CB_HESSC] > 0) h.f_hessc = fn("exa_hessc");
+    if (h.gen.layout.chain[CB_HESSC] > 0 && h.gen.layout.staged) h.f_hesscl = fn("exa_hesscl");
     h.f_cons1 = fn("exa_cons1");
     h.f_gradv = fn("exa_gradv"); h.f_gstruct = fn("exa_gstruct");
     if (m.aug_linear || m.nconaug == 0) h.f_jprod1 = fn("exa_jprod1");
@@ -789,10 +805,10 @@ void do_jac(Handle &h, const double *x, double *v) {
 }
 void do_hess(Handle &h, const double *x, const double *y, double sigma, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
-    if (h.hess_variant == 1 && h.f_hessc) {
+    if (h.hess_variant >= 1 && h.f_hessc) {
         void *sink = h.dsink.p;
         void *a[] = {&P, &x, &y, &th, &v, &sigma, &sink};
-        launch(h, h.f_hessc, h.grid[CB_HESSC], kBlock, a);
+        launch(h, h.hess_variant == 1 && h.f_hesscl && h.stage_ok ? h.f_hesscl : h.f_hessc, h.grid[CB_HESSC], kBlock, a);
         return;
     }
     void *a[] = {&P, &x, &y, &th, &v, &sigma};
@@ -2321,14 +2337,16 @@ int exa_time_callback(int id, int which, int reps, const double *x, const double
 int exa_block_order(int id, int which) {
     Handle *h = get(id);
     if (!h) return -2;
-    const int cb = which == 3 ? CB_JAC : which == 4 ? (h->hess_variant == 1 ? CB_HESSC : CB_HESS) : which == 2 ? CB_CONS : which == 5 ? CB_FUSED : -1;
+    const int cb = which == 3 ? CB_JAC : which == 4 ? (h->hess_variant >= 1 ? CB_HESSC : CB_HESS) : which == 2 ? CB_CONS : which == 5 ? CB_FUSED : -1;
     return cb < 0 ? -2 : h->order[cb];
 }
-/* which hess_coord! kernel runs: 0 exa_hess (one tile per workgroup), 1 exa_hessc (chained over groups of co-indexed
- * patterns, software-pipelined), -1 bad id */
+/* which hess_coord! kernel runs: 0 exa_hess (one tile per workgroup), 1 exa_hesscl (chained over groups of co-indexed
+ * patterns, software-pipelined, x staged through LDS), 2 exa_hessc (the same without the staging: chosen, or what 1 falls
+ * back to when the model / this shard does not fit the staging), -1 bad id */
 int exa_hess_variant(int id) {
     Handle *h = get(id);
-    return h ? h->hess_variant : -1;
+    if (!h) return -1;
+    return h->hess_variant == 1 && !(h->f_hesscl && h->stage_ok) ? 2 : h->hess_variant;
 }
 int exa_sync(int id) { return guard(id, true, [&](Handle &h) { HIPCHK(hipStreamSynchronize(h.stream)); }); }
 
@@ -2367,9 +2385,14 @@ int exa_tune(int id, int what, const double *x, const double *y) {
                 hv = need(4, h.lnnzh);
                 h.hess_variant = 0;
                 const float t0 = tune_order(h, CB_HESS, [&] { do_hess(h, x, y, sigma, hv); });
-                h.hess_variant = 1;
+                h.hess_variant = 2;
                 const float t1 = tune_order(h, CB_HESSC, [&] { do_hess(h, x, y, sigma, hv); });
-                h.hess_variant = t1 < t0 ? 1 : 0;
+                h.hess_variant = t1 < t0 ? 2 : 0;
+                if (h.f_hesscl && h.stage_ok) {
+                    h.hess_variant = 1;
+                    const float t2 = tune_order(h, CB_HESSC, [&] { do_hess(h, x, y, sigma, hv); });
+                    if (!(t2 < std::min(t0, t1))) h.hess_variant = t1 < t0 ? 2 : 0;
+                }
                 tune_store(source_key(h.gen.source), tune_signature(h, "hessvariant"), h.hess_variant);
             } else if (h.norders[CB_HESS] > 1) { hv = need(4, h.lnnzh); tune_order(h, CB_HESS, [&] { do_hess(h, x, y, sigma, hv); }); }
             if (h.norders[CB_FUSED] > 1) {

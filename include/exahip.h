@@ -309,9 +309,12 @@ int exa_sync(int id);
 /* Order of the (pattern, tile) workgroups of a multi-pattern callback: 0 patterns one after the other (default),
  * 1 interleaved in runs of 128 workgroups, -2 bad argument.  which: 2 cons, 3 jac, 4 hess, 5 fused. */
 int exa_block_order(int id, int which);
-/* hess_coord! has two generated kernels: 0 = exa_hess, one (pattern, 256-point tile) per workgroup; 1 = exa_hessc, a
+/* hess_coord! has three generated kernels: 0 = exa_hess, one (pattern, 256-point tile) per workgroup; 2 = exa_hessc, a
  * workgroup walks 4 consecutive tiles of a GROUP of co-indexed patterns with the next inputs loaded before the current
- * tile is stored — wins where a call streams gigabytes through HBM, loses on cache-resident models (twice the registers).
+ * tile is stored — wins where a call streams gigabytes through HBM, loses on cache-resident models (twice the registers);
+ * 1 = exa_hesscl, exa_hessc with each wavefront's stretch of x (64 points + halo) loaded once and staged through LDS —
+ * generated when every pattern of every group reads x at (one unit-step range) + literal offsets no more than 16 apart,
+ * and used when this shard's groups start within that halo of each other (else 1 runs exa_hessc and this returns 2).
  * Which one runs: the decision exa_tune measured and persisted, else by size (>= 1.5 GB streamed per call -> 1). */
 int exa_hess_variant(int id);
 /* Explicit, BLOCKING tuning — the only entry point that measures.  what: bit 0 = block order of cons / jac / hess / fused

@@ -206,18 +206,23 @@ def test_null_pointers_are_status_1_not_device_faults(built):
     assert m.obj(x) == m.obj(x)
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("name", list(ZOO))
-def test_chained_hess_kernel_is_the_same_function(libs, monkeypatch, name):
+def test_chained_hess_kernel_is_the_same_function(libs, monkeypatch, name, variant):
     """hess_coord! has a second generated kernel (exa_hessc: a workgroup walks 4 tiles of a GROUP of co-indexed patterns,
-    the next inputs loaded before the current tile is stored; lanes without a slot store to a sink instead of branching).
+    the next inputs loaded before the current tile is stored; lanes without a slot store to a sink instead of branching)
+    and a third (exa_hesscl, variant 1 where the model fits: the same with each wavefront's stretch of x staged through LDS).
     Forced on every zoo model — whole, sharded 3 ways at global positions and as packed local slices, NaN-poisoned
     outputs — it must write exactly the slots of the plain kernel with the oracle's values."""
     import torch
     import oracle
     from exahip import ExaModel
-    monkeypatch.setenv("EXAHIP_HESS_VARIANT", "1")
+    monkeypatch.setenv("EXAHIP_HESS_VARIANT", str(variant))
     m = ExaModel(ZOO[name]())
-    assert m._L.exa_hess_variant(m.id) == 1
+    staged = "exa_hesscl" in m.kernel_source()
+    assert m._L.exa_hess_variant(m.id) == (1 if variant == 1 and staged else 2)
+    if name.startswith("lv") and "split" not in name:
+        assert staged                                     # unit-step stencils over one range: the staging applies
     o = oracle.OracleModel(m.ir)
     x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=9)
     H = o.hess_coord(x, y, sigma)
@@ -233,13 +238,13 @@ def test_chained_hess_kernel_is_the_same_function(libs, monkeypatch, name):
     plain = ExaModel(ZOO[name]())
     assert plain._L.exa_hess_variant(plain.id) == 0
     np.testing.assert_allclose(got[:m.meta.nnzh], plain.hess_coord(xd, yd, sigma).cpu().numpy(), rtol=1e-12, atol=1e-300)
-    monkeypatch.setenv("EXAHIP_HESS_VARIANT", "1")
+    monkeypatch.setenv("EXAHIP_HESS_VARIANT", str(variant))
     world = 3
     whole = np.full(m.meta.nnzh, np.nan)
     for rank in range(world):
         m.set_shard(rank, world)
         m.set_coo_local(False)
-        assert m._L.exa_hess_variant(m.id) == 1
+        assert m._L.exa_hess_variant(m.id) in (1, 2)
         h.fill_(float("nan"))
         m.hess_coord(xd, yd, sigma, out=h)
         torch.cuda.synchronize()

@@ -23,7 +23,7 @@ y = torch.from_numpy(np.random.default_rng(1).standard_normal(N - 2)).to(dev)
 nnzh = m.meta.nnzh
 L = m._L
 L.exa_set_stream(m.id, ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
-print(f"LV N={N} nnzh={nnzh} ({8 * nnzh / 1e9:.2f} GB), kernel {'exa_hessc' if L.exa_hess_variant(m.id) else 'exa_hess'}", flush=True)
+print(f"LV N={N} nnzh={nnzh} ({8 * nnzh / 1e9:.2f} GB), kernel {('exa_hess', 'exa_hesscl', 'exa_hessc')[L.exa_hess_variant(m.id)]}", flush=True)
 
 
 def t(ptr, reps):
