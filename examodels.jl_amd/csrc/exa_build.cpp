@@ -453,7 +453,7 @@ void note_store(const std::string &key, const std::string &note, bool persist) {
 // ---- resources of a kernel, read from the code object's AMDGPU metadata (msgpack in an ELF note) -----------------------------
 // The kernel's map holds its keys in sorted order: .agpr_count ... .name ... .private_segment_fixed_size ... .vgpr_count,
 // .vgpr_spill_count.  Enough of msgpack is understood here to read the unsigned integers that follow those keys.
-bool kernel_resources(const std::vector<char> &image, const std::string &kernel, int *vgpr, int *agpr, int *scratch, int *vgpr_spill) {
+bool kernel_resources(const std::vector<char> &image, const std::string &kernel, int *vgpr, int *agpr, int *scratch, int *vgpr_spill, int *sgpr_spill) {
     const std::string img(image.begin(), image.end());
     auto mstr = [](const std::string &t) { return std::string(1, (char)(0xa0 | t.size())) + t; };      // fixstr (< 32 bytes)
     auto uint_at = [&](size_t p, long *out) {
@@ -477,11 +477,13 @@ bool kernel_resources(const std::vector<char> &image, const std::string &kernel,
         const size_t p = img.rfind(mstr(key), at);
         return p != std::string::npos && uint_at(p + 1 + key.size(), out);
     };
-    long v = 0, a = 0, sc = 0, sp = 0;
+    long v = 0, a = 0, sc = 0, sp = 0, ss = 0;
     if (!after(".private_segment_fixed_size", &sc) || !after(".vgpr_count", &v)) return false;
     (void)before(".agpr_count", &a);
     (void)after(".vgpr_spill_count", &sp);
+    (void)after(".sgpr_spill_count", &ss);
     *vgpr = (int)v; *agpr = (int)a; *scratch = (int)sc; *vgpr_spill = (int)sp;
+    if (sgpr_spill) *sgpr_spill = (int)ss;
     return true;
 }
 

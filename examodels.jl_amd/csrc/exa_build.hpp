@@ -26,8 +26,8 @@ std::string writable_cache_dir();     // "" when there is none
 // facts about a module that travel with it (exa_build.cpp "notes"): "" when there is none
 std::string note_lookup(const std::string &key);
 void note_store(const std::string &key, const std::string &note, bool persist);
-// registers, scratch bytes per lane and spilled VGPRs of a kernel, from the code object's metadata; false = not found
-bool kernel_resources(const std::vector<char> &image, const std::string &kernel, int *vgpr, int *agpr, int *scratch, int *vgpr_spill);
+// registers, scratch bytes per lane, spilled VGPRs and spilled SGPRs of a kernel, from the code object's metadata; false = not found
+bool kernel_resources(const std::vector<char> &image, const std::string &kernel, int *vgpr, int *agpr, int *scratch, int *vgpr_spill, int *sgpr_spill = nullptr);
 
 bool tune_lookup(const std::string &key, const std::string &signature, int *value);
 void tune_store(const std::string &key, const std::string &signature, int value);

@@ -152,7 +152,8 @@ def test_random_range_models_through_the_windows(libs, seed, flavour):
     kernels, block-owned windows, literal-index targets summed inside the window kernel.  Seed 227 is the regression of a
     real fault: its 12-pass Hv kernel, compiled under a 6-wave occupancy hint, spilled 820 B per lane around the block sums
     of its all-points entries and returned wrong, run-to-run different values (the hint is gone for the products, and a
-    window kernel that sums across lanes is checked for spills after compilation, exa_runtime.cpp window_kernels_spill)."""
+    window kernel is used only if it compiled within the 256 architectural VGPRs, exa_runtime.cpp window_kernels_spill: the
+    second fault of this kind, tools/range_model_check.py 1 1 blocks, had no scratch but 84 AGPRs)."""
     import torch
     import randexpr
     from exahip import ExaModel, capi
@@ -165,13 +166,19 @@ def test_random_range_models_through_the_windows(libs, seed, flavour):
     w = np.random.default_rng(seed + 3).standard_normal(m.meta.ncon)
     dev = torch.device("cuda:0")
     xd, yd, vd, wd = (torch.from_numpy(a).to(dev) for a in (x, y, v, w))
-    m.set_product_mode(2, 2)
-    for call, ref in ((lambda out: m.jtprod(xd, wd, out=out), o.jtprod(x, w)), (lambda out: m.hprod(xd, yd, vd, 0.7, out=out), o.hprod(x, y, v, 0.7))):
+    for which, call, ref in (("jtprod", lambda out: m.jtprod(xd, wd, out=out), o.jtprod(x, w)), ("hprod", lambda out: m.hprod(xd, yd, vd, 0.7, out=out), o.hprod(x, y, v, 0.7))):
+        try:
+            m.set_product_mode(2 if which == "jtprod" else -1, 2 if which == "hprod" else -1)
+        except capi.ExaHipError:
+            # a window kernel that needs more than the 256 architectural VGPRs is not used (window_kernels_spill): the
+            # product stays on its other implementation, checked all the same
+            assert "register spills" in m.product_info(which)[1]
         outs = []
         for _ in range(3):
             out = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)
             call(out)
             torch.cuda.synchronize()
             outs.append(out.cpu().numpy())
-        assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+        if m.product_info(which)[0] == 2:
+            assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
         assert relerr(outs[0], ref) <= 1e-9
