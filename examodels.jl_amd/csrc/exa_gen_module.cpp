@@ -161,7 +161,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
     }
     // obj: per-workgroup partial sums
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_obj(const long* __restrict__ P, const double* __restrict__ x, "
-          "const double* __restrict__ th, double* __restrict__ part) {\n    const long b = blockIdx.x;\n    double v = 0.0;\n";
+          "const double* __restrict__ th, double* part, unsigned* done, double* __restrict__ out) {\n    const long b = blockIdx.x;\n    double v = 0.0;\n";
     {
         const auto &act = L.active[CB_OBJ];
         const int ppt = L.ppt[CB_OBJ];
@@ -174,7 +174,20 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
                << "const double t_ = p" << act[k] << "_val(P, x, th, I < h_ ? I : h_); v += I <= h_ ? t_ : 0.0; }\n    }\n";
         }
     }
-    os << "    const double s = exa_block_sum(v);\n    if (threadIdx.x == 0) part[b] = s;\n}\n";
+    // done != null: the workgroup that finishes LAST folds the partial sums itself, in index order (deterministic), and re-arms
+    // the counter — one launch instead of two (exa_reduce_partials is the second, used when there are too many partials for
+    // one workgroup).  Release / acquire at device scope around the counter; the partials are read with device-scope loads.
+    os << "    const double s = exa_block_sum(v);\n    __shared__ int last_;\n"
+          "    if (threadIdx.x == 0) {\n        __hip_atomic_store(&part[b], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n        last_ = 0;\n"
+          "        if (done) last_ = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;\n    }\n"
+          "    __syncthreads();\n    if (!last_) return;\n"
+          "    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\");\n"
+          "    double a_[4] = {0.0, 0.0, 0.0, 0.0};\n    long i = threadIdx.x;\n    const long n_ = gridDim.x;\n"
+          "    for (; i + 3 * EXA_BLOCK < n_; i += 4 * EXA_BLOCK) {\n#pragma unroll\n        for (int q = 0; q < 4; q++) a_[q] += __hip_atomic_load(&part[i + q * EXA_BLOCK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n    }\n"
+          "    for (; i < n_; i += EXA_BLOCK) a_[0] += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
+          "    __syncthreads();\n"
+          "    const double tot = exa_block_sum((a_[0] + a_[1]) + (a_[2] + a_[3]));\n"
+          "    if (threadIdx.x == 0) { out[0] = tot; __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n}\n";
     // gradient COO + its structure (sorted grad!, gen_gradv_fn): the dispatch of exa_obj
     for (int which = 0; which < 2; which++) {
         const auto &act = L.active[CB_OBJ];

@@ -85,7 +85,7 @@ struct Handle {
     DevBuf daugcsr, daugsrc;                // exa_cons1: CSR over constraint rows of the augmentation terms (pattern << 40 | point)
     bool cons1 = false;
     DevBuf dsink;                           // 64 doubles nobody reads (ParamLayout::sink)
-    DevBuf dP, dtheta, dpart, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
+    DevBuf dP, dtheta, dpart, ddone, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
     int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation
     DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] units one after the other, [1] interleaved in runs of 128
     DevBuf dmapg[2];                        // exa_eval_all: the fused sweep's units + the gathered-gradient tiles (same two orders)
@@ -163,7 +163,7 @@ struct Handle {
         const bool switched = on_device && device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device && hipSetDevice(device) == hipSuccess;
         if (on_device) (void)hipStreamSynchronize(stream);
         if (on_device) {
-            daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); dobj.release();
+            daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); ddone.release(); dobj.release();
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
             dmapg[0].release(); dmapg[1].release();
@@ -392,6 +392,7 @@ void fill_params(Handle &h) {
         h.dP.ensure(sizeof(int64_t) * h.P.size());
         HIPCHK(hipMemcpy(h.dP.p, h.P.data(), sizeof(int64_t) * h.P.size(), hipMemcpyHostToDevice));
         h.dpart.ensure(sizeof(double) * (size_t)(std::max(h.grid[CB_OBJ], h.grid[CB_FUSED]) + 1));
+        if (!h.ddone.p) { h.ddone.ensure(64); HIPCHK(hipMemset(h.ddone.p, 0, 64)); }      // exa_obj's arrival counter (re-armed by the kernel)
     }
 }
 
@@ -686,10 +687,15 @@ void do_obj(Handle &h, const double *x, double *out_dev) {
     void *part = h.dpart.p;
     int64_t n = h.grid[CB_OBJ];
     if (n == 0) { HIPCHK(hipMemsetAsync(out_dev, 0, sizeof(double), h.stream)); allreduce(h, out_dev, 1); return; }
-    void *a1[] = {&P, &x, &th, &part};
+    // up to kObjFoldMax workgroups: the one of exa_obj that finishes last folds the partial sums (one launch); more: a second
+    // launch of 1024 threads
+    void *done = n <= kObjFoldMax ? h.ddone.p : nullptr;
+    void *a1[] = {&P, &x, &th, &part, &done, &out_dev};
     launch(h, h.f_obj, n, kBlock, a1);
-    void *a2[] = {&part, &n, &out_dev};
-    launch(h, h.f_red, 1, 1024, a2);
+    if (!done) {
+        void *a2[] = {&part, &n, &out_dev};
+        launch(h, h.f_red, 1, 1024, a2);
+    }
     allreduce(h, out_dev, 1);
 }
 // grad!.  Gathered (range-affine) objective patterns are evaluated per VARIABLE, so a sharded model shards them by variable
