@@ -77,7 +77,7 @@ struct Handle {
     std::string devname;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
+    hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_zero = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
                   f_hess = nullptr, f_hessc = nullptr, f_hesscl = nullptr, f_cons1 = nullptr, f_jprod1 = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
@@ -448,7 +448,7 @@ void to_device(Handle &h) {
     h.on_device = true;   // from here on the destructor releases whatever was acquired
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
-    h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
+    h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_zero = fn("exa_zero"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
     h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull");
     h.f_auglong = fn("exa_aug_long"); h.f_augfold = fn("exa_aug_fold");
     h.f_fused = fn("exa_fused");
@@ -534,6 +534,13 @@ void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **arg
     if (grid <= 0) return;
     if (grid > 0x7fffffffLL) throw std::runtime_error("grid too large");
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, block, 1, 1, 0, h.stream, args, nullptr));
+}
+
+// zero-fill of n doubles on the model's stream (exa_zero)
+void zero_fill(Handle &h, void *p, int64_t n) {
+    if (n <= 0) return;
+    void *a[] = {&p, &n};
+    launch(h, h.f_zero, (n + 4 * kBlock - 1) / (4 * kBlock), kBlock, a);
 }
 
 // Chooses the block order of callback `cb` by measurement (exa_tune only — callbacks never measure): both orders are
@@ -708,15 +715,15 @@ void do_grad(Handle &h, const double *x, double *g) {
     const int64_t nvar = h.m->nvar;
     const bool scatter = !h.gen.layout.active[CB_GRAD].empty(), pull = !h.gen.layout.pull.empty();     // (the MODEL's patterns, not this shard's)
     const bool owner = pull && !scatter;
-    if (pull) {
-        // gathered patterns: plain coalesced store of every g[v] (zero where nothing contributes)
+    {
+        // gathered patterns: plain coalesced store of every g[v] (zero where nothing contributes).  Without gathered patterns
+        // the same kernel is the zero-fill under the atomics: a plain launch is cheaper than hipMemsetAsync (ACOPF grad!
+        // 0.018 -> 0.009 ms, profiles/NOTES.md)
         int64_t own_lo = h.world > 1 ? own_var_lo(h, h.rank) : 0, own_hi = h.world > 1 ? own_var_lo(h, h.rank + 1) : nvar;
         int64_t vb = owner ? own_lo : 0, ve = owner ? own_hi : nvar;
         void *a0[] = {&P, &x, &th, &g, &vb, &ve, &own_lo, &own_hi};
         const int64_t per = (int64_t)kBlock * h.gen.layout.pull_ppt;
         launch(h, h.f_gradpull, (ve - vb + per - 1) / per, kBlock, a0);
-    } else {
-        HIPCHK(hipMemsetAsync(g, 0, sizeof(double) * (size_t)nvar, h.stream));
     }
     void *a[] = {&P, &x, &th, &g};
     launch(h, h.f_grad, h.grid[CB_GRAD], kBlock, a);   // scattered patterns: FP64 hardware atomics on top
@@ -882,7 +889,7 @@ void do_eval_all(Handle &h, const double *x, const double *y, double sigma, doub
         const int64_t per = (int64_t)kBlock * L.pull_ppt;
         launch(h, h.f_gradpull, (ve - vb + per - 1) / per, kBlock, a0);
     } else if (!pull) {
-        HIPCHK(hipMemsetAsync(g, 0, sizeof(double) * (size_t)nvar, h.stream));
+        zero_fill(h, g, nvar);
     }
     // (only gathered patterns: their tiles ride inside the sweep's launch)
     do_fused(h, x, y, sigma, obj_dev, c, jv, hv, g, /*with_pull=*/pull && !scatter);
@@ -896,8 +903,8 @@ void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
     const bool one = h.f_jprod1 && (h.cons1 || h.m->nconaug == 0);      // rows complete on their owner, as in do_cons
     const bool owner = one || h.m->nconaug == 0;
     if (h.world > 1 && !owner) {
-        HIPCHK(hipMemsetAsync(Jv, 0, sizeof(double) * (size_t)h.m->ncon, h.stream));
-        if (h.m->nconaug) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
+        zero_fill(h, Jv, h.m->ncon);
+        zero_fill(h, buf, h.m->nconaug);
     }
     const void *P = h.dP.p, *th = h.dtheta.p;
     if (one) {
@@ -915,13 +922,13 @@ void do_jprod(Handle &h, const double *x, const double *v, double *Jv) {
     else allreduce(h, Jv, h.m->ncon);
 }
 void do_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
-    HIPCHK(hipMemsetAsync(Jtv, 0, sizeof(double) * (size_t)h.m->nvar, h.stream));
+    zero_fill(h, Jtv, h.m->nvar);
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &th, &v, &Jtv};
     launch(h, h.f_jtprod, h.grid[CB_JTPROD], kBlock, a);
 }
 void do_hprod(Handle &h, const double *x, const double *y, const double *v, double sigma, double *Hv) {
-    HIPCHK(hipMemsetAsync(Hv, 0, sizeof(double) * (size_t)h.m->nvar, h.stream));
+    zero_fill(h, Hv, h.m->nvar);
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &y, &th, &v, &Hv, &sigma};
     launch(h, h.f_hprod, h.grid[CB_HPROD], kBlock, a);
