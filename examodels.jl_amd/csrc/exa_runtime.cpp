@@ -85,7 +85,7 @@ struct Handle {
     DevBuf daugcsr, daugsrc;                // exa_cons1: CSR over constraint rows of the augmentation terms (pattern << 40 | point)
     bool cons1 = false;
     DevBuf dsink;                           // 64 doubles nobody reads (ParamLayout::sink)
-    DevBuf dP, dtheta, dpart, ddone, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
+    DevBuf dP, dtheta, dpart, ddone, dyzero, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
     int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation
     DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] units one after the other, [1] interleaved in runs of 128
     DevBuf dmapg[2];                        // exa_eval_all: the fused sweep's units + the gathered-gradient tiles (same two orders)
@@ -163,7 +163,7 @@ struct Handle {
         const bool switched = on_device && device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device && hipSetDevice(device) == hipSuccess;
         if (on_device) (void)hipStreamSynchronize(stream);
         if (on_device) {
-            daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); ddone.release(); dobj.release();
+            daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); ddone.release(); dyzero.release(); dobj.release();
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
             dmapg[0].release(); dmapg[1].release();
@@ -815,6 +815,18 @@ void do_jac(Handle &h, const double *x, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &th, &v};
     launch(h, h.f_jac, h.grid[CB_JAC], kBlock, a);
+}
+// The objective-only forms hess_coord!(m, x, hess; obj_weight) / hprod!(m, x, v, Hv; obj_weight) (nlp.jl:1906-1915, :1942-1952):
+// y == NULL.  The constraint patterns are evaluated against a vector of zeros the library keeps (ncon doubles, allocated by
+// the FIRST such call — which therefore must not sit inside a stream capture); every constraint slot then holds 0 * h.
+const double *multipliers_or_zeros(Handle &h, const double *y) {
+    if (y || h.m->ncon == 0) return y;
+    if (!h.dyzero.p) {
+        if (capturing(h)) throw BadInput("the first objective-only call (y == NULL) allocates the zero multipliers: make it outside the stream capture");
+        h.dyzero.ensure(8 * (size_t)h.m->ncon);
+        HIPCHK(hipMemsetAsync(h.dyzero.p, 0, 8 * (size_t)h.m->ncon, h.stream));
+    }
+    return (const double *)h.dyzero.p;
 }
 void do_hess(Handle &h, const double *x, const double *y, double sigma, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
@@ -1967,8 +1979,7 @@ int exa_hess(int id, const double *x, const double *y, double w, double *v) {
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) {
         if (h.m->nnzh && !v) throw BadInput("null output");
-        if (h.m->ncon && !y) throw BadInput("null multipliers for a model with constraints");   // would be a device fault
-        do_hess(h, x, y, w, v);
+        do_hess(h, x, multipliers_or_zeros(h, y), w, v);
     });
 }
 int exa_eval_fused(int id, const double *x, const double *y, double w, double *obj_dev, double *c, double *jvals, double *hvals) {
@@ -2056,8 +2067,7 @@ int exa_jtprod(int id, const double *x, const double *v, double *Jtv) {
 int exa_hprod(int id, const double *x, const double *y, const double *v, double w, double *Hv) {
     if (!x || !v || !Hv) return 1;
     return guard(id, true, [&](Handle &h) {
-        if (h.m->ncon && !y) throw BadInput("null multipliers for a model with constraints");
-        run_hprod(h, x, y, v, w, Hv);
+        run_hprod(h, x, multipliers_or_zeros(h, y), v, w, Hv);
     });
 }
 /* 0 = atomics inside the sweep, 1 = COO + sorted gather, 2 = owner-computes windows, -1 = undecided (default): the decision
@@ -2178,7 +2188,8 @@ int exa_hess_host(int id, const double *x, const double *y, double w, double *v)
         const size_t n = 8 * (size_t)h.lnnzh;
         if (!n) return;
         h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
-        if (h.m->ncon) { if (!y) throw std::runtime_error("null multipliers"); h2d(h, h.sy, y, 8 * (size_t)h.m->ncon); }
+        if (h.m->ncon && y) h2d(h, h.sy, y, 8 * (size_t)h.m->ncon);
+        else if (h.m->ncon) { h.sy.ensure(8 * (size_t)h.m->ncon); HIPCHK(hipMemsetAsync(h.sy.p, 0, 8 * (size_t)h.m->ncon, h.stream)); }    // objective only
         else h.sy.ensure(8);
         h.sout.ensure(n);
         do_hess(h, (const double *)h.sx.p, (const double *)h.sy.p, w, (double *)h.sout.p);
@@ -2217,7 +2228,8 @@ int exa_hprod_host(int id, const double *x, const double *y, const double *v, do
         const size_t n = 8 * (size_t)h.m->nvar;
         h2d(h, h.sx, x, n);
         h2d(h, h.sv, v, n);
-        if (h.m->ncon) { if (!y) throw std::runtime_error("null multipliers"); h2d(h, h.sy, y, 8 * (size_t)h.m->ncon); }
+        if (h.m->ncon && y) h2d(h, h.sy, y, 8 * (size_t)h.m->ncon);
+        else if (h.m->ncon) { h.sy.ensure(8 * (size_t)h.m->ncon); HIPCHK(hipMemsetAsync(h.sy.p, 0, 8 * (size_t)h.m->ncon, h.stream)); }    // objective only
         else h.sy.ensure(8);
         h.sout.ensure(n);
         zero_if_sharded(h, h.sout.p, n);

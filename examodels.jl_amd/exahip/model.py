@@ -468,8 +468,9 @@ class ExaModel:
                 capi.check(getattr(self._L, "exa_" + name)(self.id, x.data_ptr(), out.data_ptr()), name)
             else:
                 y, w = extra
-                self._tcheck(y, self.meta.ncon, "y")
-                capi.check(self._L.exa_hess(self.id, x.data_ptr(), y.data_ptr(), float(w), out.data_ptr()), name)
+                if y is not None:
+                    self._tcheck(y, self.meta.ncon, "y")
+                capi.check(self._L.exa_hess(self.id, x.data_ptr(), y.data_ptr() if y is not None else None, float(w), out.data_ptr()), name)
             return out
         x = self._np(x, self.meta.nvar, "x")
         if out is None:
@@ -479,7 +480,7 @@ class ExaModel:
             capi.check(getattr(self._L, f"exa_{name}_host")(self.id, x.ctypes.data, out.ctypes.data), name)
         else:
             y, w = extra
-            y = self._np(y, self.meta.ncon, "y")
+            y = self._np(y, self.meta.ncon, "y") if y is not None else np.empty(0)
             capi.check(self._L.exa_hess_host(self.id, x.ctypes.data, y.ctypes.data if y.size else None, float(w), out.ctypes.data), name)
         return out
 
@@ -494,7 +495,9 @@ class ExaModel:
     def jac_coord(self, x, out=None):
         return self._call("jac", x, self.local_nnzj, out)
 
-    def hess_coord(self, x, y, obj_weight=1.0, out=None):
+    def hess_coord(self, x, y=None, obj_weight=1.0, out=None):
+        """hess_coord!(m, x, y, hess; obj_weight); y=None is the objective-only form hess_coord!(m, x, hess; obj_weight)
+        (nlp.jl:1906-1915): the constraint slots come back as zeros."""
         return self._call("hess", x, self.local_nnzh, out, extra=(y, obj_weight))
 
     def eval_fused(self, x, y, obj_weight=1.0, c=None, jac=None, hess=None, obj_out=None):
@@ -537,7 +540,7 @@ class ExaModel:
             if out is None:
                 out = torch.empty(n_out, dtype=torch.float64, device=x.device)
             if name == "hprod":
-                capi.check(self._L.exa_hprod(self.id, x.data_ptr(), y.data_ptr(), v.data_ptr(), float(w), out.data_ptr()), name)
+                capi.check(self._L.exa_hprod(self.id, x.data_ptr(), y.data_ptr() if y is not None else None, v.data_ptr(), float(w), out.data_ptr()), name)
             else:
                 capi.check(getattr(self._L, "exa_" + name)(self.id, x.data_ptr(), v.data_ptr(), out.data_ptr()), name)
             return out
@@ -546,7 +549,7 @@ class ExaModel:
         if out is None:
             out = np.empty(n_out)
         if name == "hprod":
-            y = self._np(y, self.meta.ncon, "y")
+            y = self._np(y, self.meta.ncon, "y") if y is not None else np.empty(0)
             capi.check(self._L.exa_hprod_host(self.id, x.ctypes.data, y.ctypes.data if y.size else None, v.ctypes.data, float(w), out.ctypes.data), name)
         else:
             capi.check(getattr(self._L, f"exa_{name}_host")(self.id, x.ctypes.data, v.ctypes.data if v.size else None, out.ctypes.data), name)
@@ -589,6 +592,7 @@ class ExaModel:
         return self._prod("jtprod", x, v, self.meta.ncon, self.meta.nvar, out)
 
     def hprod(self, x, y, v, obj_weight=1.0, out=None):
+        """hprod!(m, x, y, v, Hv; obj_weight); y=None is the objective-only form hprod!(m, x, v, Hv; obj_weight) (nlp.jl:1942-1952)"""
         return self._prod("hprod", x, v, self.meta.nvar, self.meta.nvar, out, y=y, w=obj_weight)
 
     def _structure(self, which, rows, cols, nnz, dtype):

@@ -248,6 +248,12 @@ function ExaModels.hess_coord!(m::HM, x::AbstractVector, y::AbstractVector, v::A
     chk(ccall((:exa_hess, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
               m.ext.id, pointer(x), pointer(y), Float64(obj_weight), pointer(v)), "exa_hess"); v
 end
+# objective-only form (nlp.jl:1906-1915): y == NULL, the constraint slots come back as zeros
+function ExaModels.hess_coord!(m::HM, x::AbstractVector, v::AbstractVector; obj_weight = one(eltype(x)))
+    usestream(m)
+    chk(ccall((:exa_hess, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
+              m.ext.id, pointer(x), Ptr{Cdouble}(C_NULL), Float64(obj_weight), pointer(v)), "exa_hess"); v
+end
 function ExaModels.jprod_nln!(m::HM, x::AbstractVector, v::AbstractVector, Jv::AbstractVector)
     usestream(m)
     chk(ccall((:exa_jprod, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, pointer(x), pointer(v), pointer(Jv)), "exa_jprod"); Jv
@@ -260,6 +266,12 @@ function ExaModels.hprod!(m::HM, x::AbstractVector, y::AbstractVector, v::Abstra
     usestream(m)
     chk(ccall((:exa_hprod, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
               m.ext.id, pointer(x), pointer(y), pointer(v), Float64(obj_weight), pointer(Hv)), "exa_hprod"); Hv
+end
+# objective-only form (nlp.jl:1942-1952)
+function ExaModels.hprod!(m::HM, x::AbstractVector, v::AbstractVector, Hv::AbstractVector; obj_weight = one(eltype(x)))
+    usestream(m)
+    chk(ccall((:exa_hprod, LIB), Cint, (Cint, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Cdouble}, Cdouble, Ptr{Cdouble}),
+              m.ext.id, pointer(x), Ptr{Cdouble}(C_NULL), pointer(v), Float64(obj_weight), pointer(Hv)), "exa_hprod"); Hv
 end
 # set_value!(model, param, values) (nlp.jl:1279-1287) writes model.θ; the library keeps its own device copy of θ, so the
 # update is forwarded (host values) — no rebuild, exactly as in the reference.

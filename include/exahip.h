@@ -209,10 +209,14 @@ int exa_obj_async(int id, const double *x, double *out_dev);                  /*
 int exa_grad(int id, const double *x, double *g);
 int exa_cons(int id, const double *x, double *c);
 int exa_jac (int id, const double *x, double *vals);
-int exa_hess(int id, const double *x, const double *y, double obj_weight, double *vals);
+int exa_hess(int id, const double *x, const double *y, double obj_weight, double *vals);   /* y == NULL: objective only, see below */
 int exa_jprod (int id, const double *x, const double *v, double *Jv);             /* Jv [ncon]  = J(x) v,   v [nvar] */
 int exa_jtprod(int id, const double *x, const double *v, double *Jtv);            /* Jtv [nvar] = J(x)' v,  v [ncon] */
 int exa_hprod (int id, const double *x, const double *y, const double *v, double obj_weight, double *Hv);  /* Hv [nvar] */
+/* Objective-only forms — hess_coord!(m, x, hess; obj_weight), hprod!(m, x, v, Hv; obj_weight) (nlp.jl:1906-1915, :1942-1952):
+ * exa_hess / exa_hprod (and their _host variants) with y == NULL.  The constraint slots / contributions come back as zeros
+ * (0 * second derivative).  The first such call on a model with constraints allocates the ncon zeros it evaluates against, so
+ * it must not be the first thing inside a stream capture; later calls are asynchronous like every callback. */
 /* exa_jtprod / exa_hprod have three implementations.  mode 0: FP64 atomics inside the sweep (zero-fill + atomics; order of
  * additions varies).  mode 1: COO + gather through build-time sorted lists (the reference's prod helper, KA ext :56-178,
  * :482-511; deterministic).  mode 2: OWNER-COMPUTES WINDOWS — models whose every scatter target is (range value) * literal +

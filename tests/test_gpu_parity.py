@@ -186,6 +186,33 @@ def test_direct_store_fallback_path(libs, monkeypatch):
         assert relerr(m.jac_coord(x), o.jac_coord(x)) <= RTOL
 
 
+@pytest.mark.parametrize("name", list(ZOO))
+def test_objective_only_forms(built, name):
+    """hess_coord!(m, x, hess; obj_weight) and hprod!(m, x, v, Hv; obj_weight) (nlp.jl:1906-1915, :1942-1952): y omitted.  The
+    objective's slots as with any y, the constraints' slots zero — through device and host pointers, every product mode."""
+    import torch
+    m, o = built[name]
+    x, _, sigma = point(m.meta.x0, m.meta.ncon, seed=21)
+    y0 = np.zeros(m.meta.ncon)
+    v = np.random.default_rng(22).standard_normal(m.meta.nvar)
+    H, Hv = o.hess_coord(x, y0, sigma), o.hprod(x, y0, v, sigma)
+    xd, vd = torch.from_numpy(x).cuda(), torch.from_numpy(v).cuda()
+    assert relerr(m.hess_coord(xd, None, sigma).cpu().numpy(), H) <= RTOL
+    assert relerr(m.hess_coord(x, None, sigma), H) <= RTOL
+    assert relerr(m.hess_coord(x, obj_weight=sigma), H) <= RTOL
+    for mode in (0, 1, 2):
+        try:
+            m.set_product_mode(-1, mode)
+        except Exception:
+            continue
+        assert relerr(m.hprod(xd, None, vd, sigma).cpu().numpy(), Hv) <= RTOL
+        assert relerr(m.hprod(x, None, v, sigma), Hv) <= RTOL
+    m.set_product_mode(-1, -1)
+    # and the full forms are what they were
+    y = np.random.default_rng(23).standard_normal(m.meta.ncon)
+    assert relerr(m.hess_coord(x, y, sigma), o.hess_coord(x, y, sigma)) <= RTOL
+
+
 def test_null_pointers_are_status_1_not_device_faults(built):
     """A NULL for a buffer a kernel would dereference is the caller's error, caught on the host."""
     import ctypes
@@ -195,9 +222,9 @@ def test_null_pointers_are_status_1_not_device_faults(built):
     x = torch.zeros(m.meta.nvar, dtype=torch.float64, device="cuda")
     h = torch.zeros(m.meta.nnzh, dtype=torch.float64, device="cuda")
     xp, hp = ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(h.data_ptr())
-    assert L.exa_hess(m.id, xp, None, 1.0, hp) == 1                      # multipliers missing, ncon > 0
+    assert L.exa_hess(m.id, xp, None, 1.0, hp) == 0                      # y == NULL is the objective-only form, not an error
     assert L.exa_hess(m.id, None, xp, 1.0, hp) == 1 and L.exa_hess(m.id, xp, xp, 1.0, None) == 1
-    assert L.exa_hprod(m.id, xp, None, xp, 1.0, xp) == 1
+    assert L.exa_hprod(m.id, xp, None, xp, 1.0, xp) == 0 and L.exa_hprod(m.id, xp, None, None, 1.0, xp) == 1
     assert L.exa_cons(m.id, xp, None) == 1 and L.exa_jac(m.id, xp, None) == 1 and L.exa_grad(m.id, xp, None) == 1
     ms = ctypes.c_float(0)
     assert L.exa_time_callback(m.id, 4, 1, xp, None, 1.0, hp, ctypes.addressof(ms)) == 1
