@@ -402,3 +402,29 @@ def test_kernel_resources_are_read_from_the_code_object(libs):
     assert len(objs) == 2 and all(name.startswith("exa_") and blob[:4] == b"\x7fELF" or blob[:24] == b"__CLANG_OFFLOAD_BUNDLE__" for name, blob in objs)
     assert objs[0][0] == capi.lib().exa_module_name(m.id).decode() and capi.lib().exa_module_alias(m.id).decode() == ""
     assert b"exa_hprodw" in objs[1][1] and b"exa_jtprodw" in objs[1][1]
+
+
+def test_staged_hessian_kernel_is_generated_where_the_stencil_allows(libs):
+    """exa_hesscl (x staged through LDS per wavefront) exists exactly for models whose Hessian patterns read x at one unit-step
+    range + literals at most 16 apart (pattern_stage): Luksan-Vlcek yes; the rocket (four variable arrays: literals millions
+    apart), ACOPF (data-indexed) and a stepped range no.  The plain chained kernel exists for all of them; a plan-only handle
+    reports 2 for the forced chained variant where the staged one does not apply."""
+    from exahip import ExaModel, models
+    from zoo import ZOO
+    lv = ExaModel(models.luksan_vlcek_model(5000), device=False).kernel_source()
+    assert "exa_hesscl(" in lv and "exa_hessc(" in lv and "xs[xd + " in lv
+    for mk in (lambda: models.rocket_model(500), ZOO["acopf30"], ZOO["stepped"]):
+        src = ExaModel(mk(), device=False).kernel_source()
+        assert "exa_hessc(" in src and "exa_hesscl(" not in src
+
+
+def test_generated_module_has_the_zero_fill_and_the_folding_objective(libs):
+    """exa_zero (the zero-fill under the atomics: a launch of the module instead of hipMemsetAsync) and the arrival counter of
+    exa_obj (the last workgroup folds the partial sums, up to kObjFoldMax workgroups) are part of every module."""
+    from exahip import ExaModel, models
+    src = ExaModel(models.luksan_vlcek_model(100), device=False).kernel_source()
+    assert "void __launch_bounds__(EXA_BLOCK) exa_zero(double* __restrict__ out, long n)" in src
+    assert "exa_obj(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* part, unsigned* done, double* __restrict__ out)" in src
+    assert "__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)" in src
+    # Horner steps of exa_sincos take their coefficients from SGPRs
+    assert 'asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k))' in src
