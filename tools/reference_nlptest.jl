@@ -53,6 +53,10 @@ function test_nlp(m1, m2; tol = 1e-10)             # NLPTest.jl:48-114 with the 
         NLPModels.hess_coord!(m1, x0, y0, h1); NLPModels.hess_coord!(m2, d(x0), d(y0), h2)
         @test j1 ≈ host(j2) atol = tol rtol = tol
         @test h1 ≈ host(h2) atol = tol rtol = tol
+        # the objective-only forms (nlp.jl:1906-1915, :1942-1952): exa_hess / exa_hprod with y == NULL
+        NLPModels.hess_coord!(m1, x0, h1); NLPModels.hess_coord!(m2, d(x0), h2)
+        @test h1 ≈ host(h2) atol = tol rtol = tol
+        @test NLPModels.hprod(m1, x0, u) ≈ host(NLPModels.hprod(m2, d(x0), d(u))) atol = tol rtol = tol
         for (st!, n) in ((NLPModels.jac_structure!, m1.meta.nnzj), (NLPModels.hess_structure!, m1.meta.nnzh))
             r1, c1, r2, c2 = zeros(Int, n), zeros(Int, n), zeros(Int, n), zeros(Int, n)
             st!(m1, r1, c1); st!(m2, r2, c2)
