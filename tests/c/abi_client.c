@@ -92,6 +92,21 @@ int main(int argc, char **argv) {
         printf("hess"); for (int i = 0; i < 75; i++) printf(" %.17g", hv[i]); printf("\n");
         printf("hrows"); for (int i = 0; i < 75; i++) printf(" %d", r[i]); printf("\n");
         printf("hcols"); for (int i = 0; i < 75; i++) printf(" %d", cc[i]); printf("\n");
+        /* products (jprod_nln! / jtprod_nln! / hprod!), the objective-only forms (y == NULL), the Jacobian structure */
+        double v[10], w[8], Jv[8], Jtv[10], Hv[10], Hv0[10], hv0[75];
+        int32_t jr[24], jc[24];
+        for (int i = 0; i < 10; i++) v[i] = 0.3 * i - 1.0;
+        for (int i = 0; i < 8; i++) w[i] = 0.5 - 0.2 * i;
+        st = exa_jprod_host(id, x0, v, Jv) | exa_jtprod_host(id, x0, w, Jtv) | exa_hprod_host(id, x0, y, v, 0.5, Hv) |
+             exa_hprod_host(id, x0, NULL, v, 0.5, Hv0) | exa_hess_host(id, x0, NULL, 0.5, hv0) | exa_jac_structure_host(id, jr, jc);
+        if (st) { printf("FAIL products status %d: %s\n", st, exa_last_error()); return 1; }
+        printf("jprod"); for (int i = 0; i < 8; i++) printf(" %.17g", Jv[i]); printf("\n");
+        printf("jtprod"); for (int i = 0; i < 10; i++) printf(" %.17g", Jtv[i]); printf("\n");
+        printf("hprod"); for (int i = 0; i < 10; i++) printf(" %.17g", Hv[i]); printf("\n");
+        printf("hprodobj"); for (int i = 0; i < 10; i++) printf(" %.17g", Hv0[i]); printf("\n");
+        printf("hessobj"); for (int i = 0; i < 75; i++) printf(" %.17g", hv0[i]); printf("\n");
+        printf("jrows"); for (int i = 0; i < 24; i++) printf(" %d", jr[i]); printf("\n");
+        printf("jcols"); for (int i = 0; i < 24; i++) printf(" %d", jc[i]); printf("\n");
     }
     if (exa_free(id) != 0 || exa_free(id) != 1) { printf("FAIL free convention\n"); return 1; }
     printf("OK\n");

@@ -46,7 +46,7 @@ def test_c_client_full_evaluation(client):
     vals = {}
     for line in out.splitlines():
         k, *rest = line.split()
-        if k in ("obj", "cons", "grad", "jac", "hess", "hrows", "hcols"):
+        if k in ("obj", "cons", "grad", "jac", "hess", "hrows", "hcols", "jprod", "jtprod", "hprod", "hprodobj", "hessobj", "jrows", "jcols"):
             vals[k] = np.array([float(v) for v in rest])
     o = oracle.OracleModel(models.luksan_vlcek_model(10).to_ir())
     x0 = o.meta()[0]
@@ -58,3 +58,12 @@ def test_c_client_full_evaluation(client):
     np.testing.assert_allclose(vals["hess"], o.hess_coord(x0, y, 0.5), rtol=1e-12, atol=1e-12)
     r, c = o.hess_structure()
     assert np.array_equal(vals["hrows"].astype(int), r) and np.array_equal(vals["hcols"].astype(int), c)
+    v, w, y0 = 0.3 * np.arange(10) - 1.0, 0.5 - 0.2 * np.arange(8), np.zeros(8)
+    np.testing.assert_allclose(vals["jprod"], o.jprod(x0, v), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(vals["jtprod"], o.jtprod(x0, w), rtol=1e-12, atol=1e-11)
+    np.testing.assert_allclose(vals["hprod"], o.hprod(x0, y, v, 0.5), rtol=1e-12, atol=1e-10)
+    # the objective-only forms: y == NULL
+    np.testing.assert_allclose(vals["hprodobj"], o.hprod(x0, y0, v, 0.5), rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(vals["hessobj"], o.hess_coord(x0, y0, 0.5), rtol=1e-12, atol=1e-12)
+    jr, jc = o.jac_structure()
+    assert np.array_equal(vals["jrows"].astype(int), jr) and np.array_equal(vals["jcols"].astype(int), jc)

@@ -145,6 +145,7 @@ def test_build_info_reports_how_the_module_was_obtained(libs, tmp_path, monkeypa
     from exahip import ExaModel, models
     monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))
     monkeypatch.setenv("EXAHIP_HIPCC", "/nonexistent/hipcc")      # the in-process path needs no hipcc
+    monkeypatch.delenv("EXAHIP_COMPILER", raising=False)          # (a suite run under EXAHIP_COMPILER=hipcc: this test is about hiprtc)
     t0 = time.perf_counter()
     m = ExaModel(models.luksan_vlcek_model(100))
     how, ms = m.build_info()
