@@ -177,17 +177,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
     // done != null: the workgroup that finishes LAST folds the partial sums itself, in index order (deterministic), and re-arms
     // the counter — one launch instead of two (exa_reduce_partials is the second, used when there are too many partials for
     // one workgroup).  Release / acquire at device scope around the counter; the partials are read with device-scope loads.
-    os << "    const double s = exa_block_sum(v);\n    __shared__ int last_;\n"
-          "    if (threadIdx.x == 0) {\n        __hip_atomic_store(&part[b], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n        last_ = 0;\n"
-          "        if (done) last_ = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;\n    }\n"
-          "    __syncthreads();\n    if (!last_) return;\n"
-          "    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"agent\");\n"
-          "    double a_[4] = {0.0, 0.0, 0.0, 0.0};\n    long i = threadIdx.x;\n    const long n_ = gridDim.x;\n"
-          "    for (; i + 3 * EXA_BLOCK < n_; i += 4 * EXA_BLOCK) {\n#pragma unroll\n        for (int q = 0; q < 4; q++) a_[q] += __hip_atomic_load(&part[i + q * EXA_BLOCK], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n    }\n"
-          "    for (; i < n_; i += EXA_BLOCK) a_[0] += __hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);\n"
-          "    __syncthreads();\n"
-          "    const double tot = exa_block_sum((a_[0] + a_[1]) + (a_[2] + a_[3]));\n"
-          "    if (threadIdx.x == 0) { out[0] = tot; __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }\n}\n";
+    os << "    const double s = exa_block_sum(v);\n    exa_obj_arrive(part, b, s, done, gridDim.x, out);\n}\n";
     // gradient COO + its structure (sorted grad!, gen_gradv_fn): the dispatch of exa_obj
     for (int which = 0; which < 2; which++) {
         const auto &act = L.active[CB_OBJ];
@@ -408,7 +398,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
               "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ part, double* __restrict__ cout, "
               "double* __restrict__ augout, double* __restrict__ jout, double* __restrict__ hout, double sigma, "
               "const long* __restrict__ augptr, const long* __restrict__ augsrc, const double* __restrict__ augcoef, double* __restrict__ gout, "
-              "const long* __restrict__ bmap, long v_begin, long v_end, long own_lo, long own_hi) {\n";
+              "const long* __restrict__ bmap, long v_begin, long v_end, long own_lo, long own_hi, unsigned* done, long nobj, double* __restrict__ obj_out) {\n";
         if (mx) os << "    __shared__ double lds_all[(EXA_BLOCK / 64) * " << mx << "];\n    double* lds = lds_all + (threadIdx.x >> 6) * " << mx << ";\n";
         else os << "    double* lds = nullptr;\n";
         // only the workgroups of OBJECTIVE patterns have something to add to obj: they write one partial sum each, at a
@@ -421,7 +411,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
             os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") { const double v = g" << k
                << "_fused(P, x, y, th, cout, augout, jout, hout, sigma, tid0, lds, augptr, augsrc, augcoef, gout);";
             if (m.pats[grps[k].front()].kind == EXA_PAT_OBJ)
-                os << " const double s = exa_block_sum(v); if (threadIdx.x == 0) part[P[" << L.pat[grps[k].front()].ob << "] + tile_] = s;";
+                os << " const double s = exa_block_sum(v); exa_obj_arrive(part, P[" << L.pat[grps[k].front()].ob << "] + tile_, s, done, nobj, obj_out);";
             else os << " (void)v;";
             os << " }\n";
         }

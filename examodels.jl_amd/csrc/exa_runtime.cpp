@@ -866,10 +866,12 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
         bmap = h.dmapg[h.order[CB_FUSED] ? 1 : 0].p;
         n = h.gridg;
     }
-    void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma, &ap, &as, &ac, &gout, &bmap, &vb, &ve, &own_lo, &own_hi};
-    launch(h, h.f_fused, n, kBlock, a);
+    // objective partial sums: up to kObjFoldMax of them are folded by the objective workgroup that arrives last (as in do_obj)
     int64_t nobj = h.fused_nobj;
-    if (n > 0 && nobj > 0) { void *a2[] = {&part, &nobj, &obj_dev}; launch(h, h.f_red, 1, 1024, a2); }
+    void *done = n > 0 && nobj > 0 && nobj <= kObjFoldMax ? h.ddone.p : nullptr;
+    void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma, &ap, &as, &ac, &gout, &bmap, &vb, &ve, &own_lo, &own_hi, &done, &nobj, &obj_dev};
+    launch(h, h.f_fused, n, kBlock, a);
+    if (n > 0 && nobj > 0) { if (!done) { void *a2[] = {&part, &nobj, &obj_dev}; launch(h, h.f_red, 1, 1024, a2); } }
     else HIPCHK(hipMemsetAsync(obj_dev, 0, sizeof(double), h.stream));
     if (h.m->nconaug && !inline_aug) aug_gather(h, buf, c);
     allreduce(h, obj_dev, 1);
