@@ -51,7 +51,7 @@ def main():
     w = sys.stdout.write
     w(f"# {cb['workload']}\n\nmodule `{cb['module']}`; nvar {cb['nvar']}, ncon {cb['ncon']}, nnzj {cb['nnzj']}, nnzh {cb['nnzh']}"
       + (f", compressed nnzj {cb['cnnzj']}, nnzh {cb['cnnzh']}" if "cnnzj" in cb else "") + "\n\n")
-    w("Per callback: hipEvent time per call (un-profiled run of tools/run_callbacks.py inside the stats pass), algorithmic bytes (SURVEY §8d).\n"
+    w("Per callback: hipEvent time per call (tools/run_callbacks.py, 200 calls, NO profiler attached), algorithmic bytes (SURVEY §8d).\n"
       "Per kernel: rocprofv3 --kernel-trace average duration; `frac` = algorithmic bytes of the callback / kernel duration / 8 TB/s (dominant kernel only);\n"
       f"`traffic` = WRITE_SIZE + {CORR} x FETCH_SIZE per dispatch (separate --pmc passes); VALU = SQ_INSTS_VALU wavefront-instructions per dispatch;\n"
       "wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES, issue-stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES; GUI = GRBM_GUI_ACTIVE cycles per dispatch (all XCDs).\n\n")
