@@ -22,6 +22,31 @@ def test_random_patterns_layout(libs, seed):
         assert m.pattern_comp(k, 2) == o.pattern_comp(k, 2)
 
 
+@pytest.mark.parametrize("flavour", ["mixed", "unit", "blocks"])
+@pytest.mark.parametrize("seed", range(8))
+def test_random_range_models_layout_and_plans(libs, seed, flavour):
+    """Range-iterated random models (the ones the windows, the gathered gradient and the staged kernels live on), plan only:
+    sizes, per-pattern slot maps and first/second-order component lists equal the oracle's; the product-window planner
+    returns a shape or a reason for both products; a 3-way shard's variable footprint lies inside the model."""
+    from exahip import ExaModel
+    import oracle
+    npts = (300, 1000, 1037)[seed % 3]
+    m = ExaModel(randexpr.build_range_model(seed, npts=npts, unit=flavour in ("unit", "blocks"), blocks=flavour == "blocks"), device=False)
+    o = oracle.OracleModel(m.ir)
+    assert (m.meta.nvar, m.meta.ncon, m.meta.nnzj, m.meta.nnzh, m.meta.nnzg) == (o.nvar, o.ncon, o.nnzj, o.nnzh, o.nnzg)
+    for k in range(m.npatterns):
+        assert m.pattern_info(k) == o.pattern_info(k)
+        assert m.pattern_comp(k, 1) == o.pattern_comp(k, 1) and m.pattern_comp(k, 2) == o.pattern_comp(k, 2)
+    for which in ("jtprod", "hprod"):
+        mode, text = m.product_info(which)
+        assert mode in (0, 1, 2) and text
+    for r in range(3):
+        m.set_shard(r, 3)
+        lo, hi = m.shard_var_range()
+        assert 0 <= lo <= hi <= m.meta.nvar
+    m.set_shard(0, 1)
+
+
 def relerr(a, ref):
     a, ref = np.asarray(a), np.asarray(ref)
     if ref.size == 0:
