@@ -135,3 +135,23 @@ def test_random_range_models_after_poison(libs, poison, seed, flavour):
         got = np.zeros_like(want)
         np.add.at(got, (cc - 1) * nrow + (cr - 1), np.where(np.isfinite(cv[:n]), cv[:n], 0.0))
         assert relerr(got, want) <= 1e-9, kind
+
+
+@pytest.mark.parametrize("which", ["lv", "lv_chained", "rocket", "acopf"])
+def test_benchmark_models_after_poison(libs, poison, which, monkeypatch):
+    """the benchmark models at sizes that fill the chip several times over (many wavefronts per SIMD, every kernel variant of
+    hess_coord!: plain, and the chained / staged one forced)"""
+    from exahip import ExaModel, models
+    import oracle
+    if which == "lv_chained":
+        monkeypatch.setenv("EXAHIP_HESS_VARIANT", "1")
+    core = {"lv": lambda: models.luksan_vlcek_model(1_000_000), "lv_chained": lambda: models.luksan_vlcek_model(1_000_000),
+            "rocket": lambda: models.rocket_model(100_000),
+            "acopf": lambda: models.ac_power_model(models.synthetic_power_data(20_000, 32_000, 1_700, seed=0))}[which]()
+    m = ExaModel(core)
+    o = oracle.OracleModel(m.ir)
+    x = (models.acopf_start(core) if which == "acopf" else m.meta.x0 + 0.1 * np.random.default_rng(41).uniform(-1, 1, m.meta.nvar))
+    y = np.random.default_rng(42).standard_normal(m.meta.ncon)
+    v = np.random.default_rng(43).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(44).standard_normal(m.meta.ncon)
+    check_all(m, o, x, y, v, w, poison, 1e-10)
