@@ -6,10 +6,6 @@ invisible as long as the stale contents happen to be harmless; here every archit
 filled with a NaN pattern first (a 512-register asm kernel over 4096 workgroups), then every callback runs and must still
 equal the oracle.  Small models, the deep random models (kernels with AGPR / scratch spills) and the random range models
 (windows, chunk loops) are covered."""
-import ctypes
-import os
-import subprocess
-
 import numpy as np
 import pytest
 
@@ -22,27 +18,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a
 
 @pytest.fixture(scope="module")
 def poison(tmp_path_factory):
-    import torch
-    body = ["v_mov_b32 v255, 0x7ff80000"] + [f"v_mov_b32 v{k}, 0x7ff80000" for k in range(1, 255)] + [f"v_accvgpr_write_b32 a{k}, v255" for k in range(256)]
-    clob = ", ".join(f'"v{k}"' for k in range(1, 256)) + ", " + ", ".join(f'"a{k}"' for k in range(256))
-    src = ('#include <hip/hip_runtime.h>\nextern "C" __global__ void __launch_bounds__(256) poison(int* out) {\n  asm volatile("' + "\\n".join(body)
-           + '" ::: ' + clob + ');\n  if (out && threadIdx.x == 999) out[0] = 1;\n}\n')
-    td = str(tmp_path_factory.mktemp("poison"))
-    with open(os.path.join(td, "p.hip"), "w") as fh:
-        fh.write(src)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--genco", "--offload-arch=gfx950", "-O1", "-o", os.path.join(td, "p.co"), os.path.join(td, "p.hip")])
-    hip = ctypes.CDLL("libamdhip64.so.7")
-    mod, fn = ctypes.c_void_p(), ctypes.c_void_p()
-    assert hip.hipModuleLoadData(ctypes.byref(mod), open(os.path.join(td, "p.co"), "rb").read()) == 0
-    assert hip.hipModuleGetFunction(ctypes.byref(fn), mod, b"poison") == 0
-
-    def run():
-        nullp = ctypes.c_void_p(0)
-        arr = (ctypes.c_void_p * 1)(ctypes.cast(ctypes.pointer(nullp), ctypes.c_void_p))
-        st = torch.cuda.current_stream().cuda_stream
-        assert hip.hipModuleLaunchKernel(fn, 4096, 1, 1, 256, 1, 1, 0, ctypes.c_void_p(st), arr, None) == 0
-        torch.cuda.synchronize()
-    return run
+    from poison import make_poison
+    return make_poison(str(tmp_path_factory.mktemp("poison")))
 
 
 def relerr(a, ref):

@@ -8,8 +8,10 @@ the staged / chained hess_coord! kernels, owner-sharded outputs.  Per seed:
   * J'v / H v by atomics and by the sorted gather against the default;
   * the compressed Jacobian / Hessian, densified, against the densified oracle COO;
   * 3 ranks replayed on this GPU: owner pieces into one NaN-poisoned buffer, partial sums added, COO slices tiling the whole.
-usage: range_model_check.py FIRST_SEED COUNT [mixed|unit|blocks] [NPTS]   — one line per seed, BAD at the end of a line that
-fails; a GPU fault kills the process (run chunks under `timeout`)."""
+usage: range_model_check.py FIRST_SEED COUNT [mixed|unit|blocks] [NPTS] [--poison]   — one line per seed, BAD at the end of a line
+that fails; a GPU fault kills the process (run chunks under `timeout`, ONE process at a time).  --poison: every VGPR / AGPR of
+the chip is filled with NaN before each model's callbacks (tests/poison.py): a kernel reading a lane it never wrote then fails
+every time, not when the stale contents happen to matter."""
 import os
 import sys
 
@@ -24,9 +26,16 @@ import randexpr  # noqa: E402
 from conftest import RankReplay  # noqa: E402
 from exahip import CompressedExaModel, ExaModel, capi  # noqa: E402
 
-first, count = int(sys.argv[1]), int(sys.argv[2])
-flavour = sys.argv[3] if len(sys.argv) > 3 else "mixed"
-npts_arg = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+POISON = "--poison" in sys.argv
+argv = [a for a in sys.argv if a != "--poison"]
+first, count = int(argv[1]), int(argv[2])
+flavour = argv[3] if len(argv) > 3 else "mixed"
+npts_arg = int(argv[4]) if len(argv) > 4 else 0
+poison = (lambda: None)
+if POISON:
+    import tempfile
+    from poison import make_poison
+    poison = make_poison(tempfile.mkdtemp())
 dev = torch.device("cuda:0")
 TOL = 1e-9
 
@@ -78,6 +87,7 @@ for seed in range(first, first + count):
     R = {"obj": o.obj(x), "cons": o.cons(x), "grad": o.grad(x), "jac": o.jac_coord(x), "hess": o.hess_coord(x, y, 0.7),
          "jprod": o.jprod(x, v), "jtprod": o.jtprod(x, w), "hprod": o.hprod(x, y, v, 0.7)}
     E = {}
+    poison()
     E["obj"] = abs(m.obj(x) - R["obj"]) / max(1.0, abs(R["obj"])) if np.isfinite(R["obj"]) else 0.0
     E["cons"] = rel(m.cons(x), R["cons"]); E["grad"] = rel(m.grad(x), R["grad"])
     E["jac"] = rel(m.jac_coord(x), R["jac"]); E["hess"] = rel(m.hess_coord(x, y, 0.7), R["hess"])
@@ -85,6 +95,7 @@ for seed in range(first, first + count):
     ok_struct = all(np.array_equal(a, b) for a, b in zip(m.jac_structure() + m.hess_structure(), o.jac_structure() + o.hess_structure()))
     E["struct"] = 0.0 if ok_struct else 1.0
     # all five from one sweep
+    poison()
     f, g, c, j, h = m.eval_all(xd, yd, 0.7)
     torch.cuda.synchronize()
     E["all"] = max(rel(g.cpu().numpy(), R["grad"]), rel(c.cpu().numpy()[:ncon], R["cons"]), rel(j.cpu().numpy()[:m.meta.nnzj], R["jac"]),
@@ -96,6 +107,7 @@ for seed in range(first, first + count):
         mv = with_env({"EXAHIP_HESS_VARIANT": str(var)}, lambda: ExaModel(mk()))
         kinds.append(mv._L.exa_hess_variant(mv.id))
         out = torch.full((m.meta.nnzh + 8,), float("nan"), dtype=torch.float64, device=dev)
+        poison()
         mv.hess_coord(xd, yd, 0.7, out=out)
         torch.cuda.synchronize()
         got = out.cpu().numpy()
@@ -111,10 +123,12 @@ for seed in range(first, first + count):
             m.set_product_mode(mode, mode)
         except capi.ExaHipError:
             continue
+        poison()
         E[f"jt{mode}"] = rel(m.jtprod(x, w), R["jtprod"]); E[f"hp{mode}"] = rel(m.hprod(x, y, v, 0.7), R["hprod"])
     m.set_product_mode(-1, -1)
     # compressed COO
     cm = CompressedExaModel(m)
+    poison()
     for kind, nrow in (("jac", max(ncon, 1)), ("hess", nvar)):
         r_, c_ = o.jac_structure() if kind == "jac" else o.hess_structure()
         want = densify(r_, c_, R[kind], nrow, nvar)
@@ -132,6 +146,7 @@ for seed in range(first, first + count):
     try:
         for r in range(W):
             m.set_shard(r, W)
+            poison()
             objs += m.obj(x)
             rr.add("grad", lambda out: m.grad(xd, out=out)); rr.add("cons", lambda out: m.cons(xd, out=out))
             rr.add("jprod", lambda out: m.jprod(xd, vd, out=out)); rr.add("jtprod", lambda out: m.jtprod(xd, wd, out=out))
