@@ -4,8 +4,8 @@ tools/poison_registers.py found the mechanism behind "wrong, run-to-run differen
 (profiles/NOTES.md): the compiled code read stale register lanes — contents of whatever kernel ran before.  Such a read is
 invisible as long as the stale contents happen to be harmless; here every architectural VGPR and every AGPR of the chip is
 filled with a NaN pattern first (a 512-register asm kernel over 4096 workgroups), then every callback runs and must still
-equal the oracle.  Small models, the deep random models (kernels with AGPR / scratch spills) and the random range models
-(windows, chunk loops) are covered."""
+equal the oracle.  Small models, deep random models (kernels with AGPR / scratch spills), random range models (windows, chunk
+loops) and the benchmark models are covered; tools/range_model_check.py --poison sweeps more seeds the same way."""
 import numpy as np
 import pytest
 
@@ -66,7 +66,7 @@ def test_zoo_after_poison(libs, poison, name):
     check_all(m, o, x, y, v, w, poison, 1e-10)
 
 
-@pytest.mark.parametrize("seed", [523, 541, 1011, 1013, 1029])
+@pytest.mark.parametrize("seed", [523, 1011])
 def test_deep_random_models_after_poison(libs, poison, seed, monkeypatch):
     from exahip import ExaModel
     import oracle
@@ -80,7 +80,7 @@ def test_deep_random_models_after_poison(libs, poison, seed, monkeypatch):
     check_all(m, o, x, y, v, w, poison, 1e-9)
 
 
-@pytest.mark.parametrize("seed,flavour", [(8, ""), (14, ""), (1, "blocks"), (205, "blocks"), (208, "blocks"), (227, "blocks")])
+@pytest.mark.parametrize("seed,flavour", [(8, ""), (1, "blocks"), (227, "blocks")])
 def test_random_range_models_after_poison(libs, poison, seed, flavour):
     """(1, blocks) is the model whose Hv window kernel read stale lanes; the library now refuses that kernel, and what runs
     instead must be clean as well"""
