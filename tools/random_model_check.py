@@ -20,6 +20,13 @@ import oracle  # noqa: E402
 from exahip import ExaModel  # noqa: E402
 
 seed, npat, depth = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+poison = (lambda: None)
+if os.environ.get("POISON"):
+    # every VGPR / AGPR of the chip filled with NaN before each group of calls (tests/poison.py): a kernel that reads a lane it
+    # never wrote then fails every time
+    import tempfile
+    from poison import make_poison
+    poison = make_poison(tempfile.mkdtemp())
 randexpr.NPTS = 300
 m = ExaModel(randexpr.build_model(seed, npat, depth))
 o = oracle.OracleModel(m.ir)
@@ -40,7 +47,9 @@ def rel(a, b):
 
 errs = []
 for _ in range(2):
+    poison()
     errs += [rel(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)), rel(m.jtprod(x, w), o.jtprod(x, w))]
+poison()
 errs += [rel(m.grad(x), o.grad(x))]
 m.set_grad_mode(1)
 errs += [rel(m.grad(x), o.grad(x))]
@@ -48,15 +57,18 @@ if os.environ.get("CHECK_ALL"):
     # the remaining callbacks: values, COO kernels, the fused sweep, the sorted products, the compressed COO
     import torch
     from exahip import CompressedExaModel
+    poison()
     errs += [abs(m.obj(x) - o.obj(x)) / (1 + abs(o.obj(x))), rel(m.cons(x), o.cons(x)), rel(m.jac_coord(x), o.jac_coord(x)),
              rel(m.hess_coord(x, y, 0.7), o.hess_coord(x, y, 0.7)), rel(m.jprod(x, v), o.jprod(x, v))]
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    poison()
     f, c, j, h = m.eval_fused(xd, yd, 0.7)
     errs += [abs(float(f[0]) - o.obj(x)) / (1 + abs(o.obj(x))), rel(c.cpu().numpy(), o.cons(x)), rel(j.cpu().numpy(), o.jac_coord(x)),
              rel(h.cpu().numpy(), o.hess_coord(x, y, 0.7))]
     m.set_product_mode(1, 1)
     errs += [rel(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)), rel(m.jtprod(x, w), o.jtprod(x, w))]
     cm = CompressedExaModel(m)
+    poison()
     for kind, nrow in (("jac", max(m.meta.ncon, 1)), ("hess", m.meta.nvar)):
         r, cc = (o.jac_structure() if kind == "jac" else o.hess_structure())
         vals = o.jac_coord(x) if kind == "jac" else o.hess_coord(x, y, 0.7)
