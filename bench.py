@@ -490,7 +490,9 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_for(m, config, per_gpu if world > 1 else points),
                      "kernel": HESS_KERNELS[L.exa_hess_variant(m.id)], "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                     "block_order": {0: "sequential", 1: "interleaved-128"}.get(L.exa_block_order(m.id, 4), "n/a")},
+                     "block_order": {0: "sequential", 1: "interleaved-128"}.get(L.exa_block_order(m.id, 4), "n/a"),
+                     # one hess_coord! = ONE launch whatever the number of patterns (ACOPF: 15 patterns, one launch)
+                     "launches_per_eval": 1, "patterns": int(m.npatterns)},
         "build": {"module": how, "module_name": L.exa_module_name(m.id).decode(), "hess_kernel": HESS_KERNELS[L.exa_hess_variant(m.id)],
                   "compile_ms": compile_ms, "model_build_s": build_s, "first_hess_call_ms": first_call_ms,
                   "tune_ms": tune_ms,
