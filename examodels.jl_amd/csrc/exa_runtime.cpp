@@ -1425,7 +1425,7 @@ void plan_products(Handle &h) {
 }
 // A window module, compiled or fetched — and ASKED: a kernel that sums across lanes (exa_block_sum: the all-points entries
 // summed inside a window kernel, or by exa_*s) must not spill registers.  With scratch in play such kernels have returned
-// wrong, run-to-run different sums (tools/window_sweep.py 227 1 blocks: a 12-pass Hv window kernel under a 6-wave occupancy
+// wrong, run-to-run different sums (tests/sweeps/window_sweep.py 227 1 blocks: a 12-pass Hv window kernel under a 6-wave occupancy
 // hint, 820 B of scratch per lane; the same finding as for the scatter kernels, module_for).  A window kernel is used only
 // if it compiled within the 256 architectural VGPRs: no scratch, no spilled VGPRs, no AGPRs.  The registers and scratch of
 // every kernel are in the code object's metadata.  spills(kind) -> true when a cross-lane kernel of that kind spills.

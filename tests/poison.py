@@ -1,4 +1,4 @@
-"""The register-poison kernel shared by tests/test_gpu_poison.py and tools/range_model_check.py --poison: leaves a NaN pattern in
+"""The register-poison kernel shared by tests/test_gpu_poison.py and tests/sweeps/range_model_check.py --poison: leaves a NaN pattern in
 every architectural VGPR and every AGPR of the SIMDs it runs on (a 512-register asm kernel; 4096 workgroups cover the chip
 several times).  A kernel that afterwards reads a register lane it never wrote produces NaN instead of plausible garbage."""
 import ctypes

@@ -7,7 +7,7 @@ Written for the reproducer of profiles/NOTES.md (random range model, seed 1, blo
 12-pass kernel with 256 + 74 registers).  The shipped library refuses that window kernel (window_kernels_spill); to reproduce,
 lift the rule there.  Result of 2026-09: 995 wrong entries -> 995 NaN after the poison, and they stay NaN in later launches."""
 import os, sys, subprocess, tempfile, ctypes
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("examodels.jl_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np, torch

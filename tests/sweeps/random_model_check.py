@@ -4,14 +4,14 @@ oracle: H*v and J'v by atomics (twice, interleaved: stale spill space shows on t
 Prints one line; a GPU fault kills the process, so sweeps run one process per seed:
 
     (for s in $(seq 1000 1099); do echo "$s 12 6"; done) | xargs -P 6 -L 1 sh -c \\
-        'timeout 300 python tools/random_model_check.py $0 $1 $2 2>&1 | grep seed || echo "seed $0 $1 $2 CRASH"'
+        'timeout 300 python tests/sweeps/random_model_check.py $0 $1 $2 2>&1 | grep seed || echo "seed $0 $1 $2 CRASH"'
 
 Entries whose Jacobian / Hessian values themselves differ from the oracle at 1e-6 (magnitudes of 1e20 and more: seeds
 2005, 2034 at depth 5) are conditioning of the random expression, not of the kernels."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("examodels.jl_amd", "tests", "oracle"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np  # noqa: E402

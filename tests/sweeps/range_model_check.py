@@ -15,7 +15,7 @@ every time, not when the stale contents happen to matter."""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in ("examodels.jl_amd", "oracle", "tests"):
     sys.path.insert(0, os.path.join(ROOT, p))
 import numpy as np  # noqa: E402

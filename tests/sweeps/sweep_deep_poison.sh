@@ -1,0 +1,6 @@
+# sequential sweep of deep random data-indexed models (one process per seed: a GPU fault kills only that seed), every callback
+# after a NaN poisoning of the register files.  usage: bash tests/sweeps/sweep_deep_poison.sh FIRST COUNT [NPAT=12] [DEPTH=6]
+F=${1:-2000}; C=${2:-20}; NP=${3:-12}; D=${4:-6}
+for s in $(seq $F $((F + C - 1))); do
+  POISON=1 CHECK_ALL=1 timeout 300 python tests/sweeps/random_model_check.py $s $NP $D 2>&1 | grep "^seed" | cut -c1-140 || echo "seed $s CRASH"
+done

@@ -1,11 +1,11 @@
 """No kernel of the library may read a register lane it did not write.
 
-tools/poison_registers.py found the mechanism behind "wrong, run-to-run different" window sums of an over-sized kernel
+tests/sweeps/poison_registers.py found the mechanism behind "wrong, run-to-run different" window sums of an over-sized kernel
 (profiles/NOTES.md): the compiled code read stale register lanes — contents of whatever kernel ran before.  Such a read is
 invisible as long as the stale contents happen to be harmless; here every architectural VGPR and every AGPR of the chip is
 filled with a NaN pattern first (a 512-register asm kernel over 4096 workgroups), then every callback runs and must still
 equal the oracle.  Small models, deep random models (kernels with AGPR / scratch spills), random range models (windows, chunk
-loops) and the benchmark models are covered; tools/range_model_check.py --poison sweeps more seeds the same way."""
+loops) and the benchmark models are covered; tests/sweeps/range_model_check.py --poison sweeps more seeds the same way."""
 import numpy as np
 import pytest
 

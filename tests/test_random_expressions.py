@@ -90,7 +90,7 @@ def test_random_patterns_values_on_hip(libs, seed):
 def test_deep_random_patterns_on_hip(libs, seed, monkeypatch):
     """Depth-6 trees over 300 data points: Hessian bodies of hundreds to thousands of SSA values per pattern, kernels at
     the 512-register limit with AGPR / scratch spills.  Regression cases of the scatter kernels (J'v, H*v by atomics),
-    found by sweeps over a few hundred such models (tools/random_model_check.py):
+    found by sweeps over a few hundred such models (tests/sweeps/random_model_check.py):
       523          wrong H*v and an occasional memory fault when the 16-tile loop was unrolled twice (round 1);
       541          memory fault with a lane-group peeling loop inside a 5 000-line body;
       1011, 1029   wrong / NaN entries of H*v once patterns were fused into groups — per-lane sums of shared targets
