@@ -132,3 +132,25 @@ def test_benchmark_models_after_poison(libs, poison, which, monkeypatch):
     v = np.random.default_rng(43).standard_normal(m.meta.nvar)
     w = np.random.default_rng(44).standard_normal(m.meta.ncon)
     check_all(m, o, x, y, v, w, poison, 1e-10)
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_headline_size_after_poison(libs, poison, variant, monkeypatch):
+    """BASELINE config 2 itself (Luksan-Vlcek N = 1e7, the 9e7-entry Hessian), by the plain kernel and by the chained / staged
+    one, each right after the poisoning, against the oracle's full vector"""
+    import torch
+    from exahip import ExaModel, models
+    import oracle
+    monkeypatch.setenv("EXAHIP_HESS_VARIANT", str(variant))
+    N = 10_000_000
+    m = ExaModel(models.luksan_vlcek_model(N))
+    assert m._L.exa_hess_variant(m.id) == variant
+    o = oracle.OracleModel(m.ir, threads=16)
+    x = m.meta.x0 + 0.1 * np.random.default_rng(51).uniform(-1, 1, N)
+    y = np.random.default_rng(52).standard_normal(m.meta.ncon)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    out = torch.full((m.meta.nnzh,), float("nan"), dtype=torch.float64, device="cuda")
+    poison()
+    m.hess_coord(xd, yd, 0.5, out=out)
+    torch.cuda.synchronize()
+    assert relerr(out.cpu().numpy(), o.hess_coord(x, y, 0.5)) <= 1e-10
