@@ -1,4 +1,4 @@
-// exa_build.cpp — turns a generated HIP module (exa_codegen.cpp) into a gfx950 code object.
+// exa_build.cpp — turns a generated HIP module (exa_gen_*.cpp) into a gfx950 code object.
 //
 // The reference specialises its kernels inside the process at first call (Julia's JIT behind
 // ext/ExaModelsKernelAbstractions.jl:608-653).  Here:
@@ -207,6 +207,20 @@ std::vector<std::string> base_flags() {
     }
     return f;
 }
+// Conservative register allocation for a module one of whose kernels has outgrown the 256 architectural VGPRs (AGPRs or
+// scratch as spill space).  Such kernels have returned wrong, run-to-run different sums under the default allocator
+// (profiles/NOTES.md round 3: exa_hprodw with 256 + 84 registers reads lanes it never wrote; tests/sweeps/canary); the same
+// source is exact with region splitting of live ranges switched off.  $EXAHIP_SAFE_FLAGS overrides; "none" = no fallback.
+std::vector<std::string> safe_flag_list() {
+    const char *env = getenv("EXAHIP_SAFE_FLAGS");
+    std::string text = env && *env ? env : "-mllvm -grow-region-complexity-budget=0";
+    std::vector<std::string> f;
+    if (text == "none") return f;
+    std::istringstream ss(text);
+    std::string t;
+    while (ss >> t) f.push_back(t);
+    return f;
+}
 std::string join(const std::vector<std::string> &v) {
     std::string s;
     for (const auto &t : v) { if (!s.empty()) s += ' '; s += t; }
@@ -299,11 +313,10 @@ Tool pick_tool(std::string &identity) {
     return Tool::Hipcc;
 }
 
-std::vector<char> compile_hiprtc(const std::string &source) {
+std::vector<char> compile_hiprtc(const std::string &source, const std::vector<std::string> &flags) {
     Rtc &r = rtc();
     hiprtcProgram prog = nullptr;
     if (r.create(&prog, source.c_str(), "exa_module.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) throw std::runtime_error("hiprtcCreateProgram failed");
-    const std::vector<std::string> flags = base_flags();
     std::vector<const char *> opts;
     for (const auto &f : flags) opts.push_back(f.c_str());
     const hiprtcResult rc = r.compile(prog, (int)opts.size(), opts.data());
@@ -325,13 +338,13 @@ std::vector<char> compile_hiprtc(const std::string &source) {
     return image;
 }
 
-std::vector<char> compile_hipcc(const std::string &source, const std::string &workdir) {
+std::vector<char> compile_hipcc(const std::string &source, const std::string &workdir, const std::vector<std::string> &flags) {
     if (workdir.empty()) throw std::runtime_error("hipcc needs a writable cache directory (set EXAHIP_CACHE_DIR) and none was found");
     const std::string stem = workdir + "/build" + unique_suffix();
     const std::string src = stem + ".hip", obj = stem + ".hsaco", log = stem + ".log";
     write_atomically(src, source.data(), source.size());
     auto q = [](const std::string &p) { return "'" + p + "'"; };   // paths may contain spaces; they never contain quotes
-    const std::string cmd = q(hipcc_path()) + " --genco " + join(base_flags()) + " -o " + q(obj) + " " + q(src) + " > " + q(log) + " 2>&1";
+    const std::string cmd = q(hipcc_path()) + " --genco " + join(flags) + " -o " + q(obj) + " " + q(src) + " > " + q(log) + " 2>&1";
     const int rc = std::system(cmd.c_str());
     std::vector<char> image;
     const bool ok = rc == 0 && read_regular_file(obj, image);
@@ -380,18 +393,28 @@ bool cache_add(const std::string &name, const void *blob, size_t len) {
     return true;
 }
 
-CodeObject get_code_object(const std::string &source, bool memory_only_ok) {
+std::string safe_flags() { return join(safe_flag_list()); }
+bool cache_has(const std::string &name) {
+    std::lock_guard<std::mutex> lk(g_pre_mu);
+    return g_preloaded.count(name) != 0;
+}
+
+CodeObject get_code_object(const std::string &source, bool memory_only_ok, bool safe) {
     CodeObject co;
     co.key = source_key(source);
+    co.safe = safe;
+    co.name = co.key + (safe ? "_safe" : "");
     const auto t0 = std::chrono::steady_clock::now();
     if (memory_only_ok) {      // a caller that wants the FILE (exa_compile: packing) gets a real cache entry instead
         std::lock_guard<std::mutex> lk(g_pre_mu);
-        auto it = g_preloaded.find(co.key);
-        if (it != g_preloaded.end()) { co.image = it->second; co.how = "preloaded"; co.path = "(preloaded) " + co.key; return co; }
+        auto it = g_preloaded.find(co.name);
+        if (it != g_preloaded.end()) { co.image = it->second; co.how = "preloaded"; co.path = "(preloaded) " + co.name; return co; }
     }
     std::string identity;
     const Tool tool = pick_tool(identity);
-    const std::string file = co.key + "-" + sha256_hex(join(base_flags()) + "|" + identity + "|" + kArch).substr(0, 12) + ".hsaco";
+    std::vector<std::string> flags = base_flags();
+    if (safe) for (const std::string &f : safe_flag_list()) flags.push_back(f);
+    const std::string file = co.key + "-" + sha256_hex(join(flags) + "|" + identity + "|" + kArch).substr(0, 12) + ".hsaco";
     for (const std::string &d : read_dirs()) {
         const std::string p = d + "/" + file;
         if (read_regular_file(p, co.image) && (looks_like_code_object(co.image.data(), co.image.size()) || looks_like_bundle(co.image.data(), co.image.size()))) {
@@ -400,8 +423,8 @@ CodeObject get_code_object(const std::string &source, bool memory_only_ok) {
         }
     }
     const std::string wdir = writable_cache_dir();
-    if (tool == Tool::Hiprtc) { co.image = compile_hiprtc(source); co.how = "hiprtc"; }
-    else { co.image = compile_hipcc(source, wdir); co.how = "hipcc"; }
+    if (tool == Tool::Hiprtc) { co.image = compile_hiprtc(source, flags); co.how = "hiprtc"; }
+    else { co.image = compile_hipcc(source, wdir, flags); co.how = "hipcc"; }
     co.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!wdir.empty()) {
         co.path = wdir + "/" + file;
@@ -410,11 +433,11 @@ CodeObject get_code_object(const std::string &source, bool memory_only_ok) {
             if (getenv("EXAHIP_KEEP_SOURCE")) write_atomically(wdir + "/" + co.key + ".hip", source.data(), source.size());
         } catch (const std::exception &) {
             if (!memory_only_ok) throw;
-            co.path = "(memory) " + co.key;      // a cache that cannot be written is not an error for a loaded module
+            co.path = "(memory) " + co.name;      // a cache that cannot be written is not an error for a loaded module
         }
     } else {
         if (!memory_only_ok) throw std::runtime_error("no writable kernel cache directory (EXAHIP_CACHE_DIR, <install>/kernel_cache, ~/.cache/exahip)");
-        co.path = "(memory) " + co.key;
+        co.path = "(memory) " + co.name;
     }
     return co;
 }
@@ -450,41 +473,177 @@ void note_store(const std::string &key, const std::string &note, bool persist) {
     try { write_atomically(d + "/" + key + ".note", note.data(), note.size()); } catch (const std::exception &) {}
 }
 
-// ---- resources of a kernel, read from the code object's AMDGPU metadata (msgpack in an ELF note) -----------------------------
-// The kernel's map holds its keys in sorted order: .agpr_count ... .name ... .private_segment_fixed_size ... .vgpr_count,
-// .vgpr_spill_count.  Enough of msgpack is understood here to read the unsigned integers that follow those keys.
-bool kernel_resources(const std::vector<char> &image, const std::string &kernel, int *vgpr, int *agpr, int *scratch, int *vgpr_spill, int *sgpr_spill) {
-    const std::string img(image.begin(), image.end());
-    auto mstr = [](const std::string &t) { return std::string(1, (char)(0xa0 | t.size())) + t; };      // fixstr (< 32 bytes)
-    auto uint_at = [&](size_t p, long *out) {
-        if (p >= img.size()) return false;
-        const unsigned char c = (unsigned char)img[p];
-        if (c <= 0x7f) { *out = c; return true; }
-        auto be = [&](int n) { long v = 0; for (int i = 1; i <= n; i++) v = (v << 8) | (unsigned char)img[p + i]; return v; };
-        if (c == 0xcc && p + 1 < img.size()) { *out = be(1); return true; }
-        if (c == 0xcd && p + 2 < img.size()) { *out = be(2); return true; }
-        if (c == 0xce && p + 4 < img.size()) { *out = be(4); return true; }
+// ---- resources of the kernels, read from the code object's AMDGPU metadata (msgpack in an ELF note) -------------------------
+// ELF64 -> SHT_NOTE sections (or PT_NOTE segments) -> the note (name "AMDGPU", type NT_AMDGPU_METADATA = 32) -> msgpack map
+// { "amdhsa.kernels": [ { ".name": ..., ".vgpr_count": ..., ".agpr_count": ..., ".private_segment_fixed_size": ..., ... } ] }.
+// A real (if minimal) msgpack reader: every object is either understood or skipped by its encoded length, so a kernel's
+// numbers can only come from that kernel's own map.  hipcc --genco wraps the ELF in a clang offload bundle: its amdgcn entry
+// is unwrapped first.
+namespace {
+struct MsgPack {
+    const unsigned char *p, *end;
+    bool ok = true;
+    bool need(size_t n) { if ((size_t)(end - p) < n) { ok = false; return false; } return true; }
+    uint64_t be(int n) { uint64_t v = 0; for (int i = 0; i < n; i++) v = (v << 8) | p[i]; p += n; return v; }
+    // header of the next object: kind 'm' map, 'a' array, 's' str, 'b' opaque bytes (len of them follow), 'u' unsigned,
+    // 'i' signed, 'n' nil / bool; len = element count / byte length / value
+    bool head(char &kind, uint64_t &len) {
+        if (!need(1)) return false;
+        const unsigned char c = *p++;
+        if (c <= 0x7f) { kind = 'u'; len = c; return true; }
+        if (c <= 0x8f) { kind = 'm'; len = c & 0x0f; return true; }
+        if (c <= 0x9f) { kind = 'a'; len = c & 0x0f; return true; }
+        if (c <= 0xbf) { kind = 's'; len = c & 0x1f; return true; }
+        if (c >= 0xe0) { kind = 'i'; len = (uint64_t)(int64_t)(signed char)c; return true; }
+        auto sized = [&](char k, int n) { if (!need((size_t)n)) return false; kind = k; len = be(n); return true; };
+        switch (c) {
+        case 0xc0: case 0xc2: case 0xc3: kind = 'n'; len = c == 0xc3; return true;
+        case 0xc4: return sized('b', 1);
+        case 0xc5: return sized('b', 2);
+        case 0xc6: return sized('b', 4);
+        case 0xc7: if (!sized('b', 1)) return false; len += 1; return true;     // ext: + its type byte
+        case 0xc8: if (!sized('b', 2)) return false; len += 1; return true;
+        case 0xc9: if (!sized('b', 4)) return false; len += 1; return true;
+        case 0xca: kind = 'b'; len = 4; return true;                            // float32 / float64: skipped as bytes
+        case 0xcb: kind = 'b'; len = 8; return true;
+        case 0xcc: return sized('u', 1);
+        case 0xcd: return sized('u', 2);
+        case 0xce: return sized('u', 4);
+        case 0xcf: return sized('u', 8);
+        case 0xd0: if (!sized('i', 1)) return false; len = (uint64_t)(int64_t)(int8_t)len; return true;
+        case 0xd1: if (!sized('i', 2)) return false; len = (uint64_t)(int64_t)(int16_t)len; return true;
+        case 0xd2: if (!sized('i', 4)) return false; len = (uint64_t)(int64_t)(int32_t)len; return true;
+        case 0xd3: return sized('i', 8);
+        case 0xd4: kind = 'b'; len = 2; return true;                            // fixext 1 / 2 / 4 / 8 / 16
+        case 0xd5: kind = 'b'; len = 3; return true;
+        case 0xd6: kind = 'b'; len = 5; return true;
+        case 0xd7: kind = 'b'; len = 9; return true;
+        case 0xd8: kind = 'b'; len = 17; return true;
+        case 0xd9: return sized('s', 1);
+        case 0xda: return sized('s', 2);
+        case 0xdb: return sized('s', 4);
+        case 0xdc: return sized('a', 2);
+        case 0xdd: return sized('a', 4);
+        case 0xde: return sized('m', 2);
+        case 0xdf: return sized('m', 4);
+        }
+        ok = false;
         return false;
-    };
-    const std::string name_kv = mstr(".name") + (kernel.size() < 32 ? mstr(kernel) : std::string(1, (char)0xd9) + std::string(1, (char)kernel.size()) + kernel);
-    const size_t at = img.find(name_kv);
-    if (at == std::string::npos) return false;
-    auto after = [&](const std::string &key, long *out) {      // first occurrence behind .name: the same kernel's map
-        const size_t p = img.find(mstr(key), at);
-        return p != std::string::npos && uint_at(p + 1 + key.size(), out);
-    };
-    auto before = [&](const std::string &key, long *out) {
-        const size_t p = img.rfind(mstr(key), at);
-        return p != std::string::npos && uint_at(p + 1 + key.size(), out);
-    };
-    long v = 0, a = 0, sc = 0, sp = 0, ss = 0;
-    if (!after(".private_segment_fixed_size", &sc) || !after(".vgpr_count", &v)) return false;
-    (void)before(".agpr_count", &a);
-    (void)after(".vgpr_spill_count", &sp);
-    (void)after(".sgpr_spill_count", &ss);
-    *vgpr = (int)v; *agpr = (int)a; *scratch = (int)sc; *vgpr_spill = (int)sp;
-    if (sgpr_spill) *sgpr_spill = (int)ss;
-    return true;
+    }
+    bool skip(int depth = 0) {
+        char k; uint64_t n;
+        if (depth > 64 || !head(k, n)) { ok = false; return false; }
+        if (k == 's' || k == 'b') { if (!need((size_t)n)) return false; p += n; return true; }
+        if (k == 'a') { for (uint64_t i = 0; i < n; i++) if (!skip(depth + 1)) return false; return true; }
+        if (k == 'm') { for (uint64_t i = 0; i < 2 * n; i++) if (!skip(depth + 1)) return false; return true; }
+        return true;
+    }
+    bool str(std::string &out) {
+        char k; uint64_t n;
+        if (!head(k, n) || k != 's' || !need((size_t)n)) { ok = false; return false; }
+        out.assign((const char *)p, (size_t)n); p += n;
+        return true;
+    }
+};
+uint64_t le(const unsigned char *q, int n) { uint64_t v = 0; for (int i = n - 1; i >= 0; i--) v = (v << 8) | q[i]; return v; }
+// the gfx950 ELF inside a clang offload bundle ("__CLANG_OFFLOAD_BUNDLE__", u64 entries, then per entry offset, size, triple)
+bool unbundle(const unsigned char *&b, size_t &n) {
+    if (n < 32 || memcmp(b, "__CLANG_OFFLOAD_BUNDLE__", 24) != 0) return true;      // not a bundle: as it is
+    const uint64_t cnt = le(b + 24, 8);
+    size_t at = 32;
+    for (uint64_t e = 0; e < cnt && e < 64; e++) {
+        if (at + 24 > n) return false;
+        const uint64_t off = le(b + at, 8), size = le(b + at + 8, 8), tl = le(b + at + 16, 8);
+        at += 24;
+        if (tl > n || at + tl > n) return false;
+        const std::string triple((const char *)b + at, (size_t)tl);
+        at += (size_t)tl;
+        if (triple.find("amdgcn") != std::string::npos && off <= n && size <= n - off && size >= 64) { b += off; n = (size_t)size; return true; }
+    }
+    return false;
+}
+bool parse_metadata(const unsigned char *d, size_t n, std::vector<KernelInfo> &out) {
+    MsgPack mp{d, d + n};
+    char k; uint64_t top;
+    if (!mp.head(k, top) || k != 'm') return false;
+    bool found = false;
+    for (uint64_t i = 0; i < top && mp.ok; i++) {
+        std::string key;
+        if (!mp.str(key)) return false;
+        if (key != "amdhsa.kernels") { if (!mp.skip()) return false; continue; }
+        uint64_t nk;
+        if (!mp.head(k, nk) || k != 'a') return false;
+        found = true;
+        for (uint64_t j = 0; j < nk; j++) {
+            uint64_t nf;
+            if (!mp.head(k, nf) || k != 'm') return false;
+            KernelInfo ki;
+            bool have_v = false, have_sc = false;
+            for (uint64_t f = 0; f < nf; f++) {
+                std::string fk;
+                if (!mp.str(fk)) return false;
+                if (fk == ".name") { if (!mp.str(ki.name)) return false; continue; }
+                int *dst = fk == ".vgpr_count" ? &ki.vgpr : fk == ".agpr_count" ? &ki.agpr : fk == ".sgpr_count" ? &ki.sgpr : fk == ".private_segment_fixed_size" ? &ki.scratch
+                         : fk == ".vgpr_spill_count" ? &ki.vgpr_spill : fk == ".sgpr_spill_count" ? &ki.sgpr_spill : fk == ".group_segment_fixed_size" ? &ki.lds : nullptr;
+                if (!dst) { if (!mp.skip()) return false; continue; }
+                uint64_t v;
+                if (!mp.head(k, v) || (k != 'u' && k != 'i')) return false;
+                *dst = (int)v;
+                have_v = have_v || fk == ".vgpr_count";
+                have_sc = have_sc || fk == ".private_segment_fixed_size";
+            }
+            if (ki.name.empty() || !have_v || !have_sc) return false;      // a kernel entry without its basic facts: not understood
+            out.push_back(ki);
+        }
+    }
+    return found && mp.ok;
+}
+}  // namespace
+
+bool code_object_kernels(const std::vector<char> &image, std::vector<KernelInfo> &out) {
+    out.clear();
+    const unsigned char *b = (const unsigned char *)image.data();
+    size_t n = image.size();
+    if (!unbundle(b, n) || !looks_like_code_object(b, n)) return false;
+    // notes: SHT_NOTE sections, else PT_NOTE segments
+    std::vector<std::pair<uint64_t, uint64_t>> notes;
+    const uint64_t shoff = le(b + 0x28, 8), phoff = le(b + 0x20, 8);
+    const unsigned shentsize = (unsigned)le(b + 0x3a, 2), shnum = (unsigned)le(b + 0x3c, 2), phentsize = (unsigned)le(b + 0x36, 2), phnum = (unsigned)le(b + 0x38, 2);
+    if (shoff && shentsize >= 64 && shoff <= n && (uint64_t)shentsize * shnum <= n - shoff)
+        for (unsigned i = 0; i < shnum; i++) {
+            const unsigned char *sh = b + shoff + (uint64_t)i * shentsize;
+            if (le(sh + 4, 4) == 7) notes.push_back({le(sh + 0x18, 8), le(sh + 0x20, 8)});
+        }
+    if (notes.empty() && phoff && phentsize >= 56 && phoff <= n && (uint64_t)phentsize * phnum <= n - phoff)
+        for (unsigned i = 0; i < phnum; i++) {
+            const unsigned char *ph = b + phoff + (uint64_t)i * phentsize;
+            if (le(ph, 4) == 4) notes.push_back({le(ph + 8, 8), le(ph + 0x20, 8)});
+        }
+    for (const auto &nt : notes) {
+        if (nt.first > n || nt.second > n - nt.first) continue;
+        uint64_t at = nt.first;
+        const uint64_t stop = nt.first + nt.second;
+        while (at + 12 <= stop) {
+            const uint64_t namesz = le(b + at, 4), descsz = le(b + at + 4, 4), type = le(b + at + 8, 4);
+            const uint64_t name_at = at + 12, desc_at = name_at + ((namesz + 3) & ~(uint64_t)3);
+            if (desc_at > stop || descsz > stop - desc_at) break;
+            if (type == 32 && namesz >= 6 && memcmp(b + name_at, "AMDGPU", 6) == 0) return parse_metadata(b + desc_at, (size_t)descsz, out);
+            at = desc_at + ((descsz + 3) & ~(uint64_t)3);
+        }
+    }
+    return false;
+}
+
+bool kernel_resources(const std::vector<char> &image, const std::string &kernel, int *vgpr, int *agpr, int *scratch, int *vgpr_spill, int *sgpr_spill) {
+    std::vector<KernelInfo> ks;
+    if (!code_object_kernels(image, ks)) return false;
+    for (const KernelInfo &k : ks)
+        if (k.name == kernel) {
+            *vgpr = k.vgpr; *agpr = k.agpr; *scratch = k.scratch; *vgpr_spill = k.vgpr_spill;
+            if (sgpr_spill) *sgpr_spill = k.sgpr_spill;
+            return true;
+        }
+    return false;
 }
 
 // ---- persisted tuning decisions: <cache>/<source key>.tune, lines "<signature> <value>" ---------------------------

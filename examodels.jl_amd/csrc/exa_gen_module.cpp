@@ -83,7 +83,10 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
                 for (auto &g : L.groups[cb]) {
                     int have = 0, have_raw = 0;
                     for (int q : g) { have += slots(q); have_raw += raw(q); }
-                    if ((int)g.size() < kGroupMax && have + slots(k) <= cap && have_raw + raw(k) <= rawcap && m.pats[g.front()].n == m.pats[k].n &&
+                    // (Hessian callbacks: objective patterns only among themselves — the objective-only forms, y == NULL, launch
+                    // the objective groups alone and leave exact zeros in the constraint slots, nlp.jl:1912-1914)
+                    const bool obj_mix = (cb == CB_HESS || cb == CB_HPROD) && (m.pats[g.front()].kind == EXA_PAT_OBJ) != (m.pats[k].kind == EXA_PAT_OBJ);
+                    if ((int)g.size() < kGroupMax && have + slots(k) <= cap && have_raw + raw(k) <= rawcap && m.pats[g.front()].n == m.pats[k].n && !obj_mix &&
                         !(cb == CB_FUSED && m.pats[g.front()].kind == EXA_PAT_OBJ)) {
                         g.push_back(k); placed = true; break;
                     }

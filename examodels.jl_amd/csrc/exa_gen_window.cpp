@@ -303,7 +303,8 @@ static void gen_window_x(std::ostringstream &os, const std::vector<int> &S, cons
     const KindNames &kn = kKind[wk];
     int smax = 1;
     for (int k : pk) smax = std::max(smax, S[k]);
-    os << "extern \"C\" __global__ void __launch_bounds__(1024) exa_" << kn.nm << "x(const long* __restrict__ P, const long* __restrict__ X, "
+    // (512 threads: with 1024 the 128 registers a lane may have made the rocket's Hv tail kernel spill into scratch)
+    os << "extern \"C\" __global__ void __launch_bounds__(512) exa_" << kn.nm << "x(const long* __restrict__ P, const long* __restrict__ X, "
           "const int* __restrict__ T, const int* __restrict__ E, const double* __restrict__ x, const double* __restrict__ y, "
           "const double* __restrict__ th, const double* __restrict__ v, double* __restrict__ xbuf, double* __restrict__ cout, double sigma, int nx, "
           "const double* __restrict__ part, const long* __restrict__ F) {\n"
@@ -312,15 +313,15 @@ static void gen_window_x(std::ostringstream &os, const std::vector<int> &S, cons
     for (size_t j = 0; j < pk.size(); j++)
         os << "        " << (j ? "else " : "") << "if (pk_ == " << pk[j] << ") " << fn_name(pk[j], kn.fv) << "(P, x, y, th, v, sigma, I, o_);\n";
     os << "        for (int s = 0; s < " << smax << "; s++) xbuf[t * " << smax << " + s] = o_[s];\n    }\n    __syncthreads();\n"
-          "    for (int q = t; q < (nx > 0 ? T[0] : 0); q += 1024) {\n        const int c = T[1 + 3 * q];\n        double s = cout[c];\n"
+          "    for (int q = t; q < (nx > 0 ? T[0] : 0); q += 512) {\n        const int c = T[1 + 3 * q];\n        double s = cout[c];\n"
           "        for (int e = T[2 + 3 * q]; e < T[3 + 3 * q]; e++) s += xbuf[E[e]];\n        cout[c] = s;\n    }\n"
           // fold of the shared-entry partial sums: F = [ngroups, then per group: first partial, count, entry];
           // groups in order (several may share an entry), fixed summation order
-          "    __shared__ double red[16];\n"
+          "    __shared__ double red[8];\n"
           "    for (long g = 0; g < F[0]; g++) {\n        __syncthreads();\n        const long off = F[1 + 3 * g], n = F[2 + 3 * g];\n        double a = 0.0;\n"
-          "        for (long i = t; i < n; i += 1024) a += part[off + i];\n        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);\n"
+          "        for (long i = t; i < n; i += 512) a += part[off + i];\n        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);\n"
           "        if ((t & 63) == 0) red[t >> 6] = a;\n        __syncthreads();\n"
-          "        if (t == 0) { double s = 0.0; for (int w = 0; w < 16; w++) s += red[w]; cout[F[3 + 3 * g]] += s; }\n    }\n}\n";
+          "        if (t == 0) { double s = 0.0; for (int w = 0; w < 8; w++) s += red[w]; cout[F[3 + 3 * g]] += s; }\n    }\n}\n";
 }
 
 // entries EVERY point adds to (b = 0: the rocket's step length): per-workgroup sums over the regular points (S_ = [per

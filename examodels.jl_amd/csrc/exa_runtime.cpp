@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -59,7 +60,7 @@ struct DevBuf {
 struct Handle {
     std::unique_ptr<Model> m;
     Generated gen;
-    std::string hsaco_path, build_how;
+    std::string hsaco_path, build_how, co_name, pco_name;      // co_name / pco_name: what exa_cache_add takes for the two modules
     double build_ms = 0.0;
     bool on_device = false;
     int rank = 0, world = 1;
@@ -85,11 +86,16 @@ struct Handle {
     DevBuf daugcsr, daugsrc;                // exa_cons1: CSR over constraint rows of the augmentation terms (pattern << 40 | point)
     bool cons1 = false;
     DevBuf dsink;                           // 64 doubles nobody reads (ParamLayout::sink)
-    DevBuf dP, dtheta, dpart, ddone, dyzero, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
+    DevBuf dP, dtheta, dpart, ddone, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
     int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation
     DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] units one after the other, [1] interleaved in runs of 128
     DevBuf dmapg[2];                        // exa_eval_all: the fused sweep's units + the gathered-gradient tiles (same two orders)
     int64_t gridg = 0;
+    // objective-only forms of hess_coord! / hprod! (y == NULL): a second parameter table whose CB_HESS / CB_HPROD block maps
+    // hold the objective groups alone, and the COO ranges of the constraint patterns (they receive exact zeros)
+    DevBuf dPobj, dmapobj[2];
+    int64_t gridobj[2] = {0, 0};
+    std::vector<std::pair<int64_t, int64_t>> con_hess_ranges;
     int order[CB_COUNT] = {0};              // which map is active
     int norders[CB_COUNT] = {1};            // how many maps exist: exa_tune measures all of them
     int hess_variant = 0;                   // hess_coord! kernel: 0 exa_hess (one tile per workgroup), 1 chained, grouped, pipelined: exa_hesscl
@@ -134,6 +140,9 @@ struct Handle {
     // ... and its merged-slot form for the Hessian (exa_chessm): the merged slot space has its own sorted lists
     bool merged = false;
     int device = -1;            // the HIP device that was current in exa_create (DeviceScope)
+    // what the compiled kernels of every module of this model need (audited_code_object): which -> report
+    struct Audit { std::string which, name; bool safe = false, readable = false; std::vector<KernelInfo> kernels; };
+    std::vector<Audit> audits;
     bool loopfree_scatter = false;     // the module is the one generated without loops in the scatter kernels (module_for)
     std::string first_key;             // ... and this is the key of the module with loops it replaces (its "loopfree" note)
     // grad! by sorted gather (the reference's scheme, deterministic): gradient COO + (variable, slot) lists, built on demand
@@ -163,10 +172,10 @@ struct Handle {
         const bool switched = on_device && device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device && hipSetDevice(device) == hipSuccess;
         if (on_device) (void)hipStreamSynchronize(stream);
         if (on_device) {
-            daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); ddone.release(); dyzero.release(); dobj.release();
+            daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); ddone.release(); dobj.release();
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
-            dmapg[0].release(); dmapg[1].release();
+            dmapg[0].release(); dmapg[1].release(); dPobj.release(); dmapobj[0].release(); dmapobj[1].release();
             cj.release(); ch.release(); cbuf.release();
             for (Window *w : {&wj, &wh, &wp[0], &wp[1]}) { w->Q.release(); w->R.release(); w->X.release(); w->T.release(); w->E.release(); w->xbuf.release(); w->S.release(); w->F.release(); w->part.release(); }
             sj.pos.release(); sh.pos.release(); chm.release(); dM.release();
@@ -388,6 +397,40 @@ void fill_params(Handle &h) {
             for (int k : grp)
                 if (h.P[L.stage[k].word] + h.P[L.pat[k].lo] + L.stage[k].cmax - bmin > kStageHalo) h.stage_ok = false;
         }
+    // objective-only Hessian forms: block maps of the objective groups alone + the constraint patterns' slot ranges, merged
+    h.gridobj[0] = h.gridobj[1] = 0;
+    h.con_hess_ranges.clear();
+    if (h.on_device && m.ncon > 0) {
+        std::vector<int64_t> P2 = h.P;
+        for (int which = 0; which < 2; which++) {
+            const int cb = which ? CB_HPROD : CB_HESS;
+            const bool grouped = !L.groups[cb].empty();
+            const size_t na = grouped ? L.groups[cb].size() : L.active[cb].size();
+            std::vector<int64_t> mp;
+            const int64_t tile = (int64_t)kBlock * L.ppt[cb];
+            for (size_t j = 0; j < na; j++) {
+                const int k0 = grouped ? L.groups[cb][j].front() : L.active[cb][j];
+                if (m.pats[k0].kind != EXA_PAT_OBJ) continue;
+                int64_t tiles = 0;
+                for (int k : grouped ? L.groups[cb][j] : std::vector<int>{k0}) tiles = std::max(tiles, (h.P[L.pat[k].hi] - h.P[L.pat[k].lo] + tile - 1) / tile);
+                for (int64_t t = 0; t < tiles; t++) mp.push_back(((int64_t)j << 40) | t);
+            }
+            h.gridobj[which] = (int64_t)mp.size();
+            h.dmapobj[which].ensure(8 * std::max<size_t>(mp.size(), 1));
+            if (!mp.empty()) HIPCHK(hipMemcpy(h.dmapobj[which].p, mp.data(), 8 * mp.size(), hipMemcpyHostToDevice));
+            P2[L.blk[cb]] = (int64_t)(uintptr_t)h.dmapobj[which].p;
+        }
+        for (size_t k = 0; k < m.pats.size(); k++) {
+            const Pattern &p = m.pats[k];
+            const int64_t cnt = (int64_t)p.o2step * (h.P[L.pat[k].hi] - h.P[L.pat[k].lo]);
+            if (p.kind == EXA_PAT_OBJ || cnt <= 0) continue;
+            const int64_t off = h.P[L.pat[k].o2] + (int64_t)p.o2step * h.P[L.pat[k].lo];
+            if (!h.con_hess_ranges.empty() && h.con_hess_ranges.back().first + h.con_hess_ranges.back().second == off) h.con_hess_ranges.back().second += cnt;
+            else h.con_hess_ranges.push_back({off, cnt});
+        }
+        h.dPobj.ensure(8 * P2.size());
+        HIPCHK(hipMemcpy(h.dPobj.p, P2.data(), 8 * P2.size(), hipMemcpyHostToDevice));
+    }
     if (h.on_device) {
         h.dP.ensure(sizeof(int64_t) * h.P.size());
         HIPCHK(hipMemcpy(h.dP.p, h.P.data(), sizeof(int64_t) * h.P.size(), hipMemcpyHostToDevice));
@@ -396,37 +439,84 @@ void fill_params(Handle &h) {
     }
 }
 
-// The model's first module, compiled or fetched.  A scatter kernel that SPILLS registers (bodies of hundreds to thousands
-// of SSA values) must not carry wavefront-level state across its body: with spills in play (scratch, or AGPRs used as spill
-// space) the per-lane accumulators of shared targets (summed by a butterfly after a 16-tile loop) and the peeling loop of
-// exa_scatter_add have returned wrong sums on random depth-6 models (tests/test_random_expressions.py).  The generator
-// avoids the loops for bodies it can see are huge (kHugeBody); here the COMPILED kernels are asked — their registers and
-// scratch are in the code object's metadata, no device needed — and a module whose scatter kernels spill is generated again
-// without loops.  The decision is recorded as a note of the first module's key (note_store), so plan-only handles,
-// exa_compile, exahip.pack, later processes and a packed library's consumer all arrive at the SAME final module directly.
+// ---- every compiled kernel is ASKED what it needs -----------------------------------------------------------------------
+// Kernels of this library cooperate across lanes almost everywhere: the LDS-transposed COO epilogue, block sums, butterflies
+// over shared scatter targets, the objective fold, LDS windows and planes.  A kernel that has outgrown the 256 architectural
+// VGPRs — AGPRs (spill space in a kernel without MFMA) or scratch in use — has, under the default register allocator,
+// returned wrong, run-to-run different sums: it read register lanes it never wrote (profiles/NOTES.md round 3, the standalone
+// reproducer under tests/sweeps/canary/).  So after EVERY compilation — the model's module, its product windows, the
+// windows / permuted stores of exa_compress — the code object's metadata is read for ALL of its kernels, and a module holding
+// a kernel that does not fit is compiled again with the conservative allocator flags (exa_build.cpp safe_flags; another cache
+// file, keyed by the flags).  Unreadable metadata counts as "does not fit".  The decision is remembered as the note "safe" of
+// the module's key, so later processes (and plan-only handles, exa_compile, exahip.pack) compile the final object at once; a
+// packed library hands the object over under the name <key>_safe and its consumer finds it without a compiler.
+// exa_build_audit reports every kernel of every module with its numbers and the flags its module was built with.
+bool prefer_safe(const std::string &source) {
+    const std::string key = source_key(source);
+    return !safe_flags().empty() && (note_lookup(key) == "safe" || (cache_has(key + "_safe") && !cache_has(key)));
+}
+bool all_fit(const CodeObject &co, std::vector<KernelInfo> &ks, bool *readable) {
+    *readable = code_object_kernels(co.image, ks);
+    if (!*readable) return false;
+    for (const KernelInfo &k : ks) if (!k.fits()) return false;
+    return true;
+}
+// `have`: an object of this very source fetched a moment ago (default flags or safe), reused instead of fetched again
+CodeObject audited_code_object(Handle &h, const std::string &which, const std::string &source, bool memory_only_ok, const CodeObject *have = nullptr) {
+    CodeObject co = have && have->key == source_key(source) ? *have : get_code_object(source, memory_only_ok, prefer_safe(source));
+    std::vector<KernelInfo> ks;
+    bool readable = false;
+    if (!all_fit(co, ks, &readable) && !co.safe && !safe_flags().empty()) {
+        if (verbose()) {
+            for (const KernelInfo &k : ks)
+                if (!k.fits()) fprintf(stderr, "[exahip] %s: %d VGPRs, %d AGPRs, %d bytes of scratch per lane, %d VGPRs / %d SGPRs spilled: beyond the architectural registers\n", k.name.c_str(), k.vgpr, k.agpr, k.scratch, k.vgpr_spill, k.sgpr_spill);
+            fprintf(stderr, "[exahip] module %s (%s) is compiled again with %s\n", co.key.c_str(), which.c_str(), safe_flags().c_str());
+        }
+        note_store(co.key, "safe", true);
+        CodeObject c2 = get_code_object(source, memory_only_ok, true);
+        c2.build_ms += co.build_ms;
+        co = c2;
+        (void)all_fit(co, ks, &readable);
+    }
+    Handle::Audit a;
+    a.which = which; a.name = co.name; a.safe = co.safe; a.readable = readable; a.kernels = ks;
+    bool replaced = false;
+    for (auto &q : h.audits) if (q.which == which) { q = a; replaced = true; }
+    if (!replaced) h.audits.push_back(a);
+    return co;
+}
+
+// The model's first module, compiled or fetched.  Independently of the flags, scatter kernels (bodies of hundreds to
+// thousands of SSA values) that do not fit the registers are generated again WITHOUT the loops around and inside their
+// bodies: per-lane accumulators of shared targets carried across a 16-tile loop and the peeling loop of exa_scatter_add are
+// what made them outgrow the register file (tests/test_random_expressions.py).  The generator avoids the loops for bodies it
+// can see are huge (kHugeBody); here the COMPILED kernels are asked.  The decision is recorded as the note "loopfree" of the
+// first module's key, so plan-only handles, exa_compile, exahip.pack, later processes and a packed library's consumer all
+// arrive at the SAME final module directly.
 bool scatter_kernels_spill(const CodeObject &co) {
+    std::vector<KernelInfo> ks;
+    if (!code_object_kernels(co.image, ks)) return true;        // unreadable metadata: assume the worst
     bool spills = false;
-    for (const char *name : {"exa_grad", "exa_jtprod", "exa_hprod"}) {
-        int v = 0, a = 0, sc = 0, sp = 0, ss = 0;
-        if (!kernel_resources(co.image, name, &v, &a, &sc, &sp, &ss)) continue;
-        // (AGPRs in a kernel without MFMA are spill space: the 256 architectural VGPRs are exhausted)
-        if (sc > 0 || a > 0 || sp > 0) spills = true;
-        if (verbose()) fprintf(stderr, "[exahip] %s: %d VGPRs, %d AGPRs, %d bytes of scratch per lane, %d VGPRs / %d SGPRs spilled\n", name, v, a, sc, sp, ss);
+    for (const KernelInfo &k : ks) {
+        if (k.name != "exa_grad" && k.name != "exa_jtprod" && k.name != "exa_hprod") continue;
+        spills = spills || !k.fits();
+        if (verbose()) fprintf(stderr, "[exahip] %s: %d VGPRs, %d AGPRs, %d bytes of scratch per lane, %d VGPRs / %d SGPRs spilled\n", k.name.c_str(), k.vgpr, k.agpr, k.scratch, k.vgpr_spill, k.sgpr_spill);
     }
     return spills;
 }
 CodeObject module_for(Handle &h, bool memory_only_ok) {
-    CodeObject co = get_code_object(h.gen.source, memory_only_ok);
+    CodeObject co = get_code_object(h.gen.source, memory_only_ok, prefer_safe(h.gen.source));
+    double spent = 0.0;
     if (!h.loopfree_scatter && scatter_kernels_spill(co)) {
         h.first_key = co.key;
         note_store(co.key, "loopfree", true);
         h.loopfree_scatter = true;
         h.gen = generate_module(*h.m, true);
-        CodeObject c2 = get_code_object(h.gen.source, memory_only_ok);
-        c2.build_ms += co.build_ms;
-        return c2;
+        spent = co.build_ms;
     }
-    return co;
+    CodeObject fin = audited_code_object(h, "model", h.gen.source, memory_only_ok, &co);
+    fin.build_ms += spent;
+    return fin;
 }
 
 void to_device(Handle &h) {
@@ -437,7 +527,7 @@ void to_device(Handle &h) {
         throw HipError("no HIP device available (libexahip has no CPU fallback): " + std::string(hipGetErrorString(e)));
     CodeObject co = module_for(h, true);
     std::vector<char> &image = co.image;
-    h.hsaco_path = co.path; h.build_how = co.how; h.build_ms = co.build_ms;
+    h.hsaco_path = co.path; h.build_how = co.how; h.build_ms = co.build_ms; h.co_name = co.name;
     {
         int dev = 0;
         hipDeviceProp_t prop;
@@ -817,19 +907,19 @@ void do_jac(Handle &h, const double *x, double *v) {
     launch(h, h.f_jac, h.grid[CB_JAC], kBlock, a);
 }
 // The objective-only forms hess_coord!(m, x, hess; obj_weight) / hprod!(m, x, v, Hv; obj_weight) (nlp.jl:1906-1915, :1942-1952):
-// y == NULL.  The constraint patterns are evaluated against a vector of zeros the library keeps (ncon doubles, allocated by
-// the FIRST such call — which therefore must not sit inside a stream capture); every constraint slot then holds 0 * h.
-const double *multipliers_or_zeros(Handle &h, const double *y) {
-    if (y || h.m->ncon == 0) return y;
-    if (!h.dyzero.p) {
-        if (capturing(h)) throw BadInput("the first objective-only call (y == NULL) allocates the zero multipliers: make it outside the stream capture");
-        h.dyzero.ensure(8 * (size_t)h.m->ncon);
-        HIPCHK(hipMemsetAsync(h.dyzero.p, 0, 8 * (size_t)h.m->ncon, h.stream));
-    }
-    return (const double *)h.dyzero.p;
-}
+// y == NULL.  Like the reference, the constraint patterns are NOT evaluated: the objective groups are launched alone (their own
+// block maps, fill_params) and the constraint slots receive exact zeros — a constraint whose second derivative is Inf / NaN at x
+// cannot leak 0 * Inf = NaN into the result.  (Only the sorted-gather product, which evaluates the COO through do_hess, and the
+// fused sweeps, which always have y, come through here with constraints present.)
 void do_hess(Handle &h, const double *x, const double *y, double sigma, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
+    if (!y && h.m->ncon > 0) {
+        for (const auto &r : h.con_hess_ranges) zero_fill(h, v + r.first, r.second);
+        const void *Po = h.dPobj.p;
+        void *a[] = {&Po, &x, &y, &th, &v, &sigma};
+        launch(h, h.f_hess, h.gridobj[0], kBlock, a);
+        return;
+    }
     if (h.hess_variant >= 1 && h.f_hessc) {
         void *sink = h.dsink.p;
         void *a[] = {&P, &x, &y, &th, &v, &sigma, &sink};
@@ -887,9 +977,9 @@ void do_eval_all(Handle &h, const double *x, const double *y, double sigma, doub
     const ParamLayout &L = h.gen.layout;
     const int64_t nvar = h.m->nvar;
     const bool scatter = !L.active[CB_GRAD].empty(), pull = !L.pull.empty();
-    if (h.grad_mode == 1 && grad_sorted_possible(h)) {       // deterministic grad! requested: the sorted gather, separately
-        grad_setup(h);
+    if (resolve_grad_mode(h) == 1) {       // grad! by sorted gather (explicit, or exa_tune's persisted decision — the same choice exa_grad makes): separately
         do_grad_sorted(h, x, g);
+        allreduce(h, g, nvar);
         do_fused(h, x, y, sigma, obj_dev, c, jv, hv);
         return;
     }
@@ -943,9 +1033,10 @@ void do_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
 }
 void do_hprod(Handle &h, const double *x, const double *y, const double *v, double sigma, double *Hv) {
     zero_fill(h, Hv, h.m->nvar);
-    const void *P = h.dP.p, *th = h.dtheta.p;
+    const bool obj_only = !y && h.m->ncon > 0;         // objective groups alone (see do_hess)
+    const void *P = obj_only ? h.dPobj.p : h.dP.p, *th = h.dtheta.p;
     void *a[] = {&P, &x, &y, &th, &v, &Hv, &sigma};
-    launch(h, h.f_hprod, h.grid[CB_HPROD], kBlock, a);
+    launch(h, h.f_hprod, obj_only ? h.gridobj[1] : h.grid[CB_HPROD], kBlock, a);
 }
 void do_struct(Handle &h, bool hess, bool wide, void *rows, void *cols);
 void do_jac(Handle &h, const double *x, double *v);
@@ -1423,51 +1514,42 @@ void plan_products(Handle &h) {
     }
     if (any) h.psource = generate_window_module(*h.m, h.gen.layout, h.pspec);
 }
-// A window module, compiled or fetched — and ASKED: a kernel that sums across lanes (exa_block_sum: the all-points entries
-// summed inside a window kernel, or by exa_*s) must not spill registers.  With scratch in play such kernels have returned
-// wrong, run-to-run different sums (tests/sweeps/window_sweep.py 227 1 blocks: a 12-pass Hv window kernel under a 6-wave occupancy
-// hint, 820 B of scratch per lane; the same finding as for the scatter kernels, module_for).  A window kernel is used only
-// if it compiled within the 256 architectural VGPRs: no scratch, no spilled VGPRs, no AGPRs.  The registers and scratch of
-// every kernel are in the code object's metadata.  spills(kind) -> true when a cross-lane kernel of that kind spills.
+// A window module, compiled or fetched — and ASKED (see audited_code_object).  Window kernels that sum the all-points entries
+// inside themselves (exa_block_sum) are first given the chance to fit by a re-plan: those sums in a kernel of their own
+// (no_attach) — tests/sweeps/window_sweep.py 227 1 blocks was a 12-pass Hv kernel with 820 B of scratch per lane.  What still
+// does not fit the 256 architectural VGPRs keeps its windows and is compiled with the conservative allocator flags.
 bool window_kernels_spill(const CodeObject &co, const WindowSpec &spec, int wk) {
     static const char *nm[WK_COUNT] = {"exa_cjac", "exa_chess", "exa_jtprod", "exa_hprod"};
     const WindowMatrix &wm = spec.mat[wk];
     if (wm.pats.empty()) return false;
+    std::vector<KernelInfo> ks;
+    if (!code_object_kernels(co.image, ks)) return true;        // unreadable metadata: assume the worst
     bool bad = false;
     for (const char *sfx : {"w", "s"}) {
         if (sfx[0] == 's' && wm.shared.empty()) continue;
-        int v = 0, a = 0, sc = 0, sp = 0, ss = 0;
         const std::string name = std::string(nm[wk]) + sfx;
-        if (!kernel_resources(co.image, name, &v, &a, &sc, &sp, &ss)) continue;
-        // (AGPRs count: a kernel without MFMA has them as spill space beyond the 256 architectural VGPRs.  tools/
-        // range_model_check.py 1 1 blocks: a 12-pass Hv kernel with 256 + 84 registers and 86 SGPRs parked in VGPR lanes, no
-        // scratch, returned wrong, run-to-run different window sums; compiled with -O1, or with the basic SGPR allocator, the
-        // same source is right.  SGPRs parked in lanes ALONE are not a reason: small chunk-loop kernels have them — 57 VGPRs,
-        // 18 SGPRs spilled on the zoo's stepped model — and are right in every test.)
-        const bool k_bad = sc > 0 || sp > 0 || a > 0;
-        bad = bad || k_bad;
-        if (verbose()) fprintf(stderr, "[exahip] %s: %d VGPRs, %d AGPRs, %d bytes of scratch per lane, %d VGPRs / %d SGPRs spilled%s\n", name.c_str(), v, a, sc, sp, ss, k_bad ? "  <- cooperating lanes: not with spills" : "");
+        for (const KernelInfo &k : ks) {
+            if (k.name != name) continue;
+            bad = bad || !k.fits();
+            if (verbose()) fprintf(stderr, "[exahip] %s: %d VGPRs, %d AGPRs, %d bytes of scratch per lane, %d VGPRs / %d SGPRs spilled%s\n", name.c_str(), k.vgpr, k.agpr, k.scratch, k.vgpr_spill, k.sgpr_spill, k.fits() ? "" : "  <- beyond the architectural registers");
+        }
     }
     return bad;
 }
-// the product module: first with the all-points entries summed inside the window kernels; if such a kernel spills, planned
-// again with those sums in their own kernel; a kind whose exa_*s still spills gives its windows up
 CodeObject product_module_for(Handle &h, bool memory_only_ok) {
-    for (int attempt = 0;; attempt++) {
-        CodeObject co = get_code_object(h.psource, memory_only_ok);
-        bool bad = false;
-        for (int wk : {WK_JTPROD, WK_HPROD}) bad = bad || window_kernels_spill(co, h.pspec, wk);
-        if (!bad) return co;
-        if (attempt == 0 && !h.no_attach) { h.no_attach = true; plan_products(h); if (h.psource.empty()) return CodeObject(); continue; }
-        bool any = false;
-        for (int wk : {WK_JTPROD, WK_HPROD}) {
-            Handle::Window &w = window_of(h, wk);
-            if (window_kernels_spill(co, h.pspec, wk)) { w.planned = false; w.why = "the window kernels do not compile without register spills"; h.pspec.mat[wk] = WindowMatrix(); }
-            any = any || w.planned;
-        }
-        h.psource = any ? generate_window_module(*h.m, h.gen.layout, h.pspec) : std::string();
+    CodeObject co = get_code_object(h.psource, memory_only_ok, prefer_safe(h.psource));
+    double spent = 0.0;
+    bool attached = false;
+    for (int wk : {WK_JTPROD, WK_HPROD}) attached = attached || !h.pspec.mat[wk].shared_in.empty();
+    if (!h.no_attach && attached && (window_kernels_spill(co, h.pspec, WK_JTPROD) || window_kernels_spill(co, h.pspec, WK_HPROD))) {
+        h.no_attach = true;
+        plan_products(h);
+        spent = co.build_ms;
         if (h.psource.empty()) return CodeObject();
     }
+    CodeObject fin = audited_code_object(h, "products", h.psource, memory_only_ok, &co);
+    fin.build_ms += spent;
+    return fin;
 }
 // loads the product module and uploads the tables; a module that cannot be built leaves the products on their other paths
 void load_products(Handle &h) {
@@ -1475,7 +1557,7 @@ void load_products(Handle &h) {
     try {
         CodeObject co = product_module_for(h, true);
         if (h.psource.empty()) return;
-        h.phsaco_path = co.path; h.build_ms += co.build_ms;
+        h.phsaco_path = co.path; h.build_ms += co.build_ms; h.pco_name = co.name;
         HIPCHK(hipModuleLoadData(&h.pmodule, co.image.data()));
         auto fn = [&](const std::string &name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.pmodule, name.c_str())); return f; };
         for (int wk : {WK_JTPROD, WK_HPROD}) {
@@ -1550,9 +1632,11 @@ void window_setup(Handle &h) {
     // the gather path needs no second module: a host without hipcc (a packed library's consumer) or a failed compilation
     // must not take exa_compress down with it
     try {
-        CodeObject wco = get_code_object(src, true);
-        for (int wk : {WK_CJAC, WK_CHESS})
-            if (window_kernels_spill(wco, spec, wk)) throw std::runtime_error(std::string(wk == WK_CJAC ? "exa_cjac" : "exa_chess") + ": a window kernel that sums across lanes spills registers");
+        CodeObject wco = get_code_object(src, true, prefer_safe(src));
+        bool attached = !spec.mat[WK_CJAC].shared_in.empty() || !spec.mat[WK_CHESS].shared_in.empty();
+        if (!h.no_attach_c && attached && (window_kernels_spill(wco, spec, WK_CJAC) || window_kernels_spill(wco, spec, WK_CHESS)))
+            throw std::runtime_error("a window kernel that sums the all-points entries spills registers");     // exa_compress plans again (no_attach_c)
+        wco = audited_code_object(h, "compressed", src, true, &wco);
         image = wco.image;
         HIPCHK(hipModuleLoadData(&h.wmodule, image.data()));
         auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.wmodule, name)); return f; };
@@ -1653,7 +1737,7 @@ void do_window(Handle &h, int wk, const double *x, const double *y, const double
         void *xbuf = w.xbuf.p;
         int nx = w.nx;
         void *a2[] = {&P, &X, &T, &E, &x, &y, &th, &v, &xbuf, &vals, &sigma, &nx, &part, &F};
-        HIPCHK(hipModuleLaunchKernel(w.fx, 1, 1, 1, 1024, 1, 1, 0, h.stream, a2, nullptr));     // 1024 threads: the fold is one workgroup's loop
+        HIPCHK(hipModuleLaunchKernel(w.fx, 1, 1, 1, 512, 1, 1, 0, h.stream, a2, nullptr));      // one workgroup: the irregular points, then the fold
     }
 }
 
@@ -1770,7 +1854,8 @@ int exa_code_object_count(int id) { Handle *h = get(id); return h ? (h->psource.
 int exa_code_object(int id, int k, char *name, int ncap, char *path, int pcap) {
     Handle *h = get(id);
     if (!h || k < 0 || k > 1 || (k == 1 && h->psource.empty())) return 1;
-    if (name && ncap > 0) snprintf(name, (size_t)ncap, "%s", source_key(k == 0 ? h->gen.source : h->psource).c_str());
+    const std::string &known = k == 0 ? h->co_name : h->pco_name;       // (<key>_safe for a module built with the conservative flags)
+    if (name && ncap > 0) snprintf(name, (size_t)ncap, "%s", (known.empty() ? source_key(k == 0 ? h->gen.source : h->psource) : known).c_str());
     if (path && pcap > 0) snprintf(path, (size_t)pcap, "%s", (k == 0 ? h->hsaco_path : h->phsaco_path).c_str());
     return 0;
 }
@@ -1793,8 +1878,8 @@ const char *exa_module_name(int id) {
 int exa_compile(int id) {
     return guard(id, false, [&](Handle &h) {
         CodeObject co = module_for(h, false);
-        h.hsaco_path = co.path; h.build_how = co.how; h.build_ms = co.build_ms;
-        if (!h.psource.empty()) { CodeObject pc = product_module_for(h, false); h.phsaco_path = pc.path; h.build_ms += pc.build_ms; }
+        h.hsaco_path = co.path; h.build_how = co.how; h.build_ms = co.build_ms; h.co_name = co.name;
+        if (!h.psource.empty()) { CodeObject pc = product_module_for(h, false); h.phsaco_path = pc.path; h.build_ms += pc.build_ms; h.pco_name = pc.name; }
     });
 }
 const char *exa_code_object_path(int id) {
@@ -1854,6 +1939,7 @@ int exa_meta(int id, double *x0, double *lvar, double *uvar, double *lcon, doubl
     return 0;
 }
 const char *exa_kernel_source(int id) { Handle *h = get(id); return h ? h->gen.source.c_str() : nullptr; }
+const char *exa_module_source(int id, int k) { Handle *h = get(id); return !h || k < 0 || k > 1 ? nullptr : (k == 0 ? h->gen.source.c_str() : h->psource.c_str()); }
 
 // new shard and/or COO addressing: the parameter table, and everything derived from the local COO, start over
 static void reshard(Handle &h, int rank, int world, bool coo_local) {
@@ -1981,7 +2067,7 @@ int exa_hess(int id, const double *x, const double *y, double w, double *v) {
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) {
         if (h.m->nnzh && !v) throw BadInput("null output");
-        do_hess(h, x, multipliers_or_zeros(h, y), w, v);
+        do_hess(h, x, y, w, v);
     });
 }
 int exa_eval_fused(int id, const double *x, const double *y, double w, double *obj_dev, double *c, double *jvals, double *hvals) {
@@ -2057,7 +2143,8 @@ static void run_jtprod(Handle &h, const double *x, const double *v, double *Jtv)
     allreduce(h, Jtv, h.m->nvar);
 }
 static void run_hprod(Handle &h, const double *x, const double *y, const double *v, double w, double *Hv) {
-    const int mode = resolve_mode(h, true);
+    int mode = resolve_mode(h, true);
+    if (mode == 2 && !y && h.m->ncon > 0) mode = 0;      // objective only: the window kernels evaluate every pattern; the atomics launch the objective groups alone
     if (mode == 2) { run_product_window(h, true, x, y, v, w, Hv); return; }
     if (mode == 1) do_hprod_sorted(h, x, y, v, w, Hv); else do_hprod(h, x, y, v, w, Hv);
     allreduce(h, Hv, h.m->nvar);
@@ -2069,7 +2156,7 @@ int exa_jtprod(int id, const double *x, const double *v, double *Jtv) {
 int exa_hprod(int id, const double *x, const double *y, const double *v, double w, double *Hv) {
     if (!x || !v || !Hv) return 1;
     return guard(id, true, [&](Handle &h) {
-        run_hprod(h, x, multipliers_or_zeros(h, y), v, w, Hv);
+        run_hprod(h, x, y, v, w, Hv);
     });
 }
 /* 0 = atomics inside the sweep, 1 = COO + sorted gather, 2 = owner-computes windows, -1 = undecided (default): the decision
@@ -2086,17 +2173,23 @@ int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode) {
 }
 /* What exa_jtprod (hess = 0) / exa_hprod (hess = 1) run: 0 atomics, 1 sorted gather, 2 owner-computes windows (resolved as a
  * call would resolve it, without building anything); buf <- the kernel shape of the windows or why the model has none. */
+// the implementation a call WOULD run (explicit mode, else the persisted exa_tune decision, else the windows where the model
+// has them), without building anything: shared by exa_product_info and exa_shard_layout so that the two cannot disagree
+static int product_mode_query(Handle &h, bool hess) {
+    const Handle::Window &w = h.wp[hess ? 1 : 0];
+    const int mode = hess ? h.hp_mode : h.jt_mode;
+    if (mode >= 0) return mode == 2 && !window_possible(h, hess) ? 0 : mode;
+    int v = -1;
+    if (h.on_device && tune_lookup(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 2 &&
+        (v != 2 || window_possible(h, hess)) && (v != 1 || sorted_possible(h, hess))) return v;
+    return (h.on_device ? window_possible(h, hess) : w.planned) ? 2 : 0;
+}
 int exa_product_info(int id, int hess, char *buf, int cap) {
     Handle *h = get(id);
     if (!h) return -1;
     const Handle::Window &w = h->wp[hess ? 1 : 0];
     if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", w.why.c_str());
-    const int mode = hess ? h->hp_mode : h->jt_mode;
-    if (mode >= 0) return mode == 2 && !window_possible(*h, hess != 0) ? 0 : mode;
-    int v = -1;
-    if (h->on_device && tune_lookup(source_key(h->gen.source), tune_signature(*h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 2 &&
-        (v != 2 || window_possible(*h, hess != 0)) && (v != 1 || sorted_possible(*h, hess != 0))) return v;
-    return (h->on_device ? window_possible(*h, hess != 0) : w.planned) ? 2 : 0;
+    return product_mode_query(*h, hess != 0);
 }
 /* grad!: 0 = gathered (affine patterns) + FP64 atomics (data-indexed ones), 1 = gradient COO + sorted gather (the reference's
  * scheme: deterministic, and immune to many data points sharing a few variables), -1 = undecided: the persisted exa_tune
@@ -2191,10 +2284,9 @@ int exa_hess_host(int id, const double *x, const double *y, double w, double *v)
         if (!n) return;
         h2d(h, h.sx, x, 8 * (size_t)h.m->nvar);
         if (h.m->ncon && y) h2d(h, h.sy, y, 8 * (size_t)h.m->ncon);
-        else if (h.m->ncon) { h.sy.ensure(8 * (size_t)h.m->ncon); HIPCHK(hipMemsetAsync(h.sy.p, 0, 8 * (size_t)h.m->ncon, h.stream)); }    // objective only
         else h.sy.ensure(8);
         h.sout.ensure(n);
-        do_hess(h, (const double *)h.sx.p, (const double *)h.sy.p, w, (double *)h.sout.p);
+        do_hess(h, (const double *)h.sx.p, h.m->ncon && !y ? nullptr : (const double *)h.sy.p, w, (double *)h.sout.p);      // y == NULL: objective only
         d2h(h, v, h.sout.p, n);
     });
 }
@@ -2231,11 +2323,10 @@ int exa_hprod_host(int id, const double *x, const double *y, const double *v, do
         h2d(h, h.sx, x, n);
         h2d(h, h.sv, v, n);
         if (h.m->ncon && y) h2d(h, h.sy, y, 8 * (size_t)h.m->ncon);
-        else if (h.m->ncon) { h.sy.ensure(8 * (size_t)h.m->ncon); HIPCHK(hipMemsetAsync(h.sy.p, 0, 8 * (size_t)h.m->ncon, h.stream)); }    // objective only
         else h.sy.ensure(8);
         h.sout.ensure(n);
         zero_if_sharded(h, h.sout.p, n);
-        run_hprod(h, (const double *)h.sx.p, (const double *)h.sy.p, (const double *)h.sv.p, w, (double *)h.sout.p);
+        run_hprod(h, (const double *)h.sx.p, h.m->ncon && !y ? nullptr : (const double *)h.sy.p, (const double *)h.sv.p, w, (double *)h.sout.p);
         d2h(h, Hv, h.sout.p, n);
     });
 }
@@ -2476,7 +2567,81 @@ int exa_tune(int id, int what, const double *x, const double *y) {
     });
 }
 
+// ---- test infrastructure: one launch of a product window kernel as a self-contained file ---------------------------------------
+/* Writes everything ONE launch of exa_jtprodw (hess = 0) / exa_hprodw (hess = 1) needs into `path` — grid, block, LDS bytes,
+ * every argument (scalars by value, buffers by content) and the output THIS build of the kernel produces (NaN where it writes
+ * nothing) — and the module's source into `path`.hip.  tests/sweeps/canary/canary_host.cpp replays such a file against a code
+ * object compiled from that source with any compiler and flags, without this library: the reproducer of the wrong sums an
+ * over-sized window kernel returns under the default register allocator (profiles/NOTES.md).  Format: "EXADUMP1", then
+ * int64 words and raw bytes as written below.  Status 1 when the model has no such windows. */
+int exa_debug_dump_window_launch(int id, int hess, const double *x, const double *y, const double *v, double sigma, const char *path) {
+    if (!x || !v || !path) return 1;
+    return guard(id, true, [&](Handle &h) {
+        Handle::Window &w = h.wp[hess ? 1 : 0];
+        if (!w.ok) throw BadInput("no product windows on this model: " + w.why);
+        const Model &m = *h.m;
+        std::vector<double> expect((size_t)m.nvar, std::numeric_limits<double>::quiet_NaN());
+        DevBuf out;
+        out.ensure(8 * expect.size());
+        struct Rel { DevBuf &b; ~Rel() { b.release(); } } rel{out};
+        HIPCHK(hipMemcpy(out.p, expect.data(), 8 * expect.size(), hipMemcpyHostToDevice));
+        const void *P = h.dP.p, *Q = w.Q.p, *R = w.R.p, *th = h.dtheta.p;
+        int64_t ncomp = m.nvar, w0 = 0;
+        int W = w.W;
+        void *part = w.part.p, *vals = out.p;
+        if (hess && m.ncon > 0 && !y) throw BadInput("the recorded launch evaluates every pattern: y is needed");
+        const double *yy = hess ? y : nullptr;
+        if (w.ns_blocks) {
+            const void *S = w.S.p;
+            void *a1[] = {&P, &S, &x, &yy, &th, &v, &part, &sigma};
+            HIPCHK(hipModuleLaunchKernel(w.fs, (unsigned)w.ns_blocks, 1, 1, kBlock, 1, 1, 0, h.stream, a1, nullptr));
+        }
+        void *a[] = {&P, &Q, &R, &x, &yy, &th, &v, &vals, &sigma, &ncomp, &W, &w0, &part};
+        HIPCHK(hipModuleLaunchKernel(w.fw, (unsigned)w.nwin, 1, 1, kBlock, 1, 1, (unsigned)w.lds_bytes, h.stream, a, nullptr));
+        HIPCHK(hipStreamSynchronize(h.stream));
+        HIPCHK(hipMemcpy(expect.data(), out.p, 8 * expect.size(), hipMemcpyDeviceToHost));
+        std::ofstream f(path, std::ios::binary);
+        if (!f) throw std::runtime_error(std::string("cannot write ") + path);
+        auto word = [&](int64_t q) { f.write((const char *)&q, 8); };
+        auto scalar = [&](const void *q, int64_t n) { word(0); word(n); f.write((const char *)q, n); };
+        auto buffer = [&](const void *dev, int64_t n, int64_t kind) {       // kind 1 input, 2 the output (contents = NaN fill)
+            std::vector<char> tmp((size_t)std::max<int64_t>(n, 8), 0);
+            if (dev && n) HIPCHK(hipMemcpy(tmp.data(), dev, (size_t)n, hipMemcpyDeviceToHost));
+            word(kind); word((int64_t)tmp.size()); f.write(tmp.data(), (std::streamsize)tmp.size());
+        };
+        f.write("EXADUMP1", 8);
+        const std::string kname = hess ? "exa_hprodw" : "exa_jtprodw";
+        word((int64_t)kname.size()); f.write(kname.data(), (std::streamsize)kname.size());
+        word(w.nwin); word(kBlock); word(w.lds_bytes); word(13);
+        buffer(P, 8 * (int64_t)h.P.size(), 1); buffer(Q, (int64_t)w.Q.bytes, 1); buffer(R, (int64_t)w.R.bytes, 1); buffer(x, 8 * m.nvar, 1);
+        buffer(yy, yy ? 8 * m.ncon : 0, 1); buffer(th, (int64_t)h.dtheta.bytes, 1); buffer(v, 8 * (hess ? m.nvar : std::max<int64_t>(m.ncon, 1)), 1);
+        word(2); word(8 * m.nvar);                                           // the output: the host fills it with NaN
+        scalar(&sigma, 8); scalar(&ncomp, 8); scalar(&W, 4); scalar(&w0, 8);
+        buffer(part, (int64_t)w.part.bytes, 1);
+        word(m.nvar); f.write((const char *)expect.data(), (std::streamsize)(8 * expect.size()));
+        f.close();
+        std::ofstream g(std::string(path) + ".hip", std::ios::binary);
+        g << h.psource;
+    });
+}
+
 // ---- how the module was obtained ---------------------------------------------------------------------------------------
+int exa_build_audit(int id, char *buf, int cap) {
+    Handle *h = get(id);
+    if (!h) return -1;
+    std::string out;
+    for (const Handle::Audit &a : h->audits) {
+        const std::string head = a.which + " " + a.name + " " + (a.safe ? "safe" : "default") + " ";
+        if (!a.readable) { out += head + "? unreadable\n"; continue; }
+        for (const KernelInfo &k : a.kernels) {
+            char line[256];
+            snprintf(line, sizeof line, "%s %d %d %d %d %d %d %s\n", k.name.c_str(), k.vgpr, k.agpr, k.scratch, k.vgpr_spill, k.sgpr_spill, k.lds, k.fits() ? "fits" : "oversized");
+            out += head + line;
+        }
+    }
+    if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", out.c_str());
+    return (int)out.size();
+}
 int exa_build_info(int id, char *how, int cap, double *build_ms) {
     Handle *h = get(id);
     if (!h) return 1;
@@ -2619,7 +2784,8 @@ int exa_shard_var_range(int id, int64_t *lo_out, int64_t *hi_out) {
 /* How a sharded model's rank leaves the output of callback `which` when nothing completes it (no communicator, or
  * exa_set_reduce(id, 0)): 1 = OWNER PIECES — complete values in disjoint pieces (rows of its data points, variables / windows
  * it owns), nothing else written, an all-gather makes the vector whole; 0 = PARTIAL SUMS over the whole vector, an
- * all-reduce(sum) completes it.  which: 0 obj, 1 grad, 2 cons, 5 jprod, 6 jtprod, 7 hprod (3 jac / 4 hess: always pieces).
+ * all-reduce(sum) completes it.  which: 0 obj, 1 grad, 2 cons, 5 jprod, 6 jtprod, 7 hprod (3 jac / 4 hess: always pieces),
+ * 8 the cons vector of exa_eval_fused / exa_eval_all (differs from 2 for models with non-linear augmentation terms).
  * -1 bad id / argument. */
 int exa_shard_layout(int id, int which) {
     Handle *hh = get(id);
@@ -2632,12 +2798,17 @@ int exa_shard_layout(int id, int which) {
     case 3: case 4: return 1;
     case 5: return (h.m->nconaug == 0 || (h.m->aug_linear && (h.cons1 || !h.on_device))) ? 1 : 0;
     case 6: case 7: {
+        // owner pieces only when the call really runs the windows: an explicit or a tuned mode 0 / 1 (atomics, sorted gather)
+        // leaves partial sums over the whole vector
         const bool hess = which == 7;
-        const int mode = hess ? h.hp_mode : h.jt_mode;
         const Handle::Window &w = h.wp[hess ? 1 : 0];
         const bool can = (h.on_device ? w.ok : w.planned) && w.nx == 0 && !w.has_shared;
-        return can && (mode == 2 || mode < 0) ? 1 : 0;
+        return can && product_mode_query(h, hess) == 2 ? 1 : 0;
     }
+    // cons as exa_eval_fused / exa_eval_all leave it: rows complete on their owner only when the augmentation terms are linear
+    // (added inside the sweep through the row lists); non-linear ones are partial sums there although exa_cons (which = 2)
+    // completes the rows itself
+    case 8: return h.m->nconaug == 0 || (h.m->aug_linear && (h.cons1 || !h.on_device)) ? 1 : 0;
     }
     return -1;
 }

@@ -289,6 +289,10 @@ class ExaModel:
     def kernel_source(self):
         return self._L.exa_kernel_source(self.id).decode()
 
+    def module_source(self, k=0):
+        """Generated HIP source of module k: 0 the model's, 1 the owner-computes product windows' ("" when it has none)."""
+        return self._L.exa_module_source(self.id, k).decode()
+
     def compile(self):
         capi.check(self._L.exa_compile(self.id), "exa_compile")
         return self._L.exa_code_object_path(self.id).decode()
@@ -308,6 +312,22 @@ class ExaModel:
         buf, ms = ctypes.create_string_buffer(32), ctypes.c_double(0.0)
         capi.check(self._L.exa_build_info(self.id, buf, 32, ctypes.addressof(ms)), "exa_build_info")
         return buf.value.decode(), ms.value
+
+    def build_audit(self):
+        """exa_build_audit as a list of dicts, one per compiled kernel: module, object, flags ("default" | "safe"), kernel, vgpr,
+        agpr, scratch, vgpr_spill, sgpr_spill, lds, fits (None for a module whose metadata could not be read)."""
+        n = self._L.exa_build_audit(self.id, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        self._L.exa_build_audit(self.id, buf, n + 1)
+        out = []
+        for line in buf.value.decode().splitlines():
+            f = line.split()
+            if f[3] == "?":
+                out.append(dict(module=f[0], object=f[1], flags=f[2], kernel=None, fits=None))
+                continue
+            out.append(dict(module=f[0], object=f[1], flags=f[2], kernel=f[3], vgpr=int(f[4]), agpr=int(f[5]), scratch=int(f[6]), vgpr_spill=int(f[7]),
+                            sgpr_spill=int(f[8]), lds=int(f[9]), fits=f[10] == "fits"))
+        return out
 
     def tune(self, what=7, x=None, y=None):
         """exa_tune: the explicit, blocking measurement of block orders (bit 0), product implementations (bit 1) and the
@@ -377,7 +397,7 @@ class ExaModel:
     def shard_layout(self, which):
         """"pieces" (complete values in disjoint pieces: all-gather completes) or "partial" (partial sums: all-reduce completes)
         — how a rank of a sharded model leaves the output of `which` (obj grad cons jac hess jprod jtprod hprod) on its own."""
-        k = {"obj": 0, "grad": 1, "cons": 2, "jac": 3, "hess": 4, "jprod": 5, "jtprod": 6, "hprod": 7}[which]
+        k = {"obj": 0, "grad": 1, "cons": 2, "jac": 3, "hess": 4, "jprod": 5, "jtprod": 6, "hprod": 7, "fused_cons": 8}[which]
         r = self._L.exa_shard_layout(self.id, k)
         if r < 0:
             raise capi.ExaHipError("exa_shard_layout")

@@ -92,6 +92,20 @@ int exa_code_object(int id, int k, char *name, int ncap, char *path, int pcap);
 /* How the module of a device model was obtained: how <- "preloaded" | "disk" | "hiprtc" | "hipcc", *build_ms <- the
  * compiler's time (0 unless it ran).  The reference pays this at the first call of every callback (Julia's JIT). */
 int exa_build_info(int id, char *how, int cap, double *build_ms);
+/* What the compiled kernels need.  After every compilation (the model's module, the product windows, the second module of
+ * exa_compress) the library reads the resources of ALL kernels of the code object from its metadata; a module holding a kernel
+ * that has outgrown the 256 architectural VGPRs (AGPRs or scratch as spill space), or whose metadata cannot be read, is built
+ * again with conservative register-allocation flags ($EXAHIP_SAFE_FLAGS, default "-mllvm -grow-region-complexity-budget=0";
+ * "none" switches the fallback off) — such kernels have returned wrong sums under the default allocator
+ * (tests/sweeps/canary/).  buf <- one line per kernel, "<module: model|products|compressed> <object name> <flags: default|safe>
+ * <kernel> <vgpr> <agpr> <scratch bytes per lane> <spilled vgprs> <spilled sgprs> <lds bytes> <fits|oversized>", and a line
+ * "<module> <object name> <flags> ? unreadable" for a module whose metadata could not be read.  Returns the length of the
+ * whole report (call again with a larger buffer when it is >= cap), -1 for a bad id.  Works for plan-only handles after
+ * exa_compile. */
+int exa_build_audit(int id, char *buf, int cap);
+/* Test infrastructure (tests/sweeps/canary/): everything one launch of exa_jtprodw (hess = 0) / exa_hprodw (hess = 1) needs —
+ * launch shape, arguments, the output of THIS build — into `path`, the module's source into `path`.hip.  x, y, v: device. */
+int exa_debug_dump_window_launch(int id, int hess, const double *x, const double *y, const double *v, double sigma, const char *path);
 int exa_free(int id);
 
 /* ---- sizes (cnlp: P_nvar/P_ncon/P_nnzj/P_nnzh, Compiler :1564-1582) ---------------------------- */
@@ -114,6 +128,8 @@ int     exa_pattern_comp(int id, int p, int order, int32_t *out);
 int     exa_meta(int id, double *x0, double *lvar, double *uvar, double *lcon, double *ucon);
 /* Generated HIP source of the model's module (NUL-terminated, owned by the library). */
 const char *exa_kernel_source(int id);
+/* ... of module k: 0 the model's module (= exa_kernel_source), 1 the product windows' ("" when the model has none). */
+const char *exa_module_source(int id, int k);
 
 /* ---- execution context -------------------------------------------------------------------------
  * Device: a model lives on the HIP device that was current in the thread that created it; every device call makes that
@@ -176,7 +192,10 @@ int exa_allreduce(int id, double *device_buffer, int64_t count);
 /* How a rank of a sharded model leaves the output of callback `which` when nothing completes it (no communicator, or
  * exa_set_reduce(id, 0)): 1 = OWNER PIECES (complete values in disjoint pieces, nothing else written: an all-gather makes
  * the vector whole), 0 = PARTIAL SUMS over the whole vector (an all-reduce(sum) completes it), -1 bad id / argument.
- * which: 0 obj, 1 grad, 2 cons, 3 jac, 4 hess, 5 jprod, 6 jtprod, 7 hprod. */
+ * which: 0 obj, 1 grad, 2 cons, 3 jac, 4 hess, 5 jprod, 6 jtprod, 7 hprod, 8 the cons vector of exa_eval_fused / exa_eval_all
+ * (differs from 2 for models with NON-linear augmentation terms: the fused sweeps leave partial sums there, exa_cons complete
+ * rows).  6 / 7 answer for the implementation a call would run — explicit mode, else the persisted exa_tune decision, else the
+ * windows: atomics and the sorted gather leave partial sums, the windows owner pieces (the same resolution as exa_product_info). */
 int exa_shard_layout(int id, int which);
 /* A sharded Jacobian (hess = 0) / Hessian (hess = 1) COO vector made whole on every rank: all-gather-v of the ranks' slot
  * ranges (a piece travels once; an all-reduce of zero-padded vectors would move world x the data).  `local` = what this
@@ -214,9 +233,10 @@ int exa_jprod (int id, const double *x, const double *v, double *Jv);           
 int exa_jtprod(int id, const double *x, const double *v, double *Jtv);            /* Jtv [nvar] = J(x)' v,  v [ncon] */
 int exa_hprod (int id, const double *x, const double *y, const double *v, double obj_weight, double *Hv);  /* Hv [nvar] */
 /* Objective-only forms — hess_coord!(m, x, hess; obj_weight), hprod!(m, x, v, Hv; obj_weight) (nlp.jl:1906-1915, :1942-1952):
- * exa_hess / exa_hprod (and their _host variants) with y == NULL.  The constraint slots / contributions come back as zeros
- * (0 * second derivative).  The first such call on a model with constraints allocates the ncon zeros it evaluates against, so
- * it must not be the first thing inside a stream capture; later calls are asynchronous like every callback. */
+ * exa_hess / exa_hprod (and their _host variants) with y == NULL.  As in the reference the constraint patterns are NOT evaluated:
+ * the objective patterns are launched alone and the constraint slots receive exact zeros (a constraint whose second derivative
+ * is Inf / NaN at x cannot leak 0 * Inf into the result); exa_hprod with y == NULL runs by atomics or sorted gather even where
+ * the full product has windows.  Asynchronous like every callback, capturable from the first call. */
 /* exa_jtprod / exa_hprod have three implementations.  mode 0: FP64 atomics inside the sweep (zero-fill + atomics; order of
  * additions varies).  mode 1: COO + gather through build-time sorted lists (the reference's prod helper, KA ext :56-178,
  * :482-511; deterministic).  mode 2: OWNER-COMPUTES WINDOWS — models whose every scatter target is (range value) * literal +

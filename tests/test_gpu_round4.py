@@ -1,0 +1,120 @@
+"""Round-4 boundary fixes on the HIP path: the objective-only Hessian forms do not evaluate the constraints, the shard
+layout query resolves the product mode the way a call does, exa_eval_all takes the same gradient decision as exa_grad."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from exahip import ExaCore, ExaModel, models, rng
+from exahip.graph import log
+
+pytestmark = pytest.mark.gpu
+
+
+def test_objective_only_forms_leave_exact_zeros_where_a_constraint_hessian_is_infinite(libs):
+    """nlp.jl:1912-1914, 1949-1951: without y the reference skips the constraint patterns.  At x = 0 the second derivative of
+    log(x) is -Inf: evaluated against a zero multiplier it would be 0 * Inf = NaN in the constraint slots and, in hprod, in every
+    Hv entry it shares with the objective."""
+    import torch
+    n = 300
+    c = ExaCore()
+    x = c.add_var(n, start=np.full(n, 1.0))
+    c.add_obj(lambda i: (x[i] - 2.0) ** 4 + x[i] * x[i + 1], rng(1, n - 1))
+    c.add_con(lambda i: log(x[i]) + x[i + 1] ** 2, rng(1, n - 1))
+    m = ExaModel(c)
+    x0 = np.zeros(n)                        # log''(0) = -Inf, log'(0) = Inf
+    x0[::2] = 1.5
+    v = np.random.default_rng(1).standard_normal(n)
+    H = m.hess_coord(x0, None, 0.7)
+    assert np.all(np.isfinite(H))
+    info = [m.pattern_info(k) for k in range(m.npatterns())]
+    for k, pi in enumerate(info):
+        sl = slice(pi["o2"], pi["o2"] + pi["o2step"] * pi["n"])
+        if pi["kind"] != 0:
+            assert np.all(H[sl] == 0.0) and not np.any(np.signbit(H[sl]))       # exact +0.0, like the reference's fill!
+    # objective slots: against the oracle's objective-only model
+    c2 = ExaCore()
+    x2 = c2.add_var(n, start=np.full(n, 1.0))
+    c2.add_obj(lambda i: (x2[i] - 2.0) ** 4 + x2[i] * x2[i + 1], rng(1, n - 1))
+    o2 = oracle.OracleModel(ExaModel(c2, device=False).ir)
+    Hobj = o2.hess_coord(x0, np.zeros(0), 0.7)
+    obj = [k for k, pi in enumerate(info) if pi["kind"] == 0][0]
+    sl = slice(info[obj]["o2"], info[obj]["o2"] + info[obj]["o2step"] * info[obj]["n"])
+    assert np.max(np.abs(H[sl] - Hobj) / np.maximum(1.0, np.abs(Hobj))) <= 1e-12
+    want_hv = o2.hprod(x0, np.zeros(0), v, 0.7)
+    for mode in (-1, 0, 1, 2):
+        try:
+            m.set_product_mode(-1, mode)
+        except Exception:
+            continue
+        Hv = m.hprod(x0, None, v, 0.7)
+        assert np.all(np.isfinite(Hv)) and np.max(np.abs(Hv - want_hv) / np.maximum(1.0, np.abs(want_hv))) <= 1e-12, mode
+        xd, vd = torch.from_numpy(x0).cuda(), torch.from_numpy(v).cuda()
+        assert np.array_equal(m.hprod(xd, None, vd, 0.7).cpu().numpy() == 0, Hv == 0)
+    # with y the constraint slots are what the reference computes: NaN / Inf included
+    Hy = m.hess_coord(x0, np.ones(n - 1), 0.7)
+    assert not np.all(np.isfinite(Hy))
+
+
+def test_objective_only_call_can_be_the_first_thing_in_a_capture(libs):
+    import torch
+    m = ExaModel(models.luksan_vlcek_model(500))
+    x = torch.from_numpy(m.meta.x0.copy()).cuda()
+    out = torch.zeros(m.meta.nnzh, dtype=torch.float64, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            m.hess_coord(x, None, 1.0, out=out)
+        g.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), m.hess_coord(m.meta.x0, None, 1.0))
+
+
+def test_shard_layout_follows_a_persisted_product_decision(libs, tmp_path, monkeypatch):
+    """exa_shard_layout(jtprod / hprod) answered "owner pieces" whenever windows existed and the mode was
+    undecided, although a persisted exa_tune decision of 0 / 1 makes the call leave PARTIAL SUMS.  The layout query and
+    exa_product_info now resolve the mode the same way a call does."""
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))
+    mk = lambda: ExaModel(models.luksan_vlcek_model(30000))      # noqa: E731
+    m = mk()
+    m.set_shard(1, 2)
+    assert m.product_info("jtprod")[0] == 2 and m.shard_layout("jtprod") == "pieces" and m.shard_layout("hprod") == "pieces"
+    m.tune(2)                                                    # writes "<what>:<signature> <value>" lines next to the module
+    tunes = glob.glob(os.path.join(str(tmp_path), "*.tune"))
+    assert tunes
+    for t in tunes:                                              # ... which this test overrules: atomics for J'v, sorted gather for Hv
+        lines = open(t).read().splitlines()
+        with open(t, "w") as fh:
+            for ln in lines:
+                sig, _ = ln.split()
+                fh.write(f"{sig} {0 if sig.startswith('jtprod') else 1 if sig.startswith('hprod') else _}\n")
+    del m
+    m = mk()
+    m.set_shard(1, 2)
+    m.set_coo_local(True)                                        # (the sorted gather of a shard works on its local slice)
+    assert m.product_mode() == (-1, -1)                          # undecided: the persisted decision applies
+    assert m.product_info("jtprod")[0] == 0 and m.shard_layout("jtprod") == "partial"
+    assert m.product_info("hprod")[0] == 1 and m.shard_layout("hprod") == "partial"
+    m.set_product_mode(2, 2)                                     # explicit windows: owner pieces again
+    assert m.shard_layout("jtprod") == "pieces" and m.shard_layout("hprod") == "pieces"
+    # and the fused sweeps' cons layout is its own question (non-linear augmentation terms: partial sums)
+    assert m.shard_layout("fused_cons") == m.shard_layout("cons") == "pieces"
+
+
+def test_eval_all_takes_the_gradient_decision_exa_grad_takes(libs):
+    import torch
+    data = models.synthetic_power_data(30, 45, 6, seed=3)
+    m = ExaModel(models.ac_power_model(data))
+    o = oracle.OracleModel(m.ir)
+    x = m.meta.x0 + 0.01 * np.random.default_rng(0).standard_normal(m.meta.nvar)
+    y = np.random.default_rng(1).standard_normal(m.meta.ncon)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    m.set_grad_mode(1)
+    f, g, c, j, h = m.eval_all(xd, yd, 0.5)
+    torch.cuda.synchronize()
+    g1 = m.grad(xd).cpu().numpy()
+    assert np.array_equal(g.cpu().numpy(), g1)                   # the sorted gather in both: the same bits
+    assert np.max(np.abs(g1 - o.grad(x)) / np.maximum(1.0, np.abs(o.grad(x)))) <= 1e-12
