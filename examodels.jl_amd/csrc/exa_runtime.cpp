@@ -1541,7 +1541,9 @@ CodeObject product_module_for(Handle &h, bool memory_only_ok) {
     double spent = 0.0;
     bool attached = false;
     for (int wk : {WK_JTPROD, WK_HPROD}) attached = attached || !h.pspec.mat[wk].shared_in.empty();
-    if (!h.no_attach && attached && (window_kernels_spill(co, h.pspec, WK_JTPROD) || window_kernels_spill(co, h.pspec, WK_HPROD))) {
+    // (EXAHIP_WINDOW_REPLAN=0, test infrastructure: keep the first plan — the canary's over-sized kernel — and go straight to the flags)
+    static const bool replan = [] { const char *e = getenv("EXAHIP_WINDOW_REPLAN"); return !(e && atoi(e) == 0); }();
+    if (replan && !h.no_attach && attached && (window_kernels_spill(co, h.pspec, WK_JTPROD) || window_kernels_spill(co, h.pspec, WK_HPROD))) {
         h.no_attach = true;
         plan_products(h);
         spent = co.build_ms;

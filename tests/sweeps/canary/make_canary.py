@@ -33,6 +33,9 @@ import randexpr  # noqa: E402
 from exahip import ExaModel  # noqa: E402
 from poison import make_poison  # noqa: E402
 
+# keep the FIRST plan of the product windows (all-points sums inside the window kernel: the 12-pass exa_hprodw of round 3 with 256
+# VGPRs + 84 AGPRs) instead of re-planning it into something smaller first: the flags alone must make it right
+os.environ["EXAHIP_WINDOW_REPLAN"] = "0"
 out = sys.argv[1] if len(sys.argv) > 1 else HERE
 os.makedirs(out, exist_ok=True)
 dev = torch.device("cuda:0")

@@ -29,7 +29,7 @@ def test_objective_only_forms_leave_exact_zeros_where_a_constraint_hessian_is_in
     v = np.random.default_rng(1).standard_normal(n)
     H = m.hess_coord(x0, None, 0.7)
     assert np.all(np.isfinite(H))
-    info = [m.pattern_info(k) for k in range(m.npatterns())]
+    info = [m.pattern_info(k) for k in range(m.npatterns)]
     for k, pi in enumerate(info):
         sl = slice(pi["o2"], pi["o2"] + pi["o2step"] * pi["n"])
         if pi["kind"] != 0:
@@ -81,6 +81,7 @@ def test_shard_layout_follows_a_persisted_product_decision(libs, tmp_path, monke
     mk = lambda: ExaModel(models.luksan_vlcek_model(30000))      # noqa: E731
     m = mk()
     m.set_shard(1, 2)
+    m.set_coo_local(True)                                        # (the sorted gather of a shard works on its local slice; part of the decision's signature)
     assert m.product_info("jtprod")[0] == 2 and m.shard_layout("jtprod") == "pieces" and m.shard_layout("hprod") == "pieces"
     m.tune(2)                                                    # writes "<what>:<signature> <value>" lines next to the module
     tunes = glob.glob(os.path.join(str(tmp_path), "*.tune"))
@@ -94,7 +95,7 @@ def test_shard_layout_follows_a_persisted_product_decision(libs, tmp_path, monke
     del m
     m = mk()
     m.set_shard(1, 2)
-    m.set_coo_local(True)                                        # (the sorted gather of a shard works on its local slice)
+    m.set_coo_local(True)
     assert m.product_mode() == (-1, -1)                          # undecided: the persisted decision applies
     assert m.product_info("jtprod")[0] == 0 and m.shard_layout("jtprod") == "partial"
     assert m.product_info("hprod")[0] == 1 and m.shard_layout("hprod") == "partial"
