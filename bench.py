@@ -251,7 +251,7 @@ def traffic_for(m, config, per_gpu_points):
     """HBM bytes per launch from the PMC counters: measured in separate rocprofv3 passes (cannot run inside the timed
     process) and committed under profiles/ TOGETHER WITH the name of the module they were measured on — attached only
     when this run executes exactly that module on exactly that workload, null otherwise (never a stale number)."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic_config{config}.json") for r in (3, 2)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic_config{config}.json") for r in (4, 3, 2)) if os.path.exists(q)), None)
     if path is None:
         return None
     with open(path) as fh:
@@ -260,6 +260,39 @@ def traffic_for(m, config, per_gpu_points):
     if t.get("module") != m._L.exa_module_name(m.id).decode() or t.get("points") != per_gpu_points or t.get("kernel") != kernel:
         return None
     return t.get("hbm_bytes_per_launch")
+
+
+def gather_ints(value, world, dev, backend):
+    """[value of rank 0, ..., value of rank world-1] on every rank (one small all-gather through torch.distributed)"""
+    if world == 1:
+        return [int(value)]
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [int(v.item()) for v in out]
+
+
+MALL_BYTES = 256 * 1024 * 1024      # Infinity Cache of an MI355X (MI355X_MICROARCH.md)
+
+
+def roofline_bound(alg_bytes, traffic):
+    """"hbm" when a launch must stream through HBM; "mall" when its whole working set fits the Infinity Cache or the measured HBM
+    traffic is below the algorithmic bytes (a fraction of the HBM peak is not a roofline for such a launch)"""
+    if alg_bytes < MALL_BYTES:
+        return "mall"
+    if isinstance(traffic, (int, float)) and 0 < traffic < 0.98 * alg_bytes:
+        return "mall"
+    return "hbm"
+
+
+def collective_plan(m, which):
+    import ctypes
+    buf = (ctypes.c_int64 * (4 * 64))()
+    n = m._L.exa_collective_plan(m.id, which, buf, 64)
+    names = {0: "allgather", 1: "broadcast", 2: "allreduce"}
+    return [{"op": names.get(int(buf[4 * k]), "?"), "offset": int(buf[4 * k + 1]), "count": int(buf[4 * k + 2]), "root": int(buf[4 * k + 3])} for k in range(max(0, min(n, 64)))]
 
 
 def scale_base_of(sub):
@@ -485,10 +518,17 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl, "baseline_config": config, "points": points, "nvar": nvar, "ncon": ncon, "nnzh": nnzh, "obj_weight": sigma,
                    "parallelism": f"iterator-shard x{world}, local-slice COO, no data-path collective" if world > 1 else "1 GPU",
-                   "resident_per_gpu_bytes": 8 * (n_local + (vhi - vlo) + (yhi - ylo))},
+                   "resident_per_gpu_bytes": 8 * (n_local + (vhi - vlo) + (yhi - ylo)),
+                   # the ranks' packed Hessian slices (exa_local_nnzh64 of every rank, gathered): they must tile nnzh
+                   "local_nnzh_per_rank": gather_ints(n_local, world, dev, backend)},
         "evals_per_s": steps / elapsed,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # "mall": inputs + outputs of one launch fit the 256 MiB Infinity Cache (or the PMC traffic is BELOW the algorithmic bytes): between
+        # identical calls the data never leaves the cache, `achieved` is then a cache rate quoted against the HBM peak for reference only
+        # — the honest figure for such a launch is kernel_ms against the launch floor (launch_floor_ms)
+        "roofline": {"bound": roofline_bound(alg_bytes, traffic_for(m, config, per_gpu if world > 1 else points)), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic_for(m, config, per_gpu if world > 1 else points),
+                     "resident_bytes_test": {"algorithmic_bytes": alg_bytes, "mall_bytes": MALL_BYTES, "cache_resident": alg_bytes < MALL_BYTES},
+                     "launch_floor_ms": m.time_callback("launch", 200, xs),
                      "kernel": HESS_KERNELS[L.exa_hess_variant(m.id)], "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
                      "block_order": {0: "sequential", 1: "interleaved-128"}.get(L.exa_block_order(m.id, 4), "n/a"),
                      # one hess_coord! = ONE launch whatever the number of patterns (ACOPF: 15 patterns, one launch)
@@ -544,7 +584,12 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
                 result.update({"grad_plus_allreduce_ms": t_with, "grad_partial_only_ms": t_without,
                                "grad_collective": "all-gather-v of the ranks' variable slices (owner computes: no zero-fill, nothing summed)" if layout == "pieces"
                                else "all-reduce(sum) of nvar doubles", "grad_collective_bytes": 8 * nvar,
-                               "transport": kind, "where": "inside libexahip (exa_comm_init -> RCCL on the model's stream)"})
+                               "transport": kind, "where": "inside libexahip (exa_comm_init -> RCCL on the model's stream)",
+                               # what the communicator itself reports (RCCL: ncclCommCount): the driver can check RCCL saw N ranks
+                               "n_ranks_seen": m.comm_info()[1],
+                               # the operations libexahip issues for grad! and for the gathered Hessian (exa_collective_plan): kind 0 = one
+                               # in-place ncclAllGather, 1 = broadcast (the last rank's surplus), 2 = all-reduce
+                               "grad_plan": collective_plan(m, 1), "coo_allgather_plan": collective_plan(m, 4)})
                 # the gathered-output variant of the metric: this rank's packed Hessian slice made whole
                 # on every rank by exa_allgather_coo — all-gather-v of the slot ranges, each piece travels once
                 hg = torch.empty(nnzh, dtype=torch.float64, device=dev)

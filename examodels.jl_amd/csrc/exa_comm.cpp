@@ -1,22 +1,27 @@
 // exa_comm.cpp — RCCL behind the C ABI: the collectives of a sharded model run on the model's stream.
 //
-// What needs a collective when every pattern's iterator is split over G GPUs (one process per GPU):
-//   obj        1 double            all-reduce(sum)
-//   grad!      nvar doubles        all-reduce(sum)   (what KA ext :310-336 accumulates on one device)
-//   cons_nln!  base rows are private to a data point (a slice per rank, all-gather-v to make them whole); only the rows
-//              that augmentations add to collect terms from every rank: all-reduce(sum) of those row ranges (KA ext :273-308)
-//   jprod / jtprod / hprod         all-reduce(sum) of the product vector — or, owner-computes windows (range-affine models):
-//                                  every rank evaluates complete values for the variables it owns, all-gather-v
-//   jac_coord! / hess_coord! / structures: NONE — COO slots are private to a data point, ranks own disjoint slices
-//              (exa_allgather_coo makes a sharded COO vector whole where a consumer wants that).
-// librccl is loaded lazily with dlopen (by SONAME: a process that hosts PyTorch gets the copy PyTorch already loaded),
-// so a single-GPU consumer needs no RCCL at all.  xGMI is point-to-point; message sizes here are one dense vector per
-// call, so the library issues ONE collective per callback on the whole vector and lets RCCL pick ring/tree.
+// A sharded model is sharded BY OWNER: what a callback writes belongs either to data points (COO slots: disjoint
+// slices, no collective at all) or to an owner rank that computes it completely (the rows of its data points, a range of
+// variables, a range of windows).  What needs a collective when every pattern's iterator is split over G GPUs:
+//   obj                 1 double           all-reduce(sum)
+//   grad!               owner pieces of nvar (range-affine objective) -> all-gather; partial sums (a data-indexed objective
+//                       pattern scatters) -> all-reduce(sum)            (what KA ext :310-336 accumulates on one device)
+//   cons_nln! / jprod   rows complete on their owner (exa_cons1 walks a row's augmentation terms itself) -> all-gather; only
+//                       the two-stage path (rows collecting > 512 terms) leaves partial sums -> all-reduce (KA ext :273-308)
+//   jtprod / hprod      owner-computes windows -> all-gather; atomics / sorted gather -> all-reduce(sum) of nvar
+//   jac_coord! / hess_coord! / structures: NONE (exa_allgather_coo makes a sharded COO vector whole where a consumer wants it).
+// "all-gather" = plan_allgather below: the ranks' pieces follow part_lo (equal pieces, the remainder on the last rank), so a
+// vector of one piece per rank is ONE in-place ncclAllGather — the tuned primitive; xGMI is a point-to-point mesh and RCCL picks
+// its schedule for it — plus a broadcast of the last rank's surplus; only irregular sets (gaps, empty pieces) fall back to one
+// grouped ncclBroadcast per piece.  Everything of a call sits in one ncclGroupStart / End.
+// librccl is loaded lazily with dlopen (by SONAME: a process that hosts PyTorch gets the copy PyTorch already loaded), so a
+// single-GPU consumer needs no RCCL at all.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -34,6 +39,7 @@ struct Rccl {
     ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
     ncclResult_t (*all_reduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*all_gather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*group_start)() = nullptr;
     ncclResult_t (*group_end)() = nullptr;
     ncclResult_t (*comm_count)(const ncclComm_t, int *) = nullptr;
@@ -55,6 +61,7 @@ Rccl &rccl() {
         r.comm_destroy = (decltype(r.comm_destroy))sym("ncclCommDestroy");
         r.all_reduce = (decltype(r.all_reduce))sym("ncclAllReduce");
         r.broadcast = (decltype(r.broadcast))sym("ncclBroadcast");
+        r.all_gather = (decltype(r.all_gather))sym("ncclAllGather");
         r.group_start = (decltype(r.group_start))sym("ncclGroupStart");
         r.group_end = (decltype(r.group_end))sym("ncclGroupEnd");
         r.comm_count = (decltype(r.comm_count))sym("ncclCommCount");
@@ -102,15 +109,48 @@ void rccl_allreduce_sum_f64(void *comm, double *buf, int64_t count, hipStream_t 
     Rccl &r = rccl();
     chk(r, r.all_reduce(buf, buf, (size_t)count, ncclFloat64, ncclSum, (ncclComm_t)comm, stream), "ncclAllReduce");
 }
-// All-gather of pieces of UNEQUAL length held in place: piece q of `buf` — count[q] doubles at offset off[q] — is owned by
-// rank root[q] and ends up on every rank.  One grouped set of broadcasts (the all-gather-v idiom: a piece travels once over
-// each link RCCL routes it through; nothing is zero-filled, nothing is summed).
-void rccl_allgatherv_f64(void *comm, double *buf, const int64_t *off, const int64_t *count, const int *root, int npieces, hipStream_t stream) {
+// The predicate: a set's pieces can go as ONE in-place all-gather when there is exactly one per rank, in rank order, back to
+// back, and all but the last have the same positive length c (the last >= c).  Anything else: one broadcast per piece.
+std::vector<CollOp> plan_allgather(const std::vector<Piece> &pieces, int world) {
+    std::vector<CollOp> ops;
+    std::vector<int> sets;
+    for (const Piece &q : pieces) if (std::find(sets.begin(), sets.end(), q.set) == sets.end()) sets.push_back(q.set);
+    for (int s : sets) {
+        std::vector<Piece> ps;
+        for (const Piece &q : pieces) if (q.set == s && q.count > 0) ps.push_back(q);
+        bool regular = world > 1 && (int)ps.size() == world;
+        for (int r = 0; regular && r < world; r++) {
+            regular = ps[r].root == r && (r == 0 || ps[r].off == ps[r - 1].off + ps[r - 1].count);
+            if (regular && r + 1 < world) regular = ps[r].count == ps[0].count;
+            if (regular && r + 1 == world) regular = ps[r].count >= ps[0].count;
+        }
+        if (regular) {
+            const int64_t c = ps[0].count;
+            ops.push_back({0, ps[0].off, c, -1});
+            if (ps[world - 1].count > c) ops.push_back({1, ps[world - 1].off + c, ps[world - 1].count - c, world - 1});
+        } else {
+            for (const Piece &q : ps) ops.push_back({1, q.off, q.count, q.root});
+        }
+    }
+    return ops;
+}
+void rccl_run_plan_f64(void *comm, double *buf, const std::vector<CollOp> &ops, int rank, hipStream_t stream) {
+    if (ops.empty()) return;
     Rccl &r = rccl();
     chk(r, r.group_start(), "ncclGroupStart");
-    for (int q = 0; q < npieces; q++)
-        if (count[q] > 0) chk(r, r.broadcast(buf + off[q], buf + off[q], (size_t)count[q], ncclFloat64, root[q], (ncclComm_t)comm, stream), "ncclBroadcast");
+    for (const CollOp &o : ops) {
+        if (o.count <= 0) continue;
+        if (o.kind == 0) chk(r, r.all_gather(buf + o.off + (int64_t)rank * o.count, buf + o.off, (size_t)o.count, ncclFloat64, (ncclComm_t)comm, stream), "ncclAllGather");
+        else if (o.kind == 1) chk(r, r.broadcast(buf + o.off, buf + o.off, (size_t)o.count, ncclFloat64, o.root, (ncclComm_t)comm, stream), "ncclBroadcast");
+        else chk(r, r.all_reduce(buf + o.off, buf + o.off, (size_t)o.count, ncclFloat64, ncclSum, (ncclComm_t)comm, stream), "ncclAllReduce");
+    }
     chk(r, r.group_end(), "ncclGroupEnd");
+}
+int rccl_comm_count(void *comm) {
+    Rccl &r = rccl();
+    int n = 0;
+    chk(r, r.comm_count((ncclComm_t)comm, &n), "ncclCommCount");
+    return n;
 }
 
 }  // namespace exa

@@ -127,6 +127,12 @@ Triple un_rule(Emitter &e, int fn, Val u, int order) {
             r.x = e.call(fn == EXA_U_SIN ? "sin($1)" : "cos($1)", {u});
             return r;
         }
+        // EXAHIP_FAST_TRIG=2: a value-only context takes the sine or the cosine ALONE (exa_sin1 / exa_cos1: one polynomial, <= 2.5 ulp)
+        // unless the other one of the same argument is already there
+        if (order == 0 && env_int("EXAHIP_FAST_TRIG", 1) == 2 && e.memo.find("sincos|" + e.s(u)) == e.memo.end()) {
+            r.x = e.call(fn == EXA_U_SIN ? "exa_sin1($1)" : "exa_cos1($1)", {u});
+            return r;
+        }
         // (value-only contexts too: exa_sin / exa_cos each run the whole sincos, so a pattern — or a fused group — that
         // needs both of one argument pays once)
         // one sincos per argument serves value and both derivatives (functionlist.jl:22-23)

@@ -11,6 +11,15 @@
 
 namespace exa {
 
+// How n items (data points of a pattern, variables, windows) are split over G ranks: rank r holds [part_lo(n, r, G),
+// part_lo(n, r + 1, G)) — floor(n / G) items each, the last rank the remainder (< G items) on top.  Equal pieces are what lets
+// the owner-sharded vectors be completed by ONE in-place ncclAllGather (+ a broadcast of the remainder) instead of G broadcasts.
+// Few items (n < 16 G: the remainder would be more than 6 % of a share) are split evenly instead, floor(n r / G): balance first.
+inline int64_t part_lo(int64_t n, int r, int G) {
+    if (r >= G) return n;
+    return n >= 16LL * G ? (n / G) * (int64_t)r : (int64_t)((__int128)n * r / G);
+}
+
 // malformed pattern table / unsupported construct: the caller's fault -> C-ABI status 1 (everything else -> 2)
 struct BadInput : std::runtime_error { using std::runtime_error::runtime_error; };
 

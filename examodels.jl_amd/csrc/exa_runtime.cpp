@@ -70,6 +70,7 @@ struct Handle {
     exa_allreduce_fn hook = nullptr;
     void *hook_ctx = nullptr;
     bool reduce = true;
+    bool theta_dev_newer = false;     // exa_set_value_dev wrote the device copy of theta: the host copy is refreshed on the next exa_get_value
     // COO outputs of a sharded model: false = global slot positions (ranks fill disjoint slices of one global vector),
     // true = this rank's slots packed into a slice-sized buffer, pattern after pattern (exa_set_coo_local)
     bool coo_local = false;
@@ -221,7 +222,7 @@ std::string tune_signature(const Handle &h, const std::string &what) {
 
 struct Handle;
 // variables rank r of a sharded model owns (owner-computes grad!): [own_var_lo(r), own_var_lo(r + 1))
-int64_t own_var_lo(const Handle &h, int r) { return (int64_t)((__int128)h.m->nvar * r / h.world); }
+int64_t own_var_lo(const Handle &h, int r) { return part_lo(h.m->nvar, r, h.world); }
 
 // ---- parameter table -------------------------------------------------------------------------------------
 void fill_params(Handle &h) {
@@ -237,7 +238,7 @@ void fill_params(Handle &h) {
     for (size_t k = 0; k < m.pats.size(); k++) {
         const Pattern &p = m.pats[k];
         const auto &pp = L.pat[k];
-        const int64_t lo = (int64_t)((__int128)p.n * h.rank / h.world), hi = (int64_t)((__int128)p.n * (h.rank + 1) / h.world);
+        const int64_t lo = part_lo(p.n, h.rank, h.world), hi = part_lo(p.n, h.rank + 1, h.world);
         h.P[pp.lo] = lo; h.P[pp.hi] = hi; h.P[pp.o0] = p.o0; h.P[pp.o1] = p.o1; h.P[pp.o2] = p.o2; h.P[pp.oa] = p.oa;
         // gathered objective patterns: the points of the whole pattern that touch the variables this rank owns
         h.P[pp.qlo] = 0; h.P[pp.qhi] = p.n;
@@ -715,30 +716,29 @@ void allreduce(Handle &h, double *buf, int64_t count) {
 // Windows [w0, w1) a rank of a sharded model owns, and the pieces of the output they cover (owner computes: complete
 // values, nothing to sum).  pieces: (offset, count, owner rank) for EVERY rank — what an all-gather-v needs.
 void owned_windows(const Handle &h, const Handle::Window &w, int rank, int64_t *w0, int64_t *w1) {
-    *w0 = (int64_t)((__int128)w.nwin * rank / h.world);
-    *w1 = (int64_t)((__int128)w.nwin * (rank + 1) / h.world);
+    *w0 = part_lo(w.nwin, rank, h.world);
+    *w1 = part_lo(w.nwin, rank + 1, h.world);
 }
-struct Piece { int64_t off, count; int root; };
 std::vector<Piece> window_pieces(const Handle &h, const Handle::Window &w) {
     std::vector<Piece> out;
     for (int r = 0; r < h.world; r++) {
         int64_t w0, w1;
         owned_windows(h, w, r, &w0, &w1);
-        for (const auto &sp : w.spaces) {
+        for (size_t q = 0; q < w.spaces.size(); q++) {
+            const auto &sp = w.spaces[q];
             const int64_t a = std::min(sp.o + w0 * sp.W, sp.end), b = std::min(sp.o + w1 * sp.W, sp.end);
-            if (b > a) out.push_back({a, b - a, r});
+            if (b > a) out.push_back({a, b - a, r, (int)q});
         }
     }
     return out;
 }
-// Makes a vector whole whose pieces are complete on their owners (in place): RCCL — one grouped set of broadcasts; a host
-// reducer (exa_comm_hook) only knows how to sum, so the other ranks' pieces are zeroed and the covering range summed.
+// Makes a vector whole whose pieces are complete on their owners (in place): RCCL — per set of pieces ONE in-place ncclAllGather
+// where they are regular (plan_allgather, exa_comm.cpp), grouped broadcasts otherwise; a host reducer (exa_comm_hook) only
+// knows how to sum, so the other ranks' pieces are zeroed and the covering range summed.
 void allgatherv(Handle &h, double *buf, const std::vector<Piece> &pieces, bool force = false) {
     if ((!h.reduce && !force) || h.world == 1 || pieces.empty()) return;
     if (h.nccl) {
-        std::vector<int64_t> off, cnt; std::vector<int> root;
-        for (const Piece &q : pieces) { off.push_back(q.off); cnt.push_back(q.count); root.push_back(q.root); }
-        rccl_allgatherv_f64(h.nccl, buf, off.data(), cnt.data(), root.data(), (int)pieces.size(), h.stream);
+        rccl_run_plan_f64(h.nccl, buf, plan_allgather(pieces, h.world), h.rank, h.stream);
     } else if (h.hook) {
         int64_t lo = INT64_MAX, hi = 0;
         for (const Piece &q : pieces) {
@@ -751,17 +751,18 @@ void allgatherv(Handle &h, double *buf, const std::vector<Piece> &pieces, bool f
 }
 std::vector<Piece> var_pieces(const Handle &h) {
     std::vector<Piece> out;
-    for (int r = 0; r < h.world; r++) out.push_back({own_var_lo(h, r), own_var_lo(h, r + 1) - own_var_lo(h, r), r});
+    for (int r = 0; r < h.world; r++) out.push_back({own_var_lo(h, r), own_var_lo(h, r + 1) - own_var_lo(h, r), r, 0});
     return out;
 }
 // constraint rows the ranks own: the base rows of their data points, pattern by pattern
 std::vector<Piece> row_pieces(const Handle &h) {
     std::vector<Piece> out;
     for (int r = 0; r < h.world; r++)
-        for (const Pattern &p : h.m->pats) {
+        for (size_t k = 0; k < h.m->pats.size(); k++) {
+            const Pattern &p = h.m->pats[k];
             if (p.kind != EXA_PAT_CON || p.n <= 0) continue;
-            const int64_t lo = (int64_t)((__int128)p.n * r / h.world), hi = (int64_t)((__int128)p.n * (r + 1) / h.world);
-            if (hi > lo) out.push_back({p.o0 + lo, hi - lo, r});
+            const int64_t lo = part_lo(p.n, r, h.world), hi = part_lo(p.n, r + 1, h.world);
+            if (hi > lo) out.push_back({p.o0 + lo, hi - lo, r, (int)k});
         }
     return out;
 }
@@ -769,11 +770,12 @@ std::vector<Piece> row_pieces(const Handle &h) {
 std::vector<Piece> coo_pieces(const Handle &h, bool hess) {
     std::vector<Piece> out;
     for (int r = 0; r < h.world; r++)
-        for (const Pattern &p : h.m->pats) {
+        for (size_t k = 0; k < h.m->pats.size(); k++) {
+            const Pattern &p = h.m->pats[k];
             const int64_t step = hess ? p.o2step : (p.kind != EXA_PAT_OBJ ? p.o1step : 0);
             if (step <= 0 || p.n <= 0) continue;
-            const int64_t lo = (int64_t)((__int128)p.n * r / h.world), hi = (int64_t)((__int128)p.n * (r + 1) / h.world);
-            if (hi > lo) out.push_back({(hess ? p.o2 : p.o1) + step * lo, step * (hi - lo), r});
+            const int64_t lo = part_lo(p.n, r, h.world), hi = part_lo(p.n, r + 1, h.world);
+            if (hi > lo) out.push_back({(hess ? p.o2 : p.o1) + step * lo, step * (hi - lo), r, (int)k});
         }
     return out;
 }
@@ -1106,7 +1108,7 @@ void do_struct(Handle &h, bool hess, bool wide, void *rows, void *cols) {
     launch(h, f, h.grid[hess ? CB_HSTRUCT : CB_JSTRUCT], kBlock, a);
 }
 
-// ---- windowed compressed evaluation (kernels: exa_codegen.cpp generate_window_module) -----------------
+// ---- windowed compressed evaluation (kernels: exa_gen_window.cpp generate_window_module) -----------------
 // Decides, per matrix, whether the sorted structure is regular enough for the fast path, and prepares its tables:
 //   * every slot s of every active pattern sits at compressed entry a_s + b_s*I for all points but a few at the ends
 //     (fit at the middle point, checked for every point on the device); at most kBlock such end points in total — they are
@@ -1978,10 +1980,40 @@ int exa_set_value(int id, int64_t offset, const double *vals, int64_t len) {
     });
 }
 
+/* set_value! for a parameter vector that lives on the device (the reference's set_value! is a copyto! into the device-resident
+ * θ, nlp.jl:1279-1287): theta[offset .. offset+len) <- dev_vals, a device-to-device copy ordered on the model's stream — no host
+ * hop, no synchronisation, capturable.  dev_vals must stay valid until the stream has passed the copy. */
+int exa_set_value_dev(int id, int64_t offset, const double *dev_vals, int64_t len) {
+    Handle *hh = get(id);
+    if (!hh || !dev_vals || offset < 0 || len < 0 || offset + len > hh->m->npar) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if (len) HIPCHK(hipMemcpyAsync((double *)h.dtheta.p + offset, dev_vals, 8 * (size_t)len, hipMemcpyDeviceToDevice, h.stream));
+        h.theta_dev_newer = true;
+    });
+}
+/* The device-resident parameter vector itself (npar doubles; the reference's get_value returns such a view, nlp.jl:1270-1277):
+ * kernels of this model launched after a write to it — on the model's stream, or ordered against it — see the new values.
+ * NULL for a bad id, a plan-only handle or a model without parameters. */
+double *exa_theta_ptr(int id) {
+    Handle *h = get(id);
+    if (!h || !h->on_device || h->m->npar == 0) return nullptr;
+    h->theta_dev_newer = true;          // the caller may write through it: the host copy is no longer authoritative
+    return (double *)h->dtheta.p;
+}
+
 int exa_get_value(int id, int64_t offset, double *vals, int64_t len) {
     Handle *hh = get(id);
     if (!hh || !vals || offset < 0 || len < 0 || offset + len > hh->m->npar) return 1;
-    std::memcpy(vals, hh->m->theta.data() + offset, 8 * (size_t)len);   // the host copy is authoritative (exa_set_value)
+    if (hh->on_device && hh->theta_dev_newer) {
+        // the device copy was written (exa_set_value_dev / exa_theta_ptr): bring the host copy up to date first
+        const int rc = guard(id, true, [&](Handle &h) {
+            HIPCHK(hipMemcpyAsync(h.m->theta.data(), h.dtheta.p, 8 * (size_t)h.m->npar, hipMemcpyDeviceToHost, h.stream));
+            HIPCHK(hipStreamSynchronize(h.stream));
+            // (a pointer handed out by exa_theta_ptr stays writable: only a set_value_dev is known to be over)
+        });
+        if (rc) return rc;
+    }
+    std::memcpy(vals, hh->m->theta.data() + offset, 8 * (size_t)len);   // the host copy: authoritative unless the device copy was written
     return 0;
 }
 
@@ -2437,7 +2469,7 @@ int exa_chess(int id, const double *x, const double *y, double w, double *vals) 
 
 // ---- measurement ------------------------------------------------------------------------------------------
 int exa_time_callback(int id, int which, int reps, const double *x, const double *y, double w, double *out, float *ms_out) {
-    if (reps < 1 || !ms_out || which < 0 || which > 4 || !x) return 1;   /* 0 obj 1 grad 2 cons 3 jac 4 hess */
+    if (reps < 1 || !ms_out || which < 0 || which > 5 || !x) return 1;   /* 0 obj 1 grad 2 cons 3 jac 4 hess 5 an (almost) empty launch: the floor */
     return guard(id, true, [&](Handle &h) {
         const Model &m = *h.m;
         if ((which == 1 && !out) || (which == 2 && m.ncon && !out) || (which == 3 && m.nnzj && !out) ||
@@ -2451,6 +2483,7 @@ int exa_time_callback(int id, int which, int reps, const double *x, const double
             case 2: do_cons(h, x, out); break;
             case 3: do_jac(h, x, out); break;
             case 4: do_hess(h, x, y, w, out); break;
+            case 5: zero_fill(h, h.dobj.p, 1); break;      // one workgroup writing one double: what a launch costs on this stream
             }
         }
         HIPCHK(hipEventRecord(h.ev1, h.stream));
@@ -2700,6 +2733,7 @@ int exa_comm_info(int id, int *rank, int *world, int *kind) {
     if (!h) return 1;
     if (rank) *rank = h->rank;
     if (world) *world = h->world;
+    if (world && h->nccl) { try { *world = rccl_comm_count(h->nccl); } catch (...) {} }      // what RCCL itself says (ncclCommCount): the ranks it saw
     if (kind) *kind = h->nccl ? 1 : (h->hook ? 2 : 0);
     return 0;
 }
@@ -2723,7 +2757,7 @@ int exa_coo_slices(int id, int hess, int64_t *out) {
     const Model &m = *h->m;
     for (size_t k = 0; k < m.pats.size(); k++) {
         const Pattern &p = m.pats[k];
-        const int64_t lo = (int64_t)((__int128)p.n * h->rank / h->world), hi = (int64_t)((__int128)p.n * (h->rank + 1) / h->world);
+        const int64_t lo = part_lo(p.n, h->rank, h->world), hi = part_lo(p.n, h->rank + 1, h->world);
         const bool has = hess ? p.o2step > 0 : (p.kind != EXA_PAT_OBJ && p.o1step > 0);
         const int64_t step = hess ? p.o2step : p.o1step, o = hess ? p.o2 : p.o1, cnt = has ? step * (hi - lo) : 0;
         out[3 * k] = o + step * lo;                                                     // first global slot (0-based)
@@ -2748,7 +2782,7 @@ int exa_shard_var_range(int id, int64_t *lo_out, int64_t *hi_out) {
     for (size_t k = 0; k < m.pats.size(); k++) {
         const Pattern &p = m.pats[k];
         if (p.n <= 0) continue;
-        const int64_t lo = (int64_t)((__int128)p.n * h->rank / h->world), hi = (int64_t)((__int128)p.n * (h->rank + 1) / h->world);
+        const int64_t lo = part_lo(p.n, h->rank, h->world), hi = part_lo(p.n, h->rank + 1, h->world);
         // a shard holding nothing of a pattern still re-reads one point of it (the branch-free loads of the chained
         // kernels clamp there): the last point before the shard, or point 0
         const int64_t lo_ = hi > lo ? lo : (hi > 0 ? hi - 1 : 0), hi_ = hi > lo ? hi : lo_ + 1;
@@ -2814,6 +2848,31 @@ int exa_shard_layout(int id, int which) {
     }
     return -1;
 }
+/* How the library completes (or a host layer should complete) the output of callback `which` of a sharded model: out <- up to cap
+ * operations of 4 words — kind (0 in-place all-gather: every rank `count` doubles, rank r's at offset + r * count; 1 broadcast of
+ * [offset, offset + count) from `root`; 2 all-reduce(sum) of [offset, offset + count)), offset, count, root (-1 unless kind 1).
+ * Returns the number of operations of the plan (call again with a larger buffer when > cap), 0 for world 1 / nothing to do, -1 bad
+ * argument.  which as exa_shard_layout: 0 obj, 1 grad, 2 cons, 3 jac COO, 4 hess COO (exa_allgather_coo), 5 jprod, 6 jtprod,
+ * 7 hprod, 8 the cons vector of the fused sweeps.  Host logic only: works for plan-only handles (tests/test_shard_layout.py). */
+int exa_collective_plan(int id, int which, int64_t *out, int cap) {
+    Handle *hh = get(id);
+    if (!hh || which < 0 || which > 8 || (cap > 0 && !out)) return -1;
+    Handle &h = *hh;
+    if (h.world == 1) return 0;
+    const int layout = exa_shard_layout(id, which);
+    std::vector<CollOp> ops;
+    const Model &m = *h.m;
+    auto reduce_all = [&](int64_t n) { if (n > 0) ops.push_back({2, 0, n, -1}); };
+    switch (which) {
+    case 0: reduce_all(1); break;
+    case 1: if (layout == 1) ops = plan_allgather(var_pieces(h), h.world); else reduce_all(m.nvar); break;
+    case 2: case 5: case 8: if (layout == 1) ops = plan_allgather(row_pieces(h), h.world); else reduce_all(m.ncon); break;
+    case 3: case 4: ops = plan_allgather(coo_pieces(h, which == 4), h.world); break;
+    case 6: case 7: if (layout == 1) ops = plan_allgather(window_pieces(h, h.wp[which - 6]), h.world); else reduce_all(m.nvar); break;
+    }
+    for (size_t k = 0; k < ops.size() && (int)k < cap; k++) { out[4 * k] = ops[k].kind; out[4 * k + 1] = ops[k].off; out[4 * k + 2] = ops[k].count; out[4 * k + 3] = ops[k].root; }
+    return (int)ops.size();
+}
 /* Makes a sharded Jacobian (hess = 0) / Hessian (hess = 1) COO vector whole on every rank: all-gather-v of the ranks' slot
  * ranges (a piece travels once; nothing is zero-filled or summed — an all-reduce of zero-padded vectors would move world x
  * the data).  `local`: what this rank's exa_jac / exa_hess wrote — the packed local slice (exa_set_coo_local) or
@@ -2830,7 +2889,7 @@ int exa_allgather_coo(int id, int hess, const double *local, double *global) {
                 const Pattern &p = m.pats[k];
                 const int64_t step = hess ? p.o2step : (p.kind != EXA_PAT_OBJ ? p.o1step : 0);
                 if (step <= 0 || p.n <= 0) continue;
-                const int64_t lo = (int64_t)((__int128)p.n * h.rank / h.world), hi = (int64_t)((__int128)p.n * (h.rank + 1) / h.world);
+                const int64_t lo = part_lo(p.n, h.rank, h.world), hi = part_lo(p.n, h.rank + 1, h.world);
                 const int64_t g0 = (hess ? p.o2 : p.o1) + step * lo, l0 = packed ? (hess ? h.lo2[k] : h.lo1[k]) : g0;
                 if (hi > lo && local + l0 != global + g0)
                     HIPCHK(hipMemcpyAsync(global + g0, local + l0, 8 * (size_t)(step * (hi - lo)), hipMemcpyDeviceToDevice, h.stream));

@@ -186,6 +186,14 @@ class _Iter:
             self.n = t.n
             self.template = {k: (0 if v.dtype.kind == "i" else 0.0) for k, v in t.cols.items()}
             self.dims = (self.n,)
+        elif isinstance(itr, np.ndarray) and itr.dtype == object and itr.ndim > 1:
+            # a Matrix of structs (test/NLPTest/luksan_struct.jl: data[1:end-2, :]): Base.size(itr) = its shape, elements in
+            # column-major order (Julia's linear index)
+            self.kind = "list"
+            self.lst = list(itr.flatten(order="F"))
+            self.n = len(self.lst)
+            self.dims = tuple(itr.shape)
+            self.template = _template_of(self.lst[0]) if self.n else 0
         else:
             lst = itr if isinstance(itr, (list, tuple, np.ndarray)) else list(itr)
             self.kind = "list"
@@ -645,6 +653,8 @@ def _infer_dims(it: _Iter):
     if it.kind == "product":
         return tuple(a if isinstance(a, URange) else (_as_urange(a) if isinstance(a, range) else len(a))
                      for a in it.axes)
+    if it.kind == "list" and len(it.dims) > 1:      # a Matrix of data points: the constraint block has its shape (nlp.jl:1588-1590)
+        return tuple(int(d) for d in it.dims)
     return (it.n,)
 
 

@@ -16,8 +16,13 @@ from __future__ import annotations
 
 
 def shard_range(n: int, rank: int, world: int):
-    """Data points [lo, hi) of a pattern with n points owned by `rank` — the same arithmetic as exa_set_shard."""
-    return n * rank // world, n * (rank + 1) // world
+    """Data points [lo, hi) of a pattern with n points owned by `rank` — the same arithmetic as exa_set_shard (part_lo,
+    exa_internal.hpp): n // world points each, the last rank the remainder on top — equal pieces, so that an owner-sharded vector is
+    completed by one in-place all-gather (exa_collective_plan); fewer than 16 points per rank: floor(n r / world)."""
+    if n < 16 * world:          # few items: split evenly (balance before regularity)
+        return n * rank // world, n * (rank + 1) // world
+    per = n // world
+    return per * rank, (n if rank + 1 >= world else per * (rank + 1))
 
 
 def attach_communicator(model, group=None, transport=None, coo_local=False):

@@ -115,3 +115,44 @@ def load(path):
         pmax=gen_k[:, 8] / base, pmin=gen_k[:, 9] / base, qmax=gen_k[:, 3] / base, qmin=gen_k[:, 4] / base,
         rate_a=np.concatenate([rate_a, rate_a]), rate_a_lo=-np.concatenate([rate_a, rate_a]), angmax=angmax, angmin=angmin,
     )
+
+
+def write_synthetic_case(path, nbus, nbr, ngen, seed=0):
+    """Writes a MATPOWER case file of the SHAPE of a PGLIB transmission case (pglib_opf_case78484_epigrids.m is not in the image):
+    buses numbered by area, branches listed by from-bus with ends close in the numbering (models.synthetic_power_data's "bus"
+    topology), per-branch r / x / b, taps and phase shifts on 5 % of the branches, ratings missing on 2 % (calc_thermal_limits!),
+    one slack bus, quadratic generator costs, a few inactive elements.  Numbers are printed with 17 significant digits, so
+    load(path) returns exactly the tables the returned dict describes: the file is what `bench.py --config 4 --case FILE` and the
+    round-trip test run the real-case data path on at full scale."""
+    from .models import synthetic_power_data
+    r = np.random.default_rng(seed)
+    topo = synthetic_power_data(nbus, nbr, ngen, seed=seed, topology="bus")
+    f_bus, t_bus = topo["branch"].cols["f_bus"], topo["branch"].cols["t_bus"]
+    gen_bus = topo["gen"].cols["bus"]
+    base = 100.0
+    fmt = lambda v: repr(float(v))      # noqa: E731  (shortest round-trip representation)
+    with open(path, "w") as fh:
+        fh.write("function mpc = synthetic_case\n% written by exahip.matpower.write_synthetic_case (shape of a PGLIB-OPF case; not a real network)\n")
+        fh.write("mpc.version = '2';\nmpc.baseMVA = 100.0;\n\n%% bus data\n%	bus_i	type	Pd	Qd	Gs	Bs	area	Vm	Va	baseKV	zone	Vmax	Vmin\nmpc.bus = [\n")
+        pd, qd = r.uniform(0.0, 200.0, nbus) * (r.uniform(size=nbus) < 0.6), r.uniform(-50.0, 50.0, nbus)
+        gs, bs = r.uniform(0.0, 10.0, nbus) * (r.uniform(size=nbus) < 0.1), r.uniform(0.0, 20.0, nbus) * (r.uniform(size=nbus) < 0.1)
+        for k in range(nbus):
+            fh.write(f"\t{k + 1}\t{3 if k == 0 else 1}\t{fmt(pd[k])}\t{fmt(qd[k])}\t{fmt(gs[k])}\t{fmt(bs[k])}\t{1 + k * 8 // nbus}\t1.0\t0.0\t230.0\t1\t1.1\t0.9;\n")
+        fh.write("];\n\n%% generator data\n%	bus	Pg	Qg	Qmax	Qmin	Vg	mBase	status	Pmax	Pmin\nmpc.gen = [\n")
+        pmax, qmax = r.uniform(100.0, 500.0, ngen), r.uniform(100.0, 300.0, ngen)
+        for k in range(ngen):
+            fh.write(f"\t{gen_bus[k]}\t0.0\t0.0\t{fmt(qmax[k])}\t{fmt(-qmax[k])}\t1.0\t100.0\t1\t{fmt(pmax[k])}\t0.0;\n")
+        fh.write("];\n\n%% generator cost data\n%	2	startup	shutdown	n	c(n-1)	...	c0\nmpc.gencost = [\n")
+        c2, c1, c0 = r.uniform(0.0, 0.01, ngen), r.uniform(10.0, 50.0, ngen), r.uniform(0.0, 100.0, ngen)
+        for k in range(ngen):
+            fh.write(f"\t2\t0.0\t0.0\t3\t{fmt(c2[k])}\t{fmt(c1[k])}\t{fmt(c0[k])};\n")
+        fh.write("];\n\n%% branch data\n%	fbus	tbus	r	x	b	rateA	rateB	rateC	ratio	angle	status	angmin	angmax\nmpc.branch = [\n")
+        rr, xx, bb = r.uniform(0.0005, 0.02, nbr), r.uniform(0.005, 0.2, nbr), r.uniform(0.0, 0.3, nbr)
+        rate = np.where(r.uniform(size=nbr) < 0.02, 0.0, r.uniform(100.0, 1000.0, nbr))
+        xf = r.uniform(size=nbr) < 0.05
+        tap = np.where(xf, r.uniform(0.95, 1.05, nbr), 0.0)
+        shift = np.where(xf & (r.uniform(size=nbr) < 0.3), r.uniform(-5.0, 5.0, nbr), 0.0)
+        for k in range(nbr):
+            fh.write(f"\t{f_bus[k]}\t{t_bus[k]}\t{fmt(rr[k])}\t{fmt(xx[k])}\t{fmt(bb[k])}\t{fmt(rate[k])}\t{fmt(rate[k])}\t{fmt(rate[k])}\t{fmt(tap[k])}\t{fmt(shift[k])}\t1\t-30.0\t30.0;\n")
+        fh.write("];\n")
+    return dict(nbus=nbus, nbr=nbr, ngen=ngen, baseMVA=base, f_bus=f_bus, t_bus=t_bus, gen_bus=gen_bus, pd=pd / base, rate_a=rate / base)

@@ -17,7 +17,7 @@ import numpy as np
 from . import capi
 from .core import ExaCore, ModelIR
 
-_WHICH = {"obj": 0, "grad": 1, "cons": 2, "jac": 3, "hess": 4}
+_WHICH = {"obj": 0, "grad": 1, "cons": 2, "jac": 3, "hess": 4, "launch": 5}
 
 
 class Recipe:
@@ -428,12 +428,33 @@ class ExaModel:
 
     def set_value(self, par, values):
         """set_value!(m, θ, vals): update a Parameter block without rebuilding (nlp.jl:1279-1287).  A vector of the
-        wrong length is a DimensionMismatch in the reference (GetterSetterTest.jl:33-34); a scalar fills the block."""
+        wrong length is a DimensionMismatch in the reference (GetterSetterTest.jl:33-34); a scalar fills the block.  A device
+        tensor is copied device-to-device on the model's stream (exa_set_value_dev): no host hop, no synchronisation."""
+        if _is_torch(values) and values.is_cuda:
+            if values.numel() != par.length:
+                raise ValueError(f"dimension mismatch: parameter block has {par.length} entries, got {values.numel()}")
+            self._use_torch_stream(values)
+            t = self._tcheck(values, par.length, "values")
+            capi.check(self._L.exa_set_value_dev(self.id, par.offset, t.data_ptr(), par.length), "exa_set_value_dev")
+            return
         a = np.asarray(values, dtype=np.float64)
         if a.ndim > 0 and a.size != par.length:
             raise ValueError(f"dimension mismatch: parameter block has {par.length} entries, got {a.size}")
         v = np.ascontiguousarray(np.broadcast_to(a.reshape(-1) if a.ndim else a, (par.length,)))
         capi.check(self._L.exa_set_value(self.id, par.offset, v.ctypes.data, v.size), "exa_set_value")
+
+    def theta_view(self):
+        """get_value's device view (nlp.jl:1270-1277): the library's parameter vector as a torch tensor sharing its memory (npar
+        doubles on the model's device); writes through it are seen by callbacks launched afterwards on the same stream."""
+        import torch
+        p = self._L.exa_theta_ptr(self.id)
+        if not p:
+            raise capi.ExaHipError("exa_theta_ptr: no device-resident parameters")
+        n = int(self.ir.desc.npar)
+
+        class _Mem:          # __cuda_array_interface__ carrier: torch.as_tensor wraps the memory without copying
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (int(p), False), "version": 2}
+        return torch.as_tensor(_Mem(), device="cuda")
 
     def get_value(self, par):
         """get_value(m, θ): the model's current values of a Parameter block (a copy: the storage is the library's)."""

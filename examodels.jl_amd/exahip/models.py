@@ -74,6 +74,41 @@ def luksan_vlcek_split_model(N, M=1):
     return c
 
 
+def luksan_vlcek_struct_model(N, M=1):
+    """test/NLPTest/luksan_struct.jl:1-20: the split model iterated over an array of NESTED structs — data = [I1(I2((i, j)))],
+    fields reached through the access path `i.i.i[1]`, `i.i.i[2]` (graph.jl:190-196 DataIndexed of DataIndexed).  Here: a list of
+    nested namedtuples, the same path p.i.i[0] / p.i.i[1]; each distinct path becomes one SoA column of the pattern's iterator."""
+    from collections import namedtuple
+    I2 = namedtuple("I2", "i")
+    I1 = namedtuple("I1", "i")
+    c = ExaCore()
+    data = [[I1(I2((i, j))) for j in range(1, M + 1)] for i in range(1, N + 1)]        # data[i-1][j-1], column-major when flattened below
+    x0 = np.array([[luksan_vlcek_x0(data[i][j].i.i[0]) for j in range(M)] for i in range(N)])
+    x = c.add_var(N, M, start=x0)
+    rows = np.empty((N - 2, M), dtype=object)                                         # data[1:end-2, :]: a Matrix of structs, size (N - 2, M)
+    for i in range(N - 2):
+        for j in range(M):
+            rows[i, j] = data[i][j]
+
+    def con1(p):
+        i, j = p.i.i[0], p.i.i[1]
+        return 3 * x[i + 1, j] ** 3 + 2 * x[i + 2, j] - 5
+
+    def con2(p):
+        i, j = p.i.i[0], p.i.i[1]
+        return ((i, j), sin(x[i + 1, j] - x[i + 2, j]) * sin(x[i + 1, j] + x[i + 2, j]) + 4 * x[i + 1, j]
+                - x[i, j] * exp(x[i, j] - x[i + 1, j]) - 3)
+
+    def obj(p):
+        i, j = p
+        return 100 * (x[i - 1, j] ** 2 - x[i, j]) ** 2 + (x[i - 1, j] - 1) ** 2
+
+    s = c.add_con(con1, rows)
+    c.add_con_aug(s, con2, rows)
+    c.add_obj(obj, product(rng(2, N), rng(1, M)))
+    return c
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Goddard rocket (COPS-3 "rocket") — BASELINE.json config 3
 # ---------------------------------------------------------------------------------------------------------------

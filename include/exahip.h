@@ -197,6 +197,14 @@ int exa_allreduce(int id, double *device_buffer, int64_t count);
  * rows).  6 / 7 answer for the implementation a call would run — explicit mode, else the persisted exa_tune decision, else the
  * windows: atomics and the sorted gather leave partial sums, the windows owner pieces (the same resolution as exa_product_info). */
 int exa_shard_layout(int id, int which);
+/* The collective operations that complete the output of callback `which` (numbering of exa_shard_layout; 3 / 4 = the COO vectors as
+ * exa_allgather_coo gathers them): out <- up to cap operations of 4 words: kind, offset, count, root.  kind 0 = in-place all-gather
+ * (every rank contributes `count` doubles, rank r's at offset + r * count: ONE ncclAllGather — data points, variables and windows
+ * are split into equal pieces, the remainder on the last rank), 1 = broadcast of [offset, offset + count) from `root` (the last
+ * rank's surplus; irregular pieces), 2 = all-reduce(sum) of [offset, offset + count) (vectors left as partial sums).  This is what
+ * the library issues through RCCL inside one ncclGroupStart / End, and what a host layer with its own transport (MPI.jl) should
+ * issue.  Returns the number of operations (0 for world 1), -1 for a bad argument.  No device needed. */
+int exa_collective_plan(int id, int which, int64_t *out, int cap);
 /* A sharded Jacobian (hess = 0) / Hessian (hess = 1) COO vector made whole on every rank: all-gather-v of the ranks' slot
  * ranges (a piece travels once; an all-reduce of zero-padded vectors would move world x the data).  `local` = what this
  * rank's exa_jac / exa_hess wrote: the packed local slice (exa_set_coo_local) or the global-length vector with the rank's
@@ -221,6 +229,12 @@ int     exa_coo_slices(int id, int hess, int64_t *out /* 3 * exa_npatterns */);
 int exa_shard_var_range(int id, int64_t *lo, int64_t *hi);
 /* theta update without rebuild (set_value!, nlp.jl:1279-1287; cnlp :1529-1535) */
 int exa_set_value(int id, int64_t offset, const double *vals, int64_t len);   /* theta[offset .. offset+len) <- vals (HOST) */
+/* ... and for parameters that live on the device (the reference's set_value! is a copyto! into the device-resident θ and its
+ * get_value a device view, nlp.jl:1270-1287): theta[offset .. offset+len) <- dev_vals by a device-to-device copy ordered on the
+ * model's stream — no PCIe hop, no synchronisation, capturable into a graph; exa_theta_ptr = the device vector itself (npar
+ * doubles; NULL without a device or without parameters).  exa_get_value afterwards reads the device copy back first. */
+int exa_set_value_dev(int id, int64_t offset, const double *dev_vals, int64_t len);
+double *exa_theta_ptr(int id);
 
 /* ---- callbacks, DEVICE pointers ------------------------------------------------------------------ */
 int exa_obj (int id, const double *x, double *out_host);
@@ -325,7 +339,8 @@ int exa_compress_info(int id, int hess, char *buf, int cap, int *len_out);
 
 /* ---- measurement hooks --------------------------------------------------------------------------- */
 /* Runs the named callback `reps` times on the model's stream bracketed by hipEvents recorded on THAT
- * stream and returns the average milliseconds per call in *ms_out.  which: 0 obj,1 grad,2 cons,3 jac,4 hess.
+ * stream and returns the average milliseconds per call in *ms_out.  which: 0 obj,1 grad,2 cons,3 jac,4 hess, 5 an (almost) empty
+ * launch of the model's module — the floor a launch-bound callback is measured against.
  * Device pointers as in the callbacks (unused ones may be NULL). */
 int exa_time_callback(int id, int which, int reps, const double *x, const double *y, double obj_weight,
                       double *out, float *ms_out);

@@ -201,11 +201,13 @@ def test_eight_shards_from_resident_slices_reproduce_the_model(libs):
     np.testing.assert_allclose(got, H, rtol=1e-10, atol=0)
 
 
-def test_bench_launch_path_with_two_ranks(libs):
-    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per process), on the one GPU of
-    the test box: EXAHIP_DIST_BACKEND=gloo makes the two ranks share cuda:0 and reduce through exa_comm_hook.  The numbers
-    mean nothing; the JSON contract, config 5 as the workload, the strong-scaling split, local-slice buffers and the
-    in-library collectives must all be there."""
+@pytest.mark.parametrize("world", [8])
+def test_bench_launch_path_with_eight_ranks(libs, world):
+    """`bench.py --gpus 8` exactly as the driver launches it (torch.distributed.run, one rank per process), on the one GPU of
+    the test box: EXAHIP_DIST_BACKEND=gloo makes the eight ranks share cuda:0 and reduce through exa_comm_hook.  The numbers
+    mean nothing; the JSON contract, config 5 as the workload, the strong-scaling split, local-slice buffers tiling nnzh, the
+    in-library collectives and their plan must all be there — the first 8-GPU run of the driver takes exactly this path with
+    RCCL in place of the hook (round 3 exercised it with two ranks only)."""
     import json
     import socket
     import subprocess
@@ -215,22 +217,34 @@ def test_bench_launch_path_with_two_ranks(libs):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     env = dict(os.environ, EXAHIP_DIST_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--points", "400000",
+    points = 800_000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "5", "--warmup", "2", "--points", str(points),
            "--preheat-ms", "0"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-2000:], out.stderr[-2000:])
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "strong" and d["unit"] == "nnz/s"
-    assert d["config"]["baseline_config"] == 5 and "split over 2 GPUs" in d["config"]["workload"]
-    assert d["config"]["nnzh"] == 9 * 400000 - 15
-    # each rank holds half of the COO and its stencil stretch of x / y, not the model
-    assert d["config"]["resident_per_gpu_bytes"] < 0.51 * 8 * (9 + 1 + 1) * 400000 + 4096
+    assert d["n_gpus"] == world and d["steps"] == 5 and d["warmup"] == 2 and d["scaling"] == "strong" and d["unit"] == "nnz/s"
+    assert d["config"]["baseline_config"] == 5 and f"split over {world} GPUs" in d["config"]["workload"]
+    assert d["config"]["parallelism"] == f"iterator-shard x{world}, local-slice COO, no data-path collective"
+    assert d["config"]["nnzh"] == 9 * points - 15
+    # the eight packed local slices tile the Hessian COO: equal shares, the remainder on the last rank
+    loc = d["config"]["local_nnzh_per_rank"]
+    assert len(loc) == world and sum(loc) == d["config"]["nnzh"] and len(set(loc[:-1])) == 1 and 0 <= loc[-1] - loc[0] < 9 * world
+    # each rank holds an eighth of the COO and its stencil stretch of x / y, not the model
+    assert d["config"]["resident_per_gpu_bytes"] < (1.0 / world + 0.01) * 8 * (9 + 1 + 1) * points + 4096
     assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["higher_is_better"] is True
     assert d["collectives"].get("transport") == "hook" and d["collectives"]["grad_plus_allreduce_ms"] > 0, d["collectives"]
     assert d["collectives"]["coo_allgather_ms"] > 0 and d["collectives"]["coo_allgather_bytes"] == 8 * d["config"]["nnzh"]
     assert "all-gather-v" in d["collectives"]["grad_collective"]             # LV: grad! is sharded by variable owner
+    assert d["collectives"]["n_ranks_seen"] == world                       # (RCCL: ncclCommCount; here the hook's world)
+    # ... completed by ONE in-place all-gather of equal pieces (800 000 variables over 8 ranks: no surplus); the gathered Hessian:
+    # one all-gather per pattern + the last rank's surplus slots as a broadcast
+    assert d["collectives"]["grad_plan"] == [{"op": "allgather", "offset": 0, "count": points // world, "root": -1}]
+    plan = d["collectives"]["coo_allgather_plan"]
+    assert [op["op"] for op in plan].count("allgather") == 2 and all(op["op"] in ("allgather", "broadcast") for op in plan)
+    assert sum(op["count"] * (world if op["op"] == "allgather" else 1) for op in plan) == d["config"]["nnzh"]
     # the same workload on one GPU, measured in the same run by rank 0: what a scaling ratio has to be computed against
     assert d["scale_base"]["n_gpus"] == 1 and d["scale_base"]["value"] > 0 and d["speedup_vs_scale_base"] > 0
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["value"] > 0

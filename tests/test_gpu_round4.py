@@ -119,3 +119,87 @@ def test_eval_all_takes_the_gradient_decision_exa_grad_takes(libs):
     g1 = m.grad(xd).cpu().numpy()
     assert np.array_equal(g.cpu().numpy(), g1)                   # the sorted gather in both: the same bits
     assert np.max(np.abs(g1 - o.grad(x)) / np.maximum(1.0, np.abs(o.grad(x)))) <= 1e-12
+
+
+def test_parameters_updated_on_the_device(libs):
+    """set_value! / get_value with the parameters where the reference keeps them: on the device (nlp.jl:1270-1287).
+    exa_set_value_dev = stream-ordered device-to-device copy, exa_theta_ptr = the device vector itself."""
+    import torch
+    from zoo import mixed_model, point
+    m = ExaModel(mixed_model())
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=9)
+    xd = torch.from_numpy(x).cuda()
+    th = type("P", (), {"offset": 0, "length": 3})()
+    new = np.array([1.5, -2.5, 4.0])
+    before = m.cons(xd).cpu().numpy().copy()
+    m.set_value(th, torch.from_numpy(new).cuda())                # device tensor -> exa_set_value_dev
+    o.set_value(0, new)
+    after = m.cons(xd).cpu().numpy()
+    assert not np.allclose(before, after)
+    assert np.max(np.abs(after - o.cons(x)) / np.maximum(1.0, np.abs(o.cons(x)))) <= 1e-12
+    assert np.array_equal(m.get_value(th), new)                  # the host side reads the device copy back
+    view = m.theta_view()                                        # the library's own vector
+    assert view.numel() == m.ir.desc.npar and view.is_cuda and np.array_equal(view.cpu().numpy()[:3], new)
+    view[1] = 7.25                                               # a write through the view, ordered on the same stream
+    o.set_value(0, [1.5, 7.25, 4.0])
+    H = m.hess_coord(xd, torch.from_numpy(y).cuda(), sigma).cpu().numpy()
+    Ho = o.hess_coord(x, y, sigma)
+    assert np.max(np.abs(H - Ho) / np.maximum(1.0, np.abs(Ho))) <= 1e-12
+    assert m.get_value(th)[1] == 7.25
+    # a parametric sweep captured once and replayed: the update is a node of the graph, no host hop
+    vals = torch.tensor([0.5, 0.25, 2.0], dtype=torch.float64, device="cuda")
+    out = torch.zeros(max(1, m.meta.ncon), dtype=torch.float64, device="cuda")
+    m.cons(xd, out=out)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            m.set_value(th, vals)
+            m.cons(xd, out=out)
+        for k in range(3):
+            vals.copy_(torch.tensor([0.5 + k, 0.25, 2.0 - k], dtype=torch.float64))
+            g.replay()
+            s.synchronize()
+            o.set_value(0, [0.5 + k, 0.25, 2.0 - k])
+            assert np.max(np.abs(out.cpu().numpy()[:m.meta.ncon] - o.cons(x)) / np.maximum(1.0, np.abs(o.cons(x)))) <= 1e-12
+    # bad arguments are status 1, not device faults
+    assert m._L.exa_set_value_dev(m.id, 2, vals.data_ptr(), 3) == 1 and m._L.exa_set_value_dev(m.id, 0, None, 1) == 1
+
+
+def test_a_78k_bus_case_file_through_the_real_case_path(libs, tmp_path):
+    """BASELINE config 4's real input (pglib_opf_case78484_epigrids.m) is not in the image; this is the data path it would take, at its
+    size: a generated MATPOWER file with the shape of a PGLIB case (78 484 buses, 126 015 branches, 6 800 generators, taps, phase
+    shifters, missing ratings) -> exahip.matpower.load -> test/NLPTest/power.jl's model -> every callback against the oracle, and
+    `bench.py --config 4 --case FILE` on it."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from conftest import parity
+    from exahip import matpower
+    path = str(tmp_path / "case78484_synthetic.m")
+    info = matpower.write_synthetic_case(path, 78_484, 126_015, 6_800, seed=0)
+    d = matpower.load(path)
+    assert (len(d["bus"]), len(d["branch"]), len(d["gen"])) == (78_484, 126_015, 6_800)
+    assert np.array_equal(d["branch"].cols["f_bus"], info["f_bus"]) and np.array_equal(d["bus"].cols["pd"], info["pd"])
+    m = ExaModel(models.ac_power_model(d))
+    assert m.meta.nnzh == 6_800 + 44 * 126_015 + 2 * 78_484
+    o = oracle.OracleModel(m.ir, threads=max(1, min(32, (os.cpu_count() or 2) // 2)))
+    r = np.random.default_rng(5)
+    x = m.meta.x0 + 0.05 * r.uniform(-1, 1, m.meta.nvar)
+    y = r.standard_normal(m.meta.ncon)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    parity("case78484 (generated)", "hess", m.hess_coord(xd, yd, 0.7).cpu().numpy(), o.hess_coord(x, y, 0.7))
+    parity("case78484 (generated)", "jac", m.jac_coord(xd).cpu().numpy(), o.jac_coord(x))
+    parity("case78484 (generated)", "cons", m.cons(xd).cpu().numpy(), o.cons(x))
+    parity("case78484 (generated)", "grad", m.grad(xd).cpu().numpy(), o.grad(x))
+    del m, o
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "4", "--case", path, "--steps", "20", "--warmup", "5", "--preheat-ms", "0",
+                          "--no-cpu"], capture_output=True, text=True, timeout=600, cwd=root)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.returncode, out.stdout[-1500:], out.stderr[-1500:])
+    line = json.loads(lines[0])
+    assert "case78484_synthetic.m" in line["config"]["workload"] and line["config"]["nnzh"] == 6_800 + 44 * 126_015 + 2 * 78_484
+    assert line["value"] > 0 and line["roofline"]["bound"] == "mall"          # 102 MB per launch: Infinity-Cache resident, labelled as such

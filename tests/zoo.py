@@ -75,6 +75,7 @@ ZOO = {
     "lv20_objfirst": lambda: models.luksan_vlcek_model(20, obj_first=True),
     "lv_split_20x1": lambda: models.luksan_vlcek_split_model(20, 1),
     "lv_split_20x2": lambda: models.luksan_vlcek_split_model(20, 2),
+    "lv_struct_20x2": lambda: models.luksan_vlcek_struct_model(20, 2),      # nested access paths p.i.i[k] (test/NLPTest/luksan_struct.jl)
     "lv1000": lambda: models.luksan_vlcek_model(1000),
     "rocket50": lambda: models.rocket_model(50),
     "acopf30": small_acopf,

@@ -21,7 +21,7 @@
 # augmentation model of test/NLPTest/conaug_test.jl:200-213, the two COPS models of benchmark/runbenchmark.jl:239-282 (hanging
 # chain, electrons on a sphere) and this repository's two feature models (`mixed`: parameters with an offset index range,
 # table iterators with Int and Float columns, a 1-D augmentation, literal and data exponents; `stepped`: StepRange iterators,
-# exa_sum / exa_prod, Constant algebra, a parameterised power) — 15 of the 15 fixture models.
+# exa_sum / exa_prod, Constant algebra, a parameterised power) — 16 of the 16 fixture models.
 using ExaModels, NLPModels, Printf
 import JSON   # any JSON reader will do; JSON.jl is what ExaModels' own test environment has
 
@@ -61,6 +61,18 @@ function lv_split_model(N, M)                      # test/NLPTest/luksan.jl:17-2
     @add_var(c, x, N, M; start = [lv_x0(i) for i = 1:N, j = 1:M])
     @add_con(c, s, 3x[i+1, j]^3 + 2 * x[i+2, j] - 5 for i = 1:(N-2), j = 1:M)
     @add_con!(c, s, (i, j) => sin(x[i+1, j] - x[i+2, j])sin(x[i+1, j] + x[i+2, j]) + 4x[i+1, j] - x[i, j]exp(x[i, j] - x[i+1, j]) - 3 for i = 1:(N-2), j = 1:M)
+    @add_obj(c, 100 * (x[i-1, j]^2 - x[i, j])^2 + (x[i-1, j] - 1)^2 for i = 2:N, j = 1:M)
+    return ExaModel(c; prod = true)
+end
+
+struct I2; i::Tuple{Int, Int}; end                 # test/NLPTest/luksan_struct.jl:1-20: the split model over a Matrix of NESTED structs,
+struct I1; i::I2; end                              # fields reached through the access path i.i.i[1] / i.i.i[2]
+function lv_struct_model(N, M)
+    c = ExaCore(concrete = Val(true))
+    data = [I1(I2((i, j))) for i = 1:N, j = 1:M]
+    @add_var(c, x, N, M; start = [lv_x0(i.i.i[1]) for i in data])
+    @add_con(c, s, 3x[i.i.i[1]+1, i.i.i[2]]^3 + 2 * x[i.i.i[1]+2, i.i.i[2]] - 5 for i in data[1:end-2, :])
+    @add_con!(c, s, (i.i.i[1], i.i.i[2]) => sin(x[i.i.i[1]+1, i.i.i[2]] - x[i.i.i[1]+2, i.i.i[2]])sin(x[i.i.i[1]+1, i.i.i[2]] + x[i.i.i[1]+2, i.i.i[2]]) + 4x[i.i.i[1]+1, i.i.i[2]] - x[i.i.i[1], i.i.i[2]]exp(x[i.i.i[1], i.i.i[2]] - x[i.i.i[1]+1, i.i.i[2]]) - 3 for i in data[1:end-2, :])
     @add_obj(c, 100 * (x[i-1, j]^2 - x[i, j])^2 + (x[i-1, j] - 1)^2 for i = 2:N, j = 1:M)
     return ExaModel(c; prod = true)
 end
@@ -207,7 +219,7 @@ end
 const MODELS = [
     ("lv3", a -> lv_model(3)), ("lv20", a -> lv_model(20)), ("lv20_objfirst", a -> lv_model(20; obj_first = true)),
     ("lv1000", a -> lv_model(1000)), ("lv10000", a -> lv_model(10_000)),
-    ("lv_split_20x1", a -> lv_split_model(20, 1)), ("lv_split_20x2", a -> lv_split_model(20, 2)),
+    ("lv_split_20x1", a -> lv_split_model(20, 1)), ("lv_split_20x2", a -> lv_split_model(20, 2)), ("lv_struct_20x2", a -> lv_struct_model(20, 2)),
     ("trivialmax", a -> trivialmax_model(6)), ("conaug2d", a -> conaug2d_model()),
     ("rocket50", a -> rocket_model(50)), ("acopf30", a -> acopf_model(a)),
     ("cops_chain", a -> cops_chain_model(200)), ("cops_elec", a -> cops_elec_model(25)),

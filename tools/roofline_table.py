@@ -64,12 +64,13 @@ def main():
                 continue
             s, p = ks[k], pm.get(k, {})
             gbs = c["algorithmic_bytes"] / s["avg_us"] / 1e3
+            resident = c["algorithmic_bytes"] < 256 * 1024 * 1024      # fits the Infinity Cache: no HBM fraction, time against the launch floor
             tr = None
             if "WRITE_SIZE" in p and "FETCH_SIZE" in p:
                 tr = 1024.0 * (p["WRITE_SIZE"] + CORR * p["FETCH_SIZE"])
             wc = p.get("SQ_WAVE_CYCLES")
             cells = [name if first else "", f"{c['ms']:.4f}" if first else "", f"{c['algorithmic_bytes'] / 1e6:.1f}" if first else "", f"`{k}`", str(s["calls"]),
-                     f"{s['avg_us']:.2f}", f"{gbs:.0f}" if first else "", f"{gbs / PEAK:.3f}" if first else "",
+                     f"{s['avg_us']:.2f}", f"{gbs:.0f}" if first else "", (f"mall, {s['avg_us'] / (1e3 * cb['launch_floor_ms']):.1f}x launch floor" if resident and cb.get("launch_floor_ms") else ("mall" if resident else f"{gbs / PEAK:.3f}")) if first else "",
                      f"{tr / 1e6:.1f}" if tr else "", f"{tr / c['algorithmic_bytes']:.3f}" if tr and first else "",
                      f"{p['SQ_INSTS_VALU'] / 1e6:.2f}" if "SQ_INSTS_VALU" in p else "",
                      f"{p['SQ_WAIT_ANY'] / wc:.2f}" if wc and "SQ_WAIT_ANY" in p else "", f"{p['SQ_WAIT_INST_ANY'] / wc:.2f}" if wc and "SQ_WAIT_INST_ANY" in p else "",

@@ -112,6 +112,7 @@ def main():
     # keep the clocks up before the first timed callback
     for _ in range(50):
         m.hess_coord(xd, yd, 0.5, out=h)
+    floor_ms = m.time_callback("launch", 500, xd)      # an (almost) empty launch of the model's module on the same stream
     for name, fn in calls.items():
         for _ in range(3):
             fn()
@@ -122,8 +123,14 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.reps
-        out["callbacks"][name] = {"ms": ms, "algorithmic_bytes": alg[name], "GBps": alg[name] / ms / 1e6, "frac_of_8TBps": alg[name] / ms / 1e6 / 8000.0,
-                                  "kernels": KERNELS[name]}
+        # a launch whose inputs + outputs fit the 256 MiB Infinity Cache is not an HBM measurement: no fraction of the HBM peak for it
+        # (round 3 printed 1.15 - 2.5 there), its time against the launch floor instead
+        resident = alg[name] < 256 * 1024 * 1024
+        out["callbacks"][name] = {"ms": ms, "algorithmic_bytes": alg[name], "GBps": alg[name] / ms / 1e6,
+                                  "bound": "mall (cache-resident / launch-bound)" if resident else "hbm",
+                                  "frac_of_8TBps": None if resident else alg[name] / ms / 1e6 / 8000.0,
+                                  "x_launch_floor": ms / floor_ms, "kernels": KERNELS[name]}
+    out["launch_floor_ms"] = floor_ms
     print(json.dumps(out), flush=True)
 
 
