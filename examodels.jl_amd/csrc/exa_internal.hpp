@@ -222,6 +222,10 @@ struct WindowSpec {
 // a[s] + b[s] * I (b = 0: a literal index, the same variable for every data point).  false = some target is not affine in
 // a range column (data-indexed) — such a model keeps the atomics / the sorted gather.
 bool product_items(const Model &m, const ParamLayout &L, int wk, int k, std::vector<int64_t> &a, std::vector<int64_t> &b);
+// Owner-pull products (exa_gen_pull.cpp): the module holding exa_jtkeys / exa_jtpull (jt) and exa_hpkeys / exa_hppull (hp), and
+// the number of items per fused group of CB_JTPROD / CB_HPROD (the item slots of group g are first[g] + items[g] * point + t)
+std::string generate_pull_module(const Model &m, const ParamLayout &L, bool jt, bool hp);
+std::vector<int> pull_item_counts(const Model &m, const ParamLayout &L, int cb);
 // merged Hessian slots per data point of every fused group of CB_HESS (what exa_chessm would write)
 std::vector<int> merged_hess_slots(const Model &m, const ParamLayout &L);
 // Source of the second module of a compressed model: exa_chessw / exa_chessx (and exa_cjacw / exa_cjacx).

@@ -163,7 +163,18 @@ struct Handle {
     DevBuf pjrows, pjcols, phrows, phcols;
     SortedIndex jbycol, hbyrow, hbycol;
     bool prod_ready_j = false, prod_ready_h = false;
-    int jt_mode = -1, hp_mode = -1;         // -1 undecided, 0 atomics in the sweep, 1 COO + sorted gather
+    int jt_mode = -1, hp_mode = -1;         // -1 undecided, 0 atomics in the sweep, 1 COO + sorted gather, 2 owner-computes windows, 3 owner pull
+    // owner pull (exa_gen_pull.cpp; models whose scatter targets come from data columns): kernels of the product module, the
+    // variable -> item-slot lists (built by pull_setup, never inside a callback)
+    struct Pull {
+        bool planned = false, ready = false;
+        std::vector<int> nitems;           // items per fused group of CB_JTPROD / CB_HPROD
+        hipFunction_t fkeys = nullptr, fpull = nullptr;
+        SortedIndex idx;
+        DevBuf first;                      // int64[groups]: first item slot of every group
+        int64_t total = 0;
+        std::string why;
+    } pl[2];
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     ~Handle() {
@@ -185,6 +196,7 @@ struct Handle {
             if (pmodule) (void)hipModuleUnload(pmodule);
             pjrows.release(); pjcols.release(); phrows.release(); phcols.release();
             jbycol.release(); hbyrow.release(); hbycol.release();
+            for (auto &q : pl) { q.idx.release(); q.first.release(); }
             for (auto &b : dcols) b.release();
             sx.release(); sy.release(); sv.release(); sout.release(); srows.release(); scols.release();
             if (ev0) (void)hipEventDestroy(ev0);
@@ -1515,6 +1527,22 @@ void plan_products(Handle &h) {
         any = any || w.planned;
     }
     if (any) h.psource = generate_window_module(*h.m, h.gen.layout, h.pspec);
+    // no windows because a target is reached through a data column: the owner-pull kernels instead (exa_gen_pull.cpp)
+    const char *pe = getenv("EXAHIP_PRODUCT_PULL");
+    for (int k = 0; k < 2; k++) { h.pl[k].planned = h.pl[k].ready = false; h.pl[k].why.clear(); h.pl[k].nitems.clear(); h.pl[k].total = 0; }
+    if (!any && !(pe && atoi(pe) == 0)) {
+        bool want[2] = {false, false};
+        for (int k = 0; k < 2; k++) {
+            const int cb = k ? CB_HPROD : CB_JTPROD;
+            if (h.gen.layout.active[cb].empty() || h.wp[k].why.find("data column") == std::string::npos) continue;
+            h.pl[k].nitems = pull_item_counts(*h.m, h.gen.layout, cb);
+            int tot = 0;
+            for (int n : h.pl[k].nitems) tot += n;
+            want[k] = tot > 0 && tot <= 256;          // (one specialised function per item: bounded module size)
+            h.pl[k].planned = want[k];
+        }
+        if (want[0] || want[1]) h.psource = generate_pull_module(*h.m, h.gen.layout, want[0], want[1]);
+    }
 }
 // A window module, compiled or fetched — and ASKED (see audited_code_object).  Window kernels that sum the all-points entries
 // inside themselves (exa_block_sum) are first given the chance to fit by a re-plan: those sums in a kernel of their own
@@ -1573,10 +1601,16 @@ void load_products(Handle &h) {
             window_upload(w);
             w.ok = true;
         }
+        for (int k = 0; k < 2; k++) {
+            if (!h.pl[k].planned) continue;
+            h.pl[k].fkeys = fn(k ? "exa_hpkeys" : "exa_jtkeys");
+            h.pl[k].fpull = fn(k ? "exa_hppull" : "exa_jtpull");
+        }
     } catch (const std::exception &e) {
         std::string msg = e.what();
         if (msg.size() > 300) msg.resize(300);
-        for (int wk : {WK_JTPROD, WK_HPROD}) { Handle::Window &w = window_of(h, wk); w.ok = false; w.why = "the window kernels could not be built (" + msg + ")"; }
+        for (int wk : {WK_JTPROD, WK_HPROD}) { Handle::Window &w = window_of(h, wk); if (w.planned) { w.ok = false; w.why = "the window kernels could not be built (" + msg + ")"; } }
+        for (auto &q : h.pl) if (q.planned) { q.planned = false; q.fkeys = q.fpull = nullptr; q.why = "the owner-pull kernels could not be built (" + msg + ")"; }
         if (h.pmodule) { (void)hipModuleUnload(h.pmodule); h.pmodule = nullptr; }
     }
 }
@@ -1953,6 +1987,7 @@ static void reshard(Handle &h, int rank, int world, bool coo_local) {
     fill_params(h);
     if (h.on_device) {
         drop_sorted(h, false); drop_sorted(h, true);
+        for (auto &q : h.pl) { q.idx.release(); q.ready = false; }
         if (h.compressed) {
             h.cj.release(); h.ch.release(); h.compressed = false;
             for (Handle::Window *w : {&h.wj, &h.wh}) { w->ok = false; w->why.clear(); }
@@ -2125,6 +2160,58 @@ int exa_jprod(int id, const double *x, const double *v, double *Jv) {
 // Which implementation a product runs is a property of the model fixed BEFORE the call: explicit (exa_set_product_mode),
 // measured once by exa_tune and persisted next to the cached module, or — undecided and never tuned — the atomics of the
 // sweep.  Callbacks never measure and never synchronise.
+// Owner pull: the variable -> item-slot lists.  Built once per shard geometry (here: unsharded models only — a rank of a sharded
+// model would need the items of ALL data points that touch its variables, like the windows; the atomics + all-reduce stay there).
+static bool pull_possible(const Handle &h, bool hess) {
+    const Handle::Pull &q = h.pl[hess ? 1 : 0];
+    return h.on_device && h.world == 1 && q.planned && q.fpull && q.why.empty();
+}
+static void pull_setup(Handle &h, bool hess) {
+    Handle::Pull &q = h.pl[hess ? 1 : 0];
+    if (q.ready) return;
+    const Model &m = *h.m;
+    const ParamLayout &L = h.gen.layout;
+    const int cb = hess ? CB_HPROD : CB_JTPROD;
+    std::vector<int64_t> first(L.groups[cb].size(), 0);
+    int64_t total = 0;
+    for (size_t g = 0; g < L.groups[cb].size(); g++) {
+        const auto &pp = L.pat[L.groups[cb][g].front()];
+        first[g] = total;
+        total += (int64_t)q.nitems[g] * (h.P[pp.hi] - h.P[pp.lo]);
+    }
+    if (total <= 0 || total > 0xfffffff0LL) { q.why = "no items, or more than 2^32 of them"; return; }
+    q.total = total;
+    q.first.ensure(8 * std::max<size_t>(first.size(), 1));
+    HIPCHK(hipMemcpy(q.first.p, first.data(), 8 * first.size(), hipMemcpyHostToDevice));
+    DevBuf keys, zx, zy;
+    struct Rel { DevBuf &a, &b, &c; ~Rel() { a.release(); b.release(); c.release(); } } rel{keys, zx, zy};
+    keys.ensure(8 * (size_t)total);
+    // (the key functions hold the whole body of their group; the compiler drops the value part — x, y, v are handed valid zero
+    // vectors all the same)
+    zx.ensure(8 * (size_t)std::max<int64_t>(m.nvar, 1)); zy.ensure(8 * (size_t)std::max<int64_t>(m.ncon, 1));
+    HIPCHK(hipMemsetAsync(zx.p, 0, zx.bytes, h.stream)); HIPCHK(hipMemsetAsync(zy.p, 0, zy.bytes, h.stream));
+    const void *P = h.dP.p, *th = h.dtheta.p, *xz = zx.p, *yz = zy.p, *vz = hess ? zx.p : zy.p, *fp = q.first.p;
+    void *kp = keys.p;
+    double sigma = 1.0;
+    if (hess) { void *a[] = {&P, &xz, &yz, &th, &vz, &sigma, &kp, &fp}; launch(h, q.fkeys, h.grid[cb], kBlock, a); }
+    else { void *a[] = {&P, &xz, &th, &vz, &kp, &fp}; launch(h, q.fkeys, h.grid[cb], kBlock, a); }
+    build_sorted_index(q.idx, (const int64_t *)keys.p, total, m.nvar, h.stream);
+    HIPCHK(hipStreamSynchronize(h.stream));
+    if (q.idx.nlong > 0) {       // a variable collecting more than 512 contributions (a slack shared by every point): one thread would walk them all
+        q.idx.release();
+        q.why = "a variable collects more than 512 contributions (the atomics / the sorted gather handle it cooperatively)";
+        return;
+    }
+    q.ready = true;
+}
+static void do_pull(Handle &h, bool hess, const double *x, const double *y, const double *v, double sigma, double *out) {
+    Handle::Pull &q = h.pl[hess ? 1 : 0];
+    const void *P = h.dP.p, *th = h.dtheta.p, *ptr = q.idx.ptr, *perm = q.idx.perm, *fp = q.first.p;
+    int64_t vb = 0, ve = h.m->nvar;
+    const int64_t grid = (ve - vb + kBlock - 1) / kBlock;
+    if (hess) { void *a[] = {&P, &x, &y, &th, &v, &sigma, &out, &ptr, &perm, &fp, &vb, &ve}; launch(h, q.fpull, grid, kBlock, a); }
+    else { void *a[] = {&P, &x, &th, &v, &out, &ptr, &perm, &fp, &vb, &ve}; launch(h, q.fpull, grid, kBlock, a); }
+}
 static bool sorted_possible(Handle &h, bool hess) {
     const int64_t nnz = hess ? h.lnnzh : h.lnnzj;
     return (h.world == 1 || h.coo_local) && nnz > 0;
@@ -2140,14 +2227,19 @@ static int resolve_mode(Handle &h, bool hess) {
     int &mode = hess ? h.hp_mode : h.jt_mode;
     if (mode < 0) {
         int v = -1;
-        const bool tuned = tune_lookup(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 2;
-        if (tuned && ((v == 1 && sorted_possible(h, hess)) || (v == 2 && window_possible(h, hess)) || v == 0)) mode = v;
+        const bool tuned = tune_lookup(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 3;
+        if (tuned && ((v == 1 && sorted_possible(h, hess)) || (v == 2 && window_possible(h, hess)) || (v == 3 && pull_possible(h, hess)) || v == 0)) mode = v;
         // undecided and never tuned: the windows where the model has them (rocket nh = 1e6: J'v 0.040 against 0.060 ms for the
         // atomics, Hv 0.053 against 0.067 — with the all-points entry summed inside the window kernel; as a separate
         // evaluation pass it was 0.079)
         else mode = window_possible(h, hess) ? 2 : 0;
     }
     if (mode == 2 && !window_possible(h, hess)) return 0;
+    if (mode == 3) {
+        if (!pull_possible(h, hess)) return 0;
+        if (!h.pl[hess ? 1 : 0].ready) { if (capturing(h)) return 0; pull_setup(h, hess); if (!h.pl[hess ? 1 : 0].ready) return 0; }
+        return 3;
+    }
     if (mode == 1 && !sorted_possible(h, hess)) return 0;      // sharded at global positions: nothing to sort locally
     if (mode == 1 && !(hess ? h.prod_ready_h : h.prod_ready_j)) { if (capturing(h)) return 0; prod_setup(h, hess); }
     return mode;
@@ -2173,13 +2265,15 @@ static void run_product_window(Handle &h, bool hess, const double *x, const doub
 static void run_jtprod(Handle &h, const double *x, const double *v, double *Jtv) {
     const int mode = resolve_mode(h, false);
     if (mode == 2) { run_product_window(h, false, x, nullptr, v, 0.0, Jtv); return; }
+    if (mode == 3) { do_pull(h, false, x, nullptr, v, 0.0, Jtv); return; }        // (unsharded: nothing to complete)
     if (mode == 1) do_jtprod_sorted(h, x, v, Jtv); else do_jtprod(h, x, v, Jtv);
     allreduce(h, Jtv, h.m->nvar);
 }
 static void run_hprod(Handle &h, const double *x, const double *y, const double *v, double w, double *Hv) {
     int mode = resolve_mode(h, true);
-    if (mode == 2 && !y && h.m->ncon > 0) mode = 0;      // objective only: the window kernels evaluate every pattern; the atomics launch the objective groups alone
+    if ((mode == 2 || mode == 3) && !y && h.m->ncon > 0) mode = 0;      // objective only: the window / pull kernels evaluate every pattern; the atomics launch the objective groups alone
     if (mode == 2) { run_product_window(h, true, x, y, v, w, Hv); return; }
+    if (mode == 3) { do_pull(h, true, x, y, v, w, Hv); return; }
     if (mode == 1) do_hprod_sorted(h, x, y, v, w, Hv); else do_hprod(h, x, y, v, w, Hv);
     allreduce(h, Hv, h.m->nvar);
 }
@@ -2196,8 +2290,14 @@ int exa_hprod(int id, const double *x, const double *y, const double *v, double 
 /* 0 = atomics inside the sweep, 1 = COO + sorted gather, 2 = owner-computes windows, -1 = undecided (default): the decision
  * exa_tune persisted for this module / device / sizes if there is one, else the windows where the model has them, else 0 */
 int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode) {
-    if (jtprod_mode < -1 || jtprod_mode > 2 || hprod_mode < -1 || hprod_mode > 2) return 1;
+    if (jtprod_mode < -1 || jtprod_mode > 3 || hprod_mode < -1 || hprod_mode > 3) return 1;
     return guard(id, true, [&](Handle &h) {
+        for (int k = 0; k < 2; k++) {
+            if ((k ? hprod_mode : jtprod_mode) != 3) continue;
+            if (pull_possible(h, k != 0)) pull_setup(h, k != 0);
+            if (!h.pl[k].ready) throw BadInput(std::string(k ? "Hv" : "J'v") + " has no owner-pull lists on this model: " +
+                                               (h.pl[k].why.empty() ? (h.world > 1 ? "sharded model" : h.wp[k].why.empty() ? "not planned" : "the model has owner-computes windows or no data-indexed target") : h.pl[k].why));
+        }
         if (jtprod_mode == 2 && !window_possible(h, false)) throw BadInput("J'v has no owner-computes windows on this model: " + h.wp[0].why);
         if (hprod_mode == 2 && !window_possible(h, true)) throw BadInput("Hv has no owner-computes windows on this model: " + h.wp[1].why);
         if (jtprod_mode == 1) prod_setup(h, false);      // refuses a sharded model at global positions (status 1)
@@ -2212,17 +2312,24 @@ int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode) {
 static int product_mode_query(Handle &h, bool hess) {
     const Handle::Window &w = h.wp[hess ? 1 : 0];
     const int mode = hess ? h.hp_mode : h.jt_mode;
-    if (mode >= 0) return mode == 2 && !window_possible(h, hess) ? 0 : mode;
+    if (mode >= 0) return (mode == 2 && !window_possible(h, hess)) || (mode == 3 && !pull_possible(h, hess)) ? 0 : mode;
     int v = -1;
-    if (h.on_device && tune_lookup(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 2 &&
-        (v != 2 || window_possible(h, hess)) && (v != 1 || sorted_possible(h, hess))) return v;
+    if (h.on_device && tune_lookup(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), &v) && v >= 0 && v <= 3 &&
+        (v != 2 || window_possible(h, hess)) && (v != 1 || sorted_possible(h, hess)) && (v != 3 || pull_possible(h, hess))) return v;
     return (h.on_device ? window_possible(h, hess) : w.planned) ? 2 : 0;
 }
 int exa_product_info(int id, int hess, char *buf, int cap) {
     Handle *h = get(id);
     if (!h) return -1;
     const Handle::Window &w = h->wp[hess ? 1 : 0];
-    if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", w.why.c_str());
+    const Handle::Pull &q = h->pl[hess ? 1 : 0];
+    std::string text = w.why;
+    if (q.planned || !q.why.empty()) {
+        int tot = 0;
+        for (int n : q.nitems) tot += n;
+        text += q.why.empty() ? "; owner pull available (" + std::to_string(tot) + " item functions)" : "; no owner pull: " + q.why;
+    }
+    if (buf && cap > 0) snprintf(buf, (size_t)cap, "%s", text.c_str());
     return product_mode_query(*h, hess != 0);
 }
 /* grad!: 0 = gathered (affine patterns) + FP64 atomics (data-indexed ones), 1 = gradient COO + sorted gather (the reference's
@@ -2241,9 +2348,13 @@ int exa_set_deterministic(int id, int on) {
     return guard(id, true, [&](Handle &h) {
         if (on) {
             if (grad_sorted_possible(h)) { grad_setup(h); h.grad_mode = 1; }
-            // (the owner-computes windows are deterministic too: a fixed order of additions, no atomics)
-            if (window_possible(h, false)) h.jt_mode = 2; else if (sorted_possible(h, false)) { prod_setup(h, false); h.jt_mode = 1; }
-            if (window_possible(h, true)) h.hp_mode = 2; else if (sorted_possible(h, true)) { prod_setup(h, true); h.hp_mode = 1; }
+            // (the owner-computes windows and the owner pull are deterministic too: a fixed order of additions, no atomics)
+            for (int k = 0; k < 2; k++) {
+                int &mode = k ? h.hp_mode : h.jt_mode;
+                if (window_possible(h, k != 0)) { mode = 2; continue; }
+                if (pull_possible(h, k != 0)) { pull_setup(h, k != 0); if (h.pl[k].ready) { mode = 3; continue; } }
+                if (sorted_possible(h, k != 0)) { prod_setup(h, k != 0); mode = 1; }
+            }
         } else { h.grad_mode = -1; h.jt_mode = -1; h.hp_mode = -1; }
     });
 }
@@ -2580,6 +2691,18 @@ int exa_tune(int id, int what, const double *x, const double *y) {
                                       else { if (other) do_jtprod_sorted(h, x, y, g); else do_jtprod(h, x, y, g); } };
                     auto wnd = [&] { if (hess) run_product_window(h, true, x, y, x, sigma, g); else run_product_window(h, false, x, nullptr, y, 0.0, g); };
                     if (pick_faster(h, base, wnd) == 1) { best = 2; if (other == 1) drop_sorted(h, hess != 0); }
+                }
+                if (pull_possible(h, hess != 0)) {
+                    // the owner pull against the winner so far
+                    pull_setup(h, hess != 0);
+                    if (h.pl[hess].ready) {
+                        const int other = best;
+                        auto base = [&] { if (hess) { if (other == 1) do_hprod_sorted(h, x, y, x, sigma, g); else do_hprod(h, x, y, x, sigma, g); }
+                                          else { if (other == 1) do_jtprod_sorted(h, x, y, g); else do_jtprod(h, x, y, g); } };
+                        auto pull = [&] { if (hess) do_pull(h, true, x, y, x, sigma, g); else do_pull(h, false, x, nullptr, y, 0.0, g); };
+                        if (other != 2 && pick_faster(h, base, pull) == 1) { best = 3; if (other == 1) drop_sorted(h, hess != 0); }
+                        else { h.pl[hess].idx.release(); h.pl[hess].ready = false; }
+                    }
                 }
                 mode = best;
                 tune_store(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), best);

@@ -597,8 +597,8 @@ class ExaModel:
         return out
 
     def set_product_mode(self, jtprod=-1, hprod=-1):
-        """0 atomics in the sweep, 1 COO + sorted gather, 2 owner-computes windows (range-affine models), -1 undecided
-        (default): what tune() persisted, else the windows where the model has them, else atomics."""
+        """0 atomics in the sweep, 1 COO + sorted gather, 2 owner-computes windows (range-affine models), 3 owner pull (data-indexed
+        models), -1 undecided (default): what tune() persisted, else the windows where the model has them, else atomics."""
         capi.check(self._L.exa_set_product_mode(self.id, int(jtprod), int(hprod)), "exa_set_product_mode")
 
     def set_grad_mode(self, mode=-1):

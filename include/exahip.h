@@ -251,18 +251,24 @@ int exa_hprod (int id, const double *x, const double *y, const double *v, double
  * the objective patterns are launched alone and the constraint slots receive exact zeros (a constraint whose second derivative
  * is Inf / NaN at x cannot leak 0 * Inf into the result); exa_hprod with y == NULL runs by atomics or sorted gather even where
  * the full product has windows.  Asynchronous like every callback, capturable from the first call. */
-/* exa_jtprod / exa_hprod have three implementations.  mode 0: FP64 atomics inside the sweep (zero-fill + atomics; order of
+/* exa_jtprod / exa_hprod have four implementations.  mode 0: FP64 atomics inside the sweep (zero-fill + atomics; order of
  * additions varies).  mode 1: COO + gather through build-time sorted lists (the reference's prod helper, KA ext :56-178,
  * :482-511; deterministic).  mode 2: OWNER-COMPUTES WINDOWS — models whose every scatter target is (range value) * literal +
  * literal (stencil models: LV, discretised ODEs): a workgroup owns a window of consecutive variables, evaluates the data
  * points that touch it (the few straddling two windows twice), adds their contributions in LDS in a fixed order and streams
  * the window out with plain coalesced stores — no zero-fill, no atomics, bit-reproducible; a sharded model owns a range of
- * windows per rank (complete values, all-gather-v instead of all-reduce).  -1 (default) undecided: the decision exa_tune
- * measured and persisted for this module / device / sizes ("chosen by measured contention") if there is one, else mode 2
- * where the model has windows, else 0.  The mode is fixed before a call; a callback never measures. */
+ * windows per rank (complete values, all-gather-v instead of all-reduce).  mode 3: OWNER PULL — models whose targets come from
+ * data columns (ACOPF: bus variables reached through the branch table; no windows there): a list target variable -> the (fused
+ * group, data point, item) contributions that land on it is built once (exa_set_product_mode(…, 3), exa_tune or a persisted
+ * decision at model build: never inside a callback), and a thread per variable re-evaluates its items — one specialised function
+ * per item — and stores the sum: no zero-fill, no atomics, a fixed order of additions (bit-reproducible), every entry written
+ * exactly once; unsharded models whose variables collect at most 512 contributions each (status 1 otherwise).  -1 (default)
+ * undecided: the decision exa_tune measured and persisted for this module / device / sizes ("chosen by measured contention") if
+ * there is one, else mode 2 where the model has windows, else 0.  The mode is fixed before a call; a callback never measures.
+ * EXAHIP_PRODUCT_WINDOW=0 / EXAHIP_PRODUCT_PULL=0 keep the second module from being generated at all. */
 int exa_set_product_mode(int id, int jtprod_mode, int hprod_mode);
 int exa_get_product_mode(int id, int *jtprod_mode, int *hprod_mode);
-/* What exa_jtprod (hess = 0) / exa_hprod (hess = 1) would run now: 0 | 1 | 2 as above, -1 bad id; buf <- the kernel shape of the
+/* What exa_jtprod (hess = 0) / exa_hprod (hess = 1) would run now: 0 | 1 | 2 | 3 as above, -1 bad id; buf <- the kernel shape of the
  * owner-computes windows ("one chunk per pass" | "chunk loops" | "block-owned windows, K spaces") or why the model has none.
  * Works on exa_plan_only handles too (the plan is host-only; EXAHIP_PRODUCT_WINDOW=0 disables it). */
 int exa_product_info(int id, int hess, char *buf, int cap);

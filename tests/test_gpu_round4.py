@@ -203,3 +203,46 @@ def test_a_78k_bus_case_file_through_the_real_case_path(libs, tmp_path):
     line = json.loads(lines[0])
     assert "case78484_synthetic.m" in line["config"]["workload"] and line["config"]["nnzh"] == 6_800 + 44 * 126_015 + 2 * 78_484
     assert line["value"] > 0 and line["roofline"]["bound"] == "mall"          # 102 MB per launch: Infinity-Cache resident, labelled as such
+
+
+@pytest.mark.parametrize("name", ["acopf30", "mixed", "cops_elec"])
+def test_owner_pull_products_of_data_indexed_models(libs, name):
+    """J'v / Hv mode 3 (exa_gen_pull.cpp): a thread per variable re-evaluates the contributions that land on it — no zero-fill, no
+    atomics.  Against the oracle, against the atomics, bit-reproducible, every entry written (NaN-poisoned output), after a
+    register poisoning; y == NULL falls back to the objective groups alone."""
+    import tempfile
+    import torch
+    from poison import make_poison
+    from zoo import ZOO, point
+    m = ExaModel(ZOO[name]())
+    o = oracle.OracleModel(m.ir)
+    x, y, s = point(m.meta.x0, m.meta.ncon, seed=31)
+    v = np.random.default_rng(1).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(2).standard_normal(m.meta.ncon)
+    info = m.product_info("hprod")[1]
+    try:
+        m.set_product_mode(3, 3)
+    except Exception as e:      # noqa: BLE001
+        assert "owner pull" not in info or "no owner pull" in info, (info, e)
+        pytest.skip(f"{name}: {e}")
+    assert m.product_info("jtprod")[0] == 3 and m.product_info("hprod")[0] == 3
+    poison = make_poison(tempfile.mkdtemp())
+    dev = torch.device("cuda:0")
+    xd, yd, vd, wd = (torch.from_numpy(a).to(dev) for a in (x, y, v, w))
+    out = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)
+    poison()
+    a = m.jtprod(xd, wd, out=out).cpu().numpy().copy()
+    out.fill_(float("nan"))
+    poison()
+    b = m.hprod(xd, yd, vd, s, out=out).cpu().numpy().copy()
+    rj, rh = o.jtprod(x, w), o.hprod(x, y, v, s)
+    assert np.all(np.isfinite(a)) and np.max(np.abs(a - rj) / np.maximum(1.0, np.abs(rj))) <= 1e-11
+    assert np.all(np.isfinite(b)) and np.max(np.abs(b - rh) / np.maximum(1.0, np.abs(rh))) <= 1e-11
+    for _ in range(3):                                            # a fixed order of additions: the same bits every time
+        assert np.array_equal(m.jtprod(xd, wd).cpu().numpy(), a) and np.array_equal(m.hprod(xd, yd, vd, s).cpu().numpy(), b)
+    h0 = o.hprod(x, np.zeros(m.meta.ncon), v, s)
+    got = m.hprod(xd, None, vd, s).cpu().numpy()
+    assert np.max(np.abs(got - h0) / np.maximum(1.0, np.abs(h0))) <= 1e-11
+    m.set_deterministic(True)                                     # the pull IS the deterministic implementation where it exists
+    assert m.product_mode() == (3, 3)
+    m.set_product_mode(-1, -1)
