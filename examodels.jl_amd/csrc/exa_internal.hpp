@@ -89,6 +89,7 @@ struct Model {
 
 // Planner (exa_plan.cpp): copies the description, builds AD trees, slot maps and running offsets.
 std::unique_ptr<Model> plan_model(const exa_model_desc_t *desc);   // throws std::runtime_error
+std::vector<int64_t> locality_order(const Model &m, int pattern);   // exa_locality_order (exa_plan.cpp)
 
 // ---------------------------------------------------------------------------------------------------
 // Code generator (exa_gen_*.cpp; internals in exa_gen.hpp)

@@ -2080,6 +2080,22 @@ static int value_block(int id, int k, double *get_to, const double *set_from, in
 int exa_get_value_block(int id, int k, double *vals, int len) { return value_block(id, k, vals, nullptr, len); }
 int exa_set_value_block(int id, int k, const double *vals, int len) { return value_block(id, k, nullptr, vals, len); }
 
+/* perm_out [n of pattern `pattern`] <- a locality-improving order of the pattern's data points (0-based, stable): by the smallest
+ * variable any x[...] of the pattern reaches at the point (a branch table: by from-bus, the order of a case file).  The library never
+ * re-orders the tables it is given — the order of a table's rows IS the order of the constraint rows and COO slots it produces
+ * (nlp.jl:1991-1992) — so applying the permutation (to every pattern that iterates over the same table, and to the y / bounds
+ * of their rows) is the caller's decision, made before the model is built.  Host columns are needed: a plan-only handle. */
+int exa_locality_order(int id, int pattern, int64_t *perm_out) {
+    Handle *h = get(id);
+    if (!h || !perm_out || pattern < 0 || pattern >= (int)h->m->pats.size()) return 1;
+    if (h->on_device) { set_last_error("exa_locality_order: the host columns were released when the model went to the device (use exa_plan_only)"); return 1; }
+    try {
+        const std::vector<int64_t> perm = locality_order(*h->m, pattern);
+        std::memcpy(perm_out, perm.data(), 8 * perm.size());
+        return 0;
+    } catch (const std::exception &e) { g_err = e.what(); return 2; }
+}
+
 // pattern-table view of a planned model that still holds its host columns
 int exa_describe(int id, exa_model_desc_t *out) {
     Handle *hh = get(id);

@@ -286,6 +286,12 @@ class ExaModel:
         capi.check(self._L.exa_pattern_comp(self.id, k, order, out.ctypes.data), "exa_pattern_comp")
         return out[:n].tolist()
 
+    def locality_order(self, k):
+        """exa_locality_order: a stable order of pattern k's data points by the smallest variable they reach (plan-only handles)"""
+        out = np.zeros(max(1, self.pattern_info(k)["n"]), dtype=np.int64)
+        capi.check(self._L.exa_locality_order(self.id, k, out.ctypes.data), "exa_locality_order")
+        return out[:self.pattern_info(k)["n"]]
+
     def kernel_source(self):
         return self._L.exa_kernel_source(self.id).decode()
 

@@ -87,3 +87,43 @@ def test_keep_source_and_verbose_knobs_change_nothing_but_leave_evidence(libs, t
     assert outs[0][0] == outs[1][0]                                      # same module, same numbers
     assert not any(f.endswith(".hip") for f in outs[0][2]) and sum(f.endswith(".hip") for f in outs[1][2]) == 2
     assert "[exahip]" not in outs[0][1] and "[exahip] windowed hprod" in outs[1][1]
+
+
+def test_fast_trig_2_sine_alone_in_value_contexts(libs, monkeypatch):
+    """EXAHIP_FAST_TRIG=2: cons_nln! / obj take the sine or the cosine ALONE (exa_sin1 / exa_cos1: reduction modulo pi, one odd polynomial)
+    instead of the sincos pair — <= 3 ulp against 40-digit mpmath over small, large and near-multiple-of-pi/2 arguments (the default
+    exa_sincos: 1.33, ocml 0.71), i.e. 7e-16 relative against the 1e-10 bar; derivative kernels keep exa_sincos."""
+    import mpmath
+    from exahip import ExaCore, ExaModel, models, rng
+    from exahip.graph import cos, sin
+    import oracle
+    monkeypatch.setenv("EXAHIP_FAST_TRIG", "2")
+    mpmath.mp.dps = 40
+    r = np.random.default_rng(0)
+    xs = np.concatenate([
+        r.uniform(-10, 10, 1500), 10 ** r.uniform(-8, 5.9, 1500) * r.choice([-1, 1], 1500),
+        (np.arange(1, 1001) * (np.pi / 2)) * (1 + r.uniform(-1e-12, 1e-12, 1000)),
+        np.array([0.0, 1e-300, 823549.0, 823550.0, 1e6, 1e15, 3.0e20]),
+    ])
+    n = len(xs)
+    c = ExaCore()
+    x = c.add_var(n)
+    c.add_con(lambda i: sin(x[i]), rng(1, n))
+    c.add_con(lambda i: cos(x[i]), rng(1, n))
+    m = ExaModel(c)
+    src = m.kernel_source()
+    assert "exa_sin1(" in src.split("exa_cons1(")[-1] and "exa_cos1(" in src
+    val, jac = m.cons(xs), m.jac_coord(xs)
+    for got, fn, bound in ((val[:n], mpmath.sin, 3.0), (val[n:], mpmath.cos, 3.0), (jac[:n], mpmath.cos, 2.0), (-jac[n:], mpmath.sin, 2.0)):
+        worst = 0.0
+        for g, xv in zip(got, xs):
+            t = fn(mpmath.mpf(float(xv)))
+            if t != 0:
+                worst = max(worst, float(abs(mpmath.mpf(float(g)) - t) / mpmath.mpf(2) ** (mpmath.floor(mpmath.log(abs(t), 2)) - 52)))
+        assert worst <= bound, (fn, worst)
+    # and a benchmark model under the knob: every callback within the bar
+    lv = ExaModel(models.luksan_vlcek_model(1000))
+    o = oracle.OracleModel(lv.ir)
+    xx, yy, s = point(lv.meta.x0, lv.meta.ncon, seed=3)
+    np.testing.assert_allclose(lv.cons(xx), o.cons(xx), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(lv.hess_coord(xx, yy, s), o.hess_coord(xx, yy, s), rtol=1e-10, atol=1e-12)

@@ -428,3 +428,22 @@ def test_generated_module_has_the_zero_fill_and_the_folding_objective(libs):
     assert "__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)" in src
     # Horner steps of exa_sincos take their coefficients from SGPRs
     assert 'asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k))' in src
+
+
+def test_locality_order_of_a_branch_table_is_by_bus(libs):
+    """exa_locality_order: the data points of a pattern in the order of the smallest variable they reach — a branch table: by its lower
+    bus, the order of a case file.  Host logic (plan-only handle); the library itself never re-orders a table."""
+    import numpy as np
+    from exahip import ExaModel, models
+    data = models.synthetic_power_data(300, 480, 40, seed=4, topology="random")
+    m = ExaModel(models.ac_power_model(data), device=False)
+    f, t = data["branch"].cols["f_bus"], data["branch"].cols["t_bus"]
+    k = next(k for k in range(m.npatterns) if m.pattern_info(k)["n"] == 480 and m.pattern_info(k)["kind"] == 1)
+    perm = m.locality_order(k)
+    assert sorted(perm.tolist()) == list(range(480))
+    key = np.minimum(f, t)[perm]
+    assert np.all(np.diff(key) >= 0)
+    assert np.array_equal(perm, np.argsort(np.minimum(f, t), kind="stable"))
+    # a range pattern is in order already
+    lv = ExaModel(models.luksan_vlcek_model(50), device=False)
+    assert np.array_equal(lv.locality_order(0), np.arange(lv.pattern_info(0)["n"]))
