@@ -180,11 +180,13 @@ def test_eight_shards_from_resident_slices_reproduce_the_model(libs):
         m.set_shard(rank, world)
         m.set_coo_local(True)
         vlo, vhi, ylo, yhi = resident_ranges(m, rank, world)
-        assert vhi - vlo <= N // world + 4 + 2 * 256 and yhi - ylo <= N // world + 1       # + the windows an owner-computes product reaches
+        # + the windows an owner-computes product reaches; the LAST rank also takes the remainder of the equal split (< world windows of
+        # 248 variables, < world points: what makes the other ranks' pieces equal — one in-place all-gather, exa_collective_plan)
+        assert vhi - vlo <= N // world + 4 + 2 * 256 + (world * 248 if rank == world - 1 else 0) and yhi - ylo <= N // world + world
         xs = torch.from_numpy(x[vlo:vhi].copy()).to(dev)
         ys = torch.from_numpy(y[ylo:yhi].copy()).to(dev)
         n = m.local_nnzh
-        assert abs(n - m.meta.nnzh / world) <= 9
+        assert abs(n - m.meta.nnzh / world) <= 9 * world
         h = torch.full((n + 16,), float("nan"), dtype=torch.float64, device=dev)
         rc = L.exa_hess(m.id, ctypes.c_void_p(xs.data_ptr() - 8 * vlo), ctypes.c_void_p(ys.data_ptr() - 8 * ylo), s, ctypes.c_void_p(h.data_ptr()))
         assert rc == 0
