@@ -116,7 +116,7 @@ __global__ void __launch_bounds__(256) k_compress_fold(const uint32_t *__restric
     V[list[l]] = s;
 }
 
-// ---- windowed fast path support (exa_runtime.cpp: window_setup) ----------------------------------------------------
+// ---- windowed fast path support (exa_windows.cpp: window_setup) ----------------------------------------------------
 // cmap[e] = compressed entry of original slot e
 __global__ void __launch_bounds__(256) k_slot_map(const int64_t *__restrict__ ptr, const uint32_t *__restrict__ perm, int32_t *__restrict__ cmap,
                                                   int64_t cnnz) {

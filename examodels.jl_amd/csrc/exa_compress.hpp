@@ -31,7 +31,7 @@ void compress_values(const CompressedCOO &c, const double *buf, double *V, hipSt
 // the sort is stable), so the additions are the gather's, in the gather's order
 void build_positions(const CompressedCOO &c, uint32_t *pos, hipStream_t stream);
 void compress_sorted(const CompressedCOO &c, const double *sorted, double *V, hipStream_t stream);
-// windowed fast path (exa_runtime.cpp): cmap[e] = compressed entry of original slot e (int32, device)
+// windowed fast path (exa_windows.cpp): cmap[e] = compressed entry of original slot e (int32, device)
 void build_slot_map(const CompressedCOO &c, int32_t *cmap, hipStream_t stream);
 // how many points I of [0, n) have a slot s with cmap[o + S*I + s] != a[s] + b[s]*I; e_lo = one past the last such point
 // below mid (0 if none), e_hi = the first such point at or above mid (n if none).  Synchronises the stream.

@@ -132,7 +132,7 @@ struct ParamLayout {
     // stencil operands (ds_read) — instead of two or three overlapping wide loads per pattern.  stage[k] = {word of the range
     // column, smallest and largest literal offset} of pattern k (word < 0: not staged).  The patterns' stretches start at
     // B_k = P[word] + P[lo] + cmin - 1; the kernel stages [min B_k, +64 + kStageHalo): the runtime launches it only when all
-    // stretches fit (exa_runtime.cpp stage_fits), else exa_hessc.
+    // stretches fit (exa_runtime.cpp fill_params: stage_ok), else exa_hessc.
     struct Stage { int word = -1; int64_t cmin = 0, cmax = 0; };
     std::vector<Stage> stage;
     bool staged = false;

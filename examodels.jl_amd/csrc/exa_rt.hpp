@@ -1,0 +1,387 @@
+// exa_rt.hpp — shared state of the runtime translation units (exa_runtime.cpp: model, modules, parameter table, callbacks, core ABI;
+// exa_windows.cpp: window planning + compressed COO; exa_products.cpp: product / gradient modes, tuning; exa_shard.cpp: sharding + collectives).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <unistd.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <stdexcept>
+#include "exa_build.hpp"
+#include "exa_comm.hpp"
+#include "exa_compress.hpp"
+#include "exa_internal.hpp"
+#include "../../include/exahip_recipe.h"
+#include <limits>
+
+namespace exa {
+namespace rt {
+
+extern thread_local std::string g_err;      // exa_last_error(): the message of the last failed call of this thread
+extern std::mutex g_mu;
+// EXAHIP_VERBOSE=1: one stderr line per decision (tuning, register audit, window plans)
+inline bool verbose() { static const bool v = [] { const char *e = getenv("EXAHIP_VERBOSE"); return e && atoi(e) != 0; }(); return v; }
+
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+#define HIPCHK(expr)                                                                                         \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess) throw HipError(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    void ensure(size_t n) {
+        if (n <= bytes) return;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        HIPCHK(hipMalloc(&p, n ? n : 8));
+        bytes = n;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct Handle {
+    std::unique_ptr<Model> m;
+    Generated gen;
+    std::string hsaco_path, build_how, co_name, pco_name;      // co_name / pco_name: what exa_cache_add takes for the two modules
+    double build_ms = 0.0;
+    bool on_device = false;
+    int rank = 0, world = 1;
+    // multi-GPU: either an RCCL communicator or a host-supplied reducer completes obj / grad / cons / products
+    void *nccl = nullptr;
+    bool nccl_owned = false;
+    exa_allreduce_fn hook = nullptr;
+    void *hook_ctx = nullptr;
+    bool reduce = true;
+    bool theta_dev_newer = false;     // exa_set_value_dev wrote the device copy of theta: the host copy is refreshed on the next exa_get_value
+    // COO outputs of a sharded model: false = global slot positions (ranks fill disjoint slices of one global vector),
+    // true = this rank's slots packed into a slice-sized buffer, pattern after pattern (exa_set_coo_local)
+    bool coo_local = false;
+    int64_t lnnzj = 0, lnnzh = 0;            // length of the jac / hess COO buffers in the current mode
+    std::vector<int64_t> lo1, lo2;            // local first slot per pattern (coo_local)
+    std::string devname;
+    hipStream_t stream = nullptr;
+    hipModule_t module = nullptr;
+    hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_zero = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
+                  f_hess = nullptr, f_hessc = nullptr, f_hesscl = nullptr, f_cons1 = nullptr, f_jprod1 = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
+    std::vector<int64_t> P;                 // host copy of the parameter table
+    std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);
+    DevBuf daugcoef;
+    DevBuf daugcsr, daugsrc;                // exa_cons1: CSR over constraint rows of the augmentation terms (pattern << 40 | point)
+    bool cons1 = false;
+    DevBuf dsink;                           // 64 doubles nobody reads (ParamLayout::sink)
+    DevBuf dP, dtheta, dpart, ddone, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
+    int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation
+    DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] units one after the other, [1] interleaved in runs of 128
+    DevBuf dmapg[2];                        // exa_eval_all: the fused sweep's units + the gathered-gradient tiles (same two orders)
+    int64_t gridg = 0;
+    // objective-only forms of hess_coord! / hprod! (y == NULL): a second parameter table whose CB_HESS / CB_HPROD block maps
+    // hold the objective groups alone, and the COO ranges of the constraint patterns (they receive exact zeros)
+    DevBuf dPobj, dmapobj[2];
+    int64_t gridobj[2] = {0, 0};
+    std::vector<std::pair<int64_t, int64_t>> con_hess_ranges;
+    int order[CB_COUNT] = {0};              // which map is active
+    int norders[CB_COUNT] = {1};            // how many maps exist: exa_tune measures all of them
+    int hess_variant = 0;                   // hess_coord! kernel: 0 exa_hess (one tile per workgroup), 1 chained, grouped, pipelined: exa_hesscl
+                                            // (x staged through LDS) where this shard's stretches fit, else exa_hessc; 2 exa_hessc always
+    bool stage_ok = false;                  // exa_hesscl's stretch geometry holds for this shard (fill_params)
+    double hess_stream_bytes = 0.0;         // HBM bytes one hess_coord! of this shard streams (outputs + x + y)
+    int64_t fused_nobj = 0;                 // objective partial sums written by exa_fused
+    std::vector<DevBuf> dcols;              // flattened over patterns
+    std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
+    DevBuf sx, sy, sv, sout, srows, scols;  // scratch of the *_host variants
+    CompressedCOO cj, ch;                   // duplicate-summed COO maps (exa_compress)
+    DevBuf cbuf;                            // uncompressed values of the last compressed evaluation
+    bool compressed = false;
+    // windowed fast path of exa_cjac / exa_chess (window_setup): second module, per-matrix tables
+    struct Window {
+        bool ok = false;
+        int W = 0, nx = 0, smax = 1, lds_bytes = 0;
+        int64_t nwin = 0;
+        hipFunction_t fw = nullptr, fx = nullptr, fs = nullptr;
+        int64_t ns_blocks = 0;             // workgroups of the shared-entry pass (exa_c*s)
+        DevBuf Q, R, X, T, E, xbuf, S, F, part;
+        // the tables as planned on the host (window_plan); window_upload puts them on the device.  Product windows are
+        // planned without a device (plan-only handles generate and compile their module too) and uploaded by to_device.
+        std::vector<int64_t> hQ, hX, hS, hF;
+        std::vector<int32_t> hR, hT, hE;
+        int64_t xbuf_doubles = 0, nparts = 0;
+        // output ranges: window j covers entries [o + j*W, min(o + (j+1)*W, end)) of every space (one space unless block-owned)
+        struct Space { int64_t o, end, W; };
+        std::vector<Space> spaces;
+        bool planned = false;              // products: the plan exists (host); ok = its kernels are loaded as well
+        bool has_shared = false;           // some entry is added to by every data point (partial sums + fold: not owner-shardable)
+        std::string why;                   // why the fast path was not taken (exa_compress_info / exa_product_info)
+    } wj, wh, wp[2];                       // compressed Jacobian / Hessian; J'v / Hv (WK_JTPROD, WK_HPROD)
+    hipModule_t wmodule = nullptr;
+    // owner-computes products: third module (generated at model build when every scatter target is range-affine)
+    WindowSpec pspec;
+    std::string psource, phsaco_path;
+    bool no_attach = false, no_attach_c = false;   // all-points entries by the kernel of their own, never inside a window kernel (products / compressed COO)
+    hipModule_t pmodule = nullptr;
+    // permuted-store path of exa_cjac / exa_chess for matrices the windows do not fit (exa_c*p, see WindowSpec)
+    struct Scatter { bool ok = false; hipFunction_t f = nullptr; DevBuf pos; } sj, sh;
+    // ... and its merged-slot form for the Hessian (exa_chessm): the merged slot space has its own sorted lists
+    bool merged = false;
+    int device = -1;            // the HIP device that was current in exa_create (DeviceScope)
+    // what the compiled kernels of every module of this model need (audited_code_object): which -> report
+    struct Audit { std::string which, name; bool safe = false, readable = false; std::vector<KernelInfo> kernels; };
+    std::vector<Audit> audits;
+    bool loopfree_scatter = false;     // the module is the one generated without loops in the scatter kernels (module_for)
+    std::string first_key;             // ... and this is the key of the module with loops it replaces (its "loopfree" note)
+    // grad! by sorted gather (the reference's scheme, deterministic): gradient COO + (variable, slot) lists, built on demand
+    hipFunction_t f_gradv = nullptr, f_gstruct = nullptr;
+    SortedIndex gbyvar;
+    DevBuf gbuf, gone;
+    bool grad_ready = false;
+    int grad_mode = -1;         // 0 pull + atomics, 1 sorted gather, -1 undecided (persisted exa_tune decision, else 0)
+    hipFunction_t f_chessm = nullptr, f_hstructm = nullptr;
+    CompressedCOO chm;
+    DevBuf dM;
+    int64_t nmerged = 0;
+    std::vector<BlockInfo> blocks;          // named blocks (recipes; empty for plain pattern tables)
+    std::vector<exa_pattern_t> view_pats;   // exa_describe: pattern-table view of the host copy
+    std::vector<std::vector<exa_column_t>> view_cols;
+    // sorted-gather products (the reference's prod helper): COO coordinates + entries grouped by column / by row
+    DevBuf pjrows, pjcols, phrows, phcols;
+    SortedIndex jbycol, hbyrow, hbycol;
+    bool prod_ready_j = false, prod_ready_h = false;
+    int jt_mode = -1, hp_mode = -1;         // -1 undecided, 0 atomics in the sweep, 1 COO + sorted gather, 2 owner-computes windows, 3 owner pull
+    // owner pull (exa_gen_pull.cpp; models whose scatter targets come from data columns): kernels of the product module, the
+    // variable -> item-slot lists (built by pull_setup, never inside a callback)
+    struct Pull {
+        bool planned = false, ready = false;
+        std::vector<int> nitems;           // items per fused group of CB_JTPROD / CB_HPROD
+        hipFunction_t fkeys = nullptr, fpull = nullptr;
+        SortedIndex idx;
+        DevBuf first;                      // int64[groups]: first item slot of every group
+        int64_t total = 0;
+        std::string why;
+    } pl[2];
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    ~Handle() {
+        // (every other entry point runs with the model's device current, DeviceScope; so must the teardown: hipFree /
+        // hipModuleUnload / ncclCommDestroy of a model created on GPU 1 from a thread whose current device is GPU 0)
+        int prev = -1;
+        const bool switched = on_device && device >= 0 && hipGetDevice(&prev) == hipSuccess && prev != device && hipSetDevice(device) == hipSuccess;
+        if (on_device) (void)hipStreamSynchronize(stream);
+        if (on_device) {
+            daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); ddone.release(); dobj.release();
+            daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
+            for (auto &b : dmap) { b[0].release(); b[1].release(); }
+            dmapg[0].release(); dmapg[1].release(); dPobj.release(); dmapobj[0].release(); dmapobj[1].release();
+            cj.release(); ch.release(); cbuf.release();
+            for (Window *w : {&wj, &wh, &wp[0], &wp[1]}) { w->Q.release(); w->R.release(); w->X.release(); w->T.release(); w->E.release(); w->xbuf.release(); w->S.release(); w->F.release(); w->part.release(); }
+            sj.pos.release(); sh.pos.release(); chm.release(); dM.release();
+            gbyvar.release(); gbuf.release(); gone.release();
+            if (wmodule) (void)hipModuleUnload(wmodule);
+            if (pmodule) (void)hipModuleUnload(pmodule);
+            pjrows.release(); pjcols.release(); phrows.release(); phcols.release();
+            jbycol.release(); hbyrow.release(); hbycol.release();
+            for (auto &q : pl) { q.idx.release(); q.first.release(); }
+            for (auto &b : dcols) b.release();
+            sx.release(); sy.release(); sv.release(); sout.release(); srows.release(); scols.release();
+            if (ev0) (void)hipEventDestroy(ev0);
+            if (ev1) (void)hipEventDestroy(ev1);
+            if (module) (void)hipModuleUnload(module);
+        }
+        if (nccl && nccl_owned) { try { rccl_comm_destroy(nccl); } catch (...) {} }
+        if (switched) (void)hipSetDevice(prev);
+    }
+};
+
+// ---- functions shared between the translation units (definitions: see the file named in each section of the .cpp files) ----
+extern std::vector<std::unique_ptr<Handle>> g_models;
+Handle *get(int id);
+int put(std::unique_ptr<Handle> h);
+std::string tune_signature(const Handle &h, const std::string &what);
+int64_t own_var_lo(const Handle &h, int r);
+void fill_params(Handle &h);
+bool prefer_safe(const std::string &source);
+bool all_fit(const CodeObject &co, std::vector<KernelInfo> &ks, bool *readable);
+CodeObject audited_code_object(Handle &h, const std::string &which, const std::string &source, bool memory_only_ok, const CodeObject *have = nullptr);
+bool scatter_kernels_spill(const CodeObject &co);
+CodeObject module_for(Handle &h, bool memory_only_ok);
+void to_device(Handle &h);
+void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **args);
+void zero_fill(Handle &h, void *p, int64_t n);
+void aug_gather(Handle &h, void *buf, double *c);
+void allreduce(Handle &h, double *buf, int64_t count);
+void owned_windows(const Handle &h, const Handle::Window &w, int rank, int64_t *w0, int64_t *w1);
+std::vector<Piece> window_pieces(const Handle &h, const Handle::Window &w);
+void allgatherv(Handle &h, double *buf, const std::vector<Piece> &pieces, bool force = false);
+std::vector<Piece> var_pieces(const Handle &h);
+std::vector<Piece> row_pieces(const Handle &h);
+std::vector<Piece> coo_pieces(const Handle &h, bool hess);
+void do_obj(Handle &h, const double *x, double *out_dev);
+void do_grad(Handle &h, const double *x, double *g);
+bool grad_sorted_possible(const Handle &h);
+void grad_setup(Handle &h);
+void do_grad_sorted(Handle &h, const double *x, double *g);
+bool capturing(const Handle &h);
+int resolve_grad_mode(Handle &h);
+void run_grad(Handle &h, const double *x, double *g);
+bool rows_owner_complete(const Handle &h);
+void do_cons(Handle &h, const double *x, double *c);
+void do_jac(Handle &h, const double *x, double *v);
+void do_hess(Handle &h, const double *x, const double *y, double sigma, double *v);
+void do_fused(Handle &h, const double *x, const double *y, double sigma, double *obj_dev, double *c, double *jv, double *hv, double *gout = nullptr,
+              bool with_pull = false);
+void do_eval_all(Handle &h, const double *x, const double *y, double sigma, double *obj_dev, double *g, double *c, double *jv, double *hv);
+void do_jprod(Handle &h, const double *x, const double *v, double *Jv);
+void do_jtprod(Handle &h, const double *x, const double *v, double *Jtv);
+void do_hprod(Handle &h, const double *x, const double *y, const double *v, double sigma, double *Hv);
+void prod_setup(Handle &h, bool hess);
+void drop_sorted(Handle &h, bool hess);
+void do_jtprod_sorted(Handle &h, const double *x, const double *v, double *Jtv);
+void do_hprod_sorted(Handle &h, const double *x, const double *y, const double *v, double sigma, double *Hv);
+void do_struct(Handle &h, bool hess, bool wide, void *rows, void *cols);
+Handle::Window &window_of(Handle &h, int wk);
+bool window_plan(Handle &h, int wk, const int32_t *cmap, WindowMatrix &wm);
+void window_upload(Handle::Window &w);
+void plan_products(Handle &h);
+bool window_kernels_spill(const CodeObject &co, const WindowSpec &spec, int wk);
+CodeObject product_module_for(Handle &h, bool memory_only_ok);
+void load_products(Handle &h);
+void window_setup(Handle &h);
+void do_scatter(Handle &h, bool hess, const double *x, const double *y, double sigma, double *vals);
+void do_window(Handle &h, int wk, const double *x, const double *y, const double *v, double sigma, double *vals, int64_t w0 = 0, int64_t w1 = -1);
+void zero_if_sharded(Handle &h, void *p, size_t bytes);
+void h2d(Handle &h, DevBuf &b, const void *src, size_t bytes);
+void d2h(Handle &h, void *dst, const void *src, size_t bytes);
+extern void (*g_eager_setup)(Handle &);
+int create(const exa_model_desc_t *desc, int *id_out, bool device);
+int clamp32(int64_t v);
+void reshard(Handle &h, int rank, int world, bool coo_local);
+int value_block(int id, int k, double *get_to, const double *set_from, int len);
+bool pull_possible(const Handle &h, bool hess);
+void pull_setup(Handle &h, bool hess);
+void do_pull(Handle &h, bool hess, const double *x, const double *y, const double *v, double sigma, double *out);
+bool sorted_possible(Handle &h, bool hess);
+bool window_possible(Handle &h, bool hess);
+int resolve_mode(Handle &h, bool hess);
+void eager_setup(Handle &h);
+void run_product_window(Handle &h, bool hess, const double *x, const double *y, const double *v, double w, double *out);
+void run_jtprod(Handle &h, const double *x, const double *v, double *Jtv);
+void run_hprod(Handle &h, const double *x, const double *y, const double *v, double w, double *Hv);
+int product_mode_query(Handle &h, bool hess);
+int struct_host(int id, bool hess, bool wide, void *r, void *c);
+int cstruct(int id, bool hess, bool wide, void *r, void *c);
+int ccsc(int id, bool hess, int64_t *colptr, int64_t *rowval);
+
+
+// Chooses the block order of callback `cb` by measurement (exa_tune only — callbacks never measure): both orders are
+// timed on the model's stream (the outputs are simply rewritten with the same values), the faster map is installed in
+// P[] and the decision persisted next to the cached module.  Synchronises the stream.
+template <class F>
+float tune_order(Handle &h, int cb, F &&run) {
+    const int n = std::max(1, h.norders[cb]);
+    const ParamLayout &L = h.gen.layout;
+    float t[2] = {1e30f, 1e30f};
+    // bring the clocks up first: the governor idles at ~570 MHz and needs tens of ms of load, and at low clocks the
+    // orders rank differently than in steady state (measured: cold tuning picked the slower order 2 times out of 3)
+    {
+        HIPCHK(hipEventRecord(h.ev0, h.stream));
+        for (int it = 0; it < 200; it++) {
+            for (int r = 0; r < 4; r++) run();
+            HIPCHK(hipEventRecord(h.ev1, h.stream));
+            HIPCHK(hipEventSynchronize(h.ev1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h.ev0, h.ev1));
+            if (ms > 60.f) break;
+        }
+    }
+    // A/B rounds, minimum per order: a single sample per order is within the run-to-run noise of the difference being
+    // measured (5-7 %); round 0 only warms up
+    auto install = [&](int k) {
+        if (n < 2) return;
+        h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][k].p;
+        HIPCHK(hipMemcpyAsync((int64_t *)h.dP.p + L.blk[cb], &h.P[L.blk[cb]], 8, hipMemcpyHostToDevice, h.stream));
+        h.order[cb] = k;
+    };
+    for (int round = 0; round < 4; round++) {
+        for (int k = 0; k < n; k++) {
+            install(k);
+            run();
+            HIPCHK(hipEventRecord(h.ev0, h.stream));
+            for (int r = 0; r < 4; r++) run();
+            HIPCHK(hipEventRecord(h.ev1, h.stream));
+            HIPCHK(hipEventSynchronize(h.ev1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h.ev0, h.ev1));
+            if (round > 0 && ms < t[k]) t[k] = ms;
+        }
+    }
+    const int best = n > 1 && t[1] < t[0] ? 1 : 0;
+    install(best);
+    HIPCHK(hipStreamSynchronize(h.stream));
+    if (n > 1) tune_store(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), best);
+    if (verbose()) fprintf(stderr, "[exahip] tune cb=%d: %.4f %.4f ms per 4 launches -> order %d\n", cb, t[0], n > 1 ? t[1] : 0.f, best);
+    return t[best];
+}
+template <class A, class B>
+int pick_faster(Handle &h, A &&atomics, B &&sorted) {
+    float t[2] = {0.f, 0.f};
+    for (int which = 0; which < 2; which++) {
+        for (int rep = 0; rep < 4; rep++) {
+            if (rep == 1) HIPCHK(hipEventRecord(h.ev0, h.stream));
+            if (which == 0) atomics(); else sorted();
+        }
+        HIPCHK(hipEventRecord(h.ev1, h.stream));
+        HIPCHK(hipEventSynchronize(h.ev1));
+        HIPCHK(hipEventElapsedTime(&t[which], h.ev0, h.ev1));
+    }
+    return t[1] < t[0] ? 1 : 0;
+}
+
+
+// The HIP "current device" is per host thread; a model lives on the device that was current in exa_create.  A call from
+// a thread whose current device is another one (a Julia task that migrated, a worker thread that never called
+// hipSetDevice) would allocate its scratch buffers on the wrong GPU: every device call runs with the model's device
+// current and puts the caller's back.
+struct DeviceScope {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceScope(int want) {
+        if (want < 0) return;
+        if (hipGetDevice(&prev) == hipSuccess && prev != want) switched = hipSetDevice(want) == hipSuccess;
+    }
+    ~DeviceScope() { if (switched) (void)hipSetDevice(prev); }
+};
+
+template <class F>
+int guard(int id, bool need_device, F &&f) {
+    Handle *h = get(id);
+    if (!h) return 1;
+    if (need_device && !h->on_device) { g_err = "model was planned without a device (exa_plan_only)"; return 1; }
+    try {
+        DeviceScope scope(h->on_device ? h->device : -1);
+        f(*h);
+        return 0;
+    } catch (const BadInput &e) {
+        g_err = e.what();
+        return 1;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return 2;
+    } catch (...) {
+        g_err = "unknown error";
+        return 2;
+    }
+}
+
+}  // namespace rt
+}  // namespace exa

@@ -447,3 +447,20 @@ def test_locality_order_of_a_branch_table_is_by_bus(libs):
     # a range pattern is in order already
     lv = ExaModel(models.luksan_vlcek_model(50), device=False)
     assert np.array_equal(lv.locality_order(0), np.arange(lv.pattern_info(0)["n"]))
+
+
+def test_owner_pull_module_is_planned_for_data_indexed_models_only(libs, monkeypatch):
+    """The second module of a model: product WINDOWS where every scatter target is range-affine (LV), the owner-PULL kernels where a target
+    comes from a data column (ACOPF), nothing with EXAHIP_PRODUCT_PULL=0.  Host logic: plan-only handles."""
+    from exahip import ExaModel, models
+    from zoo import ZOO
+    a = ExaModel(ZOO["acopf30"](), device=False)
+    assert "owner pull available" in a.product_info("jtprod")[1] and a._L.exa_code_object_count(a.id) == 2
+    src = a.module_source(1)
+    assert "exa_jtpull(" in src and "exa_hppull(" in src and "exa_jtkeys(" in src and "exa_jtprodw" not in src
+    assert a.product_info("jtprod")[0] == 0                       # undecided and untuned: the atomics (the pull is slower, profiles/r4_pull_ab.txt)
+    lv = ExaModel(models.luksan_vlcek_model(100), device=False)
+    assert "owner pull" not in lv.product_info("jtprod")[1] and "exa_jtprodw" in lv.module_source(1) and "exa_jtpull" not in lv.module_source(1)
+    monkeypatch.setenv("EXAHIP_PRODUCT_PULL", "0")
+    b = ExaModel(ZOO["acopf30"](), device=False)
+    assert "owner pull" not in b.product_info("jtprod")[1] and b._L.exa_code_object_count(b.id) == 1 and b.module_source(1) == ""

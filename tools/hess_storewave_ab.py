@@ -34,7 +34,7 @@ def function_text(src, name):
     return src[i:j]
 
 
-def variant_source(src, NC, R, NBUF):
+def variant_source(src, NC, R, NBUF, WIDE=0):
     """exa_hess_sw for the LV module `src`; returns (text, flush template arguments of the two patterns)"""
     out, targs = "", []
     for k in (0, 1):
@@ -62,6 +62,27 @@ static __device__ __forceinline__ void sw_flag_write(unsigned a, int v) {{
 #define SW_R {R}
 #define SW_NB {NBUF}
 #define SW_TILE {T0 + T1}
+#define SW_WIDE {WIDE}
+// WIDE store role: the store wave waits for ALL compute waves of a round and streams the round's contiguous output — NC * 64 * S doubles
+// of each pattern: NC = 4: 12 288 B of constraint slots = three 4 KB-aligned 4 KB units — with 16-byte stores (1 KB per instruction)
+template <int S, int LD>
+static __device__ __forceinline__ void sw_flush_round(double* __restrict__ out, double* __restrict__ sink, long obase, long npts, const double* tiles, int tile_stride, int lane) {{
+    constexpr int PER = 64 * S;                 // doubles per compute wave's tile
+    constexpr int CNT = SW_NC * PER;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int k = 0; k * 128 < CNT; k++) {{
+        const int e = k * 128 + 2 * lane;       // two consecutive doubles of the round's run (PER is even: never across two tiles)
+        const int w = e / PER, j = e - w * PER;
+        const int l0 = j / S, s0 = j - l0 * S, l1 = (j + 1) / S, s1 = (j + 1) - l1 * S;
+        const double* t = tiles + w * tile_stride;
+        d2 v; v.x = t[s0 * LD + l0]; v.y = t[s1 * LD + l1];
+        const bool ok = e < CNT && (long)(w * 64 + l1) < npts;
+        const bool ok0 = e < CNT && (long)(w * 64 + l0) < npts;
+        if (ok) __builtin_nontemporal_store(v, (d2*)(out + obase + e));
+        else if (ok0) __builtin_nontemporal_store(v.x, out + obase + e);
+    }}
+}}
 extern "C" __global__ void __launch_bounds__((SW_NC + 1) * 64) exa_hess_sw(const long* __restrict__ P, const double* __restrict__ x,
         const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma, double* __restrict__ sink) {{
     __shared__ double tile_all[SW_NC * SW_NB * SW_TILE];
@@ -109,6 +130,17 @@ extern "C" __global__ void __launch_bounds__((SW_NC + 1) * 64) exa_hess_sw(const
         }}
     }} else {{
         __builtin_amdgcn_s_setprio(3);
+#if SW_WIDE
+#pragma unroll 1
+        for (int r = 0; r < SW_R; r++) {{
+            for (int w = 0; w < SW_NC; w++) {{ const unsigned f = sw_lds_addr(&flag_all[w * SW_NB + (r % SW_NB)]); while (sw_flag_read(f) == 0) __builtin_amdgcn_s_sleep(1); }}
+            const double* tiles = tile_all + (r % SW_NB) * SW_TILE;            // wave w's buffer: + w * SW_NB * SW_TILE
+            const long tid0 = base0 + (long)r * (SW_NC * 64);
+            {{ const long I0 = P[0] + tid0; sw_flush_round<{S0}, {LD0}>(out, sink, P[4] + {S0}L * I0, P[1] - I0, tiles, SW_NB * SW_TILE, lane); }}
+            {{ const long I0 = P[10] + tid0; sw_flush_round<{S1}, {LD1}>(out, sink, P[14] + {S1}L * I0, P[11] - I0, tiles + {T0}, SW_NB * SW_TILE, lane); }}
+            for (int w = 0; w < SW_NC; w++) sw_flag_write(sw_lds_addr(&flag_all[w * SW_NB + (r % SW_NB)]), 0);
+        }}
+#else
 #pragma unroll 1
         for (int r = 0; r < SW_R; r++)
 #pragma unroll 1
@@ -121,6 +153,7 @@ extern "C" __global__ void __launch_bounds__((SW_NC + 1) * 64) exa_hess_sw(const
                 {{ const long I0 = P[10] + tidw; exa_flush_points_nb<{targs[1]}>(out, sink, P[14] + {S1}L * I0, P[11] - I0, tile + {T0}, lane, 0); }}
                 sw_flag_write(f, 0);
             }}
+#endif
     }}
 }}
 """
@@ -155,8 +188,10 @@ def main():
     print(f"LV N={N}: hess_coord!, one output buffer, A/B rounds against the shipped exa_hesscl of the same module; algorithmic bytes {alg / 1e9:.2f} GB", flush=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 20 if N >= 5e7 else 60
-    for NC, R, NBUF in combos:
-        text, _ = variant_source(src, NC, R, NBUF)
+    for combo in combos:
+        NC, R, NBUF = combo[:3]
+        WIDE = combo[3] if len(combo) > 3 else 0
+        text, _ = variant_source(src, NC, R, NBUF, WIDE)
         with tempfile.TemporaryDirectory() as td:
             hip = os.path.join(td, "ab.hip")
             with open(hip, "w") as fh:
@@ -207,7 +242,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[name].append(e0.elapsed_time(e1) / reps)
-        print(f" NC={NC} compute waves + 1 store wave, R={R} rounds per workgroup, {NBUF} LDS buffers per compute wave:", flush=True)
+        print(f" NC={NC} compute waves + 1 store wave, R={R} rounds per workgroup, {NBUF} LDS buffers per compute wave{', WIDE stores (16 B per lane over the whole round)' if WIDE else ''}:", flush=True)
         for name in fns:
             t = min(times[name])
             print(f"  {name:12s} min {t:.4f} ms  med {float(np.median(times[name])):.4f} ms  {alg / t / 1e6 / 8000:.3f} of 8 TB/s  VGPRs/occupancy/LDS {regs.get(name)}  {res[name]}", flush=True)
