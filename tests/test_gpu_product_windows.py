@@ -151,9 +151,10 @@ def test_random_range_models_through_the_windows(libs, seed, flavour):
     """Random trees over range iterators (tests/randexpr.py; tests/sweeps/window_sweep.py ran 200 seeds): chunk loops, one-chunk
     kernels, block-owned windows, literal-index targets summed inside the window kernel.  Seed 227 is the regression of a
     real fault: its 12-pass Hv kernel, compiled under a 6-wave occupancy hint, spilled 820 B per lane around the block sums
-    of its all-points entries and returned wrong, run-to-run different values (the hint is gone for the products, and a
-    window kernel is used only if it compiled within the 256 architectural VGPRs, exa_windows.cpp window_kernels_spill: the
-    second fault of this kind, tests/sweeps/range_model_check.py 1 1 blocks, had no scratch but 84 AGPRs)."""
+    of its all-points entries and returned wrong, run-to-run different values (the hint is gone for the products; since round 4 a
+    module holding a kernel beyond the 256 architectural VGPRs is rebuilt with conservative allocator flags and keeps its windows,
+    exa_runtime.cpp audited_code_object: the second fault of this kind, tests/sweeps/range_model_check.py 1 1 blocks — now the
+    standalone canary, tests/sweeps/canary/ —, had no scratch but 84 AGPRs)."""
     import torch
     import randexpr
     from exahip import ExaModel, capi
