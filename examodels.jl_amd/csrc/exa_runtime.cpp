@@ -332,6 +332,12 @@ CodeObject module_for(Handle &h, bool memory_only_ok) {
         h.loopfree_scatter = true;
         h.gen = generate_module(*h.m, true);
         spent = co.build_ms;
+        // the kernels the regeneration does not touch are the same code in the new module: if one of THEM is over-sized the new module
+        // will need the conservative flags too — note it now and save the compilation that would only find that out
+        std::vector<KernelInfo> ks;
+        bool others = !code_object_kernels(co.image, ks);
+        for (const KernelInfo &k : ks) others = others || (!k.fits() && k.name != "exa_grad" && k.name != "exa_jtprod" && k.name != "exa_hprod");
+        if (others && !safe_flags().empty()) note_store(source_key(h.gen.source), "safe", true);
     }
     CodeObject fin = audited_code_object(h, "model", h.gen.source, memory_only_ok, &co);
     fin.build_ms += spent;

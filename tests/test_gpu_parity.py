@@ -14,7 +14,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a
 RTOL = 1e-10
 # zoo models on which the STRICT (component-wise) 1e-10 is asserted as well; the others are reported (their worst entries are sums
 # that cancel: the absolute error is at the level of the terms' rounding, the entry itself orders of magnitude smaller)
-STRICT = {"lv3", "lv20", "lv20_objfirst", "lv_split_20x1", "lv_split_20x2", "lv1000", "rocket50"}
+STRICT = {"lv3", "lv20", "lv20_objfirst", "lv_split_20x1", "lv_split_20x2", "lv_struct_20x2", "lv1000", "rocket50"}
 
 
 def relerr(a, ref):
@@ -254,7 +254,7 @@ def test_chained_hess_kernel_is_the_same_function(libs, monkeypatch, name, varia
     m = ExaModel(ZOO[name]())
     staged = "exa_hesscl" in m.kernel_source()
     assert m._L.exa_hess_variant(m.id) == (1 if variant == 1 and staged else 2)
-    if name.startswith("lv") and "split" not in name:
+    if name.startswith("lv") and "split" not in name and "struct" not in name:      # (the struct model reaches x through table columns)
         assert staged                                     # unit-step stencils over one range: the staging applies
     o = oracle.OracleModel(m.ir)
     x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=9)

@@ -18,6 +18,9 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs a
 
 @pytest.fixture(scope="module")
 def poison(tmp_path_factory):
+    from conftest import PREBUILD
+    if PREBUILD:                 # (kernel prebuild on the CPU, tests/conftest.py: nothing runs, the poison is never called)
+        return lambda: None
     from poison import make_poison
     return make_poison(str(tmp_path_factory.mktemp("poison")))
 

@@ -246,7 +246,7 @@ def test_grad_tuning_picks_the_sorted_gather_for_hot_targets(libs, tmp_path, mon
 @pytest.mark.parametrize("name", ["acopf30", "rocket50", "mixed", "lv1000"])
 def test_deterministic_switch_makes_every_callback_bit_reproducible(libs, name):
     """exa_set_deterministic: grad! by sorted gather, jtprod and hprod by owner-computes windows where the model has them
-    (fixed order of additions, no atomics), else by sorted gather.  Ten evaluations of everything, interleaved: one bit
+    (fixed order of additions, no atomics), else by owner pull (data-indexed targets), else by sorted gather.  Ten evaluations of everything, interleaved: one bit
     pattern per output — and still the oracle's values."""
     import torch
     import oracle
@@ -254,7 +254,9 @@ def test_deterministic_switch_makes_every_callback_bit_reproducible(libs, name):
     m = ExaModel(ZOO[name]())
     o = oracle.OracleModel(m.ir)
     m.set_deterministic(True)
-    assert m.grad_mode() == 1 and m.product_mode() == ((2, 2) if name in ("rocket50", "lv1000") else (1, 1))
+    # windows where the model has them, else the owner pull (data-indexed targets, round 4), else the sorted gather
+    pull = "owner pull available" in m.product_info("jtprod")[1]
+    assert m.grad_mode() == 1 and m.product_mode() == ((2, 2) if name in ("rocket50", "lv1000") else (3, 3) if pull else (1, 1))
     x, y, s = point(m.meta.x0, m.meta.ncon, seed=29)
     v = np.random.default_rng(5).standard_normal(m.meta.nvar)
     w = np.random.default_rng(6).standard_normal(max(m.meta.ncon, 1))[:m.meta.ncon]
