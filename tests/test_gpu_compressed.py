@@ -318,7 +318,7 @@ def test_no_compiler_for_the_window_module_falls_back_to_the_gather(libs, monkey
     assert _check_against_uncompressed(m, cm, 1) == ["gather", "gather"]
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(5))          # (its second module is compiled on the GPU box at exa_compress: 8 s a seed)
 def test_random_table_models_take_the_merged_permuted_store(libs, seed):
     """Random models whose 12 patterns all iterate ONE table (tests/randexpr.py build_model): identical columns are
     aliased, the patterns form fused groups, and the compressed Hessian goes through merged slots + permuted store
