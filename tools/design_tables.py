@@ -31,7 +31,7 @@ sub("| 3 | rocket", f"| 3 | rocket nh = 1e6 | `{k}` | {ms:.4f} | {v:.3g} | 528 M
 d = b["config4"]; ms, v, f, t, k = g(d); one, allc = d["cpu_baseline"]["value"], d["cpu_baseline"]["all_cores"]["value"]
 sub("| 4 | ACOPF", f"| 4 | ACOPF 78 484 buses (synthetic) | `{k}` | {ms:.4f} | {v:.3g} | 102 MB | {t / 1e6:.0f} MB (MALL-resident) | mall: {ms / d['roofline']['launch_floor_ms']:.1f}× the launch floor ({f:.2f} of the HBM peak as a cache rate) | {one:.2g} / {allc:.2g} | {v / one:,.0f}× |")
 d = b["config5_n1"]; ms, v, f, t, k = g(d)
-sub("| 5 at N = 1", f"| 5 at N = 1 (`scale_base`) | LV N = 1e8 | `{k}` | {ms:.3f} | {v:.3g} | 8.80 GB | {t / 1e9:.2f} GB | {f:.3f} (0.67–0.72 across boxes of the pool) | — | — |")
+sub("| 5 at N = 1", f"| 5 at N = 1 (`scale_base`) | LV N = 1e8 | `{k}` | {ms:.3f} | {v:.3g} | 8.80 GB | {t / 1e9:.2f} GB | {f:.3f} (0.66–0.73 across boxes of the pool) | — | — |")
 
 
 def c(key, cfg):
