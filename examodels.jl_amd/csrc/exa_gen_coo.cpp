@@ -25,11 +25,11 @@ static bool is_memory_read(const std::string &expr) {
         if (expr.compare(0, strlen(pre), pre) == 0) return true;
     return false;
 }
-// staged != null: x loads listed there (name -> literal offset from the pattern's smallest one) are NOT loaded: the
-// evaluation stage reads them from the wavefront's staged stretch, xs[xd + offset]
-static Split split_body_staged(const Emitter &e, const std::map<std::string, int64_t> *staged);
+// staged != null: x loads listed there (name -> LDS index expression: stretch base + the cluster's lane offset + literal distance) are
+// NOT loaded: the evaluation stage reads them from the wavefront's staged stretches, xs[...]
+static Split split_body_staged(const Emitter &e, const std::map<std::string, std::string> *staged);
 Split split_body(const Emitter &e) { return split_body_staged(e, nullptr); }
-static Split split_body_staged(const Emitter &e, const std::map<std::string, int64_t> *staged) {
+static Split split_body_staged(const Emitter &e, const std::map<std::string, std::string> *staged) {
     Split sp;
     size_t d = 0;
     for (size_t li = 0; li < e.lines.size(); li++) {
@@ -37,7 +37,7 @@ static Split split_body_staged(const Emitter &e, const std::map<std::string, int
         if (d < e.defs.size() && e.defs[d].line == (int)li) {
             const Emitter::Def &df = e.defs[d++];
             if (staged && df.expr.compare(0, 2, "x[") == 0 && staged->count(df.name)) {
-                sp.eval.push_back("const double " + df.name + " = xs[xd + " + std::to_string(staged->at(df.name)) + "];");
+                sp.eval.push_back("const double " + df.name + " = xs[" + staged->at(df.name) + "];");
             } else if (is_memory_read(df.expr)) {
                 sp.load.push_back(line);
                 if (df.is_int) {
@@ -302,18 +302,23 @@ void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     if (L.chain[CB_HESSC] > 0 && L.staged) {
         // the staged pair (exa_hesscl): pK_hessclL loads what is NOT x (multipliers, table columns, parameters), pK_hessclE
         // takes its x operands from the staged stretch
-        std::map<std::string, int64_t> off;
-        for (const auto &kv : b.xoff) off[kv.first] = kv.second.second - L.stage[pi].cmin;
+        std::map<std::string, std::string> off;
+        for (const auto &kv : b.xoff) {
+            const auto &cls = L.stage[pi].cl;
+            for (size_t c = 0; c < cls.size(); c++)
+                if (kv.second.second >= cls[c].cmin && kv.second.second <= cls[c].cmax)
+                    off[kv.first] = std::to_string(cls[c].stretch * (64 + kStageHalo)) + " + xd[" + std::to_string(c) + "] + " + std::to_string(kv.second.second - cls[c].cmin);
+        }
         const Split sp = split_body_staged(b.e, &off);
         g_handover[{CB_COUNT, pi}] = {sp.nin, sp.nik};
-        os << "static __device__ __forceinline__ void " << fn_name(pi, "hesscl") << "L(const long* __restrict__ P, const double* __restrict__ y, "
+        os << "static __device__ __forceinline__ void " << fn_name(pi, "hesscl") << "L(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ y, "
            << "const double* __restrict__ th, long tid, double* in, long* ik) {\n"
            << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n"
            << "    const long I = I0 < hi ? I0 : (hi > 0 ? hi - 1 : 0);\n";
         for (const auto &l : sp.load) os << "    " << l << "\n";
         os << "    (void)I;\n}\n";
         os << "static __device__ __forceinline__ void " << fn_name(pi, "hesscl") << "E(const long* __restrict__ P, const double* in, const long* ik, "
-           << "const double* xs, int xd, double* __restrict__ out, double* __restrict__ sink, double sigma, long tid, double* lds) {\n"
+           << "const double* xs, const int* xd, double* __restrict__ out, double* __restrict__ sink, double sigma, long tid, double* lds) {\n"
            << "    const long I0 = " << b.P(L.pat[pi].lo) << " + tid;\n    const long hi = " << b.P(L.pat[pi].hi) << ";\n"
            << "    const int lane = threadIdx.x & 63;\n    const long I = I0 < hi ? I0 : (hi > 0 ? hi - 1 : 0);\n";
         for (const auto &l : sp.eval) os << "    " << l << "\n";
@@ -322,22 +327,30 @@ void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     }
 }
 
-// ParamLayout::stage of pattern pi: every x index of its second-order body is (ONE unit-step range column) + literal
+// ParamLayout::stage of pattern pi: the x indices of its second-order body of the form (ONE unit-step range column) + literal, their
+// literals clustered (a new cluster where the gap to the cluster's first literal exceeds the halo: another variable block).  A pattern
+// without such an index (only literal / data-indexed reads) qualifies with no cluster: all its loads stay in the load stage.  false:
+// two different range columns, or more than 8 clusters.
 bool pattern_stage(const Model &m, int pi, const ParamLayout &L, ParamLayout::Stage *out) {
     Body b(m, pi, L);
     const Pattern &p = b.p;
     b.forward(p.ad_root, 2, false);
-    if (b.xother || b.xoff.empty()) return false;
+    *out = ParamLayout::Stage();
     int col = -1;
-    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    std::vector<int64_t> lits;
     for (const auto &kv : b.xoff) {
         if (col >= 0 && kv.second.first != col) return false;
         col = kv.second.first;
-        lo = std::min(lo, kv.second.second); hi = std::max(hi, kv.second.second);
+        if (std::find(lits.begin(), lits.end(), kv.second.second) == lits.end()) lits.push_back(kv.second.second);
     }
-    if (hi - lo > kStageHalo) return false;
-    out->word = L.pat[pi].col[col]; out->cmin = lo; out->cmax = hi;
-    return true;
+    if (col < 0) return true;
+    std::sort(lits.begin(), lits.end());
+    out->word = L.pat[pi].col[col];
+    for (int64_t v : lits) {
+        if (out->cl.empty() || v - out->cl.back().cmin > kStageHalo) { ParamLayout::Stage::Cluster c; c.cmin = c.cmax = v; out->cl.push_back(c); }
+        else out->cl.back().cmax = v;
+    }
+    return out->cl.size() <= 8;
 }
 
 // jac_coord! / hess_coord! (exa_jac / exa_hess): one device function per FUSED GROUP — the patterns of exactly the same
@@ -587,65 +600,93 @@ void gen_dispatch_chained(std::ostringstream &os, const ParamLayout &L, int cb, 
     }
 }
 
-// exa_hesscl: the chained dispatch with the x operands staged through LDS (ParamLayout::stage).  Per wavefront and tile the
-// stretch [B + 64 w + 256 t, + 64 + halo) of x — B = the smallest of the patterns' stretch bases — is loaded once (one 8-byte
-// load per lane + a halo load by `halo_` lanes; the next tile's, like the other loads, BEFORE the current tile is evaluated),
-// written to the wavefront's LDS stretch at the top of the iteration, and every pattern of the group reads its operands from
-// there at lane + (its base - B) + literal.
+// exa_hesscl: the chained dispatch with the x operands staged through LDS (ParamLayout::stage).  Per wavefront, tile and STRETCH s of
+// the group the run [B_s + 64 w + 256 t, + 64 + halo_s) of x — B_s = the smallest base of the stretch's member clusters — is loaded
+// once (one 8-byte load per lane + a halo load by `halo_s` lanes; the next tile's, like the other loads, BEFORE the current tile is
+// evaluated), written to the wavefront's LDS run of that stretch at the top of the iteration, and every pattern reads its operands
+// from there at lane + (its cluster's base - B_s) + literal distance.
 void gen_dispatch_chained_staged(std::ostringstream &os, const Model &m, const ParamLayout &L) {
     const int cb = CB_HESSC, T = L.chain[cb];
+    const int RUN = 64 + kStageHalo;
     const auto &groups = L.groups[cb];
     auto ld = [&](int pk, const std::string &tid, const std::string &sfx) {
-        os << "p" << pk << "_hessclL(P, y, th, " << tid << ", in" << pk << sfx << ", ik" << pk << sfx << ");";
+        os << "p" << pk << "_hessclL(P, x, y, th, " << tid << ", in" << pk << sfx << ", ik" << pk << sfx << ");";
     };
     auto ev = [&](int pk, const std::string &tid) {
-        os << "p" << pk << "_hessclE(P, in" << pk << ", ik" << pk << ", xs, lane + d" << pk << "_, out, sink, sigma, " << tid << ", lds);";
+        os << "p" << pk << "_hessclE(P, in" << pk << ", ik" << pk << ", xs, xd" << pk << "_, out, sink, sigma, " << tid << ", lds);";
     };
     os << "    const long e_ = ((const long*)P[" << L.blk[cb] << "])[blockIdx.x];\n    const int gs_ = (int)(e_ >> 40);\n"
        << "    const long t0_ = (e_ & ((1L << 40) - 1)) * " << T << ";\n    const int lane = threadIdx.x & 63;\n";
     for (size_t g = 0; g < groups.size(); g++) {
         const auto &grp = groups[g];
         const int first = grp.front();
+        const int ns = L.gstretch[g];
         os << "    " << (g ? "else " : "") << "if (gs_ == " << g << ") {\n        const long tend_ = t0_ + " << T << " < P[" << L.gtiles[cb][g] << "] ? t0_ + " << T
            << " : P[" << L.gtiles[cb][g] << "];\n";
-        // stretch geometry (scalars): base of every pattern, the common base, the patterns' distances from it, the halo, the
-        // last variable any point of the group reads (loads beyond it are clamped onto it)
+        // stretch geometry (scalars): base of every cluster, the stretches' bases, the clusters' distances from them, the halos, the
+        // last variable any point of a stretch's members reads (loads beyond it are clamped onto it)
         for (int pk : grp)
-            os << "        const long B" << pk << "_ = P[" << L.stage[pk].word << "] + P[" << L.pat[pk].lo << "] + (" << L.stage[pk].cmin << "L) - 1L;\n";
-        os << "        long B_ = B" << first << "_;\n";
-        for (int pk : grp) os << "        B_ = B" << pk << "_ < B_ ? B" << pk << "_ : B_;\n";
-        os << "        int halo_ = 0;\n        long xlast_ = 0;\n";
-        for (int pk : grp)
-            os << "        const int d" << pk << "_ = (int)(B" << pk << "_ - B_);\n        halo_ = d" << pk << "_ + " << (L.stage[pk].cmax - L.stage[pk].cmin) << " > halo_ ? d" << pk << "_ + "
-               << (L.stage[pk].cmax - L.stage[pk].cmin) << " : halo_;\n        { const long l_ = P[" << L.stage[pk].word << "] + P[" << L.pat[pk].hi << "] - 1L + (" << L.stage[pk].cmax
-               << "L) - 1L; xlast_ = l_ > xlast_ ? l_ : xlast_; }\n";
+            for (size_t c = 0; c < L.stage[pk].cl.size(); c++)
+                os << "        const long B" << pk << "_" << c << "_ = P[" << L.stage[pk].word << "] + P[" << L.pat[pk].lo << "] + (" << L.stage[pk].cl[c].cmin << "L) - 1L;\n";
+        for (int s = 0; s < ns; s++) {
+            os << "        long S" << s << "_ = 0x7fffffffffffffffL; long xlast" << s << "_ = 0;\n";
+            for (int pk : grp)
+                for (size_t c = 0; c < L.stage[pk].cl.size(); c++) {
+                    if (L.stage[pk].cl[c].stretch != s) continue;
+                    os << "        S" << s << "_ = B" << pk << "_" << c << "_ < S" << s << "_ ? B" << pk << "_" << c << "_ : S" << s << "_;\n"
+                       << "        { const long l_ = P[" << L.stage[pk].word << "] + P[" << L.pat[pk].hi << "] - 1L + (" << L.stage[pk].cl[c].cmax << "L) - 1L; xlast" << s
+                       << "_ = l_ > xlast" << s << "_ ? l_ : xlast" << s << "_; }\n";
+                }
+            os << "        int halo" << s << "_ = 0;\n";
+            for (int pk : grp)
+                for (size_t c = 0; c < L.stage[pk].cl.size(); c++) {
+                    if (L.stage[pk].cl[c].stretch != s) continue;
+                    const int64_t span = L.stage[pk].cl[c].cmax - L.stage[pk].cl[c].cmin;
+                    os << "        { const int h_ = (int)(B" << pk << "_" << c << "_ - S" << s << "_) + " << span << "; halo" << s << "_ = h_ > halo" << s << "_ ? h_ : halo" << s << "_; }\n";
+                }
+        }
+        // per pattern: the lane's position inside each of its clusters' stretches
+        for (int pk : grp) {
+            const size_t nc = L.stage[pk].cl.size();
+            os << "        int xd" << pk << "_[" << std::max<size_t>(nc, 1) << "] = {";
+            for (size_t c = 0; c < nc; c++) os << (c ? ", " : "") << "lane + (int)(B" << pk << "_" << c << "_ - S" << L.stage[pk].cl[c].stretch << "_)";
+            if (nc == 0) os << "0";
+            os << "};\n";
+        }
         for (int pk : grp) {
             const auto ho = g_handover[{CB_COUNT, pk}];
             os << "        double in" << pk << "[" << std::max(1, ho.first) << "]; long ik" << pk << "[" << std::max(1, ho.second) << "];\n";
         }
         const auto h0 = g_handover[{CB_COUNT, first}];
-        os << "        double in" << first << "n[" << std::max(1, h0.first) << "]; long ik" << first << "n[" << std::max(1, h0.second) << "];\n"
-           << "        double g0_, g1_;\n";
+        os << "        double in" << first << "n[" << std::max(1, h0.first) << "]; long ik" << first << "n[" << std::max(1, h0.second) << "];\n";
+        if (ns) os << "        double g0_[" << ns << "], g1_[" << ns << "];\n";
         auto G = [&](const std::string &t) {
-            os << "        { const long a_ = B_ + (" << t << ") * EXA_BLOCK + (threadIdx.x & ~63); long a0_ = a_ + lane; a0_ = a0_ < xlast_ ? a0_ : xlast_; "
-                  "long a1_ = a_ + 64 + lane; a1_ = a1_ < xlast_ ? a1_ : xlast_; g0_ = x[a0_]; g1_ = x[lane < halo_ ? a1_ : a0_]; }\n";
+            for (int s = 0; s < ns; s++)
+                os << "        { const long a_ = S" << s << "_ + (" << t << ") * EXA_BLOCK + (threadIdx.x & ~63); long a0_ = a_ + lane; a0_ = a0_ < xlast" << s << "_ ? a0_ : xlast" << s
+                   << "_; long a1_ = a_ + 64 + lane; a1_ = a1_ < xlast" << s << "_ ? a1_ : xlast" << s << "_; g0_[" << s << "] = x[a0_]; g1_[" << s << "] = x[lane < halo" << s
+                   << "_ ? a1_ : a0_]; }\n";
+        };
+        auto claim = [&](const char *ind) {
+            for (int s = 0; s < ns; s++) os << ind << "asm volatile(\"\" : \"+v\"(g0_[" << s << "])); asm volatile(\"\" : \"+v\"(g1_[" << s << "]));\n";
         };
         G("t0_");
         os << "        "; ld(first, "t0_ * EXA_BLOCK + threadIdx.x", "");
-        os << "\n        asm volatile(\"\" : \"+v\"(g0_)); asm volatile(\"\" : \"+v\"(g1_));\n"
-           << "#pragma unroll\n        for (int q = 0; q < " << std::max(1, h0.first) << "; q++) asm volatile(\"\" : \"+v\"(in" << first << "[q]));\n"
+        os << "\n";
+        claim("        ");
+        os << "#pragma unroll\n        for (int q = 0; q < " << std::max(1, h0.first) << "; q++) asm volatile(\"\" : \"+v\"(in" << first << "[q]));\n"
            << "#pragma unroll\n        for (int q = 0; q < " << std::max(1, h0.second) << "; q++) asm volatile(\"\" : \"+v\"(ik" << first << "[q]));\n"
            << "#pragma unroll 1\n        for (long t = t0_; t < tend_; t++) {\n            const long tid = t * EXA_BLOCK + threadIdx.x;\n"
-           << "            __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier();\n"
-           << "            xs[lane] = g0_;\n            if (lane < halo_) xs[64 + lane] = g1_;\n"
-           << "            __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n";
+           << "            __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier();\n";
+        for (int s = 0; s < ns; s++)
+            os << "            xs[" << s * RUN << " + lane] = g0_[" << s << "];\n            if (lane < halo" << s << "_) xs[" << s * RUN + 64 << " + lane] = g1_[" << s << "];\n";
+        os << "            __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n";
         for (size_t j = 1; j < grp.size(); j++) { os << "            "; ld(grp[j], "tid", ""); os << "\n"; }
         os << "    ";
         G("t + 1 < tend_ ? t + 1 : t");
         os << "            "; ld(first, "(t + 1 < tend_ ? t + 1 : t) * EXA_BLOCK + threadIdx.x", "n"); os << "\n";
         for (size_t j = 0; j < grp.size(); j++) { os << "            "; ev(grp[j], "tid"); os << "\n"; }
-        os << "            asm volatile(\"\" : \"+v\"(g0_)); asm volatile(\"\" : \"+v\"(g1_));\n"
-           << "#pragma unroll\n            for (int q = 0; q < " << std::max(1, h0.first) << "; q++) { asm volatile(\"\" : \"+v\"(in" << first << "n[q])); in" << first << "[q] = in" << first << "n[q]; }\n"
+        claim("            ");
+        os << "#pragma unroll\n            for (int q = 0; q < " << std::max(1, h0.first) << "; q++) { asm volatile(\"\" : \"+v\"(in" << first << "n[q])); in" << first << "[q] = in" << first << "n[q]; }\n"
            << "#pragma unroll\n            for (int q = 0; q < " << std::max(1, h0.second) << "; q++) { asm volatile(\"\" : \"+v\"(ik" << first << "n[q])); ik" << first << "[q] = ik" << first << "n[q]; }\n        }\n    }\n";
     }
     (void)m;

@@ -8,7 +8,7 @@ namespace exa {
 
 using namespace gen;
 
-Generated generate_module(const Model &m, bool loopfree_scatter) {
+Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
     // the scatter bookkeeping above (g_lds_need, g_lit_idx) is module-level state of one generation: serialise
     // concurrent model builds here (planning and hipcc still run in parallel)
     std::lock_guard<std::mutex> gen_lock(g_gen_mu);
@@ -97,11 +97,34 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
 
     // exa_hesscl (ParamLayout::stage): only when EVERY pattern of EVERY chained group qualifies
     L.stage.assign(np, ParamLayout::Stage());
-    L.staged = L.chain[CB_HESSC] > 0 && !L.groups[CB_HESSC].empty();
+    L.gstretch.assign(L.groups[CB_HESSC].size(), 0);
+    L.max_stretch = 0;
+    L.staged = !nostage && L.chain[CB_HESSC] > 0 && !L.groups[CB_HESSC].empty();
     if (L.staged)
         for (const auto &grp : L.groups[CB_HESSC])
             for (int k : grp) L.staged = L.staged && pattern_stage(m, k, L, &L.stage[k]);
-    if (!L.staged) L.stage.assign(np, ParamLayout::Stage());
+    if (L.staged) {
+        // the clusters of a group's patterns -> the group's stretches: in ascending order of their literals, merged while the union stays
+        // within the halo (patterns whose ranges start a few points apart — LV's constraint and objective — share a stretch; whether the
+        // actual bases do lie that close is checked per shard by the runtime)
+        for (size_t g = 0; g < L.groups[CB_HESSC].size(); g++) {
+            struct Ref { int k, c; };
+            std::vector<Ref> refs;
+            for (int k : L.groups[CB_HESSC][g]) for (size_t c = 0; c < L.stage[k].cl.size(); c++) refs.push_back({k, (int)c});
+            std::sort(refs.begin(), refs.end(), [&](const Ref &a, const Ref &b) { return L.stage[a.k].cl[a.c].cmin < L.stage[b.k].cl[b.c].cmin; });
+            int ns = 0;
+            int64_t smin = 0;
+            for (const Ref &r : refs) {
+                ParamLayout::Stage::Cluster &cl = L.stage[r.k].cl[r.c];
+                if (ns == 0 || cl.cmax - smin > kStageHalo) { ns++; smin = cl.cmin; }
+                cl.stretch = ns - 1;
+            }
+            L.gstretch[g] = ns;
+            L.max_stretch = std::max(L.max_stretch, ns);
+        }
+        L.staged = L.max_stretch >= 1 && L.max_stretch <= 8;
+    }
+    if (!L.staged) { L.stage.assign(np, ParamLayout::Stage()); L.gstretch.assign(L.groups[CB_HESSC].size(), 0); L.max_stretch = 0; }
     // streaming value kernels keep more loads in flight per wavefront with several points per thread (measured)
     // (measured, LV 1e7: obj 0.037 -> 0.020 ms with 8 points per thread; 2 - 16 points per thread moved cons / jac / hess by
     // +-2 %, profiles/NOTES.md)
@@ -116,6 +139,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
     os << prelude_text(L);
     os << "// patterns=" << np << " (sizes, offsets and column pointers are run-time parameters in P[])\n";
     if (loopfree_scatter) os << "// scatter kernels without loops: the first build of this module spilled registers there\n";
+    if (nostage) os << "// no LDS-staged chained kernel (exa_hesscl): it outgrew the architectural registers in the first build of this module\n";
     {
         // dry pass over the scatter bodies: which callbacks hold a huge body (g_scatter_lines) and must be generated
         // without loops; its output and bookkeeping are discarded
@@ -381,7 +405,8 @@ Generated generate_module(const Model &m, bool loopfree_scatter) {
         os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hesscl(const long* __restrict__ P, const double* __restrict__ x, "
               "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma, double* __restrict__ sink) {\n";
         lds_decl(CB_HESS, true);
-        os << "    __shared__ double xs_all[(EXA_BLOCK / 64) * " << 64 + kStageHalo << "];\n    double* xs = xs_all + (threadIdx.x >> 6) * " << 64 + kStageHalo << ";\n";
+        os << "    __shared__ double xs_all[(EXA_BLOCK / 64) * " << L.max_stretch * (64 + kStageHalo) << "];\n    double* xs = xs_all + (threadIdx.x >> 6) * "
+           << L.max_stretch * (64 + kStageHalo) << ";\n";
         gen_dispatch_chained_staged(os, m, L);
         os << "}\n";
     }

@@ -126,15 +126,23 @@ struct ParamLayout {
     // share vmcnt in order, so loads issued after a tile's stores would wait for those stores to drain).
     // chain = 0: one (pattern, tile) per workgroup, the plain dispatch.  gtiles = P word with each group's tile count.
     int chain[CB_COUNT];
-    // exa_hesscl — exa_hessc with the inputs STAGED THROUGH LDS: generated when every x index of every pattern of every chained
-    // group is (unit-step range value) + literal.  A wavefront's 64 points of a tile then read one stretch of x: one coalesced
-    // 8-byte load per lane + a halo load by a few lanes, written to LDS, from which every pattern of the group takes its
-    // stencil operands (ds_read) — instead of two or three overlapping wide loads per pattern.  stage[k] = {word of the range
-    // column, smallest and largest literal offset} of pattern k (word < 0: not staged).  The patterns' stretches start at
-    // B_k = P[word] + P[lo] + cmin - 1; the kernel stages [min B_k, +64 + kStageHalo): the runtime launches it only when all
-    // stretches fit (exa_runtime.cpp fill_params: stage_ok), else exa_hessc.
-    struct Stage { int word = -1; int64_t cmin = 0, cmax = 0; };
+    // exa_hesscl — exa_hessc with the inputs STAGED THROUGH LDS.  Every x index of the form (unit-step range value) + literal is
+    // staged; the literals of a pattern fall into CLUSTERS (gaps of more than kStageHalo: the variable blocks of a model laid out as
+    // separate arrays — the rocket's h / v / m / tau — bake their offsets into the literals), and the clusters of all patterns of a
+    // chained group are merged into the group's STRETCHES (by literal proximity; the runtime verifies the geometry, stage_ok).  Per
+    // wavefront, tile and stretch ONE run of 64 + halo variables is loaded (one coalesced 8-byte load per lane + a halo load by a few
+    // lanes) and written to LDS, from which every pattern takes its stencil operands (ds_read) — instead of two or three overlapping
+    // wide loads per pattern and array.  x loads of any other form (a literal index: the rocket's step length; a data column) stay
+    // ordinary loads of the load stage.  stage[k] = {word of the range column, clusters {smallest, largest literal, stretch of the
+    // group}}; cluster (k, c) starts at B = P[word] + P[lo] + cmin - 1, stretch s at the smallest B of its members.
+    struct Stage {
+        int word = -1;
+        struct Cluster { int64_t cmin = 0, cmax = 0; int stretch = 0; };
+        std::vector<Cluster> cl;
+    };
     std::vector<Stage> stage;
+    std::vector<int> gstretch;          // stretches per chained group (CB_HESSC)
+    int max_stretch = 0;
     bool staged = false;
     std::vector<std::vector<int>> groups[CB_COUNT];
     std::vector<int> gtiles[CB_COUNT];
@@ -154,7 +162,8 @@ constexpr int kBlock = 256;
 // loopfree_scatter: no loop around or inside the bodies of exa_grad / exa_jtprod / exa_hprod (see kHugeBody in
 // exa_gen.hpp); the generator turns it on by itself for huge bodies, the runtime asks for it when a scatter kernel of the
 // compiled module turns out to spill registers.
-Generated generate_module(const Model &m, bool loopfree_scatter = false);
+// nostage: no exa_hesscl (the LDS-staged chained kernel outgrew the architectural registers where this module was first compiled).
+Generated generate_module(const Model &m, bool loopfree_scatter = false, bool nostage = false);
 bool pattern_var_range(const Pattern &p, int64_t lo, int64_t hi, int64_t *vmin, int64_t *vmax);
 // data points [jlo, jhi) of a gathered objective pattern with a first-order slot on one of the 1-based variables [v_lo, v_hi]
 void pull_point_range(const Pattern &p, int64_t v_lo, int64_t v_hi, int64_t *jlo, int64_t *jhi);       // exa_gen_scatter.cpp   // exa_gen_module.cpp

@@ -140,7 +140,8 @@ struct Handle {
     struct Audit { std::string which, name; bool safe = false, readable = false; std::vector<KernelInfo> kernels; };
     std::vector<Audit> audits;
     bool loopfree_scatter = false;     // the module is the one generated without loops in the scatter kernels (module_for)
-    std::string first_key;             // ... and this is the key of the module with loops it replaces (its "loopfree" note)
+    bool nostage = false;              // ... and / or without exa_hesscl (it alone outgrew the architectural registers)
+    std::string first_key, first_note; // the key of the module this one replaces and the note that says so ("loopfree", "nostage", "loopfree+nostage")
     // grad! by sorted gather (the reference's scheme, deterministic): gradient COO + (variable, slot) lists, built on demand
     hipFunction_t f_gradv = nullptr, f_gstruct = nullptr;
     SortedIndex gbyvar;

@@ -203,18 +203,22 @@ void fill_params(Handle &h) {
         else if (tune_lookup(source_key(h.gen.source), tune_signature(h, "hessvariant"), &pv)) h.hess_variant = std::min(2, std::max(0, pv));
         else h.hess_variant = h.hess_stream_bytes >= 1.5e9;
     }
-    // exa_hesscl stages, per wavefront and tile, ONE stretch of 64 + kStageHalo variables for all patterns of a group: the
-    // patterns' first variables (of THIS shard's first points) must lie within the halo of each other
+    // exa_hesscl stages, per wavefront, tile and stretch, ONE run of 64 + kStageHalo variables for the member clusters of the stretch: their
+    // first variables (of THIS shard's first points) must lie within the halo of each other (ParamLayout::Stage)
     h.stage_ok = L.staged;
     if (L.staged)
-        for (const auto &grp : L.groups[CB_HESSC]) {
-            int64_t bmin = INT64_MAX;
-            for (int k : grp) {
-                if (h.P[L.pat[k].hi] <= h.P[L.pat[k].lo]) h.stage_ok = false;
-                bmin = std::min(bmin, h.P[L.stage[k].word] + h.P[L.pat[k].lo] + L.stage[k].cmin);
+        for (size_t g = 0; g < L.groups[CB_HESSC].size(); g++) {
+            const auto &grp = L.groups[CB_HESSC][g];
+            for (int k : grp) if (h.P[L.pat[k].hi] <= h.P[L.pat[k].lo]) h.stage_ok = false;
+            for (int sidx = 0; sidx < L.gstretch[g]; sidx++) {
+                int64_t bmin = INT64_MAX;
+                for (int k : grp)
+                    for (const auto &cl : L.stage[k].cl)
+                        if (cl.stretch == sidx) bmin = std::min(bmin, h.P[L.stage[k].word] + h.P[L.pat[k].lo] + cl.cmin);
+                for (int k : grp)
+                    for (const auto &cl : L.stage[k].cl)
+                        if (cl.stretch == sidx && h.P[L.stage[k].word] + h.P[L.pat[k].lo] + cl.cmax - bmin > kStageHalo) h.stage_ok = false;
             }
-            for (int k : grp)
-                if (h.P[L.stage[k].word] + h.P[L.pat[k].lo] + L.stage[k].cmax - bmin > kStageHalo) h.stage_ok = false;
         }
     // objective-only Hessian forms: block maps of the objective groups alone + the constraint patterns' slot ranges, merged
     h.gridobj[0] = h.gridobj[1] = 0;
@@ -326,17 +330,30 @@ bool scatter_kernels_spill(const CodeObject &co) {
 CodeObject module_for(Handle &h, bool memory_only_ok) {
     CodeObject co = get_code_object(h.gen.source, memory_only_ok, prefer_safe(h.gen.source));
     double spent = 0.0;
-    if (!h.loopfree_scatter && scatter_kernels_spill(co)) {
+    // ... and exa_hesscl (the LDS-staged chained kernel: a few registers more than exa_hessc per staged stretch) is dropped when it ALONE is
+    // what outgrew the architectural registers (the rocket: 278 against 254): the model then runs exa_hessc where it would have run
+    // exa_hesscl, instead of having its whole module rebuilt with the conservative flags for a kernel it can do without
+    bool regen = false;
+    {
+        std::vector<KernelInfo> ks;
+        if (!h.nostage && h.gen.layout.staged && code_object_kernels(co.image, ks)) {
+            bool cl_big = false, rest_big = false;
+            for (const KernelInfo &k : ks) { if (k.name == "exa_hesscl") cl_big = !k.fits(); else if (k.name != "exa_grad" && k.name != "exa_jtprod" && k.name != "exa_hprod") rest_big = rest_big || !k.fits(); }
+            if (cl_big && !rest_big) { h.nostage = true; regen = true; }
+        }
+    }
+    if (!h.loopfree_scatter && scatter_kernels_spill(co)) { h.loopfree_scatter = true; regen = true; }
+    if (regen) {
         h.first_key = co.key;
-        note_store(co.key, "loopfree", true);
-        h.loopfree_scatter = true;
-        h.gen = generate_module(*h.m, true);
+        h.first_note = std::string(h.loopfree_scatter ? "loopfree" : "") + (h.loopfree_scatter && h.nostage ? "+" : "") + (h.nostage ? "nostage" : "");
+        note_store(co.key, h.first_note, true);
+        h.gen = generate_module(*h.m, h.loopfree_scatter, h.nostage);
         spent = co.build_ms;
         // the kernels the regeneration does not touch are the same code in the new module: if one of THEM is over-sized the new module
         // will need the conservative flags too — note it now and save the compilation that would only find that out
         std::vector<KernelInfo> ks;
         bool others = !code_object_kernels(co.image, ks);
-        for (const KernelInfo &k : ks) others = others || (!k.fits() && k.name != "exa_grad" && k.name != "exa_jtprod" && k.name != "exa_hprod");
+        for (const KernelInfo &k : ks) others = others || (!k.fits() && k.name != "exa_grad" && k.name != "exa_jtprod" && k.name != "exa_hprod" && !(h.nostage && k.name == "exa_hesscl"));
         if (others && !safe_flags().empty()) note_store(source_key(h.gen.source), "safe", true);
     }
     CodeObject fin = audited_code_object(h, "model", h.gen.source, memory_only_ok, &co);
@@ -761,10 +778,13 @@ int create(const exa_model_desc_t *desc, int *id_out, bool device) {
         auto h = std::make_unique<Handle>();
         h->m = plan_model(desc);
         h->gen = generate_module(*h->m);
-        if (note_lookup(source_key(h->gen.source)) == "loopfree" && h->gen.source.find("// scatter kernels without loops") == std::string::npos) {       // decided where this module was first compiled
+        const std::string note0 = note_lookup(source_key(h->gen.source));
+        if (note0.find("loopfree") != std::string::npos || note0.find("nostage") != std::string::npos) {       // decided where this module was first compiled
             h->first_key = source_key(h->gen.source);
-            h->loopfree_scatter = true;
-            h->gen = generate_module(*h->m, true);
+            h->first_note = note0;
+            h->loopfree_scatter = note0.find("loopfree") != std::string::npos;
+            h->nostage = note0.find("nostage") != std::string::npos;
+            h->gen = generate_module(*h->m, h->loopfree_scatter, h->nostage);
         }
         plan_products(*h);
         if (device) { to_device(*h); load_products(*h); if (g_eager_setup) g_eager_setup(*h); }
@@ -856,6 +876,13 @@ const char *exa_module_alias(int id) {
     static thread_local std::string name;
     name = h->first_key;
     return name.c_str();
+}
+const char *exa_module_alias_note(int id) {
+    Handle *h = get(id);
+    if (!h) return nullptr;
+    static thread_local std::string note;
+    note = h->first_note;
+    return note.c_str();
 }
 const char *exa_module_name(int id) {
     Handle *h = get(id);

@@ -16,7 +16,7 @@ _LIB = None
 # every symbol include/exahip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "exa_abi_version", "exa_last_error", "exa_new_from_table", "exa_plan_only", "exa_compile", "exa_code_object_path",
-    "exa_free", "exa_module_name", "exa_cache_add", "exa_cache_note", "exa_module_alias", "exa_code_object_count", "exa_code_object", "exa_nvar", "exa_ncon", "exa_nnzj", "exa_nnzh", "exa_nvar64", "exa_ncon64", "exa_nnzj64", "exa_nnzh64",
+    "exa_free", "exa_module_name", "exa_cache_add", "exa_cache_note", "exa_module_alias", "exa_module_alias_note", "exa_code_object_count", "exa_code_object", "exa_nvar", "exa_ncon", "exa_nnzj", "exa_nnzh", "exa_nvar64", "exa_ncon64", "exa_nnzj64", "exa_nnzh64",
     "exa_nnzg64", "exa_npatterns", "exa_pattern_info", "exa_pattern_comp", "exa_meta", "exa_locality_order", "exa_kernel_source", "exa_module_source",
     "exa_set_stream", "exa_set_shard", "exa_set_value", "exa_set_value_dev", "exa_theta_ptr", "exa_obj", "exa_obj_async", "exa_grad", "exa_cons", "exa_jac",
     "exa_hess", "exa_jprod", "exa_jtprod", "exa_hprod", "exa_jprod_host", "exa_jtprod_host", "exa_hprod_host", "exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",
@@ -80,6 +80,8 @@ def lib():
     L.exa_cache_note.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     L.exa_module_alias.restype = ctypes.c_char_p
     L.exa_module_alias.argtypes = [i32]
+    L.exa_module_alias_note.restype = ctypes.c_char_p
+    L.exa_module_alias_note.argtypes = [i32]
     L.exa_code_object_count.argtypes = [i32]
     L.exa_code_object.argtypes = [i32, i32, ctypes.c_char_p, i32, ctypes.c_char_p, i32]
     L.exa_free.argtypes = [i32]

@@ -84,6 +84,10 @@ int exa_cache_add(const char *name, const void *code_object, size_t len);
  * name to attach it to ("" when the model's module replaces nothing). */
 int exa_cache_note(const char *name, const char *note);
 const char *exa_module_alias(int id);
+/* ... and the note to attach to it: "loopfree", "nostage" (the LDS-staged chained kernel exa_hesscl alone outgrew the architectural
+ * registers where the module was first compiled: the model's module is the one generated without it) or "loopfree+nostage"; "" when
+ * the model's module replaces nothing. */
+const char *exa_module_alias_note(int id);
 /* The code objects of a compiled model (after exa_compile, or a device model): k = 0 the model's module, k = 1 the module of
  * the owner-computes product windows when the model has them (exa_product_info).  name <- what exa_cache_add takes,
  * path <- the file.  exahip.pack embeds all of them. */

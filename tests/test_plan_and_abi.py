@@ -404,18 +404,30 @@ def test_kernel_resources_are_read_from_the_code_object(libs):
     assert b"exa_hprodw" in objs[1][1] and b"exa_jtprodw" in objs[1][1]
 
 
-def test_staged_hessian_kernel_is_generated_where_the_stencil_allows(libs):
-    """exa_hesscl (x staged through LDS per wavefront) exists exactly for models whose Hessian patterns read x at one unit-step
-    range + literals at most 16 apart (pattern_stage): Luksan-Vlcek yes; the rocket (four variable arrays: literals millions
-    apart), ACOPF (data-indexed) and a stepped range no.  The plain chained kernel exists for all of them; a plan-only handle
-    reports 2 for the forced chained variant where the staged one does not apply."""
+def test_staged_hessian_kernel_is_generated_where_the_stencil_allows(libs, tmp_path, monkeypatch):
+    """exa_hesscl (x staged through LDS per wavefront): every x index of the form (unit-step range) + literal is staged, the literals of a
+    pattern clustered into stretches (round 4: one stretch per variable array — cops_chain reads u, x1, x2, x3; Luksan-Vlcek one); ACOPF
+    (data-indexed: nothing to stage) and a stepped range have none.  The rocket's four-stretch kernel is generated, found to need 278
+    registers where the plain chained kernel needs 254, and dropped again ("nostage" note: the model runs exa_hessc, its module keeps the
+    default flags).  The plain chained kernel exists for all of them."""
     from exahip import ExaModel, models
     from zoo import ZOO
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))
     lv = ExaModel(models.luksan_vlcek_model(5000), device=False).kernel_source()
-    assert "exa_hesscl(" in lv and "exa_hessc(" in lv and "xs[xd + " in lv
-    for mk in (lambda: models.rocket_model(500), ZOO["acopf30"], ZOO["stepped"]):
+    assert "exa_hesscl(" in lv and "exa_hessc(" in lv and "xs[0 + xd[0] + " in lv and "double g0_[1]" in lv
+    chain = ExaModel(ZOO["cops_chain"](), device=False).kernel_source()
+    assert "exa_hesscl(" in chain and "double g0_[" in chain and "double g0_[1]" not in chain          # several stretches
+    for mk in (ZOO["acopf30"], ZOO["stepped"]):
         src = ExaModel(mk(), device=False).kernel_source()
         assert "exa_hessc(" in src and "exa_hesscl(" not in src
+    r = ExaModel(models.rocket_model(500), device=False)
+    assert "exa_hesscl(" in r.kernel_source() and "double g0_[4]" in r.kernel_source()
+    r.compile()                                                   # ... asks the compiled kernels
+    assert "exa_hesscl(" not in r.kernel_source() and "no LDS-staged chained kernel" in r.kernel_source()
+    assert r._L.exa_module_alias_note(r.id) == b"nostage" and r._L.exa_module_alias(r.id) != b""
+    assert all(a["fits"] and a["flags"] == "default" for a in r.build_audit())
+    r2 = ExaModel(models.rocket_model(500), device=False)         # the note: a later build arrives at the final module at once
+    assert r2.kernel_source() == r.kernel_source()
 
 
 def test_generated_module_has_the_zero_fill_and_the_folding_objective(libs):
