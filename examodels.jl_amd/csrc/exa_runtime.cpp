@@ -217,7 +217,10 @@ void fill_params(Handle &h) {
                         if (cl.stretch == sidx) bmin = std::min(bmin, h.P[L.stage[k].word] + h.P[L.pat[k].lo] + cl.cmin);
                 for (int k : grp)
                     for (const auto &cl : L.stage[k].cl)
-                        if (cl.stretch == sidx && h.P[L.stage[k].word] + h.P[L.pat[k].lo] + cl.cmax - bmin > kStageHalo) h.stage_ok = false;
+                        if (cl.stretch == sidx && h.P[L.stage[k].word] + h.P[L.pat[k].lo] + cl.cmax - bmin > kStageHalo) {
+                            if (verbose() && h.stage_ok) fprintf(stderr, "[exahip] exa_hesscl not usable on this shard: group %zu stretch %d: pattern %d reaches %ld variables beyond the stretch's first\n", g, sidx, k, (long)(h.P[L.stage[k].word] + h.P[L.pat[k].lo] + cl.cmax - bmin));
+                            h.stage_ok = false;
+                        }
             }
         }
     // objective-only Hessian forms: block maps of the objective groups alone + the constraint patterns' slot ranges, merged
