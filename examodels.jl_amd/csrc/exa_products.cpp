@@ -375,15 +375,37 @@ int exa_tune(int id, int what, const double *x, const double *y) {
             if (h.f_hessc && h.lnnzh > 0) {
                 // the two hess_coord! kernels, each at the better of its block orders
                 hv = need(4, h.lnnzh);
+                // each kernel's block order first, then the kernels against each other, interleaved (see ab_min)
                 h.hess_variant = 0;
-                const float t0 = tune_order(h, CB_HESS, [&] { do_hess(h, x, y, sigma, hv); });
+                (void)tune_order(h, CB_HESS, [&] { do_hess(h, x, y, sigma, hv); });
                 h.hess_variant = 2;
-                const float t1 = tune_order(h, CB_HESSC, [&] { do_hess(h, x, y, sigma, hv); });
-                h.hess_variant = t1 < t0 ? 2 : 0;
+                (void)tune_order(h, CB_HESSC, [&] { do_hess(h, x, y, sigma, hv); });
+                const int order_c = h.order[CB_HESSC];
+                int order_cl = order_c;
+                std::vector<int> cand = {0, 2};
                 if (h.f_hesscl && h.stage_ok) {
                     h.hess_variant = 1;
-                    const float t2 = tune_order(h, CB_HESSC, [&] { do_hess(h, x, y, sigma, hv); });
-                    if (!(t2 < std::min(t0, t1))) h.hess_variant = t1 < t0 ? 2 : 0;
+                    (void)tune_order(h, CB_HESSC, [&] { do_hess(h, x, y, sigma, hv); });
+                    order_cl = h.order[CB_HESSC];
+                    cand.push_back(1);
+                }
+                const std::vector<float> tv = ab_min(h, (int)cand.size(), 7, 6, [&](int k) {
+                    h.hess_variant = cand[(size_t)k];
+                    if (cand[(size_t)k] != 0 && h.order[CB_HESSC] != (cand[(size_t)k] == 1 ? order_cl : order_c)) install_order(h, CB_HESSC, cand[(size_t)k] == 1 ? order_cl : order_c);
+                    do_hess(h, x, y, sigma, hv);
+                });
+                // the plain kernel stays unless another one wins by more than the noise of the measurement (1 %)
+                size_t best = 0;
+                for (size_t k = 1; k < cand.size(); k++)
+                    if (tv[k] < 0.99f * tv[0] && (best == 0 || tv[k] < tv[best])) best = k;
+                h.hess_variant = cand[best];
+                install_order(h, CB_HESSC, h.hess_variant == 1 ? order_cl : order_c);
+                HIPCHK(hipStreamSynchronize(h.stream));
+                if (h.norders[CB_HESSC] > 1) tune_store(source_key(h.gen.source), tune_signature(h, "order" + std::to_string((int)CB_HESSC)), h.order[CB_HESSC]);
+                if (verbose()) {
+                    fprintf(stderr, "[exahip] tune hess_coord kernels (ms per 6 launches):");
+                    for (size_t k = 0; k < cand.size(); k++) fprintf(stderr, " variant %d: %.4f", cand[k], tv[k]);
+                    fprintf(stderr, " -> variant %d\n", h.hess_variant);
                 }
                 tune_store(source_key(h.gen.source), tune_signature(h, "hessvariant"), h.hess_variant);
             } else if (h.norders[CB_HESS] > 1) { hv = need(4, h.lnnzh); tune_order(h, CB_HESS, [&] { do_hess(h, x, y, sigma, hv); }); }

@@ -284,13 +284,41 @@ int cstruct(int id, bool hess, bool wide, void *r, void *c);
 int ccsc(int id, bool hess, int64_t *colptr, int64_t *rowval);
 
 
+// Installs block order k of callback cb (the map pointer in the parameter table) on the model's stream.
+inline void install_order(Handle &h, int cb, int k) {
+    if (h.norders[cb] < 2) return;
+    const ParamLayout &L = h.gen.layout;
+    h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][k].p;
+    HIPCHK(hipMemcpyAsync((int64_t *)h.dP.p + L.blk[cb], &h.P[L.blk[cb]], 8, hipMemcpyHostToDevice, h.stream));
+    h.order[cb] = k;
+}
+// Interleaved A/B/..: `rounds` rounds, in each one every candidate runs once untimed and then `launches` times between two
+// events; the minimum over the rounds (the first one only warms up) is the candidate's time.  Candidates measured one after
+// the other instead see different clocks (the governor keeps moving for hundreds of ms after load starts): measured on
+// the headline model, back-to-back tuning ranked a 16 % slower kernel first in one run out of three.
+template <class F>
+std::vector<float> ab_min(Handle &h, int ncand, int rounds, int launches, F &&run) {
+    std::vector<float> t((size_t)ncand, 1e30f);
+    for (int round = 0; round < rounds; round++)
+        for (int k = 0; k < ncand; k++) {
+            run(k);
+            HIPCHK(hipEventRecord(h.ev0, h.stream));
+            for (int r = 0; r < launches; r++) run(k);
+            HIPCHK(hipEventRecord(h.ev1, h.stream));
+            HIPCHK(hipEventSynchronize(h.ev1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, h.ev0, h.ev1));
+            if (round > 0 && ms < t[(size_t)k]) t[(size_t)k] = ms;
+        }
+    return t;
+}
+
 // Chooses the block order of callback `cb` by measurement (exa_tune only — callbacks never measure): both orders are
 // timed on the model's stream (the outputs are simply rewritten with the same values), the faster map is installed in
 // P[] and the decision persisted next to the cached module.  Synchronises the stream.
 template <class F>
 float tune_order(Handle &h, int cb, F &&run) {
     const int n = std::max(1, h.norders[cb]);
-    const ParamLayout &L = h.gen.layout;
     float t[2] = {1e30f, 1e30f};
     // bring the clocks up first: the governor idles at ~570 MHz and needs tens of ms of load, and at low clocks the
     // orders rank differently than in steady state (measured: cold tuning picked the slower order 2 times out of 3)
@@ -307,27 +335,12 @@ float tune_order(Handle &h, int cb, F &&run) {
     }
     // A/B rounds, minimum per order: a single sample per order is within the run-to-run noise of the difference being
     // measured (5-7 %); round 0 only warms up
-    auto install = [&](int k) {
-        if (n < 2) return;
-        h.P[L.blk[cb]] = (int64_t)(uintptr_t)h.dmap[cb][k].p;
-        HIPCHK(hipMemcpyAsync((int64_t *)h.dP.p + L.blk[cb], &h.P[L.blk[cb]], 8, hipMemcpyHostToDevice, h.stream));
-        h.order[cb] = k;
-    };
-    for (int round = 0; round < 4; round++) {
-        for (int k = 0; k < n; k++) {
-            install(k);
-            run();
-            HIPCHK(hipEventRecord(h.ev0, h.stream));
-            for (int r = 0; r < 4; r++) run();
-            HIPCHK(hipEventRecord(h.ev1, h.stream));
-            HIPCHK(hipEventSynchronize(h.ev1));
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, h.ev0, h.ev1));
-            if (round > 0 && ms < t[k]) t[k] = ms;
-        }
+    {
+        const std::vector<float> tm = ab_min(h, std::min(n, 2), 4, 4, [&](int k) { install_order(h, cb, k); run(); });
+        for (size_t k = 0; k < tm.size(); k++) t[k] = tm[k];
     }
     const int best = n > 1 && t[1] < t[0] ? 1 : 0;
-    install(best);
+    install_order(h, cb, best);
     HIPCHK(hipStreamSynchronize(h.stream));
     if (n > 1) tune_store(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), best);
     if (verbose()) fprintf(stderr, "[exahip] tune cb=%d: %.4f %.4f ms per 4 launches -> order %d\n", cb, t[0], n > 1 ? t[1] : 0.f, best);
@@ -335,16 +348,7 @@ float tune_order(Handle &h, int cb, F &&run) {
 }
 template <class A, class B>
 int pick_faster(Handle &h, A &&atomics, B &&sorted) {
-    float t[2] = {0.f, 0.f};
-    for (int which = 0; which < 2; which++) {
-        for (int rep = 0; rep < 4; rep++) {
-            if (rep == 1) HIPCHK(hipEventRecord(h.ev0, h.stream));
-            if (which == 0) atomics(); else sorted();
-        }
-        HIPCHK(hipEventRecord(h.ev1, h.stream));
-        HIPCHK(hipEventSynchronize(h.ev1));
-        HIPCHK(hipEventElapsedTime(&t[which], h.ev0, h.ev1));
-    }
+    const std::vector<float> t = ab_min(h, 2, 3, 3, [&](int k) { if (k == 0) atomics(); else sorted(); });
     return t[1] < t[0] ? 1 : 0;
 }
 

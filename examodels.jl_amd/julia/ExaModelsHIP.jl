@@ -274,13 +274,38 @@ function ExaModels.hprod!(m::HM, x::AbstractVector, v::AbstractVector, Hv::Abstr
               m.ext.id, pointer(x), Ptr{Cdouble}(C_NULL), pointer(v), Float64(obj_weight), pointer(Hv)), "exa_hprod"); Hv
 end
 # set_value!(model, param, values) (nlp.jl:1279-1287) writes model.θ; the library keeps its own device copy of θ, so the
-# update is forwarded (host values) — no rebuild, exactly as in the reference.
+# update is forwarded — no rebuild, exactly as in the reference.  Values that already live on the device (a ROCArray: model.θ of a
+# device model is one) go device-to-device on the model's stream (exa_set_value_dev: no PCIe hop, no synchronisation, capturable);
+# host values through exa_set_value.
 function ExaModels.set_value!(m::ExaModels.ExaModel{T,VT,E}, param::ExaModels.Parameter, values) where {T,VT,E<:HIPExtension}
     length(values) == param.length || throw(DimensionMismatch("expected $(param.length) elements, got $(length(values))"))
-    copyto!(view(m.θ, param.offset+1:param.offset+param.length), values)
-    v = Array{Float64}(values)
-    chk(ccall((:exa_set_value, LIB), Cint, (Cint, Int64, Ptr{Cdouble}, Int64), m.ext.id, param.offset, v, length(v)), "exa_set_value")
+    dst = view(m.θ, param.offset+1:param.offset+param.length)
+    copyto!(dst, values)
+    if m.θ isa Array
+        v = Array{Float64}(values)
+        chk(ccall((:exa_set_value, LIB), Cint, (Cint, Int64, Ptr{Cdouble}, Int64), m.ext.id, param.offset, v, length(v)), "exa_set_value")
+    else
+        usestream(m)
+        chk(ccall((:exa_set_value_dev, LIB), Cint, (Cint, Int64, Ptr{Cdouble}, Int64), m.ext.id, param.offset, pointer(dst), param.length), "exa_set_value_dev")
+    end
     return nothing
+end
+# the library's own device-resident parameter vector (npar doubles; get_value's view, nlp.jl:1270-1277): wrap it with
+# unsafe_wrap(ROCArray, convert(ROCPtr{Float64}, theta_ptr(m)), npar) to write parameters in place
+theta_ptr(m) = ccall((:exa_theta_ptr, LIB), Ptr{Cdouble}, (Cint,), m.ext.id)
+# what the compiled kernels of the model need and which flags their modules were built with (exa_build_audit): one line per kernel
+function build_audit(m)
+    n = ccall((:exa_build_audit, LIB), Cint, (Cint, Ptr{UInt8}, Cint), m.ext.id, C_NULL, 0)
+    buf = Vector{UInt8}(undef, n + 1)
+    ccall((:exa_build_audit, LIB), Cint, (Cint, Ptr{UInt8}, Cint), m.ext.id, buf, n + 1)
+    return split(unsafe_string(pointer(buf)), '\n'; keepempty = false)
+end
+# the collective operations that complete callback `which` of a sharded model (exa_collective_plan): rows of (kind, offset, count, root),
+# kind 0 in-place all-gather, 1 broadcast, 2 all-reduce(sum) — for a host that issues them itself (MPI.jl) after exa_set_reduce(id, 0)
+function collective_plan(m, which::Integer)
+    ops = Matrix{Int64}(undef, 4, 64)
+    n = ccall((:exa_collective_plan, LIB), Cint, (Cint, Cint, Ptr{Int64}, Cint), m.ext.id, which, ops, 64)
+    return permutedims(ops[:, 1:max(0, min(n, 64))])
 end
 function ExaModels.jac_structure!(m::HM, rows::AbstractVector, cols::AbstractVector)
     usestream(m)
