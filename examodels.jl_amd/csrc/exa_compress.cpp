@@ -71,6 +71,18 @@ __global__ void __launch_bounds__(256) k_compress(double *__restrict__ V, const 
     for (; j < e; j++) s += buf[perm[j]];
     V[k] = s;
 }
+// a matrix without duplicates (cnnz == nnz, ptr = identity): a permutation — four independent gathers per thread, no ptr reads
+__global__ void __launch_bounds__(256) k_permute(double *__restrict__ V, const double *__restrict__ buf, const uint32_t *__restrict__ perm, int64_t n) {
+    const int64_t k0 = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    uint32_t q[4];
+    double a[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) q[u] = k0 + 256 * u < n ? perm[k0 + 256 * u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; u++) a[u] = buf[q[u]];
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (k0 + 256 * u < n) V[k0 + 256 * u] = a[u];
+}
 __global__ void __launch_bounds__(256) k_positions(const uint32_t *__restrict__ perm, uint32_t *__restrict__ pos, int64_t n) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j < n) pos[perm[j]] = (uint32_t)j;
@@ -482,6 +494,10 @@ void attach_unit(SortedIndex &s, hipStream_t stream) {
 
 void compress_values(const CompressedCOO &c, const double *buf, double *V, hipStream_t stream) {
     if (c.cnnz == 0) return;
+    if (c.cnnz == c.nnz) {
+        hipLaunchKernelGGL(k_permute, dim3((unsigned)((c.cnnz + 1023) / 1024)), dim3(256), 0, stream, V, buf, (const uint32_t *)c.perm, c.cnnz);
+        return;
+    }
     hipLaunchKernelGGL(k_compress, dim3(grid_for(c.cnnz)), dim3(256), 0, stream, V, buf, (const int64_t *)c.ptr, (const uint32_t *)c.perm,
                        c.cnnz);
     if (c.nlong) {

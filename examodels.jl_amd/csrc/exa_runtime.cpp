@@ -960,7 +960,7 @@ const char *exa_module_source(int id, int k) { Handle *h = get(id); return !h ||
 int exa_set_stream(int id, void *s) { return guard(id, true, [&](Handle &h) { h.stream = (hipStream_t)s; }); }
 int exa_set_value(int id, int64_t offset, const double *vals, int64_t len) {
     Handle *hh = get(id);
-    if (!hh || !vals || offset < 0 || len < 0 || offset + len > hh->m->npar) return 1;
+    if (!hh || !vals || offset < 0 || len < 0 || offset > hh->m->npar || len > hh->m->npar - offset) return 1;
     return guard(id, false, [&](Handle &h) {
         std::memcpy(h.m->theta.data() + offset, vals, 8 * (size_t)len);
         if (h.on_device && len) {
@@ -975,7 +975,7 @@ int exa_set_value(int id, int64_t offset, const double *vals, int64_t len) {
  * hop, no synchronisation, capturable.  dev_vals must stay valid until the stream has passed the copy. */
 int exa_set_value_dev(int id, int64_t offset, const double *dev_vals, int64_t len) {
     Handle *hh = get(id);
-    if (!hh || !dev_vals || offset < 0 || len < 0 || offset + len > hh->m->npar) return 1;
+    if (!hh || !dev_vals || offset < 0 || len < 0 || offset > hh->m->npar || len > hh->m->npar - offset) return 1;
     return guard(id, true, [&](Handle &h) {
         if (len) HIPCHK(hipMemcpyAsync((double *)h.dtheta.p + offset, dev_vals, 8 * (size_t)len, hipMemcpyDeviceToDevice, h.stream));
         h.theta_dev_newer = true;
@@ -993,7 +993,7 @@ double *exa_theta_ptr(int id) {
 
 int exa_get_value(int id, int64_t offset, double *vals, int64_t len) {
     Handle *hh = get(id);
-    if (!hh || !vals || offset < 0 || len < 0 || offset + len > hh->m->npar) return 1;
+    if (!hh || !vals || offset < 0 || len < 0 || offset > hh->m->npar || len > hh->m->npar - offset) return 1;
     if (hh->on_device && hh->theta_dev_newer) {
         // the device copy was written (exa_set_value_dev / exa_theta_ptr): bring the host copy up to date first
         const int rc = guard(id, true, [&](Handle &h) {

@@ -28,6 +28,10 @@ if os.environ.get("POISON"):
     from poison import make_poison
     poison = make_poison(tempfile.mkdtemp())
 randexpr.NPTS = 300
+if os.environ.get("PREBUILD"):           # without a GPU: plan + compile into the kernel cache (which travels to the GPU box)
+    ExaModel(randexpr.build_model(seed, npat, depth), device=False).compile()
+    print(f"seed {seed} {npat} {depth} prebuilt")
+    sys.exit(0)
 m = ExaModel(randexpr.build_model(seed, npat, depth))
 o = oracle.OracleModel(m.ir)
 m.set_product_mode(0, 0)
@@ -67,6 +71,14 @@ if os.environ.get("CHECK_ALL"):
              rel(h.cpu().numpy(), o.hess_coord(x, y, 0.7))]
     m.set_product_mode(1, 1)
     errs += [rel(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)), rel(m.jtprod(x, w), o.jtprod(x, w))]
+    try:                                   # owner pull (data-indexed targets), where the model has it
+        m.set_product_mode(3, 3)
+        poison()
+        errs += [rel(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)), rel(m.jtprod(x, w), o.jtprod(x, w))]
+    except Exception as e:                 # noqa: BLE001
+        if "pull" not in str(e) and "mode" not in str(e):
+            raise
+    m.set_product_mode(1, 1)
     cm = CompressedExaModel(m)
     poison()
     for kind, nrow in (("jac", max(m.meta.ncon, 1)), ("hess", m.meta.nvar)):

@@ -8,7 +8,7 @@ the staged / chained hess_coord! kernels, owner-sharded outputs.  Per seed:
   * J'v / H v by atomics and by the sorted gather against the default;
   * the compressed Jacobian / Hessian, densified, against the densified oracle COO;
   * 3 ranks replayed on this GPU: owner pieces into one NaN-poisoned buffer, partial sums added, COO slices tiling the whole.
-usage: range_model_check.py FIRST_SEED COUNT [mixed|unit|blocks] [NPTS] [--poison]   — one line per seed, BAD at the end of a line
+usage: range_model_check.py FIRST_SEED COUNT [mixed|unit|blocks] [NPTS] [--poison] [--prebuild]   — one line per seed, BAD at the end of a line
 that fails; a GPU fault kills the process (run chunks under `timeout`, ONE process at a time).  --poison: every VGPR / AGPR of
 the chip is filled with NaN before each model's callbacks (tests/poison.py): a kernel reading a lane it never wrote then fails
 every time, not when the stale contents happen to matter."""
@@ -27,7 +27,8 @@ from conftest import RankReplay  # noqa: E402
 from exahip import CompressedExaModel, ExaModel, capi  # noqa: E402
 
 POISON = "--poison" in sys.argv
-argv = [a for a in sys.argv if a != "--poison"]
+PREBUILD = "--prebuild" in sys.argv       # on a machine without a GPU: plan + compile every seed's modules into the kernel cache
+argv = [a for a in sys.argv if a not in ("--poison", "--prebuild")]
 first, count = int(argv[1]), int(argv[2])
 flavour = argv[3] if len(argv) > 3 else "mixed"
 npts_arg = int(argv[4]) if len(argv) > 4 else 0
@@ -36,7 +37,7 @@ if POISON:
     import tempfile
     from poison import make_poison
     poison = make_poison(tempfile.mkdtemp())
-dev = torch.device("cuda:0")
+dev = torch.device("cpu" if PREBUILD else "cuda:0")
 TOL = 1e-9
 
 
@@ -76,6 +77,10 @@ bad = 0
 for seed in range(first, first + count):
     npts = npts_arg or (300, 1000, 1037, 4099, 20011)[seed % 5]
     mk = lambda: randexpr.build_range_model(seed, npts=npts, unit=flavour in ("unit", "blocks"), blocks=flavour == "blocks")      # noqa: E731
+    if PREBUILD:
+        ExaModel(mk(), device=False).compile()
+        print(f"seed {seed} {flavour} npts {npts} prebuilt", flush=True)
+        continue
     m = ExaModel(mk())
     o = oracle.OracleModel(m.ir)
     nvar, ncon = m.meta.nvar, m.meta.ncon
@@ -119,7 +124,7 @@ for seed in range(first, first + count):
         del mv
     # products by the other implementations
     info = (m.product_info("jtprod")[1], m.product_info("hprod")[1])
-    for mode in (0, 1):
+    for mode in (0, 1, 3):
         try:
             m.set_product_mode(mode, mode)
         except capi.ExaHipError:
