@@ -419,6 +419,7 @@ CodeObject get_code_object(const std::string &source, bool memory_only_ok, bool 
         const std::string p = d + "/" + file;
         if (read_regular_file(p, co.image) && (looks_like_code_object(co.image.data(), co.image.size()) || looks_like_bundle(co.image.data(), co.image.size()))) {
             co.how = "disk"; co.path = p;
+            (void)utimensat(AT_FDCWD, p.c_str(), nullptr, 0);      // "last used" stamp: what a cache pruner goes by (a read-only cache just keeps its dates)
             return co;
         }
     }
