@@ -163,10 +163,13 @@ __global__ void __launch_bounds__(256) k_narrow(const int64_t *__restrict__ src,
     if (i < n) dst[i] = (T)src[i];
 }
 
-__global__ void __launch_bounds__(256) k_keys0(const int64_t *__restrict__ keys1, uint32_t *__restrict__ k0, uint32_t *__restrict__ idx, int64_t n) {
+__global__ void __launch_bounds__(256) k_keys0(const int64_t *__restrict__ keys1, uint32_t *__restrict__ k0, uint32_t *__restrict__ idx, int64_t n, int64_t ndim,
+                                               unsigned long long *__restrict__ bad) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    k0[i] = (uint32_t)(keys1[i] - 1);
+    const int64_t key = keys1[i];
+    if (key < 1 || key > ndim) { atomicAdd(bad, 1ull); k0[i] = 0; }        // (counted; the caller refuses the list)
+    else k0[i] = (uint32_t)(key - 1);
     idx[i] = (uint32_t)i;
 }
 
@@ -404,7 +407,15 @@ void build_sorted_index(SortedIndex &s, const int64_t *keys1, int64_t nnz, int64
     HIPCHK_C(hipMalloc(&s.perm, 4 * (size_t)(nnz ? nnz : 1)));
     Tmp k0(4 * (size_t)nnz), k1(4 * (size_t)nnz), idx(4 * (size_t)nnz);
     if (nnz) {
-        hipLaunchKernelGGL(k_keys0, dim3(grid_for(nnz)), dim3(256), 0, stream, keys1, (uint32_t *)k0.p, (uint32_t *)idx.p, nnz);
+        // keys outside [1, ndim] (a key kernel that skipped entries, an index column pointing outside the variables) would be
+        // mis-sorted by the ndim-bit radix sort and send k_ptr_from_sorted past its array: counted, and refused
+        Tmp bad(8);
+        HIPCHK_C(hipMemsetAsync(bad.p, 0, 8, stream));
+        hipLaunchKernelGGL(k_keys0, dim3(grid_for(nnz)), dim3(256), 0, stream, keys1, (uint32_t *)k0.p, (uint32_t *)idx.p, nnz, ndim, (unsigned long long *)bad.p);
+        unsigned long long nbad = 0;
+        HIPCHK_C(hipMemcpyAsync(&nbad, bad.p, 8, hipMemcpyDeviceToHost, stream));
+        HIPCHK_C(hipStreamSynchronize(stream));
+        if (nbad) { s.release(); throw std::runtime_error("sorted index: " + std::to_string(nbad) + " of " + std::to_string(nnz) + " keys lie outside 1.." + std::to_string(ndim)); }
         unsigned bits = 1;
         while (bits < 32 && (1ull << bits) < (unsigned long long)ndim) bits++;
         size_t tb = 0;

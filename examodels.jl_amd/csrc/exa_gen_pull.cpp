@@ -79,13 +79,17 @@ std::string generate_pull_module(const Model &m, const ParamLayout &L, bool jt, 
                 os << "    return " << gi.E.sd(gi.items[t].val) << ";\n}\n";
             }
         }
+        // the block map of the scattering kernel this list mirrors: an entry stands for EXA_BLOCK * ppt data points (ppt = 16 when a
+        // target is shared by every point, gen_dispatch) — the keys kernel must visit all of them (it did not: the keys of 15 points
+        // out of 16 stayed uninitialised on such models, found by the deep random sweep of round 4)
+        const int ppt = std::max(1, L.ppt[cb]);
         const std::string head = "    const long e_ = ((const long*)P[" + std::to_string(L.blk[cb]) + "])[blockIdx.x];\n    const int ps_ = (int)(e_ >> 40);\n"
-                                 "    const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
+                                 "    const long tid0 = (e_ & ((1L << 40) - 1)) * (EXA_BLOCK * " + std::to_string(ppt) + ") + threadIdx.x;\n";
         os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_" << nm << "keys(" << params << "long* __restrict__ keys, const long* __restrict__ first) {\n" << head;
         for (size_t g = 0; g < ng; g++) {
             const auto &pp = L.pat[L.groups[cb][g].front()];
-            os << "    " << (g ? "else " : "") << "if (ps_ == " << g << ") { const long I = P[" << pp.lo << "] + tid0; if (I < P[" << pp.hi << "]) g" << g << "_" << nm
-               << "keys(" << args << "keys, first[" << g << "] + " << nt[g] << "L * tid0, I); }\n";
+            os << "    " << (g ? "else " : "") << "if (ps_ == " << g << ") {\n#pragma unroll 1\n        for (int u = 0; u < " << ppt << "; u++) { const long t_ = tid0 + u * EXA_BLOCK, I = P["
+               << pp.lo << "] + t_; if (I < P[" << pp.hi << "]) g" << g << "_" << nm << "keys(" << args << "keys, first[" << g << "] + " << nt[g] << "L * t_, I); }\n    }\n";
         }
         os << "}\n";
         os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_" << nm << "pull(" << params

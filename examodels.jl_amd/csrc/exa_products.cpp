@@ -91,7 +91,15 @@ void pull_setup(Handle &h, bool hess) {
     double sigma = 1.0;
     if (hess) { void *a[] = {&P, &xz, &yz, &th, &vz, &sigma, &kp, &fp}; launch(h, q.fkeys, h.grid[cb], kBlock, a); }
     else { void *a[] = {&P, &xz, &th, &vz, &kp, &fp}; launch(h, q.fkeys, h.grid[cb], kBlock, a); }
-    build_sorted_index(q.idx, (const int64_t *)keys.p, total, m.nvar, h.stream);
+    try {
+        build_sorted_index(q.idx, (const int64_t *)keys.p, total, m.nvar, h.stream);
+    } catch (const HipError &) {
+        throw;
+    } catch (const std::exception &e) {      // keys outside the variables: no pull lists (the other implementations stay)
+        q.idx.release();
+        q.why = e.what();
+        return;
+    }
     HIPCHK(hipStreamSynchronize(h.stream));
     if (q.idx.nlong > 0) {       // a variable collecting more than 512 contributions (a slack shared by every point): one thread would walk them all
         q.idx.release();

@@ -205,6 +205,40 @@ def test_a_78k_bus_case_file_through_the_real_case_path(libs, tmp_path):
     assert line["value"] > 0 and line["roofline"]["bound"] == "mall"          # 102 MB per launch: Infinity-Cache resident, labelled as such
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3021, 3003])
+def test_owner_pull_on_random_models_with_a_target_shared_by_all_points(libs, seed):
+    """Deep random data-indexed models in which one variable is touched by EVERY data point (the scattering kernels then take 16
+    tiles per block-map entry): the pull lists must still cover every data point.  Round 4's closing sweep: J'v / Hv wrong by
+    factors, or a memory fault, on exactly these models (seeds 3021 / 3039 / 3003 / 3005 / 2031) — the key kernels visited one
+    tile in 16.  Against the oracle and against the atomics, NaN-poisoned outputs."""
+    import torch
+    import randexpr
+    randexpr.NPTS = 300
+    m = ExaModel(randexpr.build_model(seed, 8, 4))
+    o = oracle.OracleModel(m.ir)
+    x = m.meta.x0 + 0.05 * np.random.default_rng(seed).uniform(-1, 1, m.meta.nvar)
+    y = np.random.default_rng(seed + 1).standard_normal(m.meta.ncon)
+    v = np.random.default_rng(seed + 2).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(seed + 3).standard_normal(m.meta.ncon)
+    dev = torch.device("cuda:0")
+    xd, yd, vd, wd = (torch.from_numpy(a).to(dev) for a in (x, y, v, w))
+    rj, rh = o.jtprod(x, w), o.hprod(x, y, v, 0.7)
+    got = {}
+    for mode in (0, 3):
+        m.set_product_mode(mode, mode)
+        assert m.product_mode() == (mode, mode)
+        out = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)
+        a = m.jtprod(xd, wd, out=out).cpu().numpy().copy()
+        out.fill_(float("nan"))
+        b = m.hprod(xd, yd, vd, 0.7, out=out).cpu().numpy().copy()
+        assert np.all(np.isfinite(a) == np.isfinite(rj)) and np.all(np.isfinite(b) == np.isfinite(rh))
+        fj, fh = np.isfinite(rj), np.isfinite(rh)
+        assert np.max(np.abs(a[fj] - rj[fj]) / (1.0 + np.abs(rj[fj]))) <= 1e-9, (mode, "jtprod")
+        assert np.max(np.abs(b[fh] - rh[fh]) / (1.0 + np.abs(rh[fh]))) <= 1e-9, (mode, "hprod")
+        got[mode] = (a, b)
+
+
 @pytest.mark.parametrize("name", ["acopf30", "mixed", "cops_elec"])
 def test_owner_pull_products_of_data_indexed_models(libs, name):
     """J'v / Hv mode 3 (exa_gen_pull.cpp): a thread per variable re-evaluates the contributions that land on it — no zero-fill, no

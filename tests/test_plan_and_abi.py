@@ -476,3 +476,30 @@ def test_owner_pull_module_is_planned_for_data_indexed_models_only(libs, monkeyp
     monkeypatch.setenv("EXAHIP_PRODUCT_PULL", "0")
     b = ExaModel(ZOO["acopf30"](), device=False)
     assert "owner pull" not in b.product_info("jtprod")[1] and b._L.exa_code_object_count(b.id) == 1 and b.module_source(1) == ""
+
+
+@pytest.mark.parametrize("seed", [3021, 3003])
+def test_pull_key_kernels_walk_the_block_map_like_the_scatter_kernels(libs, seed):
+    """The owner-pull lists are keyed by kernels that mirror the block map of exa_jtprod / exa_hprod.  When a target is shared by
+    every data point those kernels take EXA_BLOCK * 16 points per map entry; the key kernels took EXA_BLOCK (15 keys out of 16
+    uninitialised: wrong J'v / Hv and memory faults on deep random models, round 4 closing sweep).  Same factor in both."""
+    import randexpr
+    from exahip import ExaModel
+    randexpr.NPTS = 300
+    m = ExaModel(randexpr.build_model(seed, 8, 4), device=False)
+    main, pull = m.kernel_source(), m.module_source(1)
+    assert "exa_jtkeys(" in pull and "exa_hpkeys(" in pull
+
+    def factor(src, kernel):
+        body = src[src.index("void __launch_bounds__(EXA_BLOCK) " + kernel + "("):]
+        body = body[:body.index("\n}\n")]
+        mm = re.search(r"tid0 = \(e_ & \(\(1L << 40\) - 1\)\) \* \(?EXA_BLOCK(?: \* (\d+)\))? \+ threadIdx\.x", body)
+        assert mm, (kernel, body[:400])
+        return int(mm.group(1) or 1), body
+    for scatter, keys in (("exa_jtprod", "exa_jtkeys"), ("exa_hprod", "exa_hpkeys")):
+        f_main, _ = factor(main, scatter)
+        f_keys, body = factor(pull, keys)
+        assert f_main == f_keys, (scatter, f_main, f_keys)
+        if f_keys > 1:
+            assert f"u < {f_keys}" in body
+    assert any(factor(main, k)[0] == 16 for k in ("exa_jtprod", "exa_hprod"))          # these seeds DO have a shared target
