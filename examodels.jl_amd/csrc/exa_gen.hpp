@@ -166,7 +166,8 @@ Val pow_any(Emitter &e, Val x1, Val x2);
 // generate_module and generate_window_module (models may be built and compressed from several host threads).
 extern std::mutex g_gen_mu;
 extern const char *kPrelude;                 // exa_gen_prelude.cpp
-std::string prelude_text(const ParamLayout &L);   // kPrelude with its @TAGS@ filled in
+extern const char *kSpecialPrelude;          // the SpecialFunctions routines (only for models that use them)
+std::string prelude_text(const Model &m, const ParamLayout &L);   // kPrelude with its @TAGS@ filled in (+ kSpecialPrelude)
 
 // ---------------------------------------------------------------------------------------------------
 // per-pattern body generator

@@ -136,7 +136,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
     g_scatter_lines.clear();
     std::ostringstream os;
     L.pull_ppt = 2;
-    os << prelude_text(L);
+    os << prelude_text(m, L);
     os << "// patterns=" << np << " (sizes, offsets and column pointers are run-time parameters in P[])\n";
     if (loopfree_scatter) os << "// scatter kernels without loops: the first build of this module spilled registers there\n";
     if (nostage) os << "// no LDS-staged chained kernel (exa_hesscl): it outgrew the architectural registers in the first build of this module\n";

@@ -52,7 +52,7 @@ std::string generate_pull_module(const Model &m, const ParamLayout &L, bool jt, 
     using namespace gen;
     std::lock_guard<std::mutex> gen_lock(g_gen_mu);
     std::ostringstream os;
-    os << prelude_text(L);
+    os << prelude_text(m, L);
     os << "// owner-pull products: one thread per variable re-evaluates the items that land on it (exa_gen_pull.cpp)\n";
     for (int cb : {CB_JTPROD, CB_HPROD}) {
         if (!(cb == CB_JTPROD ? jt : hp)) continue;

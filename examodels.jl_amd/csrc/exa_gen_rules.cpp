@@ -93,6 +93,28 @@ static const UnSpec *un_spec(int fn) {
                           "(fabs($1) > 1.0 ? __builtin_nan(\"\") : 2.0 * $1 * exa_sq(1.0 / (1.0 - $1 * $1)))"};
         T[EXA_U_ACOTH] = {"atanh(1.0 / $1)", "(fabs($1) < 1.0 ? __builtin_nan(\"\") : 1.0 / (1.0 - $1 * $1))",
                           "(fabs($1) < 1.0 ? __builtin_nan(\"\") : 2.0 * $1 * exa_sq(1.0 / (1.0 - $1 * $1)))"};
+        // ---- the SpecialFunctions extension (ext/functionlist.jl:6-102).  Primal functions: ocml where it has them (erf, erfc,
+        // erfcx, erfinv, erfcinv, tgamma, j0/j1/jn, y0/y1/yn), else the exa_* routines of the special prelude (exa_gen_prelude.cpp).
+        // The table's derivative formulas, written through the primal ($2) / first derivative ($3) where that is the same algebra.
+        T[EXA_U_ERF] = {"erf($1)", "(2.0 * EXA_INVSQRTPI) * exp(-($1 * $1))", "-2.0 * $1 * $3"};
+        T[EXA_U_ERFC] = {"erfc($1)", "-(2.0 * EXA_INVSQRTPI) * exp(-($1 * $1))", "-2.0 * $1 * $3"};
+        T[EXA_U_ERFI] = {"exa_erfi($1)", "(2.0 * EXA_INVSQRTPI) * exp($1 * $1)", "2.0 * $1 * $3"};
+        T[EXA_U_ERFCX] = {"erfcx($1)", "2.0 * (-EXA_INVSQRTPI + $1 * $2)", "2.0 * ($2 + $1 * $3)"};
+        T[EXA_U_DIGAMMA] = {"exa_polygamma<0>($1)", "exa_polygamma<1>($1)", "exa_polygamma<2>($1)"};
+        T[EXA_U_TRIGAMMA] = {"exa_polygamma<1>($1)", "exa_polygamma<2>($1)", "exa_polygamma<3>($1)"};
+        T[EXA_U_INVDIGAMMA] = {"exa_invdigamma($1)", "1.0 / exa_polygamma<1>($2)", "-exa_polygamma<2>($2) * ($3 * $3 * $3)"};
+        T[EXA_U_GAMMA] = {"tgamma($1)", "$2 * exa_polygamma<0>($1)", "$2 * (exa_polygamma<1>($1) + exa_sq(exa_polygamma<0>($1)))"};
+        T[EXA_U_AIRYAI] = {"exa_airy<0>($1)", "exa_airy<1>($1)", "$1 * $2"};
+        T[EXA_U_AIRYBI] = {"exa_airy<2>($1)", "exa_airy<3>($1)", "$1 * $2"};
+        T[EXA_U_AIRYAIPRIME] = {"exa_airy<1>($1)", "$1 * exa_airy<0>($1)", "exa_airy<0>($1) + $1 * $2"};
+        T[EXA_U_AIRYBIPRIME] = {"exa_airy<3>($1)", "$1 * exa_airy<2>($1)", "exa_airy<2>($1) + $1 * $2"};
+        T[EXA_U_BESSELJ0] = {"j0($1)", "-j1($1)", "0.5 * (jn(2, $1) - $2)"};
+        T[EXA_U_BESSELY0] = {"y0($1)", "-y1($1)", "0.5 * (yn(2, $1) - $2)"};
+        T[EXA_U_BESSELJ1] = {"j1($1)", "0.5 * (j0($1) - jn(2, $1))", "0.5 * (0.5 * (jn(3, $1) - $2) - $2)"};
+        T[EXA_U_BESSELY1] = {"y1($1)", "0.5 * (y0($1) - yn(2, $1))", "0.5 * (0.5 * (yn(3, $1) - $2) - $2)"};
+        T[EXA_U_DAWSON] = {"exa_dawson($1)", "1.0 - 2.0 * $1 * $2", "-2.0 * $2 - 2.0 * $1 * $3"};
+        T[EXA_U_ERFINV] = {"erfinv($1)", "EXA_SQRTPIHALF * exp($2 * $2)", "2.0 * $2 * $3 * $3"};
+        T[EXA_U_ERFCINV] = {"erfcinv($1)", "-EXA_SQRTPIHALF * exp($2 * $2)", "2.0 * $2 * $3 * $3"};
     }
     return &T[fn];
 }
@@ -304,6 +326,31 @@ Six bin_rule(Emitter &e, int fn, Val x1, Val x2, int order) {
         r.y1 = e.call("($1 < $2 ? 1.0 : 0.0)", {x1, x2});
         r.y2 = e.call("($1 < $2 ? 0.0 : 1.0)", {x1, x2});
         return r;
+    case EXA_B_BETA:
+    case EXA_B_LOGBETA: {
+        // ext/functionlist.jl:109-124: with p1 = digamma(x1) - digamma(x1 + x2), p2 = digamma(x2) - digamma(x1 + x2),
+        // t. = trigamma(.):  logbeta: (p1, p2, t1 - t12, -t12, t2 - t12);  beta: B * (p1, p2, t1 - t12 + p1^2, -t12 + p1 p2, t2 - t12 + p2^2)
+        const bool lg = fn == EXA_B_LOGBETA;
+        r.x = e.call(lg ? "exa_logbeta($1, $2)" : "exa_beta($1, $2)", {x1, x2});
+        if (order >= 1) {
+            Val s = e.add(x1, x2);
+            Val ds = e.call("exa_polygamma<0>($1)", {s});
+            Val p1 = e.sub(e.call("exa_polygamma<0>($1)", {x1}), ds), p2 = e.sub(e.call("exa_polygamma<0>($1)", {x2}), ds);
+            r.y1 = lg ? p1 : e.mul(r.x, p1);
+            r.y2 = lg ? p2 : e.mul(r.x, p2);
+            if (order >= 2) {
+                Val ts = e.call("exa_polygamma<1>($1)", {s});
+                Val a11 = e.sub(e.call("exa_polygamma<1>($1)", {x1}), ts), a22 = e.sub(e.call("exa_polygamma<1>($1)", {x2}), ts);
+                if (lg) { r.h11 = a11; r.h12 = e.neg(ts); r.h22 = a22; }
+                else {
+                    r.h11 = e.mul(r.x, e.add(a11, e.sq(p1)));
+                    r.h12 = e.add(e.neg(e.mul(r.x, ts)), e.mul(e.mul(r.x, p1), p2));
+                    r.h22 = e.mul(r.x, e.add(a22, e.sq(p2)));
+                }
+            }
+        }
+        return r;
+    }
     }
     fail("unknown bivariate function");
 }

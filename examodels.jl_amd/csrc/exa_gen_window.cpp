@@ -366,7 +366,7 @@ std::vector<int> merged_hess_slots(const Model &m, const ParamLayout &L) {
 std::string generate_window_module(const Model &m, const ParamLayout &L, const WindowSpec &spec) {
     std::lock_guard<std::mutex> gen_lock(g_gen_mu);
     std::ostringstream os;
-    os << prelude_text(L);
+    os << prelude_text(m, L);
     // LDS position of window entry c: the low four bits (the 64-bit bank) are XOR-ed with the next four, so that lanes
     // striding through the window by 2, 3, 12 ... entries (the stride of a pass) spread over the banks instead of
     // hitting the same 2-4 of them (rocket, stride 12: 8-way conflicts on every read-modify-write); a bijection within

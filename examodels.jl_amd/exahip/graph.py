@@ -23,8 +23,12 @@ UN_FNS = [
     "log1p", "log10", "sin", "cos", "tan", "asin", "acos", "atan", "acot", "csc", "sec", "cot", "sinh", "cosh",
     "tanh", "asinh", "acosh", "csch", "sech", "coth", "sind", "cosd", "tand", "cscd", "secd", "cotd", "atand",
     "acotd", "sinpi", "cospi", "sinc", "deg2rad", "rad2deg", "signbit", "floor", "ceil", "atanh", "acoth",
+    # the SpecialFunctions extension (ext/functionlist.jl:6-102)
+    "erf", "erfc", "erfi", "erfcx", "digamma", "trigamma", "invdigamma", "gamma", "airyai", "airybi", "airyaiprime",
+    "airybiprime", "besselj0", "bessely0", "besselj1", "bessely1", "dawson", "erfinv", "erfcinv",
 ]
-BIN_FNS = ["+", "-", "*", "/", "^", "atan", "hypot", "max", "min"]
+BIN_FNS = ["+", "-", "*", "/", "^", "atan", "hypot", "max", "min", "beta", "logbeta"]
+SPECIAL_UN = UN_FNS[UN_FNS.index("erf"):]
 UN_ID = {n: i for i, n in enumerate(UN_FNS)}
 BIN_ID = {n: i for i, n in enumerate(BIN_FNS)}
 
@@ -257,7 +261,16 @@ _PY_BIN = {
     "hypot": math.hypot,
     "max": max,
     "min": min,
+    "beta": lambda a, b: _scipy_special("beta")(a, b),
+    "logbeta": lambda a, b: _scipy_special("betaln")(a, b),
 }
+
+
+def _scipy_special(name):
+    """Plain-number arguments of the SpecialFunctions entries (constant folding at build time only): scipy.special."""
+    import scipy.special as sp
+
+    return getattr(sp, name)
 
 
 def _bin(fn, a, b):
@@ -399,7 +412,37 @@ _PY_UN = {
     "ceil": math.ceil,
     "atanh": math.atanh,
     "acoth": lambda x: math.atanh(1.0 / x),
+    "erf": math.erf,
+    "erfc": math.erfc,
+    "erfi": lambda x: float(_scipy_special("erfi")(x)),
+    "erfcx": lambda x: float(_scipy_special("erfcx")(x)),
+    "digamma": lambda x: float(_scipy_special("digamma")(x)),
+    "trigamma": lambda x: float(_scipy_special("polygamma")(1, x)),
+    "invdigamma": lambda x: _invdigamma(x),
+    "gamma": math.gamma,
+    "airyai": lambda x: float(_scipy_special("airy")(x)[0]),
+    "airyaiprime": lambda x: float(_scipy_special("airy")(x)[1]),
+    "airybi": lambda x: float(_scipy_special("airy")(x)[2]),
+    "airybiprime": lambda x: float(_scipy_special("airy")(x)[3]),
+    "besselj0": lambda x: float(_scipy_special("j0")(x)),
+    "bessely0": lambda x: float(_scipy_special("y0")(x)),
+    "besselj1": lambda x: float(_scipy_special("j1")(x)),
+    "bessely1": lambda x: float(_scipy_special("y1")(x)),
+    "dawson": lambda x: float(_scipy_special("dawsn")(x)),
+    "erfinv": lambda x: float(_scipy_special("erfinv")(x)),
+    "erfcinv": lambda x: float(_scipy_special("erfcinv")(x)),
 }
+
+
+def _invdigamma(y):
+    x = math.exp(y) + 0.5 if y >= -2.22 else -1.0 / (y + 0.5772156649015329)
+    dg, pg = _scipy_special("digamma"), _scipy_special("polygamma")
+    for _ in range(25):
+        xn = x - (float(dg(x)) - y) / float(pg(1, x))
+        if abs(xn - x) <= 1e-15 * abs(xn):
+            return xn
+        x = xn
+    return x
 
 
 def _make_un(name):
@@ -460,6 +503,9 @@ floor = _make_un("floor")
 ceil = _make_un("ceil")
 atanh = _make_un("atanh")
 acoth = _make_un("acoth")
+for _name in SPECIAL_UN:      # erf, erfc, ..., erfcinv as module-level functions (docstring: ext/functionlist.jl)
+    globals()[_name] = _make_un(_name)
+    globals()[_name].__doc__ = f"`{_name}` of the SpecialFunctions extension, registered as a univariate node function (ext/functionlist.jl:6-102)."
 uplus = _make_un("+")
 uminus = _make_un("-")
 
@@ -473,6 +519,16 @@ def atan(y, x=None):
 
 def hypot(a, b):
     return _bin("hypot", a, b)
+
+
+def beta(a, b):
+    """Bivariate `beta` of the SpecialFunctions extension (ext/functionlist.jl:109-116)."""
+    return _bin("beta", a, b)
+
+
+def logbeta(a, b):
+    """Bivariate `logbeta` (log|B(a, b)|) of the SpecialFunctions extension (ext/functionlist.jl:117-124)."""
+    return _bin("logbeta", a, b)
 
 
 def maximum(a, b):

@@ -41,6 +41,11 @@ const UN = Dict(f => Int32(i - 1) for (i, f) in enumerate((+, -, inv, sqrt, cbrt
     acosh, csch, sech, coth, sind, cosd, tand, cscd, secd, cotd, atand, acotd, sinpi, cospi, sinc, deg2rad, rad2deg,
     signbit, floor, ceil, atanh, acoth)))
 const BIN = Dict(f => Int32(i - 1) for (i, f) in enumerate((+, -, *, /, ^, atan, hypot, max, min)))
+# the SpecialFunctions extension (ext/functionlist.jl; include/exahip_ir.h EXA_U_ERF.., EXA_B_BETA..): SpecialFunctions.jl is a weak
+# dependency of ExaModels, so these are matched by NAME (nameof of the node's function) and need no import here
+const UN_SPECIAL = (:erf, :erfc, :erfi, :erfcx, :digamma, :trigamma, :invdigamma, :gamma, :airyai, :airybi, :airyaiprime,
+    :airybiprime, :besselj0, :bessely0, :besselj1, :bessely1, :dawson, :erfinv, :erfcinv)
+const BIN_SPECIAL = (:beta, :logbeta)
 
 # ---- lowering of one expression tree (graph.jl:37-300) ------------------------------------------------------
 mutable struct Lower
@@ -66,7 +71,10 @@ lower!(l, v::ParameterNode) = push_node!(l, OP_PAR, 0, lower!(l, v.i), -1, 0.0, 
 # functions registered by the user (@register_univariate / @register_bivariate outside src/functionlist.jl) have no
 # entry in the library's derivative table: say so instead of failing with a bare KeyError
 fncode(tab, f, arity) = get(tab, f) do
-    error("ExaModelsHIP: the $arity function `$f` is not in libexahip's derivative table (src/functionlist.jl entries only)")
+    special = tab === UN ? UN_SPECIAL : BIN_SPECIAL
+    k = findfirst(==(nameof(f)), special)
+    k === nothing && error("ExaModelsHIP: the $arity function `$f` is not in libexahip's derivative table (src/functionlist.jl and ext/functionlist.jl entries only)")
+    Int32(length(tab) + k - 1)
 end
 lower!(l, n::Node1{F}) where {F} = push_node!(l, OP_UN, fncode(UN, F.instance, "univariate"), lower!(l, n.inner), -1, 0.0, 0)
 function lower!(l, n::Node2{F}) where {F}

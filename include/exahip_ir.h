@@ -49,15 +49,24 @@ enum exa_un_fn {
     EXA_U_ATAND, EXA_U_ACOTD, EXA_U_SINPI, EXA_U_COSPI, EXA_U_SINC,
     EXA_U_DEG2RAD, EXA_U_RAD2DEG, EXA_U_SIGNBIT, EXA_U_FLOOR, EXA_U_CEIL,
     EXA_U_ATANH, EXA_U_ACOTH,
+    /* the SpecialFunctions extension; order = reference ext/functionlist.jl:6-102 (erf ... erfcinv) */
+    EXA_U_ERF, EXA_U_ERFC, EXA_U_ERFI, EXA_U_ERFCX, EXA_U_DIGAMMA, EXA_U_TRIGAMMA, EXA_U_INVDIGAMMA,
+    EXA_U_GAMMA, EXA_U_AIRYAI, EXA_U_AIRYBI, EXA_U_AIRYAIPRIME, EXA_U_AIRYBIPRIME,
+    EXA_U_BESSELJ0, EXA_U_BESSELY0, EXA_U_BESSELJ1, EXA_U_BESSELY1, EXA_U_DAWSON,
+    EXA_U_ERFINV, EXA_U_ERFCINV,
     EXA_U_COUNT
 };
+#define EXA_U_FIRST_SPECIAL EXA_U_ERF
 
 /* Bivariate functions; order = reference src/functionlist.jl:71-81 (_BIVARIATES). */
 enum exa_bin_fn {
     EXA_B_ADD = 0, EXA_B_SUB, EXA_B_MUL, EXA_B_DIV, EXA_B_POW, EXA_B_ATAN2, EXA_B_HYPOT,
     EXA_B_MAX, EXA_B_MIN,
+    /* the SpecialFunctions extension; reference ext/functionlist.jl:109-124 */
+    EXA_B_BETA, EXA_B_LOGBETA,
     EXA_B_COUNT
 };
+#define EXA_B_FIRST_SPECIAL EXA_B_BETA
 
 typedef struct exa_node {
     int32_t op;    /* enum exa_opcode */

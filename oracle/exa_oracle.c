@@ -121,7 +121,10 @@ static inline double cospi_(double x) {
 static inline double sinc_(double x) { return x == 0.0 ? 1.0 : sinpi_(x) / (M_PI * x); }
 static inline double sign_(double x) { return x > 0 ? 1.0 : (x < 0 ? -1.0 : x); }
 
+#include "exa_special.h"
+
 static double un_f(int fn, double x) {
+    if (fn >= EXA_U_FIRST_SPECIAL) return sf_f(fn, x);
     switch (fn) {
     case EXA_U_PLUS: return x;            case EXA_U_MINUS: return -x;
     case EXA_U_INV: return 1.0 / x;       case EXA_U_SQRT: return sqrt(x);
@@ -155,6 +158,7 @@ static double un_f(int fn, double x) {
 }
 
 static double un_df(int fn, double x) {
+    if (fn >= EXA_U_FIRST_SPECIAL) return sf_df(fn, x);
     switch (fn) {
     case EXA_U_PLUS: return 1.0;
     case EXA_U_MINUS: return -1.0;
@@ -211,6 +215,7 @@ static double un_df(int fn, double x) {
 }
 
 static double un_ddf(int fn, double x) {
+    if (fn >= EXA_U_FIRST_SPECIAL) return sf_ddf(fn, x);
     switch (fn) {
     case EXA_U_PLUS: case EXA_U_MINUS: return 0.0;
     case EXA_U_INV: return 2 / (cb(x));
@@ -268,6 +273,7 @@ static double un_ddf(int fn, double x) {
 /* bivariate: operands typed because `^` distinguishes Int exponents (Base.^ dispatch) */
 static double bin_f(int fn, val_t a, val_t b) {
     double x1 = asf(a), x2 = asf(b);
+    if (fn >= EXA_B_FIRST_SPECIAL) return sfb_f(fn, x1, x2);
     switch (fn) {
     case EXA_B_ADD: return x1 + x2;   case EXA_B_SUB: return x1 - x2;
     case EXA_B_MUL: return x1 * x2;   case EXA_B_DIV: return x1 / x2;
@@ -282,6 +288,7 @@ static double bin_f(int fn, val_t a, val_t b) {
 static inline val_t vadd(val_t v, int64_t k) { return v.is_int ? VI(v.i + k) : VF(v.f + (double)k); }
 static double bin_d1(int fn, val_t a, val_t b) {
     double x1 = asf(a), x2 = asf(b);
+    if (fn >= EXA_B_FIRST_SPECIAL) return sfb_d1(fn, x1, x2);
     switch (fn) {
     case EXA_B_ADD: return 1.0;       case EXA_B_SUB: return 1.0;
     case EXA_B_MUL: return x2;        case EXA_B_DIV: return 1 / x2;
@@ -295,6 +302,7 @@ static double bin_d1(int fn, val_t a, val_t b) {
 }
 static double bin_d2(int fn, val_t a, val_t b) {
     double x1 = asf(a), x2 = asf(b);
+    if (fn >= EXA_B_FIRST_SPECIAL) return sfb_d2(fn, x1, x2);
     switch (fn) {
     case EXA_B_ADD: return 1.0;       case EXA_B_SUB: return -1.0;
     case EXA_B_MUL: return x1;        case EXA_B_DIV: return (-x1) / (sq(x2));
@@ -308,6 +316,7 @@ static double bin_d2(int fn, val_t a, val_t b) {
 }
 static double bin_d11(int fn, val_t a, val_t b) {
     double x1 = asf(a), x2 = asf(b);
+    if (fn >= EXA_B_FIRST_SPECIAL) return sfb_d11(fn, x1, x2);
     switch (fn) {
     case EXA_B_POW: return asf(vadd(b, -1)) * x2 * powv(x1, vadd(b, -2));
     case EXA_B_ATAN2: return (-2 * x1 * x2) / (sq(sq(x1) + sq(x2)));
@@ -317,6 +326,7 @@ static double bin_d11(int fn, val_t a, val_t b) {
 }
 static double bin_d12(int fn, val_t a, val_t b) {
     double x1 = asf(a), x2 = asf(b);
+    if (fn >= EXA_B_FIRST_SPECIAL) return sfb_d12(fn, x1, x2);
     switch (fn) {
     case EXA_B_MUL: return 1.0;
     case EXA_B_DIV: return -1 / (sq(x2));
@@ -328,6 +338,7 @@ static double bin_d12(int fn, val_t a, val_t b) {
 }
 static double bin_d22(int fn, val_t a, val_t b) {
     double x1 = asf(a), x2 = asf(b);
+    if (fn >= EXA_B_FIRST_SPECIAL) return sfb_d22(fn, x1, x2);
     switch (fn) {
     case EXA_B_DIV: return (2 * x1) / (cb(x2));
     case EXA_B_POW: return (sq(log(x1))) * powv(x1, b);

@@ -6,8 +6,9 @@ differentiates it symbolically and evaluates with 40-digit mpmath — an oracle 
 oracle and the HIP code generator.
 
 Rows 1-63 restate the reference's own AD test list (test/ADTest/ADTest.jl:6-121: FUNCTIONS and
-PARAMETER_FUNCTIONS) minus the SpecialFunctions rows (erf, gamma, beta, bessel, airy — out of scope, SURVEY §2
-row 22); the remaining rows cover every other table entry of src/functionlist.jl plus the benchmark patterns.
+PARAMETER_FUNCTIONS) minus the SpecialFunctions rows, which are SPECIAL_EXPRS below (golden vectors:
+special_golden.json, make_special_golden.py); the remaining rows cover every other table entry of src/functionlist.jl plus
+the benchmark patterns.
 """
 
 EXPRS = [
@@ -107,6 +108,66 @@ EXPRS = [
     ("rocket-vel", lambda x, th, F: -x[1] + x[2] + 0.5 * x[9] * (
         (x[3] - 310.0 * x[1] ** 2 * F.exp(-5.0 * (x[5] + 0.5 - 1.0) / 1.0) - (x[7] + 0.3) * 1.0 * (1.0 / (x[5] + 0.5)) ** 2) / (x[7] + 0.3)
         + (x[4] - 310.0 * x[2] ** 2 * F.exp(-5.0 * (x[6] + 0.5 - 1.0) / 1.0) - (x[8] + 0.3) * 1.0 * (1.0 / (x[6] + 0.5)) ** 2) / (x[8] + 0.3))),
+]
+
+# The SpecialFunctions rows of the reference's AD test list (test/ADTest/ADTest.jl:59-64, 80-106, 118-120) and one row per entry
+# of ext/functionlist.jl:6-124 (composed with the variables so that gradient and Hessian have several entries).
+SPECIAL_EXPRS = [
+    # --- ADTest.jl:59-64 ---
+    ("special-erfi", lambda x, th, F: F.erfi(x[1])),
+    ("special-erfcinv", lambda x, th, F: F.erfcinv(x[1])),
+    ("special-airybiprime", lambda x, th, F: F.airybiprime(x[1])),
+    ("special-besselj0", lambda x, th, F: F.besselj0(x[1])),
+    ("special-beta", lambda x, th, F: F.beta(x[1], x[2])),
+    ("special-logbeta", lambda x, th, F: F.logbeta(x[1], x[2])),
+    # --- ADTest.jl:80-106 "composite-functions" with SpecialFunctions ---
+    ("composite-1-1", lambda x, th, F: F.beta(F.erf(x[1] / x[2] / 3.0) + 3.0 * x[2], F.erf(x[9]) ** 2)),
+    ("composite-1-3", lambda x, th, F: F.beta(F.cos(F.log(F.abs2(F.inv(F.inv(x[1]))) + 1.0)), F.erfc(F.tanh(0 * x[1])))),
+    ("composite-1-6", lambda x, th, F: F.beta(2 * F.logbeta(x[1], x[5]), F.beta(x[2], x[3]))),
+    ("composite-1-7", lambda x, th, F: F.besselj0(F.exp(F.erf(-x[1])))),
+    ("composite-1-8", lambda x, th, F: F.erfc(F.abs2(x[1] ** 2 / x[2]) ** x[9] / x[10])),
+    ("composite-1-9", lambda x, th, F: F.erfc(x[1]) ** F.erf(2.5 * x[2])),
+    ("composite-1-14", lambda x, th, F: F.beta(F.beta(F.tan(F.beta(x[1], 1) + 2.0), F.cos(F.sin(x[2]))), x[3])),
+    # --- ADTest.jl:118-120 ---
+    ("parameter-composite-2", lambda x, th, F: F.beta(x[1] + th[1], x[2] + th[2])),
+    ("parameter-composite-4", lambda x, th, F: F.gamma(x[1] + 1) * th[1] + F.erf(x[2] * th[2])),
+    # --- every entry of ext/functionlist.jl ---
+    ("sf-erf", lambda x, th, F: F.erf(x[1] * x[2] - x[3])),
+    ("sf-erfc", lambda x, th, F: F.erfc(2 * x[1] + x[2] ** 2)),
+    ("sf-erfi", lambda x, th, F: F.erfi(3 * x[1] - x[2] * x[3])),
+    ("sf-erfi-large", lambda x, th, F: F.erfi(8 * x[1] + 4 * x[2])),
+    ("sf-erfcx", lambda x, th, F: F.erfcx(x[1] * 5 - x[2])),
+    ("sf-erfcx-neg", lambda x, th, F: F.erfcx(-3 * x[1] * x[2])),
+    ("sf-digamma", lambda x, th, F: F.digamma(x[1] + 3 * x[2])),
+    ("sf-digamma-neg", lambda x, th, F: F.digamma(-2.0 - x[1] * x[2])),
+    ("sf-trigamma", lambda x, th, F: F.trigamma(x[1] * x[2] + x[3])),
+    ("sf-trigamma-neg", lambda x, th, F: F.trigamma(x[1] - 3.0 - x[2] / 4)),
+    ("sf-invdigamma", lambda x, th, F: F.invdigamma(x[1] - 4 * x[2])),
+    ("sf-invdigamma-pos", lambda x, th, F: F.invdigamma(3 * x[1] * x[2] + 1)),
+    ("sf-gamma", lambda x, th, F: F.gamma(4 * x[1] + x[2])),
+    ("sf-gamma-neg", lambda x, th, F: F.gamma(x[1] * x[2] - 1.5)),
+    ("sf-airyai", lambda x, th, F: F.airyai(3 * x[1] - 5 * x[2])),
+    ("sf-airyai-pos", lambda x, th, F: F.airyai(6 * x[1] + 3 * x[2])),
+    ("sf-airyai-asym", lambda x, th, F: F.airyai(9 + 4 * x[1] * x[2]) * 1e6 + F.airyai(-10 - 3 * x[1] - x[2])),
+    ("sf-airybi", lambda x, th, F: F.airybi(2 * x[1] - 6 * x[2])),
+    ("sf-airybi-asym", lambda x, th, F: F.airybi(9.5 + x[1] * x[2]) * 1e-8 + F.airybi(-12 - x[1] + x[2])),
+    ("sf-airyaiprime", lambda x, th, F: F.airyaiprime(4 * x[1] - 7 * x[2]) + F.airyaiprime(10 + x[3]) * 1e8 + F.airyaiprime(-11 - x[3])),
+    ("sf-airybiprime", lambda x, th, F: F.airybiprime(x[1] - 6 * x[2]) + F.airybiprime(9 + x[3]) * 1e-9 + F.airybiprime(-10 - x[3])),
+    ("sf-besselj0", lambda x, th, F: F.besselj0(10 * x[1] + x[2])),
+    ("sf-bessely0", lambda x, th, F: F.bessely0(3 * x[1] + 8 * x[2])),
+    ("sf-besselj1", lambda x, th, F: F.besselj1(7 * x[1] * x[2] + x[3])),
+    ("sf-bessely1", lambda x, th, F: F.bessely1(x[1] + 12 * x[2])),
+    ("sf-dawson", lambda x, th, F: F.dawson(2 * x[1] - 3 * x[2])),
+    ("sf-dawson-large", lambda x, th, F: F.dawson(9 * x[1] + 5 * x[2])),
+    ("sf-erfinv", lambda x, th, F: F.erfinv(x[1] * x[2] - x[3] / 2)),
+    ("sf-erfinv-edge", lambda x, th, F: F.erfinv(1 - x[1] * 1e-3)),
+    ("sf-erfcinv", lambda x, th, F: F.erfcinv(x[1] + x[2])),
+    ("sf-erfcinv-small", lambda x, th, F: F.erfcinv(x[1] * x[2] * 1e-6)),
+    ("sf-beta", lambda x, th, F: F.beta(3 * x[1] + x[2], x[2] * x[3] + 0.5)),
+    ("sf-beta-neg", lambda x, th, F: F.beta(x[1] - 1.5, x[2] + 2.0)),
+    ("sf-beta-fixed", lambda x, th, F: F.beta(x[1] + x[2], 2.5) + F.beta(1.5, x[3]) + F.beta(th[1], x[1] * x[3])),
+    ("sf-logbeta", lambda x, th, F: F.logbeta(5 * x[1], x[2] + 7 * x[3])),
+    ("sf-logbeta-fixed", lambda x, th, F: F.logbeta(x[1] * x[2], 0.75) + F.logbeta(th[2], x[3])),
 ]
 
 NVAR, NPAR = 10, 2

@@ -13,7 +13,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
-from exprs import EXPRS, NPAR, NVAR  # noqa: E402
+from exprs import EXPRS, NPAR, NVAR, SPECIAL_EXPRS  # noqa: E402
 
 from exahip import ExaCore, graph, rng  # noqa: E402
 
@@ -21,6 +21,12 @@ with open(os.path.join(HERE, "golden", "ad_golden.json")) as fh:
     GOLD = json.load(fh)
 CASES = {c["name"]: c for c in GOLD["cases"]}
 X0, T0 = np.array(GOLD["x"]), np.array(GOLD["theta"])
+# the SpecialFunctions rows (ext/functionlist.jl; ADTest.jl:59-120): same point, tests/golden/make_special_golden.py
+with open(os.path.join(HERE, "golden", "special_golden.json")) as fh:
+    SPECIAL_GOLD = json.load(fh)
+assert SPECIAL_GOLD["x"] == GOLD["x"] and SPECIAL_GOLD["theta"] == GOLD["theta"]
+CASES.update({c["name"]: c for c in SPECIAL_GOLD["cases"]})
+ALL_EXPRS = EXPRS + SPECIAL_EXPRS
 
 TOL = 1e-11   # oracle (glibc libm, double) vs 40-digit symbolic truth
 
@@ -57,10 +63,10 @@ def build_case(f, as_constraint):
     return c
 
 
-@pytest.mark.parametrize("name", [n for n, _ in EXPRS])
+@pytest.mark.parametrize("name", [n for n, _ in ALL_EXPRS])
 def test_oracle_matches_symbolic_derivatives(libs, name):
     import oracle
-    f = dict(EXPRS)[name]
+    f = dict(ALL_EXPRS)[name]
     g = CASES[name]
     gold_H = np.tril(np.array(g["hess"]))
     # as an objective: obj / grad! / hess_coord!(obj_weight)

@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 
 from conftest import has_gpu  # noqa: E402
-from exprs import EXPRS, NPAR, NVAR  # noqa: E402
+from exprs import EXPRS, NPAR, NVAR, SPECIAL_EXPRS  # noqa: E402
 from test_golden_oracle import CASES, T0, X0, NodeF, close, dense_lower  # noqa: E402
 from test_known_answers import CONS_CASES, LSTAR, XSTAR  # noqa: E402
 
@@ -33,19 +33,37 @@ class Shifted:
         return self.X[(self.i - 1) * NVAR + k]
 
 
-@pytest.fixture(scope="module")
-def golden_model(libs):
+def one_model(rows):
     from exahip import ExaCore, ExaModel, rng
     c = ExaCore()
     X = c.add_var(NVAR * NCOPY, start=np.tile(X0, NCOPY))
     th = c.add_par(NPAR, value=T0)
-    for name, f in EXPRS:
+    for name, f in rows:
         c.add_con(lambda i, f=f: f(Shifted(X, i), th, NodeF()), rng(1, NCOPY))
     return ExaModel(c)
 
 
+@pytest.fixture(scope="module")
+def golden_model(libs):
+    return one_model(EXPRS)
+
+
+@pytest.fixture(scope="module")
+def special_model(libs):
+    """The SpecialFunctions rows (ext/functionlist.jl, ADTest.jl:59-120) in a model of their own: its module carries the special
+    prelude (csrc/exa_gen_prelude.cpp kSpecialPrelude), the other one does not."""
+    return one_model(SPECIAL_EXPRS)
+
+
+def test_all_special_function_rows_in_one_model(special_model):
+    check_rows(special_model, SPECIAL_EXPRS)
+
+
 def test_all_golden_expressions_in_one_model(golden_model):
-    m = golden_model
+    check_rows(golden_model, EXPRS)
+
+
+def check_rows(m, EXPRS):
     x = np.tile(X0, NCOPY)
     y = np.ones(m.meta.ncon)
     cons = m.cons(x)
@@ -99,8 +117,9 @@ def test_lv10_published_kkt_point_on_hip(libs):
 def test_objective_callbacks_on_golden_rows(libs):
     """A few rows as objectives: obj / grad! / hess_coord!(obj_weight) (exercises the atomic grad scatter)."""
     from exahip import ExaCore, ExaModel
-    for name in ("lv-obj", "composite-1-5", "pow-negint", "table-atan2", "rocket-vel"):
-        f = dict(EXPRS)[name]
+    for name in ("lv-obj", "composite-1-5", "pow-negint", "table-atan2", "rocket-vel", "composite-1-1", "composite-1-14", "parameter-composite-4",
+                 "sf-airyai", "sf-invdigamma", "sf-bessely1"):
+        f = dict(EXPRS + SPECIAL_EXPRS)[name]
         c = ExaCore()
         x = c.add_var(NVAR, start=X0)
         th = c.add_par(NPAR, value=T0)

@@ -38,11 +38,13 @@ def _model(fn):
 
 def test_every_univariate_at_special_arguments(libs):
     from exahip import ExaModel
-    from exahip.graph import UN_FNS
+    from exahip.graph import SPECIAL_UN, UN_FNS
     import oracle
     y = np.ones(len(SPECIAL))
     bad = []
-    for fn in UN_FNS:
+    # (the SpecialFunctions entries raise DomainError outside their domains in the reference — no NaN convention to keep: they are
+    # compared over their domains in tests/test_gpu_special_functions.py)
+    for fn in [f for f in UN_FNS if f not in SPECIAL_UN]:
         m = ExaModel(_model(fn))
         o = oracle.OracleModel(m.ir)
         with np.errstate(all="ignore"):
@@ -69,7 +71,7 @@ def test_bivariates_at_special_arguments(libs):
     A, B = (v.ravel() for v in np.meshgrid(a, a))
     n = len(A)
     bad = []
-    for fn in BIN_FNS:
+    for fn in [f for f in BIN_FNS if f not in ("beta", "logbeta")]:
         c = ExaCore()
         x = c.add_var(2 * n)
         c.add_con(lambda i: Node2(fn, x[i], x[i + n]), rng(1, n))

@@ -296,10 +296,11 @@ def test_julia_shim_wire_format_matches_the_header():
     alias = {"+": "plus", "-": "minus", "*": "mul", "/": "div", "^": "pow"}
     un = re.search(r"const UN = Dict\(.*?enumerate\(\((.*?)\)\)\)", shim, re.S).group(1)
     jl_un = [alias.get(t.strip(), t.strip()) for t in un.replace("\n", " ").split(",")]
-    assert jl_un == enum_names("EXA_U_", "EXA_U_COUNT")
+    sym = lambda name: [t.strip()[1:] for t in re.search(r"const %s = \((.*?)\)" % name, shim, re.S).group(1).replace("\n", " ").split(",")]
+    assert jl_un + sym("UN_SPECIAL") == enum_names("EXA_U_", "EXA_U_COUNT")
     bn = re.search(r"const BIN = Dict\(.*?enumerate\(\((.*?)\)\)\)", shim, re.S).group(1)
     jl_bin = [{"+": "add", "-": "sub", "atan": "atan2"}.get(t.strip(), alias.get(t.strip(), t.strip())) for t in bn.split(",")]
-    assert jl_bin == enum_names("EXA_B_", "EXA_B_COUNT")
+    assert jl_bin + sym("BIN_SPECIAL") == enum_names("EXA_B_", "EXA_B_COUNT")
     # wire structs: (type, name) sequences
     ctype = {"int32_t": "Int32", "int64_t": "Int64", "double": "Float64"}
 

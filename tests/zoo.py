@@ -69,6 +69,24 @@ def trivialmax_model(n=6):
     return c
 
 
+def specialfn_model(n=40):
+    """Every entry of the SpecialFunctions extension (ext/functionlist.jl:6-124) inside ordinary patterns: range-indexed objective, a
+    table-indexed constraint, beta / logbeta with both operands variable and with a fixed one, an augmentation."""
+    from exahip import graph as G
+    c = ExaCore()
+    x = c.add_var(n, start=np.linspace(0.45, 1.35, n))
+    th = c.add_par(2, value=[1.25, 0.5])
+    tab = Table(i=np.arange(1, n - 1, 3), j=np.arange(3, n + 1, 3)[: len(np.arange(1, n - 1, 3))], w=np.linspace(0.5, 2.0, len(np.arange(1, n - 1, 3))))
+    c.add_obj(lambda i: G.erf(x[i] - x[i + 1]) * G.gamma(x[i] + 1.0) + G.beta(x[i] + 0.5, x[i + 1] + th[1]) + G.airyai(2.0 * x[i] - 3.0 * x[i + 1])
+              + G.besselj0(4.0 * x[i]) + G.dawson(x[i] * x[i + 1]) + G.erfcx(x[i] - 2.0) + G.digamma(x[i] + 0.2), rng(1, n - 1))
+    g = c.add_con(lambda i: G.erfinv(x[i] * 0.5) + G.invdigamma(x[i] - x[i + 1]) + G.logbeta(x[i] + 0.1, 2.0) + G.airybiprime(x[i + 1] - 2.0)
+                  + G.bessely1(x[i] + 0.5) + G.erfi(x[i]) + G.trigamma(x[i] + 0.3) + G.erfcinv(x[i]) + G.erfc(x[i] * x[i + 2]), rng(1, n - 2))
+    c.add_con(lambda d: d.w * G.besselj1(x[d.i] * 3.0) * G.bessely0(x[d.j] + 1.0) + G.airybi(-x[d.i] * x[d.j]) + G.airyaiprime(x[d.j])
+              + G.beta(th[2] + 1.0, x[d.i]) * G.logbeta(x[d.i], x[d.j]), tab, lcon=-5.0, ucon=5.0)
+    c.add_con_aug(g, lambda k: (k, G.erf(x[k] * x[k + 5]) + G.gamma(x[k + 2])), rng(1, 6))
+    return c
+
+
 ZOO = {
     "lv3": lambda: models.luksan_vlcek_model(3),
     "lv20": lambda: models.luksan_vlcek_model(20),
@@ -85,4 +103,5 @@ ZOO = {
     "cops_chain": lambda: models.cops_chain_model(200),
     "cops_elec": lambda: models.cops_elec_model(25),
     "trivialmax": trivialmax_model,
+    "specialfn": specialfn_model,
 }

@@ -23,6 +23,7 @@
 # table iterators with Int and Float columns, a 1-D augmentation, literal and data exponents; `stepped`: StepRange iterators,
 # exa_sum / exa_prod, Constant algebra, a parameterised power) — 16 of the 16 fixture models.
 using ExaModels, NLPModels, Printf
+using SpecialFunctions   # loads ExaModelsSpecialFunctions (ext/): the `specialfn` model
 import JSON   # any JSON reader will do; JSON.jl is what ExaModels' own test environment has
 
 const DUMP = (k = findfirst(==("--dump"), ARGS); k === nothing ? nothing : ARGS[k+1])
@@ -204,6 +205,22 @@ function mixed_model()                             # tests/zoo.py mixed_model, s
     return ExaModel(c; prod = true)
 end
 
+function specialfn_model(n = 40)                    # tests/zoo.py specialfn_model: every entry of ext/functionlist.jl (needs `using SpecialFunctions`)
+    c = ExaCore(concrete = Val(true))
+    @add_var(c, x, n; start = collect(range(0.45, 1.35; length = n)))
+    c, th = add_par(c, 2; value = [1.25, 0.5])
+    is = collect(1:3:(n-2)); js = collect(3:3:n)[1:length(is)]; ws = collect(range(0.5, 2.0; length = length(is)))
+    tab = [(i = i, j = j, w = w) for (i, j, w) in zip(is, js, ws)]
+    @add_obj(c, erf(x[i] - x[i+1]) * gamma(x[i] + 1.0) + beta(x[i] + 0.5, x[i+1] + th[1]) + airyai(2.0 * x[i] - 3.0 * x[i+1])
+                + besselj0(4.0 * x[i]) + dawson(x[i] * x[i+1]) + erfcx(x[i] - 2.0) + digamma(x[i] + 0.2) for i = 1:(n-1))
+    @add_con(c, g, erfinv(x[i] * 0.5) + invdigamma(x[i] - x[i+1]) + logbeta(x[i] + 0.1, 2.0) + airybiprime(x[i+1] - 2.0)
+                + bessely1(x[i] + 0.5) + erfi(x[i]) + trigamma(x[i] + 0.3) + erfcinv(x[i]) + erfc(x[i] * x[i+2]) for i = 1:(n-2))
+    @add_con(c, g2, d.w * besselj1(x[d.i] * 3.0) * bessely0(x[d.j] + 1.0) + airybi(-x[d.i] * x[d.j]) + airyaiprime(x[d.j])
+                + beta(th[2] + 1.0, x[d.i]) * logbeta(x[d.i], x[d.j]) for d in tab; lcon = fill(-5.0, length(tab)), ucon = fill(5.0, length(tab)))
+    @add_con!(c, g, k => erf(x[k] * x[k+5]) + gamma(x[k+2]) for k = 1:6)
+    return ExaModel(c; prod = true)
+end
+
 function stepped_model()                           # tests/zoo.py stepped_model: StepRange iterators, exa_sum / exa_prod, Constant
     N = 50
     c = ExaCore(concrete = Val(true))
@@ -223,7 +240,7 @@ const MODELS = [
     ("trivialmax", a -> trivialmax_model(6)), ("conaug2d", a -> conaug2d_model()),
     ("rocket50", a -> rocket_model(50)), ("acopf30", a -> acopf_model(a)),
     ("cops_chain", a -> cops_chain_model(200)), ("cops_elec", a -> cops_elec_model(25)),
-    ("mixed", a -> mixed_model()), ("stepped", a -> stepped_model()),
+    ("mixed", a -> mixed_model()), ("stepped", a -> stepped_model()), ("specialfn", a -> specialfn_model()),
 ]
 # `stepped`: tests/zoo.py builds exa_sum / exa_prod as the reference's SumNode / ProdNode over the literal offsets 0:2 and the last
 # constraint's sum from a list — if the first run shows a structure mismatch on this model only, compare that row's
