@@ -108,9 +108,9 @@ static const UnSpec *un_spec(int fn) {
         T[EXA_U_AIRYBI] = {"exa_airy<2>($1)", "exa_airy<3>($1)", "$1 * $2"};
         T[EXA_U_AIRYAIPRIME] = {"exa_airy<1>($1)", "$1 * exa_airy<0>($1)", "exa_airy<0>($1) + $1 * $2"};
         T[EXA_U_AIRYBIPRIME] = {"exa_airy<3>($1)", "$1 * exa_airy<2>($1)", "exa_airy<2>($1) + $1 * $2"};
-        T[EXA_U_BESSELJ0] = {"j0($1)", "-j1($1)", "0.5 * (jn(2, $1) - $2)"};
+        T[EXA_U_BESSELJ0] = {"j0($1)", "-j1($1)", "0.5 * (exa_jn(2, $1) - $2)"};
         T[EXA_U_BESSELY0] = {"y0($1)", "-y1($1)", "0.5 * (yn(2, $1) - $2)"};
-        T[EXA_U_BESSELJ1] = {"j1($1)", "0.5 * (j0($1) - jn(2, $1))", "0.5 * (0.5 * (jn(3, $1) - $2) - $2)"};
+        T[EXA_U_BESSELJ1] = {"j1($1)", "0.5 * (j0($1) - exa_jn(2, $1))", "0.5 * (0.5 * (exa_jn(3, $1) - $2) - $2)"};
         T[EXA_U_BESSELY1] = {"y1($1)", "0.5 * (y0($1) - yn(2, $1))", "0.5 * (0.5 * (yn(3, $1) - $2) - $2)"};
         T[EXA_U_DAWSON] = {"exa_dawson($1)", "1.0 - 2.0 * $1 * $2", "-2.0 * $2 - 2.0 * $1 * $3"};
         T[EXA_U_ERFINV] = {"erfinv($1)", "EXA_SQRTPIHALF * exp($2 * $2)", "2.0 * $2 * $3 * $3"};
