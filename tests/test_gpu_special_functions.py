@@ -141,3 +141,16 @@ def test_special_functions_plan(libs):
     assert [alias.get(n, n) for n in names] == UN_FNS
     assert SPECIAL_UN[0] == "erf" and SPECIAL_UN[-1] == "erfcinv" and len(SPECIAL_UN) == 19
     assert BIN_FNS[-2:] == ["beta", "logbeta"]
+
+
+def test_device_routines_on_the_host_against_mpmath():
+    """-m "not gpu": the text of the special prelude compiled for the host WITH contraction (hipcc's default) is within 1e-12 of 40-digit
+    mpmath on every routine (tools/special_accuracy.py; measured 7e-14 at worst) — the error-free transformations of the double-double
+    Airy series survive -ffp-contract=fast only because they are fenced (`#pragma clang fp contract(off)`): the first GPU run was 9e-7 off."""
+    import os
+    import sys
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang++"):
+        pytest.skip("no ROCm clang")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import special_accuracy
+    assert special_accuracy.main() == 0
