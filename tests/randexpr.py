@@ -11,8 +11,21 @@ BIN = ["+", "-", "*", "/", "^i", "^f", "atan2", "hypot", "max", "min", "^v"]
 NVAR, NPTS = 40, 7
 
 
+# the SpecialFunctions extension (ext/functionlist.jl), each with the map that keeps its argument inside the domain
+SPECIAL = {
+    "erf": lambda a: a, "erfc": lambda a: a, "erfcx": lambda a: a, "dawson": lambda a: a, "erfi": lambda a: 1.5 * graph.tanh(a),
+    "airyai": lambda a: 4.0 * graph.tanh(a), "airybi": lambda a: 3.0 * graph.tanh(a), "airyaiprime": lambda a: 4.0 * graph.tanh(a),
+    "airybiprime": lambda a: 3.0 * graph.tanh(a), "besselj0": lambda a: a, "besselj1": lambda a: a,
+    "bessely0": lambda a: 1.5 + a * a, "bessely1": lambda a: 1.5 + a * a, "gamma": lambda a: 1.5 + graph.tanh(a),
+    "digamma": lambda a: 1.25 + a * a, "trigamma": lambda a: 1.25 + a * a, "invdigamma": lambda a: 2.0 * graph.tanh(a),
+    "erfinv": lambda a: 0.9 * graph.tanh(a), "erfcinv": lambda a: 1.0 + 0.9 * graph.tanh(a),
+}
+
+
 class Gen:
     block_stride = 0      # > 0: symbolic indices also pick one of three variable blocks this far apart (x, u, z arrays)
+    special = 0.0         # > 0: this share of the univariate / bivariate picks comes from the SpecialFunctions extension (the draws of
+                          # the default generator are untouched: recorded seeds keep their models)
 
     def __init__(self, seed):
         self.r = np.random.default_rng(seed)
@@ -37,6 +50,17 @@ class Gen:
     def tree(self, x, th, d, depth):
         if depth == 0 or self.r.uniform() < 0.15:
             return self.leaf(x, th, d)
+        if self.special and self.r.uniform() < self.special:
+            names = list(SPECIAL) + ["beta", "logbeta"]
+            f = names[self.r.integers(0, len(names))]
+            a = self.tree(x, th, d, depth - 1)
+            if not isinstance(a, graph.Node):
+                a = a + x[d.i]
+            if f in ("beta", "logbeta"):
+                b = self.tree(x, th, d, depth - 1)
+                b = 1.25 + b * b if isinstance(b, graph.Node) else abs(float(b)) + 0.5      # a fixed second operand now and then
+                return getattr(graph, f)(1.5 + a * a, b)
+            return getattr(graph, f)(SPECIAL[f](a))
         if self.r.uniform() < 0.45:
             f = UN_SAFE[self.r.integers(0, len(UN_SAFE))]
             a = self.tree(x, th, d, depth - 1)
@@ -85,7 +109,7 @@ class Gen:
         return graph.minimum(a, b)
 
 
-def build_model(seed, npat=12, depth=4):
+def build_model(seed, npat=12, depth=4, special=0.0):
     """One model with `npat` random objective/constraint/augmentation patterns over a small table iterator."""
     g = Gen(seed)
     c = ExaCore()
@@ -97,7 +121,10 @@ def build_model(seed, npat=12, depth=4):
     base = None
     for k in range(npat):
         kind = k % 4
-        fn = (lambda d, s=int(g.r.integers(0, 2**31)): Gen(s).tree(x, th, d, depth))
+        def fn(d, s=int(g.r.integers(0, 2**31))):
+            gen = Gen(s)
+            gen.special = special
+            return gen.tree(x, th, d, depth)
         if kind == 0:
             c.add_obj(fn, tab)
         elif kind in (1, 2) or base is None:

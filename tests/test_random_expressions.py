@@ -84,6 +84,50 @@ def test_random_patterns_values_on_hip(libs, seed):
     assert relerr(m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7)) <= tol
 
 
+def _special_case(seed):
+    """Random trees in which a third of the function picks come from the SpecialFunctions extension (ext/functionlist.jl), composed with the
+    Base entries, fixed operands, parameters and shared augmentation rows (6 patterns of depth 3: the special routines are inlined per use,
+    these are the largest kernels of the suite)."""
+    core = randexpr.build_model(7000 + seed, npat=6, depth=3, special=0.35)
+    x0 = np.asarray(core.to_ir().x0)
+    return core, x0 + 0.05 * np.random.default_rng(seed).uniform(-1, 1, len(x0))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_special_function_trees_oracle_against_central_differences(libs, seed):
+    """-m "not gpu": the oracle's gradient of such a model against central differences of its own objective — an AD-independent check of
+    the restated table inside compositions (the single entries are pinned by tests/golden/special_golden.json)."""
+    import oracle
+    core, x = _special_case(seed)
+    o = oracle.OracleModel(core.to_ir())
+    g = o.grad(x)
+    h = 1e-6
+    fd = np.array([(o.obj(x + h * e) - o.obj(x - h * e)) / (2 * h) for e in np.eye(len(x))])
+    assert np.all(np.isfinite(g)) and np.max(np.abs(fd - g)) <= 1e-5 * max(1.0, float(np.max(np.abs(g))))
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+@pytest.mark.parametrize("seed", range(6))
+def test_special_function_trees_on_hip(libs, seed):
+    """Every callback of the same models on the HIP path against the oracle."""
+    import oracle
+    from exahip import ExaModel
+    core, x = _special_case(seed)
+    m = ExaModel(core)
+    o = oracle.OracleModel(m.ir)
+    y = np.random.default_rng(seed + 1).standard_normal(m.meta.ncon)
+    v = np.random.default_rng(seed + 2).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(seed + 3).standard_normal(m.meta.ncon)
+    tol = 1e-9          # (Bessel second derivatives: differences of ocml / glibc values near their zeros)
+    assert abs(m.obj(x) - o.obj(x)) <= tol * max(1.0, abs(o.obj(x)))
+    for name, a, b in (("cons", m.cons(x), o.cons(x)), ("grad", m.grad(x), o.grad(x)), ("jac", m.jac_coord(x), o.jac_coord(x)),
+                       ("hess", m.hess_coord(x, y, 0.7), o.hess_coord(x, y, 0.7)), ("jprod", m.jprod(x, v), o.jprod(x, v)),
+                       ("jtprod", m.jtprod(x, w), o.jtprod(x, w)), ("hprod", m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7))):
+        assert np.all(np.isfinite(b)), name
+        assert relerr(a, b) <= tol, (name, relerr(a, b))
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
 @pytest.mark.parametrize("seed", [523, 541, 1011, 1013, 1029])
