@@ -8,6 +8,47 @@
 #include "exa_gen.hpp"
 
 namespace exa {
+
+// ---- user-registered functions ---------------------------------------------------------------------------------------------------
+static std::mutex g_user_mu;
+static std::vector<std::unique_ptr<UserFn>> g_user_un, g_user_bin;      // id = EXA_USER_FN_BASE + index; entries are never removed
+static bool ident_ok(const std::string &n) {
+    if (n.empty() || n.size() > 64 || (n[0] >= '0' && n[0] <= '9')) return false;
+    for (char c : n) if (!((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_')) return false;
+    return true;
+}
+int register_user_fn(bool bivariate, const UserFn &fn, std::string *err) {
+    if (!ident_ok(fn.name)) { *err = "function name must be an identifier of at most 64 characters"; return -1; }
+    // placeholders: univariate f: $1 | df: $1 $2(primal) | ddf: $1 $2 $3(first derivative);  bivariate f: $1 $2 | partials: $1 $2 $3(primal)
+    struct Rule { const std::string *t; int nph; };
+    std::vector<Rule> rules;
+    if (bivariate) rules = {{&fn.f, 2}, {&fn.d1, 3}, {&fn.d2, 3}, {&fn.d11, 3}, {&fn.d12, 3}, {&fn.d22, 3}};
+    else rules = {{&fn.f, 1}, {&fn.d1, 2}, {&fn.d11, 3}};
+    for (const Rule &r : rules) {
+        if (r.t->empty()) { *err = "every rule of `" + fn.name + "` needs an expression ('=0' for an exact zero)"; return -1; }
+        for (size_t i = 0; i + 1 < r.t->size(); i++)
+            if ((*r.t)[i] == '$' && ((*r.t)[i + 1] < '1' || (*r.t)[i + 1] > char('0' + r.nph)))
+                { *err = "rule `" + *r.t + "` of `" + fn.name + "` refers to a placeholder it does not have"; return -1; }
+    }
+    std::lock_guard<std::mutex> lk(g_user_mu);
+    auto &tab = bivariate ? g_user_bin : g_user_un;
+    for (size_t i = 0; i < tab.size(); i++)
+        if (tab[i]->name == fn.name) {
+            const UserFn &o = *tab[i];      // registering the same rules again returns the same id; different rules are refused
+            if (o.f == fn.f && o.d1 == fn.d1 && o.d2 == fn.d2 && o.d11 == fn.d11 && o.d12 == fn.d12 && o.d22 == fn.d22 && o.helpers == fn.helpers)
+                return EXA_USER_FN_BASE + (int)i;
+            *err = "`" + fn.name + "` is already registered with other rules"; return -1;
+        }
+    tab.push_back(std::make_unique<UserFn>(fn));
+    return EXA_USER_FN_BASE + (int)tab.size() - 1;
+}
+const UserFn *user_fn(bool bivariate, int fn) {
+    std::lock_guard<std::mutex> lk(g_user_mu);
+    auto &tab = bivariate ? g_user_bin : g_user_un;
+    const int k = fn - EXA_USER_FN_BASE;
+    return k >= 0 && k < (int)tab.size() ? tab[(size_t)k].get() : nullptr;
+}
+
 namespace gen {
 
 std::string fmt_double(double v) {
@@ -202,7 +243,12 @@ Triple un_rule(Emitter &e, int fn, Val u, int order) {
     if (fn == EXA_U_MINUS) { r.x = e.neg(u); r.y = Emitter::litf(-1); r.h = Emitter::litf(0); return r; }
     if (fn == EXA_U_PLUS) { r.x = u; r.y = Emitter::litf(1); r.h = Emitter::litf(0); return r; }
     if (fn == EXA_U_ABS2) { r.x = e.mul(u, u); r.y = e.mul(Emitter::litf(2), u); r.h = Emitter::litf(2); return r; }
-    const UnSpec *sp = un_spec(fn);
+    UnSpec user;
+    const UnSpec *sp;
+    if (const UserFn *uf = user_fn(false, fn)) {          // exa_register_univariate: $1 argument, $2 primal, $3 first derivative (ddf only)
+        user = {uf->f.c_str(), uf->d1.c_str(), uf->d11.c_str()};
+        sp = &user;
+    } else sp = un_spec(fn);
     if (!sp->f) fail("univariate function without rule");
     r.x = e.call(sp->f, {u});
     if (order >= 1) r.y = lit_or_tmpl(e, sp->df, u, r.x, r.x);
@@ -351,6 +397,19 @@ Six bin_rule(Emitter &e, int fn, Val x1, Val x2, int order) {
         }
         return r;
     }
+    }
+    if (const UserFn *uf = user_fn(true, fn)) {       // exa_register_bivariate: $1, $2 the arguments, $3 the primal
+        r.x = e.call(uf->f, {x1, x2});
+        if (order >= 1) {
+            r.y1 = lit_or_tmpl(e, uf->d1.c_str(), x1, x2, r.x);
+            r.y2 = lit_or_tmpl(e, uf->d2.c_str(), x1, x2, r.x);
+            if (order >= 2) {
+                r.h11 = lit_or_tmpl(e, uf->d11.c_str(), x1, x2, r.x);
+                r.h12 = lit_or_tmpl(e, uf->d12.c_str(), x1, x2, r.x);
+                r.h22 = lit_or_tmpl(e, uf->d22.c_str(), x1, x2, r.x);
+            }
+        }
+        return r;
     }
     fail("unknown bivariate function");
 }

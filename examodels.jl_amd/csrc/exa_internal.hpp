@@ -254,4 +254,13 @@ int create_model(const exa_model_desc_t *desc, int *id_out, bool device);   // C
 int attach_blocks(int id, std::vector<BlockInfo> blocks);
 void set_last_error(const std::string &text);
 
+
+// ---- user-registered functions (exa_register_univariate / _bivariate; exa_gen_rules.cpp) ------------------------------------------
+// The reference's @register_univariate / @register_bivariate (src/register.jl:56-74, 123-276) with the derivative rules given as HIP
+// device expressions.  Function ids start at EXA_USER_FN_BASE in both tables; a registration lives as long as the process.
+constexpr int EXA_USER_FN_BASE = 1000;
+struct UserFn { std::string name, f, d1, d2, d11, d12, d22, helpers; };
+int register_user_fn(bool bivariate, const UserFn &fn, std::string *err);      // the new id, or -1 with *err set
+const UserFn *user_fn(bool bivariate, int fn);                                  // nullptr: not registered
+
 }  // namespace exa

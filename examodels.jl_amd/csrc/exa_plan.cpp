@@ -38,11 +38,11 @@ void check_pattern(const Pattern &p, int pi) {
             break;
         case EXA_OP_PAR: case EXA_OP_VAR: case EXA_OP_UN:
             if (nd.a < 0 || nd.a >= k) bad("child must precede parent", k);
-            if (nd.op == EXA_OP_UN && (nd.fn < 0 || nd.fn >= EXA_U_COUNT)) bad("unknown univariate function", k);
+            if (nd.op == EXA_OP_UN && (nd.fn < 0 || nd.fn >= EXA_U_COUNT) && !user_fn(false, nd.fn)) bad("unknown univariate function", k);
             break;
         case EXA_OP_BIN:
             if (nd.a < 0 || nd.a >= k || nd.b < 0 || nd.b >= k) bad("child must precede parent", k);
-            if (nd.fn < 0 || nd.fn >= EXA_B_COUNT) bad("unknown bivariate function", k);
+            if ((nd.fn < 0 || nd.fn >= EXA_B_COUNT) && !user_fn(true, nd.fn)) bad("unknown bivariate function", k);
             break;
         default: bad("unknown opcode", k);
         }

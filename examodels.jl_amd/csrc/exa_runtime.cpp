@@ -847,6 +847,24 @@ extern "C" {
 
 int exa_abi_version(void) { return EXAHIP_ABI_VERSION; }
 const char *exa_last_error(void) { return g_err.c_str(); }
+int exa_register_univariate(const char *name, const char *f, const char *df, const char *ddf, const char *helpers) {
+    g_err.clear();
+    if (!name || !f || !df || !ddf) { g_err = "exa_register_univariate: NULL argument"; return -1; }
+    UserFn u; u.name = name; u.f = f; u.d1 = df; u.d11 = ddf; u.helpers = helpers ? helpers : "";
+    std::string err;
+    const int id = register_user_fn(false, u, &err);
+    if (id < 0) g_err = "exa_register_univariate: " + err;
+    return id;
+}
+int exa_register_bivariate(const char *name, const char *f, const char *d1, const char *d2, const char *d11, const char *d12, const char *d22, const char *helpers) {
+    g_err.clear();
+    if (!name || !f || !d1 || !d2 || !d11 || !d12 || !d22) { g_err = "exa_register_bivariate: NULL argument"; return -1; }
+    UserFn u; u.name = name; u.f = f; u.d1 = d1; u.d2 = d2; u.d11 = d11; u.d12 = d12; u.d22 = d22; u.helpers = helpers ? helpers : "";
+    std::string err;
+    const int id = register_user_fn(true, u, &err);
+    if (id < 0) g_err = "exa_register_bivariate: " + err;
+    return id;
+}
 
 int exa_new_from_table(const exa_model_desc_t *desc, int *id_out) { return create(desc, id_out, true); }
 int exa_plan_only(const exa_model_desc_t *desc, int *id_out) { return create(desc, id_out, false); }

@@ -445,6 +445,50 @@ def _invdigamma(y):
     return x
 
 
+def register_univariate(name, f, df, ddf, helpers="", py=None):
+    """The reference's `@register_univariate(f, df, ddf)` (src/register.jl:56-74) across the C ABI: the three rules are HIP device
+    expressions — `f` in `$1` (the argument), `df` in `$1 $2` (= f), `ddf` in `$1 $2 $3` (= df); `"=0"`-style strings are exact constants;
+    `helpers` is device code the expressions may call (include/exahip.h: exa_register_univariate).  Returns the node constructor:
+
+        softplus = register_univariate("softplus", "log1p(exp($1))", "1.0 / (1.0 + exp(-$1))", "$3 * (1.0 - $3)")
+        c.add_obj(lambda i: softplus(x[i] - x[i + 1]), rng(1, N - 1))
+
+    `py` (optional): the same function on plain Python numbers, for arguments that are literal constants at build time."""
+    from . import capi
+    enc = lambda t: None if t is None else str(t).encode()
+    fid = capi.lib().exa_register_univariate(enc(name), enc(f), enc(df), enc(ddf), enc(helpers) if helpers else None)
+    if fid < 0:
+        raise ValueError(capi.lib().exa_last_error().decode())
+    UN_ID[name] = fid
+    if py is not None:
+        _PY_UN[name] = py
+    elif name not in _PY_UN:
+        _PY_UN[name] = lambda x, _n=name: (_ for _ in ()).throw(TypeError(f"`{_n}` of a literal constant: give register_univariate a `py` callable"))
+    return _make_un(name)
+
+
+def register_bivariate(name, f, d1, d2, d11, d12, d22, helpers="", py=None):
+    """`@register_bivariate(f, d1, d2, d11, d12, d22)` (src/register.jl:123-276): rules in `$1 $2` (the arguments) and, for the partials,
+    `$3` (= f).  With one operand constant the node becomes the reference's FirstFixed / SecondFixed form, which takes d2/d22 or d1/d11
+    of these same rules.  Returns the node constructor `g(a, b)`."""
+    from . import capi
+    enc = lambda t: None if t is None else str(t).encode()
+    fid = capi.lib().exa_register_bivariate(enc(name), enc(f), enc(d1), enc(d2), enc(d11), enc(d12), enc(d22), enc(helpers) if helpers else None)
+    if fid < 0:
+        raise ValueError(capi.lib().exa_last_error().decode())
+    BIN_ID[name] = fid
+    if py is not None:
+        _PY_BIN[name] = py
+    elif name not in _PY_BIN:
+        _PY_BIN[name] = lambda a, b, _n=name: (_ for _ in ()).throw(TypeError(f"`{_n}` of two literal constants: give register_bivariate a `py` callable"))
+
+    def g(a, b):
+        return _bin(name, a, b)
+
+    g.__name__ = name
+    return g
+
+
 def _make_un(name):
     def f(x):
         return _un(name, x)

@@ -70,10 +70,30 @@ lower!(l, v::Var) = push_node!(l, OP_VAR, 0, lower!(l, v.i), -1, 0.0, 0)
 lower!(l, v::ParameterNode) = push_node!(l, OP_PAR, 0, lower!(l, v.i), -1, 0.0, 0)
 # functions registered by the user (@register_univariate / @register_bivariate outside src/functionlist.jl) have no
 # entry in the library's derivative table: say so instead of failing with a bare KeyError
+# User functions: in the reference `@register_univariate(f, df, ddf)` / `@register_bivariate(f, d1, d2, d11, d12, d22)` (src/register.jl) take
+# Julia lambdas; libexahip compiles the rules into its kernels, so here they are given as HIP device expressions (include/exahip.h:
+# exa_register_univariate / exa_register_bivariate — placeholders $1, $2, $3).  Call these once per process, after the reference's macro:
+#     @register_univariate(softplus, x -> 1 / (1 + exp(-x)), x -> ...)            # the reference's registration (CPU path, tracing)
+#     ExaModelsHIP.register_univariate(softplus, "log1p(exp(\$1))", "1.0 / (1.0 + exp(-\$1))", "\$3 * (1.0 - \$3)")
+const USER_UN = Dict{Any,Int32}()
+const USER_BIN = Dict{Any,Int32}()
+function register_univariate(f, fx::String, dfx::String, ddfx::String; helpers::String = "")
+    id = ccall((:exa_register_univariate, LIB), Cint, (Cstring, Cstring, Cstring, Cstring, Cstring), string(nameof(f)), fx, dfx, ddfx, helpers)
+    id < 0 && error(unsafe_string(ccall((:exa_last_error, LIB), Cstring, ())))
+    USER_UN[f] = Int32(id)
+end
+function register_bivariate(f, fx::String, d1::String, d2::String, d11::String, d12::String, d22::String; helpers::String = "")
+    id = ccall((:exa_register_bivariate, LIB), Cint, (Cstring, Cstring, Cstring, Cstring, Cstring, Cstring, Cstring, Cstring),
+               string(nameof(f)), fx, d1, d2, d11, d12, d22, helpers)
+    id < 0 && error(unsafe_string(ccall((:exa_last_error, LIB), Cstring, ())))
+    USER_BIN[f] = Int32(id)
+end
 fncode(tab, f, arity) = get(tab, f) do
+    user = tab === UN ? USER_UN : USER_BIN
+    haskey(user, f) && return user[f]
     special = tab === UN ? UN_SPECIAL : BIN_SPECIAL
     k = findfirst(==(nameof(f)), special)
-    k === nothing && error("ExaModelsHIP: the $arity function `$f` is not in libexahip's derivative table (src/functionlist.jl and ext/functionlist.jl entries only)")
+    k === nothing && error("ExaModelsHIP: the $arity function `$f` is not in libexahip's derivative table (src/functionlist.jl, ext/functionlist.jl) and was not given to ExaModelsHIP.register_univariate / register_bivariate")
     Int32(length(tab) + k - 1)
 end
 lower!(l, n::Node1{F}) where {F} = push_node!(l, OP_UN, fncode(UN, F.instance, "univariate"), lower!(l, n.inner), -1, 0.0, 0)

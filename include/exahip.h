@@ -238,6 +238,21 @@ int     exa_coo_slices(int id, int hess, int64_t *out /* 3 * exa_npatterns */);
  * column; the shard's stencil footprint when all indices are range-affine — the host may then keep only that stretch
  * resident and pass `x_slice - lo` as x (and analogously y rows [o0+lo, o0+hi) per constraint pattern). */
 int exa_shard_var_range(int id, int64_t *lo, int64_t *hi);
+/* User-registered functions — the reference's @register_univariate / @register_bivariate (src/register.jl:56-74, 123-276: a function
+ * with closed-form first and second derivatives becomes a node type).  There the rules are Julia lambdas; across a C ABI they are HIP
+ * device EXPRESSIONS (C++ text, Float64) with placeholders, compiled into the modules of the models that use the function:
+ *   univariate:  f in $1 (the argument);  df in $1, $2 (= f($1), already computed);  ddf in $1, $2, $3 (= df)
+ *   bivariate:   f in $1, $2;  d1, d2, d11, d12, d22 in $1, $2, $3 (= f($1, $2))
+ * A rule that is an exact constant may be written "=0", "=1", "=-2.5": the reverse sweep then folds it like the table's own constants.
+ * `helpers` (may be NULL): device code placed once in front of the kernels of every module that uses the function (static __device__
+ * functions, #defines) — anything the expressions call beyond the HIP math library.  Returns the function id (>= 1000) to put into
+ * exa_node_t.fn with op = EXA_OP_UN / EXA_OP_BIN, or -1 (exa_last_error: bad name, missing rule, unknown placeholder, the name already
+ * registered with other rules; the same rules again return the same id).  A registration lasts for the process; a model file / recipe that
+ * uses such ids (include/exahip_recipe.h) must be loaded into a process that registered the same functions in the same order.  A rule that
+ * does not compile fails the model build (status 4, the compiler's message in exa_last_error), not the registration. */
+int exa_register_univariate(const char *name, const char *f, const char *df, const char *ddf, const char *helpers);
+int exa_register_bivariate(const char *name, const char *f, const char *d1, const char *d2, const char *d11, const char *d12,
+                           const char *d22, const char *helpers);
 /* theta update without rebuild (set_value!, nlp.jl:1279-1287; cnlp :1529-1535) */
 int exa_set_value(int id, int64_t offset, const double *vals, int64_t len);   /* theta[offset .. offset+len) <- vals (HOST) */
 /* ... and for parameters that live on the device (the reference's set_value! is a copyto! into the device-resident θ and its
