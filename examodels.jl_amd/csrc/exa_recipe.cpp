@@ -6,6 +6,7 @@
 // is on the evaluation path: an instance is an ordinary model of exa_runtime.cpp afterwards.
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -269,7 +270,33 @@ std::unique_ptr<Recipe> parse(const void *bytes, size_t len) {
         }
         r->pats.push_back(std::move(p));
     }
-    if (rd.p != rd.end) throw BadInput("recipe: trailing bytes");
+    // optional trailing section: the user-registered functions the patterns use (exa_register_univariate / _bivariate), by the ids the
+    // WRITER's process had given them.  Loading registers them here (the same rules again return the id they already have; a name that
+    // is taken by other rules refuses the file) and renumbers the nodes, so a model file does not depend on what the loading process
+    // registered before, nor in which order.
+    if (rd.p != rd.end) {
+        std::map<std::pair<int, int>, int> remap;       // (bivariate, id in the file) -> id in this process
+        const int nu = rd.count(1 << 16);
+        for (int k = 0; k < nu; k++) {
+            const int biv = rd.i32(), fid = rd.i32();
+            UserFn u;
+            u.name = rd.str(); u.f = rd.str(); u.d1 = rd.str(); u.d2 = rd.str(); u.d11 = rd.str(); u.d12 = rd.str(); u.d22 = rd.str();
+            u.helpers = rd.str();
+            if ((biv != 0 && biv != 1) || fid < EXA_USER_FN_BASE || remap.count({biv, fid})) throw BadInput("recipe: bad user-function entry");
+            std::string err;
+            const int id = register_user_fn(biv == 1, u, &err);
+            if (id < 0) throw BadInput("recipe: user function: " + err);
+            remap[{biv, fid}] = id;
+        }
+        if (rd.p != rd.end) throw BadInput("recipe: trailing bytes");
+        for (RPattern &p : r->pats)
+            for (exa_node_t &nd : p.nodes)
+                if ((nd.op == EXA_OP_UN || nd.op == EXA_OP_BIN) && nd.fn >= EXA_USER_FN_BASE) {
+                    auto it = remap.find({nd.op == EXA_OP_BIN ? 1 : 0, nd.fn});
+                    if (it == remap.end()) throw BadInput("recipe: a node uses a registered function the file does not define");
+                    nd.fn = it->second;
+                }
+    }
     describe(*r);
     return r;
 }

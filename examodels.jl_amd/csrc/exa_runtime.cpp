@@ -866,6 +866,15 @@ int exa_register_bivariate(const char *name, const char *f, const char *d1, cons
     return id;
 }
 
+int exa_user_function(int bivariate, int fn, int which, char *buf, int cap) {
+    const UserFn *u = user_fn(bivariate != 0, fn);
+    if (!u || which < 0 || which > 7 || cap < 0 || (cap > 0 && !buf)) return -1;
+    const std::string *t[8] = {&u->name, &u->f, &u->d1, &u->d2, &u->d11, &u->d12, &u->d22, &u->helpers};
+    const std::string &s = *t[which];
+    if (cap > 0) { const size_t n = std::min(s.size(), (size_t)cap - 1); std::memcpy(buf, s.data(), n); buf[n] = 0; }
+    return (int)s.size();
+}
+
 int exa_new_from_table(const exa_model_desc_t *desc, int *id_out) { return create(desc, id_out, true); }
 int exa_plan_only(const exa_model_desc_t *desc, int *id_out) { return create(desc, id_out, false); }
 

@@ -359,6 +359,22 @@ class _W:
             self.i64(int(v))
 
 
+USER_FN_BASE = 1000                 # exa_register_univariate / _bivariate ids start here (include/exahip.h)
+
+
+def _user_text(bivariate, fn, which):
+    """One text of a registration, read back from the library (exa_user_function: 0 name, 1 f, 2 d1, 3 d2, 4 d11, 5 d12, 6 d22, 7 helpers)."""
+    import ctypes
+    from . import capi
+    L = capi.lib()
+    n = L.exa_user_function(bivariate, fn, which, None, 0)
+    if n < 0:
+        raise ValueError(f"function id {fn} is not registered in this process")
+    buf = ctypes.create_string_buffer(n + 1)
+    L.exa_user_function(bivariate, fn, which, buf, n + 1)
+    return buf.value.decode()
+
+
 def dumps(core) -> bytes:
     """Serialise `core` (a recipe, or a fully concrete core = a recipe with no fields) to the wire format."""
     from . import core as C
@@ -390,8 +406,10 @@ def dumps(core) -> bytes:
         for d in dims:
             body.ival(d)
     body.i32(len(core.patterns))
+    user = set()                    # (bivariate, fn) of the user-registered functions the patterns use
     for p in core.patterns:
         nodes, cols, root, target = C.lower_pattern(p, symbolic=True)
+        user.update((1 if op == C.OP_BIN else 0, fn) for op, fn, *_ in nodes if op in (C.OP_UN, C.OP_BIN) and fn >= USER_FN_BASE)
         body.i32(p.kind)
         body.i32(root)
         body.i32(target)
@@ -433,6 +451,13 @@ def dumps(core) -> bytes:
                 body.arr(c[1], np.int64 if kind == RCOL_AXIS_INLINE_I64 else np.float64)
                 body.ival(c[2])
                 body.ival(c[3])
+    if user:                        # trailing section: the registrations, so that the file loads into any process (exahip_recipe.h)
+        body.i32(len(user))
+        for biv, fn in sorted(user):
+            body.i32(biv)
+            body.i32(fn)
+            for which in range(8):
+                body.s(_user_text(biv, fn, which))
     head = _W()
     head.b += MAGIC
     head.i32(1 if core.minimize else 0)

@@ -248,11 +248,16 @@ int exa_shard_var_range(int id, int64_t *lo, int64_t *hi);
  * functions, #defines) — anything the expressions call beyond the HIP math library.  Returns the function id (>= 1000) to put into
  * exa_node_t.fn with op = EXA_OP_UN / EXA_OP_BIN, or -1 (exa_last_error: bad name, missing rule, unknown placeholder, the name already
  * registered with other rules; the same rules again return the same id).  A registration lasts for the process; a model file / recipe that
- * uses such ids (include/exahip_recipe.h) must be loaded into a process that registered the same functions in the same order.  A rule that
+ * uses such ids carries the registrations (trailing section of the wire format, include/exahip_recipe.h): loading registers them and
+ * renumbers the nodes, whatever the loading process registered before.  A rule that
  * does not compile fails the model build (status 4, the compiler's message in exa_last_error), not the registration. */
 int exa_register_univariate(const char *name, const char *f, const char *df, const char *ddf, const char *helpers);
 int exa_register_bivariate(const char *name, const char *f, const char *d1, const char *d2, const char *d11, const char *d12,
                            const char *d22, const char *helpers);
+/* Read a registration back (what a writer of model files needs to make them self-contained, include/exahip_recipe.h): which = 0 name,
+ * 1 f, 2 d1 (df), 3 d2, 4 d11 (ddf), 5 d12, 6 d22, 7 helpers.  Copy-out convention of the cnlp ABI: returns the byte length of the text and
+ * copies what fits into buf (NUL-terminated when cap > 0); -1 = no such function / bad argument. */
+int exa_user_function(int bivariate, int fn, int which, char *buf, int cap);
 /* theta update without rebuild (set_value!, nlp.jl:1279-1287; cnlp :1529-1535) */
 int exa_set_value(int id, int64_t offset, const double *vals, int64_t len);   /* theta[offset .. offset+len) <- vals (HOST) */
 /* ... and for parameters that live on the device (the reference's set_value! is a copyto! into the device-resident θ and its

@@ -134,3 +134,103 @@ def test_registered_functions_equal_their_builtin_twins_on_hip(libs):
     ch = CompressedExaModel(m).hess_coord(xd, yd, 0.7)          # duplicate-summed COO: same total
     torch.cuda.synchronize()
     assert abs(float(ch.sum()) - float(o.hess_coord(x, y, 0.7).sum())) <= 1e-10 * float(np.abs(o.hess_coord(x, y, 0.7)).sum())
+
+
+_LOADER = r"""
+import sys, numpy as np
+sys.path[:0] = [{pkg!r}, {tests!r}]
+from exahip import ExaCore, ExaModel, Recipe, capi, graph as G, rng
+L = capi.lib()
+# this process registers OTHER functions first, so every id of the file's writer means something else here ...
+for k in range(7):
+    assert L.exa_register_univariate(b"decoy%d" % k, b"cosh($1)", b"sinh($1)", b"$2", None) == 1000 + k
+    assert L.exa_register_bivariate(b"decoyb%d" % k, b"$1 - $2", b"=1", b"=-1", b"=0", b"=0", b"=0", None) == 1000 + k
+rec = Recipe.load({path!r})
+m = rec.instantiate(device=False)
+src = m.kernel_source()
+assert "exa_user_cube" in src and "hypot(" in src and "cosh(" not in src, "the file's own rules, not the decoys"
+names = set()
+for biv in (0, 1):
+    for fn in range(1000, 1020):
+        n = L.exa_user_function(biv, fn, 0, None, 0)
+        if n >= 0:
+            import ctypes
+            b = ctypes.create_string_buffer(n + 1); L.exa_user_function(biv, fn, 0, b, n + 1); names.add(b.value.decode())
+assert {{"mysin", "myexp", "mycube", "myhyp", "mymul"}} <= names, names
+print("KSRC", __import__("hashlib").sha256(src.encode()).hexdigest())
+print("INFO", [m.pattern_info(k) for k in range(4)])
+# ... and a name the file defines, already taken here by other rules, refuses the file
+"""
+
+
+def test_a_model_file_carries_its_registered_functions(libs, tmp_path):
+    """A recipe / model file that uses registered functions loads into a process that never registered them (or registered others
+    first): the trailing section of the wire format (include/exahip_recipe.h) registers them at load and renumbers the nodes."""
+    import os, subprocess, sys, hashlib
+    from exahip import ExaModel, Recipe
+    user, _ = _pair()
+    path = str(tmp_path / "user.exarcp")
+    Recipe(user).save(path)
+    here = ExaModel(user, device=False)
+    # the same process: load == direct build (ids already registered: same rules, same ids)
+    again = Recipe.load(path).instantiate(device=False)
+    assert again.kernel_source() == here.kernel_source()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = _LOADER.format(pkg=os.path.join(root, "examodels.jl_amd"), tests=os.path.join(root, "tests"), path=path)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = dict(l.split(" ", 1) for l in out.stdout.splitlines() if l.startswith(("KSRC", "INFO")))
+    # same generated text as here except for nothing: the rule texts are what the generator emits, ids never appear in the source
+    assert lines["KSRC"] == hashlib.sha256(here.kernel_source().encode()).hexdigest()
+    assert lines["INFO"] == str([here.pattern_info(k) for k in range(4)])
+
+
+def test_a_model_file_whose_function_name_is_taken_by_other_rules_is_refused(libs, tmp_path):
+    import os, subprocess, sys
+    from exahip import Recipe
+    user, _ = _pair()
+    path = str(tmp_path / "user.exarcp")
+    Recipe(user).save(path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys
+sys.path[:0] = [{os.path.join(root, "examodels.jl_amd")!r}]
+from exahip import Recipe, capi
+assert capi.lib().exa_register_univariate(b"mysin", b"cos($1)", b"-sin($1)", b"-$2", None) >= 1000      # NOT the file's mysin
+try:
+    Recipe.load({path!r})
+except capi.ExaHipError as e:
+    assert "already registered with other rules" in str(e), str(e)
+    print("REFUSED")
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "REFUSED" in out.stdout, out.stderr[-2000:]
+
+
+def test_user_function_section_is_validated(libs):
+    """Malformed trailing sections are refused, never half-applied: truncated text, an id below 1000, a node whose function the section
+    does not define, bytes after the section."""
+    import struct
+    from exahip import Recipe, capi
+    user, _ = _pair()
+    good = Recipe(user).bytes
+    Recipe(good)
+    for bad, why in ((good[:-3], "truncated"), (good + b"\0", "trailing")):
+        with pytest.raises(capi.ExaHipError):
+            Recipe(bad)
+    # drop the last entry of the section (and fix the count): a node now uses an undefined function
+    from exahip import recipe as R
+    L = capi.lib()
+    ids = sorted({(b, f) for b in (0, 1) for f in range(1000, 1100) if L.exa_user_function(b, f, 0, None, 0) >= 0})
+    texts = lambda b, f: b"".join((lambda t: struct.pack("<i", len(t)) + t)(R._user_text(b, f, w).encode()) for w in range(8))
+    used = [(b, f) for b, f in ids if struct.pack("<ii", b, f) + texts(b, f) in good]
+    assert len(used) == 5
+    tail = b"".join(struct.pack("<ii", b, f) + texts(b, f) for b, f in used)
+    assert good.endswith(struct.pack("<i", 5) + tail)
+    head = good[: -len(struct.pack("<i", 5) + tail)]
+    short = head + struct.pack("<i", 4) + b"".join(struct.pack("<ii", b, f) + texts(b, f) for b, f in used[:-1])
+    with pytest.raises(capi.ExaHipError, match="does not define"):
+        Recipe(short)
+    low = head + struct.pack("<i", 5) + tail.replace(struct.pack("<ii", *used[0]), struct.pack("<ii", used[0][0], 7), 1)
+    with pytest.raises(capi.ExaHipError, match="bad user-function entry"):
+        Recipe(low)
