@@ -234,3 +234,53 @@ def test_user_function_section_is_validated(libs):
     low = head + struct.pack("<i", 5) + tail.replace(struct.pack("<ii", *used[0]), struct.pack("<ii", used[0][0], 7), 1)
     with pytest.raises(capi.ExaHipError, match="bad user-function entry"):
         Recipe(low)
+
+
+_CONSUMER = r"""
+import ctypes, json, sys, numpy as np
+lib = ctypes.CDLL({path!r})                  # nothing but the library: this process never registers a function
+vp = ctypes.c_void_p
+assert lib.cnlp_nmodels() == 1 and lib.userm_nargs() == 0
+out = {{"loaded": True}}
+if {gpu}:
+    mid = lib.userm_new(0)
+    assert mid > 0
+    nvar, ncon, nnzh = lib.userm_nvar(mid), lib.userm_ncon(mid), lib.userm_nnzh(mid)
+    x = np.linspace(0.5, 1.5, nvar); y = np.linspace(-1.0, 1.0, ncon)
+    f = np.zeros(1); c = np.zeros(ncon); h = np.zeros(nnzh)
+    assert lib.userm_obj(mid, vp(x.ctypes.data), vp(f.ctypes.data)) == 0
+    assert lib.userm_cons(mid, vp(x.ctypes.data), vp(c.ctypes.data)) == 0
+    assert lib.userm_hess(mid, vp(x.ctypes.data), vp(y.ctypes.data), ctypes.c_double(0.5), vp(h.ctypes.data)) == 0
+    out.update(obj=float(f[0]), cons=c.tolist(), hess=h.tolist())
+print("RESULT " + json.dumps(out))
+"""
+
+
+def _packed_consumer(tmp_path, gpu):
+    import json, subprocess, sys
+    from exahip.pack import pack_library
+    user, twin = _pair()
+    path = pack_library(str(tmp_path / "userlib"), ("userm", user))
+    out = subprocess.run([sys.executable, "-c", _CONSUMER.format(path=path, gpu=gpu)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][0][7:]), twin
+
+
+def test_a_packed_library_carries_its_registered_functions(libs, tmp_path):
+    """exahip.pack embeds the recipe bytes: the consumer process loads `libuserlib.so` alone and finds the model (its catalogue entry parses
+    only if the loader accepted and registered the functions of the trailing section)."""
+    res, _ = _packed_consumer(tmp_path, False)
+    assert res == {"loaded": True}
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+def test_a_packed_library_with_registered_functions_evaluates_in_a_fresh_process(libs, tmp_path):
+    from exahip import ExaModel
+    import oracle
+    res, twin = _packed_consumer(tmp_path, True)
+    o = oracle.OracleModel(ExaModel(twin, device=False).ir)
+    x, y = np.linspace(0.5, 1.5, o.nvar), np.linspace(-1.0, 1.0, o.ncon)
+    np.testing.assert_allclose(res["obj"], o.obj(x), rtol=1e-12)
+    np.testing.assert_allclose(res["cons"], o.cons(x), rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(res["hess"], o.hess_coord(x, y, 0.5), rtol=1e-10, atol=1e-12)
