@@ -23,7 +23,11 @@ int register_user_fn(bool bivariate, const UserFn &fn, std::string *err) {
     struct Rule { const std::string *t; int nph; };
     std::vector<Rule> rules;
     if (bivariate) rules = {{&fn.f, 2}, {&fn.d1, 3}, {&fn.d2, 3}, {&fn.d11, 3}, {&fn.d12, 3}, {&fn.d22, 3}};
-    else rules = {{&fn.f, 1}, {&fn.d1, 2}, {&fn.d11, 3}};
+    else if (!fn.fused.empty()) {
+        rules = {{&fn.fused, 4}};      // $1 argument; $2 $3 $4 receive f, f', f''
+        for (const char *ph : {"$1", "$2", "$3", "$4"})
+            if (fn.fused.find(ph) == std::string::npos) { *err = "the fused rule of `" + fn.name + "` must use $1 and assign $2, $3 and $4"; return -1; }
+    } else rules = {{&fn.f, 1}, {&fn.d1, 2}, {&fn.d11, 3}};
     for (const Rule &r : rules) {
         if (r.t->empty()) { *err = "every rule of `" + fn.name + "` needs an expression ('=0' for an exact zero)"; return -1; }
         for (size_t i = 0; i + 1 < r.t->size(); i++)
@@ -35,7 +39,7 @@ int register_user_fn(bool bivariate, const UserFn &fn, std::string *err) {
     for (size_t i = 0; i < tab.size(); i++)
         if (tab[i]->name == fn.name) {
             const UserFn &o = *tab[i];      // registering the same rules again returns the same id; different rules are refused
-            if (o.f == fn.f && o.d1 == fn.d1 && o.d2 == fn.d2 && o.d11 == fn.d11 && o.d12 == fn.d12 && o.d22 == fn.d22 && o.helpers == fn.helpers)
+            if (o.f == fn.f && o.d1 == fn.d1 && o.d2 == fn.d2 && o.d11 == fn.d11 && o.d12 == fn.d12 && o.d22 == fn.d22 && o.helpers == fn.helpers && o.fused == fn.fused)
                 return EXA_USER_FN_BASE + (int)i;
             *err = "`" + fn.name + "` is already registered with other rules"; return -1;
         }
@@ -245,7 +249,27 @@ Triple un_rule(Emitter &e, int fn, Val u, int order) {
     if (fn == EXA_U_ABS2) { r.x = e.mul(u, u); r.y = e.mul(Emitter::litf(2), u); r.h = Emitter::litf(2); return r; }
     UnSpec user;
     const UnSpec *sp;
-    if (const UserFn *uf = user_fn(false, fn)) {          // exa_register_univariate: $1 argument, $2 primal, $3 first derivative (ddf only)
+    const UserFn *uf = user_fn(false, fn);
+    if (uf && !uf->fused.empty()) {
+        // exa_register_univariate_fused: one statement per distinct argument gives value and both derivatives (what the table does for
+        // sin / cos through sincos); value-only kernels let the compiler drop what they do not read
+        const std::string key = "userfused|" + std::to_string(fn) + "|" + e.s(u);
+        Val v[3];
+        if (e.memo.find(key) == e.memo.end()) {
+            std::string decl = "double ", stmt;
+            for (int k = 0; k < 3; k++) { v[k].k = Val::SF; v[k].id = e.next++; decl += (k ? ", t" : "t") + std::to_string(v[k].id); }
+            for (size_t i = 0; i < uf->fused.size(); i++) {
+                const char c = uf->fused[i], d = i + 1 < uf->fused.size() ? uf->fused[i + 1] : 0;
+                if (c == '$' && d >= '1' && d <= '4') { stmt += d == '1' ? "(" + e.sd(u) + ")" : e.s(v[d - '2']); i++; }
+                else stmt += c;
+            }
+            e.lines.push_back(decl + "; " + stmt + (stmt.empty() || stmt.back() == ';' ? "" : ";"));
+            e.memo[key] = v[0]; e.memo[key + "|d"] = v[1]; e.memo[key + "|h"] = v[2];
+        }
+        r.x = e.memo[key]; r.y = e.memo[key + "|d"]; r.h = e.memo[key + "|h"];
+        return r;
+    }
+    if (uf) {          // exa_register_univariate: $1 argument, $2 primal, $3 first derivative (ddf only)
         user = {uf->f.c_str(), uf->d1.c_str(), uf->d11.c_str()};
         sp = &user;
     } else sp = un_spec(fn);

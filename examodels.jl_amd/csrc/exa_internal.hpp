@@ -259,7 +259,9 @@ void set_last_error(const std::string &text);
 // The reference's @register_univariate / @register_bivariate (src/register.jl:56-74, 123-276) with the derivative rules given as HIP
 // device expressions.  Function ids start at EXA_USER_FN_BASE in both tables; a registration lives as long as the process.
 constexpr int EXA_USER_FN_BASE = 1000;
-struct UserFn { std::string name, f, d1, d2, d11, d12, d22, helpers; };
+// `fused` (univariate only, exa_register_univariate_fused): ONE device statement that leaves value, first and second derivative in
+// $2 $3 $4 from the argument $1 — for functions whose derivatives share work with the value (a range reduction, an exp): then f/d1/d11 are empty.
+struct UserFn { std::string name, f, d1, d2, d11, d12, d22, helpers, fused; };
 int register_user_fn(bool bivariate, const UserFn &fn, std::string *err);      // the new id, or -1 with *err set
 const UserFn *user_fn(bool bivariate, int fn);                                  // nullptr: not registered
 

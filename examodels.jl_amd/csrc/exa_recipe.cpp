@@ -281,7 +281,7 @@ std::unique_ptr<Recipe> parse(const void *bytes, size_t len) {
             const int biv = rd.i32(), fid = rd.i32();
             UserFn u;
             u.name = rd.str(); u.f = rd.str(); u.d1 = rd.str(); u.d2 = rd.str(); u.d11 = rd.str(); u.d12 = rd.str(); u.d22 = rd.str();
-            u.helpers = rd.str();
+            u.helpers = rd.str(); u.fused = rd.str();
             if ((biv != 0 && biv != 1) || fid < EXA_USER_FN_BASE || remap.count({biv, fid})) throw BadInput("recipe: bad user-function entry");
             std::string err;
             const int id = register_user_fn(biv == 1, u, &err);

@@ -856,6 +856,15 @@ int exa_register_univariate(const char *name, const char *f, const char *df, con
     if (id < 0) g_err = "exa_register_univariate: " + err;
     return id;
 }
+int exa_register_univariate_fused(const char *name, const char *stmt, const char *helpers) {
+    g_err.clear();
+    if (!name || !stmt) { g_err = "exa_register_univariate_fused: NULL argument"; return -1; }
+    UserFn u; u.name = name; u.fused = stmt; u.helpers = helpers ? helpers : "";
+    std::string err;
+    const int id = register_user_fn(false, u, &err);
+    if (id < 0) g_err = "exa_register_univariate_fused: " + err;
+    return id;
+}
 int exa_register_bivariate(const char *name, const char *f, const char *d1, const char *d2, const char *d11, const char *d12, const char *d22, const char *helpers) {
     g_err.clear();
     if (!name || !f || !d1 || !d2 || !d11 || !d12 || !d22) { g_err = "exa_register_bivariate: NULL argument"; return -1; }
@@ -868,8 +877,8 @@ int exa_register_bivariate(const char *name, const char *f, const char *d1, cons
 
 int exa_user_function(int bivariate, int fn, int which, char *buf, int cap) {
     const UserFn *u = user_fn(bivariate != 0, fn);
-    if (!u || which < 0 || which > 7 || cap < 0 || (cap > 0 && !buf)) return -1;
-    const std::string *t[8] = {&u->name, &u->f, &u->d1, &u->d2, &u->d11, &u->d12, &u->d22, &u->helpers};
+    if (!u || which < 0 || which > 8 || cap < 0 || (cap > 0 && !buf)) return -1;
+    const std::string *t[9] = {&u->name, &u->f, &u->d1, &u->d2, &u->d11, &u->d12, &u->d22, &u->helpers, &u->fused};
     const std::string &s = *t[which];
     if (cap > 0) { const size_t n = std::min(s.size(), (size_t)cap - 1); std::memcpy(buf, s.data(), n); buf[n] = 0; }
     return (int)s.size();

@@ -445,7 +445,7 @@ def _invdigamma(y):
     return x
 
 
-def register_univariate(name, f, df, ddf, helpers="", py=None):
+def register_univariate(name, f=None, df=None, ddf=None, helpers="", py=None, fused=None):
     """The reference's `@register_univariate(f, df, ddf)` (src/register.jl:56-74) across the C ABI: the three rules are HIP device
     expressions — `f` in `$1` (the argument), `df` in `$1 $2` (= f), `ddf` in `$1 $2 $3` (= df); `"=0"`-style strings are exact constants;
     `helpers` is device code the expressions may call (include/exahip.h: exa_register_univariate).  Returns the node constructor:
@@ -453,10 +453,17 @@ def register_univariate(name, f, df, ddf, helpers="", py=None):
         softplus = register_univariate("softplus", "log1p(exp($1))", "1.0 / (1.0 + exp(-$1))", "$3 * (1.0 - $3)")
         c.add_obj(lambda i: softplus(x[i] - x[i + 1]), rng(1, N - 1))
 
-    `py` (optional): the same function on plain Python numbers, for arguments that are literal constants at build time."""
+    `py` (optional): the same function on plain Python numbers, for arguments that are literal constants at build time.
+    `fused` (instead of f / df / ddf): ONE device statement that computes all three — `$1` the argument, `$2 $3 $4` receive f, f', f'' —
+    for functions whose derivatives share work with the value: `fused="exa_sincos($1, &$2, &$3); $4 = -$2;"` (exa_register_univariate_fused)."""
     from . import capi
     enc = lambda t: None if t is None else str(t).encode()
-    fid = capi.lib().exa_register_univariate(enc(name), enc(f), enc(df), enc(ddf), enc(helpers) if helpers else None)
+    if fused is not None:
+        if f is not None or df is not None or ddf is not None:
+            raise ValueError("give either the three rules or `fused`")
+        fid = capi.lib().exa_register_univariate_fused(enc(name), enc(fused), enc(helpers) if helpers else None)
+    else:
+        fid = capi.lib().exa_register_univariate(enc(name), enc(f), enc(df), enc(ddf), enc(helpers) if helpers else None)
     if fid < 0:
         raise ValueError(capi.lib().exa_last_error().decode())
     UN_ID[name] = fid

@@ -363,7 +363,7 @@ USER_FN_BASE = 1000                 # exa_register_univariate / _bivariate ids s
 
 
 def _user_text(bivariate, fn, which):
-    """One text of a registration, read back from the library (exa_user_function: 0 name, 1 f, 2 d1, 3 d2, 4 d11, 5 d12, 6 d22, 7 helpers)."""
+    """One text of a registration, read back from the library (exa_user_function: 0 name, 1 f, 2 d1, 3 d2, 4 d11, 5 d12, 6 d22, 7 helpers, 8 fused)."""
     import ctypes
     from . import capi
     L = capi.lib()
@@ -456,7 +456,7 @@ def dumps(core) -> bytes:
         for biv, fn in sorted(user):
             body.i32(biv)
             body.i32(fn)
-            for which in range(8):
+            for which in range(9):
                 body.s(_user_text(biv, fn, which))
     head = _W()
     head.b += MAGIC

@@ -82,6 +82,13 @@ function register_univariate(f, fx::String, dfx::String, ddfx::String; helpers::
     id < 0 && error(unsafe_string(ccall((:exa_last_error, LIB), Cstring, ())))
     USER_UN[f] = Int32(id)
 end
+# one statement for value and both derivatives (exa_register_univariate_fused: $1 argument, $2 $3 $4 receive f, f', f''), for functions
+# whose derivatives share work with the value:  register_univariate_fused(mysin, "exa_sincos(\$1, &\$2, &\$3); \$4 = -\$2;")
+function register_univariate_fused(f, stmt::String; helpers::String = "")
+    id = ccall((:exa_register_univariate_fused, LIB), Cint, (Cstring, Cstring, Cstring), string(nameof(f)), stmt, helpers)
+    id < 0 && error(unsafe_string(ccall((:exa_last_error, LIB), Cstring, ())))
+    USER_UN[f] = Int32(id)
+end
 function register_bivariate(f, fx::String, d1::String, d2::String, d11::String, d12::String, d22::String; helpers::String = "")
     id = ccall((:exa_register_bivariate, LIB), Cint, (Cstring, Cstring, Cstring, Cstring, Cstring, Cstring, Cstring, Cstring),
                string(nameof(f)), fx, d1, d2, d11, d12, d22, helpers)

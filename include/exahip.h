@@ -254,8 +254,15 @@ int exa_shard_var_range(int id, int64_t *lo, int64_t *hi);
 int exa_register_univariate(const char *name, const char *f, const char *df, const char *ddf, const char *helpers);
 int exa_register_bivariate(const char *name, const char *f, const char *d1, const char *d2, const char *d11, const char *d12,
                            const char *d22, const char *helpers);
+/* A univariate function whose derivatives share work with the value (a range reduction, an exponential, a series): ONE device STATEMENT
+ * `stmt` computes all three — $1 the argument, $2 / $3 / $4 the variables that receive f, f', f'' — e.g.
+ *   "exa_sincos($1, &$2, &$3); $4 = -$2;"        (what the table itself does for sin: src/functionlist.jl:22)
+ * emitted once per distinct argument; kernels that need the value only leave the rest to the compiler's dead-code elimination.  Measured
+ * on LV N = 1e7 (profiles/r4_userfn_ab.txt): a sine registered this way costs what the table's sine costs; as three separate rules it pays
+ * the reduction twice (jac_coord! +26 %, hess_coord! +9 %).  Same id space, return values and lifetime as exa_register_univariate. */
+int exa_register_univariate_fused(const char *name, const char *stmt, const char *helpers);
 /* Read a registration back (what a writer of model files needs to make them self-contained, include/exahip_recipe.h): which = 0 name,
- * 1 f, 2 d1 (df), 3 d2, 4 d11 (ddf), 5 d12, 6 d22, 7 helpers.  Copy-out convention of the cnlp ABI: returns the byte length of the text and
+ * 1 f, 2 d1 (df), 3 d2, 4 d11 (ddf), 5 d12, 6 d22, 7 helpers, 8 the fused statement.  Copy-out convention of the cnlp ABI: returns the byte length of the text and
  * copies what fits into buf (NUL-terminated when cap > 0); -1 = no such function / bad argument. */
 int exa_user_function(int bivariate, int fn, int which, char *buf, int cap);
 /* theta update without rebuild (set_value!, nlp.jl:1279-1287; cnlp :1529-1535) */

@@ -50,7 +50,8 @@
  *   }
  *   optional, only when a pattern uses a user-registered function (exahip.h: exa_register_univariate / _bivariate; node fn >= 1000):
  *   i32 nuserfns  { i32 bivariate; i32 fn (the id the nodes above use); str name; str f; str d1; str d2; str d11; str d12; str d22;
- *                   str helpers }      -- univariate: d1 = df, d11 = ddf, the others empty.  exa_recipe_load registers each entry (the same
+ *                   str helpers; str fused }      -- univariate: d1 = df, d11 = ddf, the others empty; fused: the one-statement form
+ *                   (exa_register_univariate_fused; then f, d1, d11 are empty too).  exa_recipe_load registers each entry (the same
  *                   rules again give the id they already have; a name taken by OTHER rules refuses the file) and renumbers the nodes:
  *                   the file is self-contained.  A file with this section must define every fn >= 1000 its nodes use.
  * A fully concrete model is the special case nfields = 0, nsyms = 0 (everything literal / inline): the same

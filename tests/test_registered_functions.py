@@ -25,6 +25,30 @@ def _fns():
     return mysin, myexp, mycube, myhyp, mymul
 
 
+def _fused_fns():
+    """The one-statement form (exa_register_univariate_fused): value and both derivatives from one evaluation."""
+    from exahip import graph as G
+    fsin = G.register_univariate("fsin", fused="exa_sincos($1, &$2, &$3); $4 = -$2;", py=np.sin)
+    fexp = G.register_univariate("fexp", fused="$2 = exp($1); $3 = $2; $4 = $2")          # no trailing semicolon: the generator adds it
+    return fsin, fexp
+
+
+def _lv_pair(n=50):
+    from exahip import ExaCore, graph as G, rng
+    from exahip.models import lv_x0
+    fsin, fexp = _fused_fns()
+
+    def build(sin, exp):
+        c = ExaCore()
+        x = c.add_var(n, start=lv_x0(n))
+        c.add_con(lambda i: 3 * x[i + 1] ** 3 + 2 * x[i + 2] - 5 + sin(x[i + 1] - x[i + 2]) * sin(x[i + 1] + x[i + 2]) + 4 * x[i + 1]
+                  - x[i] * exp(x[i] - x[i + 1]) - 3, rng(1, n - 2))
+        c.add_obj(lambda i: 100 * (x[i - 1] ** 2 - x[i]) ** 2 + (x[i - 1] - 1) ** 2 + exp(sin(x[i])) * sin(x[i]), rng(2, n))
+        return c
+
+    return build(fsin, fexp), build(G.sin, G.exp)
+
+
 def _pair(n=60):
     """The same model twice: with registered functions and with their built-in twins."""
     from exahip import ExaCore, Table, graph as G, rng
@@ -89,6 +113,26 @@ def test_unregistered_ids_are_refused_and_registered_ones_plan_like_their_twins(
         del G.UN_ID["ghost"]
 
 
+def test_fused_registration(libs):
+    from exahip import ExaModel, capi
+    L = capi.lib()
+    assert L.exa_register_univariate_fused(b"fz", b"$2 = $1;", None) == -1 and b"must use $1 and assign $2, $3 and $4" in L.exa_last_error()
+    assert L.exa_register_univariate_fused(b"fz", b"$2 = $1; $3 = 1.0; $4 = $5;", None) == -1 and b"placeholder" in L.exa_last_error()
+    user, twin = _lv_pair()
+    mu, mt = ExaModel(user, device=False), ExaModel(twin, device=False)
+    assert [mu.pattern_info(k) for k in range(2)] == [mt.pattern_info(k) for k in range(2)]
+    src = mu.kernel_source()
+    def body(name):
+        i = src.index(name + "(")
+        return src[i: src.index("\n}\n", i)]
+    # one statement per DISTINCT argument: a - b and a + b in the constraint; sin(x[i]) appears twice in the objective -> once
+    assert body("g0_hess").count("exa_sincos(") == 2 and body("g1_hess").count("exa_sincos(") == 1
+    mu.compile()
+    from exahip import Recipe
+    again = Recipe(Recipe(user).bytes).instantiate(device=False)          # the wire format carries the fused statement
+    assert again.kernel_source() == src
+
+
 def test_a_rule_that_does_not_compile_fails_the_build_with_the_compiler_message(libs):
     from exahip import ExaCore, ExaModel, graph as G, rng
     broken = G.register_univariate("broken_rule", "no_such_function($1)", "=1", "=0")
@@ -98,6 +142,25 @@ def test_a_rule_that_does_not_compile_fails_the_build_with_the_compiler_message(
     m = ExaModel(c, device=False)
     with pytest.raises(Exception, match="no_such_function"):
         m.compile()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+def test_fused_registered_functions_equal_the_table_on_hip(libs):
+    """fsin's statement is the table's own (one exa_sincos): the LV-shaped model must agree with the built-in one to the last bit in
+    cons / jac, and to rounding in the Hessian (fexp's second derivative is the value here, the table's is written the same way)."""
+    from exahip import ExaModel
+    user, twin = _lv_pair(2000)
+    mu, mt = ExaModel(user), ExaModel(twin)
+    x = np.asarray(mu.meta.x0) + 0.05 * np.random.default_rng(0).uniform(-1, 1, mu.meta.nvar)
+    y = np.random.default_rng(1).standard_normal(mu.meta.ncon)
+    assert mu.obj(x) == pytest.approx(mt.obj(x), rel=1e-14)
+    assert np.array_equal(mu.cons(x), mt.cons(x)) and np.array_equal(mu.jac_coord(x), mt.jac_coord(x))
+    np.testing.assert_allclose(mu.grad(x), mt.grad(x), rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(mu.hess_coord(x, y, 0.7), mt.hess_coord(x, y, 0.7), rtol=1e-12, atol=1e-300)
+    import oracle
+    o = oracle.OracleModel(ExaModel(twin, device=False).ir)
+    np.testing.assert_allclose(mu.hess_coord(x, y, 0.7), o.hess_coord(x, y, 0.7), rtol=1e-10, atol=1e-12)
 
 
 @pytest.mark.gpu
@@ -222,7 +285,7 @@ def test_user_function_section_is_validated(libs):
     from exahip import recipe as R
     L = capi.lib()
     ids = sorted({(b, f) for b in (0, 1) for f in range(1000, 1100) if L.exa_user_function(b, f, 0, None, 0) >= 0})
-    texts = lambda b, f: b"".join((lambda t: struct.pack("<i", len(t)) + t)(R._user_text(b, f, w).encode()) for w in range(8))
+    texts = lambda b, f: b"".join((lambda t: struct.pack("<i", len(t)) + t)(R._user_text(b, f, w).encode()) for w in range(9))
     used = [(b, f) for b, f in ids if struct.pack("<ii", b, f) + texts(b, f) in good]
     assert len(used) == 5
     tail = b"".join(struct.pack("<ii", b, f) + texts(b, f) for b, f in used)

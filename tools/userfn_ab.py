@@ -5,6 +5,7 @@ LV N = 1e7, every callback, three spellings of the model's sin / exp:
   table     the built-in nodes (sin goes through the library's fused sincos: one range reduction for value and derivative)
   user-ocml registered "sin($1)" / "cos($1)" / "exp($1)": the HIP math library's routines, value and derivative reduced separately
   user-lib  registered with the library's own device routines (exa_sin / exa_cos of the prelude every module carries)
+  fused     exa_register_univariate_fused: one statement per argument gives value and both derivatives ("exa_sincos($1, &$2, &$3); $4 = -$2;")
 usage (GPU box): python tools/userfn_ab.py [N]"""
 import sys
 sys.path.insert(0, "examodels.jl_amd")
@@ -27,9 +28,11 @@ def lv(sin, exp):
 usin = G.register_univariate("ab_sin_ocml", "sin($1)", "cos($1)", "-$2")
 uexp = G.register_univariate("ab_exp", "exp($1)", "$2", "$3")
 lsin = G.register_univariate("ab_sin_lib", "exa_sin($1)", "exa_cos($1)", "-$2")
-spell = {"table": (G.sin, G.exp), "user-ocml": (usin, uexp), "user-lib": (lsin, uexp)}
+fsin = G.register_univariate("ab_sin_fused", fused="exa_sincos($1, &$2, &$3); $4 = -$2;")
+fexp = G.register_univariate("ab_exp_fused", fused="$2 = exp($1); $3 = $2; $4 = $2;")
+spell = {"table": (G.sin, G.exp), "user-ocml": (usin, uexp), "user-lib": (lsin, uexp), "fused": (fsin, fexp)}
 ref = None
-print(f"# LV N = {N:.0e}: ms per call (exa_time_callback, min of 5 x 200 calls), the same buffers for the three spellings")
+print(f"# LV N = {N:.0e}: ms per call (exa_time_callback, min of 5 x 200 calls), the same inputs for the four spellings")
 print(f"{'':10s} {'obj':>8s} {'cons':>8s} {'grad':>8s} {'jac':>8s} {'hess':>8s}   max |difference| / |table| of cons, jac, hess")
 for name, (s, e) in spell.items():
     m = ExaModel(lv(s, e))
