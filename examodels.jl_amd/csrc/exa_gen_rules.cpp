@@ -263,7 +263,8 @@ Triple un_rule(Emitter &e, int fn, Val u, int order) {
                 if (c == '$' && d >= '1' && d <= '4') { stmt += d == '1' ? "(" + e.sd(u) + ")" : e.s(v[d - '2']); i++; }
                 else stmt += c;
             }
-            e.lines.push_back(decl + "; " + stmt + (stmt.empty() || stmt.back() == ';' ? "" : ";"));
+            // the statement in its own block: temporaries it declares do not collide between two uses in one kernel
+            e.lines.push_back(decl + "; { " + stmt + (stmt.empty() || stmt.back() == ';' ? "" : ";") + " }");
             e.memo[key] = v[0]; e.memo[key + "|d"] = v[1]; e.memo[key + "|h"] = v[2];
         }
         r.x = e.memo[key]; r.y = e.memo[key + "|d"]; r.h = e.memo[key + "|h"];

@@ -257,7 +257,7 @@ int exa_register_bivariate(const char *name, const char *f, const char *d1, cons
 /* A univariate function whose derivatives share work with the value (a range reduction, an exponential, a series): ONE device STATEMENT
  * `stmt` computes all three — $1 the argument, $2 / $3 / $4 the variables that receive f, f', f'' — e.g.
  *   "exa_sincos($1, &$2, &$3); $4 = -$2;"        (what the table itself does for sin: src/functionlist.jl:22)
- * emitted once per distinct argument; kernels that need the value only leave the rest to the compiler's dead-code elimination.  Measured
+ * emitted once per distinct argument inside a block of its own (it may declare temporaries); kernels that need the value only leave the rest to the compiler's dead-code elimination.  Measured
  * on LV N = 1e7 (profiles/r4_userfn_ab.txt): a sine registered this way costs what the table's sine costs; as three separate rules it pays
  * the reduction twice (jac_coord! +26 %, hess_coord! +9 %).  Same id space, return values and lifetime as exa_register_univariate. */
 int exa_register_univariate_fused(const char *name, const char *stmt, const char *helpers);

@@ -27,8 +27,14 @@ class Gen:
     special = 0.0         # > 0: this share of the univariate / bivariate picks comes from the SpecialFunctions extension (the draws of
                           # the default generator are untouched: recorded seeds keep their models)
 
+    user = None           # {table name: constructor}: these entries are taken from the caller (user-registered twins of table functions,
+                          # tests/test_registered_functions.py) — the draws do not change, so the tree is the table's tree
+
     def __init__(self, seed):
         self.r = np.random.default_rng(seed)
+
+    def fn(self, name):
+        return (self.user or {}).get(name) or getattr(graph, name)
 
     def leaf(self, x, th, d):
         k = self.r.integers(0, 10)
@@ -76,7 +82,7 @@ class Gen:
                 return +a
             if f == "abs":
                 return abs(a)
-            return getattr(graph, f)(a)
+            return self.fn(f)(a)
         op = BIN[self.r.integers(0, len(BIN))]
         a = self.tree(x, th, d, depth - 1)
         b = self.tree(x, th, d, depth - 1)
@@ -103,13 +109,13 @@ class Gen:
         if op == "atan2":
             return graph.atan(a, 1.5 + b * b if isinstance(b, graph.Node) else b)
         if op == "hypot":
-            return graph.hypot(a, 1.0 + b)
+            return self.fn("hypot")(a, 1.0 + b)
         if op == "max":
             return graph.maximum(a, b)
         return graph.minimum(a, b)
 
 
-def build_model(seed, npat=12, depth=4, special=0.0):
+def build_model(seed, npat=12, depth=4, special=0.0, user=None):
     """One model with `npat` random objective/constraint/augmentation patterns over a small table iterator."""
     g = Gen(seed)
     c = ExaCore()
@@ -124,6 +130,7 @@ def build_model(seed, npat=12, depth=4, special=0.0):
         def fn(d, s=int(g.r.integers(0, 2**31))):
             gen = Gen(s)
             gen.special = special
+            gen.user = user
             return gen.tree(x, th, d, depth)
         if kind == 0:
             c.add_obj(fn, tab)

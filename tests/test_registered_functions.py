@@ -347,3 +347,82 @@ def test_a_packed_library_with_registered_functions_evaluates_in_a_fresh_process
     np.testing.assert_allclose(res["obj"], o.obj(x), rtol=1e-12)
     np.testing.assert_allclose(res["cons"], o.cons(x), rtol=1e-10, atol=1e-12)
     np.testing.assert_allclose(res["hess"], o.hess_coord(x, y, 0.5), rtol=1e-10, atol=1e-12)
+
+
+def _random_twins():
+    """Registered twins of ten table entries (rules copied from src/functionlist.jl's derivative column, in HIP spelling) for random trees."""
+    from exahip import graph as G
+    R = G.register_univariate
+    return {
+        "sin": R("rt_sin", fused="exa_sincos($1, &$2, &$3); $4 = -$2;"),
+        "cos": R("rt_cos", fused="double s_; exa_sincos($1, &s_, &$2); $3 = -s_; $4 = -$2;"),
+        "tanh": R("rt_tanh", "tanh($1)", "1.0 - $2 * $2", "-2.0 * $2 * $3"),
+        "atan": R("rt_atan", "atan($1)", "1.0 / (1.0 + $1 * $1)", "-2.0 * $1 * $3 * $3"),
+        "exp": R("rt_exp", fused="$2 = exp($1); $3 = $2; $4 = $2;"),
+        "asinh": R("rt_asinh", "asinh($1)", "1.0 / sqrt($1 * $1 + 1.0)", "-$1 * $3 * $3 * $3"),
+        "sinh": R("rt_sinh", "sinh($1)", "cosh($1)", "$2"),
+        "cosh": R("rt_cosh", "cosh($1)", "sinh($1)", "$2"),
+        "log1p": R("rt_log1p", "log1p($1)", "1.0 / (1.0 + $1)", "-$3 * $3"),
+        "sqrt": R("rt_sqrt", "sqrt($1)", "0.5 / $2", "-0.5 * $3 / $1"),
+        "hypot": G.register_bivariate("rt_hypot", "hypot($1, $2)", "$1 / $3", "$2 / $3", "($2 * $2) / ($3 * $3 * $3)", "-($1 * $2) / ($3 * $3 * $3)",
+                                      "($1 * $1) / ($3 * $3 * $3)"),
+    }
+
+
+def _random_pair(seed):
+    import randexpr
+    return randexpr.build_model(9000 + seed, npat=8, depth=4, user=_random_twins()), randexpr.build_model(9000 + seed, npat=8, depth=4)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_trees_with_registered_twins_plan_like_the_table(libs, seed):
+    from exahip import ExaModel
+    user, twin = _random_pair(seed)
+    mu, mt = ExaModel(user, device=False), ExaModel(twin, device=False)
+    assert mu.meta.nnzj == mt.meta.nnzj and mu.meta.nnzh == mt.meta.nnzh
+    assert [mu.pattern_info(k) for k in range(8)] == [mt.pattern_info(k) for k in range(8)]
+    assert "user-registered function `rt_" in mu.kernel_source()
+    if seed == 1:
+        mu.compile()
+
+
+def test_fused_statements_with_temporaries_do_not_collide(libs):
+    """rt_cos declares a temporary (`double s_;`): two uses with different arguments in one kernel compile, each statement in its own block."""
+    from exahip import ExaCore, ExaModel, rng
+    cos = _random_twins()["cos"]
+    c = ExaCore()
+    x = c.add_var(10, start=0.5)
+    c.add_obj(lambda i: cos(x[i]) * cos(x[i + 1]) + cos(x[i] * x[i + 1]), rng(1, 9))
+    m = ExaModel(c, device=False)
+    i = m.kernel_source().index("g0_hess(")
+    assert m.kernel_source()[i: m.kernel_source().index("\n}\n", i)].count("double s_;") == 3
+    m.compile()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
+@pytest.mark.parametrize("seed", range(6))
+def test_random_trees_with_registered_twins_on_hip(libs, seed):
+    """Registered functions at random places of random trees (under other functions, as fixed operands' partners, in shared augmentation
+    rows): every callback against the oracle, which evaluates the table's tree."""
+    from exahip import ExaModel
+    import oracle
+    user, twin = _random_pair(seed)
+    m = ExaModel(user)
+    o = oracle.OracleModel(ExaModel(twin, device=False).ir)
+    x = np.asarray(m.meta.x0) + 0.02 * np.random.default_rng(seed).uniform(-1, 1, m.meta.nvar)
+    y = np.random.default_rng(seed + 1).standard_normal(m.meta.ncon)
+    v = np.random.default_rng(seed + 2).standard_normal(m.meta.nvar)
+    w = np.random.default_rng(seed + 3).standard_normal(m.meta.ncon)
+    for a, b in zip(m.jac_structure() + m.hess_structure(), o.jac_structure() + o.hess_structure()):
+        assert np.array_equal(a, b)
+
+    def rel(a, b):
+        a, b = np.asarray(a, float), np.asarray(b, float)
+        return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-3 * max(1.0, float(np.max(np.abs(b)))))))
+
+    assert abs(m.obj(x) - o.obj(x)) <= 1e-10 * max(1.0, abs(o.obj(x)))
+    for name, a, b in (("cons", m.cons(x), o.cons(x)), ("grad", m.grad(x), o.grad(x)), ("jac", m.jac_coord(x), o.jac_coord(x)),
+                       ("hess", m.hess_coord(x, y, 0.7), o.hess_coord(x, y, 0.7)), ("jprod", m.jprod(x, v), o.jprod(x, v)),
+                       ("jtprod", m.jtprod(x, w), o.jtprod(x, w)), ("hprod", m.hprod(x, y, v, 0.7), o.hprod(x, y, v, 0.7))):
+        assert rel(a, b) <= 1e-10, (seed, name, rel(a, b))
