@@ -30,15 +30,28 @@ static int xi(int off) {
 int main(int argc, char **argv) {
     const char *mode = argc > 1 ? argv[1] : "plan";
     const int64_t Nv = 10;
+    /* "plan-user" / "eval-user": the same model with sin and exp REGISTERED from C (the reference's @register_univariate, src/register.jl:56-74):
+     * sin as one fused statement, exp as three rules; the ids take the place of EXA_U_SIN / EXA_U_EXP in the table */
+    int fn_sin = EXA_U_SIN, fn_exp = EXA_U_EXP;
+    if (strstr(mode, "-user")) {
+        fn_sin = exa_register_univariate_fused("c_sin", "exa_sincos($1, &$2, &$3); $4 = -$2;", NULL);
+        fn_exp = exa_register_univariate("c_exp", "exp($1)", "$2", "$3", NULL);
+        if (fn_sin < 1000 || fn_exp < 1000 || fn_sin == fn_exp) { printf("FAIL register: %s\n", exa_last_error()); return 1; }
+        if (exa_register_univariate("c_exp", "exp($1)", "$2", "$3", NULL) != fn_exp) { printf("FAIL same rules, other id\n"); return 1; }
+        if (exa_register_univariate("c_exp", "exp2($1)", "$2", "$3", NULL) != -1) { printf("FAIL other rules accepted\n"); return 1; }
+        char buf[64];
+        if (exa_user_function(0, fn_sin, 8, buf, sizeof buf) != 35 || strncmp(buf, "exa_sincos(", 11)) { printf("FAIL read back\n"); return 1; }
+        mode = !strncmp(mode, "plan", 4) ? "plan" : "eval";
+    }
     /* constraint: 3x[i+1]^3 + 2x[i+2] - 5 + sin(x[i+1]-x[i+2])sin(x[i+1]+x[i+2]) + 4x[i+1] - x[i]exp(x[i]-x[i+1]) - 3, i = 1:N-2 */
     nn = 0;
     int t1 = bin(EXA_B_MUL, ci(3), bin(EXA_B_POW, xi(1), ci(3)));
     int t2 = bin(EXA_B_MUL, ci(2), xi(2));
     int s = bin(EXA_B_SUB, bin(EXA_B_ADD, t1, t2), ci(5));
-    int sn = bin(EXA_B_MUL, un(EXA_U_SIN, bin(EXA_B_SUB, xi(1), xi(2))), un(EXA_U_SIN, bin(EXA_B_ADD, xi(1), xi(2))));
+    int sn = bin(EXA_B_MUL, un(fn_sin, bin(EXA_B_SUB, xi(1), xi(2))), un(fn_sin, bin(EXA_B_ADD, xi(1), xi(2))));
     s = bin(EXA_B_ADD, s, sn);
     s = bin(EXA_B_ADD, s, bin(EXA_B_MUL, ci(4), xi(1)));
-    s = bin(EXA_B_SUB, s, bin(EXA_B_MUL, xi(0), un(EXA_U_EXP, bin(EXA_B_SUB, xi(0), xi(1)))));
+    s = bin(EXA_B_SUB, s, bin(EXA_B_MUL, xi(0), un(fn_exp, bin(EXA_B_SUB, xi(0), xi(1)))));
     int con_root = bin(EXA_B_SUB, s, ci(3));
     int con_n = nn;
     exa_node_t *con_nodes = malloc(sizeof(exa_node_t) * con_n);

@@ -29,8 +29,10 @@ def run(exe, mode):
     return out.returncode, out.stdout + out.stderr
 
 
-def test_c_client_plan_only(client):
-    rc, out = run(client, "plan")
+@pytest.mark.parametrize("mode", ["plan", "plan-user"])
+def test_c_client_plan_only(client, mode):
+    """(`plan-user`: sin and exp registered from C — exa_register_univariate_fused / exa_register_univariate — same plan.)"""
+    rc, out = run(client, mode)
     assert rc == 0 and out.strip().endswith("OK"), out
     assert "nvar 10 ncon 8 nnzj 24 nnzh 75" in out
     assert "con o2step 6 comp2 1 1 2 3 1 2 3 1 3 4 2 5 5 1 6 5 6" in out
@@ -38,10 +40,11 @@ def test_c_client_plan_only(client):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")
-def test_c_client_full_evaluation(client):
+@pytest.mark.parametrize("mode", ["eval", "eval-user"])
+def test_c_client_full_evaluation(client, mode):
     import oracle
     from exahip import models
-    rc, out = run(client, "eval")
+    rc, out = run(client, mode)
     assert rc == 0 and out.strip().endswith("OK"), out
     vals = {}
     for line in out.splitlines():
