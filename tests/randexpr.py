@@ -115,6 +115,26 @@ class Gen:
         return graph.minimum(a, b)
 
 
+def registered_twins():
+    """User-registered twins of eleven table entries (exa_register_univariate / _fused / _bivariate; rules = the derivative columns of
+    src/functionlist.jl in HIP spelling): pass as `user=` and the model is the table's model with these nodes registered instead."""
+    R = graph.register_univariate
+    return {
+        "sin": R("rt_sin", fused="exa_sincos($1, &$2, &$3); $4 = -$2;"),
+        "cos": R("rt_cos", fused="double s_; exa_sincos($1, &s_, &$2); $3 = -s_; $4 = -$2;"),
+        "tanh": R("rt_tanh", "tanh($1)", "1.0 - $2 * $2", "-2.0 * $2 * $3"),
+        "atan": R("rt_atan", "atan($1)", "1.0 / (1.0 + $1 * $1)", "-2.0 * $1 * $3 * $3"),
+        "exp": R("rt_exp", fused="$2 = exp($1); $3 = $2; $4 = $2;"),
+        "asinh": R("rt_asinh", "asinh($1)", "1.0 / sqrt($1 * $1 + 1.0)", "-$1 * $3 * $3 * $3"),
+        "sinh": R("rt_sinh", "sinh($1)", "cosh($1)", "$2"),
+        "cosh": R("rt_cosh", "cosh($1)", "sinh($1)", "$2"),
+        "log1p": R("rt_log1p", "log1p($1)", "1.0 / (1.0 + $1)", "-$3 * $3"),
+        "sqrt": R("rt_sqrt", "sqrt($1)", "0.5 / $2", "-0.5 * $3 / $1"),
+        "hypot": graph.register_bivariate("rt_hypot", "hypot($1, $2)", "$1 / $3", "$2 / $3", "($2 * $2) / ($3 * $3 * $3)",
+                                          "-($1 * $2) / ($3 * $3 * $3)", "($1 * $1) / ($3 * $3 * $3)"),
+    }
+
+
 def build_model(seed, npat=12, depth=4, special=0.0, user=None):
     """One model with `npat` random objective/constraint/augmentation patterns over a small table iterator."""
     g = Gen(seed)

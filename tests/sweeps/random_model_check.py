@@ -28,12 +28,15 @@ if os.environ.get("POISON"):
     from poison import make_poison
     poison = make_poison(tempfile.mkdtemp())
 randexpr.NPTS = 300
+# USERFN=1: eleven table entries are taken from user-registered twins (randexpr.registered_twins: exa_register_univariate / _fused /
+# _bivariate); the oracle, which knows no user function, evaluates the table's model of the same seed
+user = randexpr.registered_twins() if os.environ.get("USERFN") else None
 if os.environ.get("PREBUILD"):           # without a GPU: plan + compile into the kernel cache (which travels to the GPU box)
-    ExaModel(randexpr.build_model(seed, npat, depth), device=False).compile()
+    ExaModel(randexpr.build_model(seed, npat, depth, user=user), device=False).compile()
     print(f"seed {seed} {npat} {depth} prebuilt")
     sys.exit(0)
-m = ExaModel(randexpr.build_model(seed, npat, depth))
-o = oracle.OracleModel(m.ir)
+m = ExaModel(randexpr.build_model(seed, npat, depth, user=user))
+o = oracle.OracleModel(ExaModel(randexpr.build_model(seed, npat, depth), device=False).ir if user else m.ir)
 m.set_product_mode(0, 0)
 x = m.meta.x0 + 0.05 * np.random.default_rng(seed).uniform(-1, 1, m.meta.nvar)
 y = np.random.default_rng(seed + 1).standard_normal(m.meta.ncon)

@@ -1,5 +1,6 @@
 # sequential sweep of deep random data-indexed models (one process per seed: a GPU fault kills only that seed), every callback
 # after a NaN poisoning of the register files.  usage: bash tests/sweeps/sweep_deep_poison.sh FIRST COUNT [NPAT=12] [DEPTH=6]
+# USERFN=1 in the environment: registered twins of table entries in every tree (random_model_check.py).
 # A seed without a result line (GPU fault, exception, timeout) is reported as CRASH with the last line of its output.
 F=${1:-2000}; C=${2:-20}; NP=${3:-12}; D=${4:-6}
 for s in $(seq $F $((F + C - 1))); do
