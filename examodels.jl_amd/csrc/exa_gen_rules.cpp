@@ -17,7 +17,7 @@ static bool ident_ok(const std::string &n) {
     for (char c : n) if (!((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_')) return false;
     return true;
 }
-int register_user_fn(bool bivariate, const UserFn &fn, std::string *err) {
+int register_user_fn(bool bivariate, const UserFn &fn, std::string *err, bool dry_run) {
     if (!ident_ok(fn.name)) { *err = "function name must be an identifier of at most 64 characters"; return -1; }
     // placeholders: univariate f: $1 | df: $1 $2(primal) | ddf: $1 $2 $3(first derivative);  bivariate f: $1 $2 | partials: $1 $2 $3(primal)
     struct Rule { const std::string *t; int nph; };
@@ -43,6 +43,7 @@ int register_user_fn(bool bivariate, const UserFn &fn, std::string *err) {
                 return EXA_USER_FN_BASE + (int)i;
             *err = "`" + fn.name + "` is already registered with other rules"; return -1;
         }
+    if (dry_run) return EXA_USER_FN_BASE + (int)tab.size();
     tab.push_back(std::make_unique<UserFn>(fn));
     return EXA_USER_FN_BASE + (int)tab.size() - 1;
 }

@@ -276,26 +276,39 @@ std::unique_ptr<Recipe> parse(const void *bytes, size_t len) {
     // registered before, nor in which order.
     if (rd.p != rd.end) {
         std::map<std::pair<int, int>, int> remap;       // (bivariate, id in the file) -> id in this process
+        struct Entry { int biv, fid; UserFn u; };
+        std::vector<Entry> entries;
+        std::map<std::pair<int, std::string>, size_t> by_name;
         const int nu = rd.count(1 << 16);
         for (int k = 0; k < nu; k++) {
-            const int biv = rd.i32(), fid = rd.i32();
-            UserFn u;
+            Entry en;
+            en.biv = rd.i32(); en.fid = rd.i32();
+            UserFn &u = en.u;
             u.name = rd.str(); u.f = rd.str(); u.d1 = rd.str(); u.d2 = rd.str(); u.d11 = rd.str(); u.d12 = rd.str(); u.d22 = rd.str();
             u.helpers = rd.str(); u.fused = rd.str();
-            if ((biv != 0 && biv != 1) || fid < EXA_USER_FN_BASE || remap.count({biv, fid})) throw BadInput("recipe: bad user-function entry");
+            if ((en.biv != 0 && en.biv != 1) || en.fid < EXA_USER_FN_BASE || remap.count({en.biv, en.fid}) || by_name.count({en.biv, u.name}))
+                throw BadInput("recipe: bad user-function entry");
+            remap[{en.biv, en.fid}] = -1;
+            by_name[{en.biv, u.name}] = entries.size();
+            // every check of a registration, nothing entered yet: a file that is refused leaves the process as it was
             std::string err;
-            const int id = register_user_fn(biv == 1, u, &err);
-            if (id < 0) throw BadInput("recipe: user function: " + err);
-            remap[{biv, fid}] = id;
+            if (register_user_fn(en.biv == 1, u, &err, true) < 0) throw BadInput("recipe: user function: " + err);
+            entries.push_back(std::move(en));
         }
         if (rd.p != rd.end) throw BadInput("recipe: trailing bytes");
+        for (const RPattern &p : r->pats)
+            for (const exa_node_t &nd : p.nodes)
+                if ((nd.op == EXA_OP_UN || nd.op == EXA_OP_BIN) && nd.fn >= EXA_USER_FN_BASE && !remap.count({nd.op == EXA_OP_BIN ? 1 : 0, nd.fn}))
+                    throw BadInput("recipe: a node uses a registered function the file does not define");
+        for (const Entry &en : entries) {
+            std::string err;
+            const int id = register_user_fn(en.biv == 1, en.u, &err);
+            if (id < 0) throw BadInput("recipe: user function: " + err);       // (another thread took the name in between)
+            remap[{en.biv, en.fid}] = id;
+        }
         for (RPattern &p : r->pats)
             for (exa_node_t &nd : p.nodes)
-                if ((nd.op == EXA_OP_UN || nd.op == EXA_OP_BIN) && nd.fn >= EXA_USER_FN_BASE) {
-                    auto it = remap.find({nd.op == EXA_OP_BIN ? 1 : 0, nd.fn});
-                    if (it == remap.end()) throw BadInput("recipe: a node uses a registered function the file does not define");
-                    nd.fn = it->second;
-                }
+                if ((nd.op == EXA_OP_UN || nd.op == EXA_OP_BIN) && nd.fn >= EXA_USER_FN_BASE) nd.fn = remap[{nd.op == EXA_OP_BIN ? 1 : 0, nd.fn}];
     }
     describe(*r);
     return r;

@@ -53,7 +53,8 @@
  *                   str helpers; str fused }      -- univariate: d1 = df, d11 = ddf, the others empty; fused: the one-statement form
  *                   (exa_register_univariate_fused; then f, d1, d11 are empty too).  exa_recipe_load registers each entry (the same
  *                   rules again give the id they already have; a name taken by OTHER rules refuses the file) and renumbers the nodes:
- *                   the file is self-contained.  A file with this section must define every fn >= 1000 its nodes use.
+ *                   the file is self-contained.  A file with this section must define every fn >= 1000 its nodes use.  All entries are
+ *                   checked before any is registered: a file that is refused leaves the process as it was.
  * A fully concrete model is the special case nfields = 0, nsyms = 0 (everything literal / inline): the same
  * bytes are the library's model file format (exa_recipe_load + exa_recipe_new).
  */

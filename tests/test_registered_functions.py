@@ -259,11 +259,14 @@ def test_a_model_file_whose_function_name_is_taken_by_other_rules_is_refused(lib
 import sys
 sys.path[:0] = [{os.path.join(root, "examodels.jl_amd")!r}]
 from exahip import Recipe, capi
-assert capi.lib().exa_register_univariate(b"mysin", b"cos($1)", b"-sin($1)", b"-$2", None) >= 1000      # NOT the file's mysin
+L = capi.lib()
+assert L.exa_register_bivariate(b"mymul", b"$1 + $2", b"=1", b"=1", b"=0", b"=0", b"=0", None) >= 1000      # NOT the file's mymul
 try:
     Recipe.load({path!r})
 except capi.ExaHipError as e:
     assert "already registered with other rules" in str(e), str(e)
+    # ... and the refused file left nothing behind: its univariate entries come BEFORE mymul in the section, none is registered
+    assert L.exa_user_function(0, 1000, 0, None, 0) == -1 and L.exa_user_function(1, 1001, 0, None, 0) == -1
     print("REFUSED")
 """
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
