@@ -249,21 +249,20 @@ int exa_shard_var_range(int id, int64_t *lo, int64_t *hi);
  * exa_node_t.fn with op = EXA_OP_UN / EXA_OP_BIN, or -1 (exa_last_error: bad name, missing rule, unknown placeholder, the name already
  * registered with other rules; the same rules again return the same id).  A registration lasts for the process; a model file / recipe that
  * uses such ids carries the registrations (trailing section of the wire format, include/exahip_recipe.h): loading registers them and
- * renumbers the nodes, whatever the loading process registered before.  A rule that
- * does not compile fails the model build (status 4, the compiler's message in exa_last_error), not the registration. */
+ * renumbers the nodes, whatever the loading process registered before.  A rule that does not compile fails the model build (status 4, the compiler's message in exa_last_error), not the registration. */
 int exa_register_univariate(const char *name, const char *f, const char *df, const char *ddf, const char *helpers);
 int exa_register_bivariate(const char *name, const char *f, const char *d1, const char *d2, const char *d11, const char *d12,
                            const char *d22, const char *helpers);
 /* A univariate function whose derivatives share work with the value (a range reduction, an exponential, a series): ONE device STATEMENT
  * `stmt` computes all three — $1 the argument, $2 / $3 / $4 the variables that receive f, f', f'' — e.g.
  *   "exa_sincos($1, &$2, &$3); $4 = -$2;"        (what the table itself does for sin: src/functionlist.jl:22)
- * emitted once per distinct argument inside a block of its own (it may declare temporaries); kernels that need the value only leave the rest to the compiler's dead-code elimination.  Measured
- * on LV N = 1e7 (profiles/r4_userfn_ab.txt): a sine registered this way costs what the table's sine costs; as three separate rules it pays
+ * emitted once per distinct argument inside a block of its own (it may declare temporaries); kernels that need the value only leave
+ * the rest to the compiler's dead-code elimination.  Measured on LV N = 1e7 (profiles/r4_userfn_ab.txt): a sine registered this way costs what the table's sine costs; as three separate rules it pays
  * the reduction twice (jac_coord! +26 %, hess_coord! +9 %).  Same id space, return values and lifetime as exa_register_univariate. */
 int exa_register_univariate_fused(const char *name, const char *stmt, const char *helpers);
 /* Read a registration back (what a writer of model files needs to make them self-contained, include/exahip_recipe.h): which = 0 name,
- * 1 f, 2 d1 (df), 3 d2, 4 d11 (ddf), 5 d12, 6 d22, 7 helpers, 8 the fused statement.  Copy-out convention of the cnlp ABI: returns the byte length of the text and
- * copies what fits into buf (NUL-terminated when cap > 0); -1 = no such function / bad argument. */
+ * 1 f, 2 d1 (df), 3 d2, 4 d11 (ddf), 5 d12, 6 d22, 7 helpers, 8 the fused statement.  Copy-out convention of the cnlp ABI: returns the
+ * byte length of the text and copies what fits into buf (NUL-terminated when cap > 0); -1 = no such function / bad argument. */
 int exa_user_function(int bivariate, int fn, int which, char *buf, int cap);
 /* theta update without rebuild (set_value!, nlp.jl:1279-1287; cnlp :1529-1535) */
 int exa_set_value(int id, int64_t offset, const double *vals, int64_t len);   /* theta[offset .. offset+len) <- vals (HOST) */
