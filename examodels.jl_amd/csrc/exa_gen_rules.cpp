@@ -17,7 +17,8 @@ static bool ident_ok(const std::string &n) {
     for (char c : n) if (!((c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || (c >= '0' && c <= '9') || c == '_')) return false;
     return true;
 }
-int register_user_fn(bool bivariate, const UserFn &fn, std::string *err, bool dry_run) {
+int register_user_fn(bool bivariate, const UserFn &fn, std::string *err, bool dry_run, bool *known) {
+    if (known) *known = false;
     if (!ident_ok(fn.name)) { *err = "function name must be an identifier of at most 64 characters"; return -1; }
     // placeholders: univariate f: $1 | df: $1 $2(primal) | ddf: $1 $2 $3(first derivative);  bivariate f: $1 $2 | partials: $1 $2 $3(primal)
     struct Rule { const std::string *t; int nph; };
@@ -28,11 +29,17 @@ int register_user_fn(bool bivariate, const UserFn &fn, std::string *err, bool dr
         for (const char *ph : {"$1", "$2", "$3", "$4"})
             if (fn.fused.find(ph) == std::string::npos) { *err = "the fused rule of `" + fn.name + "` must use $1 and assign $2, $3 and $4"; return -1; }
     } else rules = {{&fn.f, 1}, {&fn.d1, 2}, {&fn.d11, 3}};
+    if (bivariate && !fn.fused.empty()) { *err = "`" + fn.name + "`: a bivariate registration has no fused form"; return -1; }
     for (const Rule &r : rules) {
         if (r.t->empty()) { *err = "every rule of `" + fn.name + "` needs an expression ('=0' for an exact zero)"; return -1; }
-        for (size_t i = 0; i + 1 < r.t->size(); i++)
-            if ((*r.t)[i] == '$' && ((*r.t)[i + 1] < '1' || (*r.t)[i + 1] > char('0' + r.nph)))
+        for (size_t i = 0; i < r.t->size(); i++) {
+            if ((*r.t)[i] != '$') continue;
+            // a placeholder is '$' + ONE digit the rule has: a bare '$' at the end and "$10" (would paste as $1 followed by 0) are refused here,
+            // not by the compiler at model build
+            const char d = i + 1 < r.t->size() ? (*r.t)[i + 1] : '\0', d2 = i + 2 < r.t->size() ? (*r.t)[i + 2] : '\0';
+            if (d < '1' || d > char('0' + r.nph) || (d2 >= '0' && d2 <= '9'))
                 { *err = "rule `" + *r.t + "` of `" + fn.name + "` refers to a placeholder it does not have"; return -1; }
+        }
     }
     std::lock_guard<std::mutex> lk(g_user_mu);
     auto &tab = bivariate ? g_user_bin : g_user_un;
@@ -40,7 +47,7 @@ int register_user_fn(bool bivariate, const UserFn &fn, std::string *err, bool dr
         if (tab[i]->name == fn.name) {
             const UserFn &o = *tab[i];      // registering the same rules again returns the same id; different rules are refused
             if (o.f == fn.f && o.d1 == fn.d1 && o.d2 == fn.d2 && o.d11 == fn.d11 && o.d12 == fn.d12 && o.d22 == fn.d22 && o.helpers == fn.helpers && o.fused == fn.fused)
-                return EXA_USER_FN_BASE + (int)i;
+                { if (known) *known = true; return EXA_USER_FN_BASE + (int)i; }
             *err = "`" + fn.name + "` is already registered with other rules"; return -1;
         }
     if (dry_run) return EXA_USER_FN_BASE + (int)tab.size();

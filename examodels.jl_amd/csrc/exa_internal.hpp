@@ -262,7 +262,7 @@ constexpr int EXA_USER_FN_BASE = 1000;
 // `fused` (univariate only, exa_register_univariate_fused): ONE device statement that leaves value, first and second derivative in
 // $2 $3 $4 from the argument $1 — for functions whose derivatives share work with the value (a range reduction, an exp): then f/d1/d11 are empty.
 struct UserFn { std::string name, f, d1, d2, d11, d12, d22, helpers, fused; };
-int register_user_fn(bool bivariate, const UserFn &fn, std::string *err, bool dry_run = false);   // the new id, or -1 with *err set
+int register_user_fn(bool bivariate, const UserFn &fn, std::string *err, bool dry_run = false, bool *known = nullptr);   // known: these very rules were registered before   // the new id, or -1 with *err set
                                                                   // (dry_run: every check, nothing entered; the id it would get)
 const UserFn *user_fn(bool bivariate, int fn);                                  // nullptr: not registered
 

@@ -6,6 +6,7 @@
 // is on the evaluation path: an instance is an ordinary model of exa_runtime.cpp afterwards.
 #include <algorithm>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -121,6 +122,15 @@ struct Reader {
 };
 
 const char *tname(int t) { return t == T_I64 ? "i64" : "f64"; }
+
+// may model files bring device code of their own? -1 = not said (the environment decides), 0 / 1 = exa_recipe_trust_code
+std::atomic<int> g_trust_code{-1};
+bool trust_model_code() {
+    const int v = g_trust_code.load();
+    if (v >= 0) return v > 0;
+    const char *e = getenv("EXAHIP_TRUST_MODEL_CODE");
+    return e && *e && std::string(e) != "0";
+}
 
 void describe(Recipe &r) {
     // schema JSON exactly in the shape the cnlp consumers parse (ExaModelsCompiler.jl:567-576)
@@ -274,11 +284,16 @@ std::unique_ptr<Recipe> parse(const void *bytes, size_t len) {
     // WRITER's process had given them.  Loading registers them here (the same rules again return the id they already have; a name that
     // is taken by other rules refuses the file) and renumbers the nodes, so a model file does not depend on what the loading process
     // registered before, nor in which order.
+    // TRUST BOUNDARY: the rule texts and `helpers` are HIP device source that hipcc / hiprtc will compile and the GPU will run.  A file
+    // whose entries are not, rule for rule, registrations this process has already made itself is therefore REFUSED unless the host
+    // opted in (exa_recipe_trust_code(1), or EXAHIP_TRUST_MODEL_CODE=1 in the environment): without that a model file stays what it
+    // was before files could carry registrations — validated data.
+    struct Entry { int biv, fid; UserFn u; };
+    std::vector<Entry> entries;
+    std::map<std::pair<int, int>, int> remap;       // (bivariate, id in the file) -> id in this process
     if (rd.p != rd.end) {
-        std::map<std::pair<int, int>, int> remap;       // (bivariate, id in the file) -> id in this process
-        struct Entry { int biv, fid; UserFn u; };
-        std::vector<Entry> entries;
         std::map<std::pair<int, std::string>, size_t> by_name;
+        std::string fresh;
         const int nu = rd.count(1 << 16);
         for (int k = 0; k < nu; k++) {
             Entry en;
@@ -292,25 +307,33 @@ std::unique_ptr<Recipe> parse(const void *bytes, size_t len) {
             by_name[{en.biv, u.name}] = entries.size();
             // every check of a registration, nothing entered yet: a file that is refused leaves the process as it was
             std::string err;
-            if (register_user_fn(en.biv == 1, u, &err, true) < 0) throw BadInput("recipe: user function: " + err);
+            bool known = false;
+            if (register_user_fn(en.biv == 1, u, &err, true, &known) < 0) throw BadInput("recipe: user function: " + err);
+            if (!known) fresh += (fresh.empty() ? "`" : ", `") + u.name + "`";
             entries.push_back(std::move(en));
         }
         if (rd.p != rd.end) throw BadInput("recipe: trailing bytes");
-        for (const RPattern &p : r->pats)
-            for (const exa_node_t &nd : p.nodes)
-                if ((nd.op == EXA_OP_UN || nd.op == EXA_OP_BIN) && nd.fn >= EXA_USER_FN_BASE && !remap.count({nd.op == EXA_OP_BIN ? 1 : 0, nd.fn}))
-                    throw BadInput("recipe: a node uses a registered function the file does not define");
-        for (const Entry &en : entries) {
-            std::string err;
-            const int id = register_user_fn(en.biv == 1, en.u, &err);
-            if (id < 0) throw BadInput("recipe: user function: " + err);       // (another thread took the name in between)
-            remap[{en.biv, en.fid}] = id;
-        }
-        for (RPattern &p : r->pats)
-            for (exa_node_t &nd : p.nodes)
-                if ((nd.op == EXA_OP_UN || nd.op == EXA_OP_BIN) && nd.fn >= EXA_USER_FN_BASE) nd.fn = remap[{nd.op == EXA_OP_BIN ? 1 : 0, nd.fn}];
+        if (!fresh.empty() && !trust_model_code())
+            throw BadInput("recipe: the file carries device code (registered function " + fresh + ") that this process has not registered itself: "
+                           "refused unless exa_recipe_trust_code(1) was called or EXAHIP_TRUST_MODEL_CODE=1 is set");
     }
+    // (a file WITHOUT the section must not name registered functions at all: the ids are the writer's, and binding them to whatever
+    // this process happens to have registered under those numbers could silently mean another function)
+    for (const RPattern &p : r->pats)
+        for (const exa_node_t &nd : p.nodes)
+            if ((nd.op == EXA_OP_UN || nd.op == EXA_OP_BIN) && nd.fn >= EXA_USER_FN_BASE && !remap.count({nd.op == EXA_OP_BIN ? 1 : 0, nd.fn}))
+                throw BadInput("recipe: a node uses a registered function the file does not define");
     describe(*r);
+    // every check has passed: only now is anything entered into the process-wide tables
+    for (const Entry &en : entries) {
+        std::string err;
+        const int id = register_user_fn(en.biv == 1, en.u, &err);
+        if (id < 0) throw BadInput("recipe: user function: " + err);       // (another thread took the name in between)
+        remap[{en.biv, en.fid}] = id;
+    }
+    for (RPattern &p : r->pats)
+        for (exa_node_t &nd : p.nodes)
+            if ((nd.op == EXA_OP_UN || nd.op == EXA_OP_BIN) && nd.fn >= EXA_USER_FN_BASE) nd.fn = remap[{nd.op == EXA_OP_BIN ? 1 : 0, nd.fn}];
     return r;
 }
 
@@ -549,6 +572,11 @@ using namespace exa;
 
 extern "C" {
 
+int exa_recipe_trust_code(int on) {
+    const int before = trust_model_code() ? 1 : 0;
+    if (on >= 0) g_trust_code.store(on ? 1 : 0);
+    return before;
+}
 int exa_recipe_load(const void *bytes, size_t len) {
     if (!bytes) return 0;
     try {

@@ -754,6 +754,11 @@ int exa_chess(int id, const double *x, const double *y, double w, double *vals) 
     if (!x) return 1;
     return guard(id, true, [&](Handle &h) {
         if (!h.compressed) throw BadInput("exa_compress has not been called");
+        // y == NULL = the objective-only form (as exa_hess).  The window / permuted-store kernels evaluate EVERY pattern and read y (and
+        // have released the gather lists the other route needs): on a constrained model they refuse it instead of faulting on the GPU;
+        // the uncompressed evaluation + gather handles it (objective groups alone, the rest zero-filled)
+        if (!y && h.m->ncon > 0 && (h.wh.ok || h.sh.ok))
+            throw BadInput("exa_chess: y == NULL (objective only) is not available where the compressed Hessian runs by windows / permuted store: pass y = 0");
         if (h.wh.ok) { do_window(h, WK_CHESS, x, y, nullptr, w, vals); return; }
         if (h.sh.ok) { do_scatter(h, true, x, y, w, vals); return; }
         do_hess(h, x, y, w, (double *)h.cbuf.p);

@@ -368,7 +368,7 @@ int exa_chess_structure64(int id, int64_t *rows, int64_t *cols);
 int exa_cjac_csc (int id, int64_t *colptr, int64_t *rowval);
 int exa_chess_csc(int id, int64_t *colptr, int64_t *rowval);
 int exa_cjac (int id, const double *x, double *vals);                          /* vals [cnnzj], DEVICE pointers */
-int exa_chess(int id, const double *x, const double *y, double obj_weight, double *vals);
+int exa_chess(int id, const double *x, const double *y, double obj_weight, double *vals);   /* y == NULL on a constrained model: objective only where the gather runs (exa_compress_info == 0), status 1 (bad input) where windows / the permuted store do */
 /* Which implementation exa_cjac (hess = 0) / exa_chess (hess = 1) run: 2 = permuted store (matrices the windows do not fit
  * — data-indexed targets such as ACOPF's bus variables: the sweep stores every slot at its position in the (col, row)-sorted
  * order, so the duplicates of an entry are contiguous and are summed with sequential reads, in ascending slot order like the

@@ -53,8 +53,14 @@
  *                   str helpers; str fused }      -- univariate: d1 = df, d11 = ddf, the others empty; fused: the one-statement form
  *                   (exa_register_univariate_fused; then f, d1, d11 are empty too).  exa_recipe_load registers each entry (the same
  *                   rules again give the id they already have; a name taken by OTHER rules refuses the file) and renumbers the nodes:
- *                   the file is self-contained.  A file with this section must define every fn >= 1000 its nodes use.  All entries are
- *                   checked before any is registered: a file that is refused leaves the process as it was.
+ *                   the file is self-contained.  Every fn >= 1000 a node uses must be defined by this section (a file without the
+ *                   section must not use any).  All entries — and everything else about the file — are checked before any is
+ *                   registered: a file that is refused leaves the process as it was.
+ *                   TRUST BOUNDARY: the rule texts and `helpers` are HIP device SOURCE — hipcc / hiprtc compile it and the GPU runs
+ *                   it in the host's context.  A file with this section is CODE, not data.  exa_recipe_load therefore refuses a file
+ *                   whose entries are not, rule for rule, registrations the process has already made itself, unless the host opted
+ *                   in: exa_recipe_trust_code(1), or EXAHIP_TRUST_MODEL_CODE=1 in the environment.  (A packed library, exahip.pack, is
+ *                   native code already: its loader opts in for its own embedded recipe only.)
  * A fully concrete model is the special case nfields = 0, nsyms = 0 (everything literal / inline): the same
  * bytes are the library's model file format (exa_recipe_load + exa_recipe_new).
  */
@@ -69,7 +75,11 @@ extern "C" {
 #endif
 
 /* ---- recipes ---------------------------------------------------------------------------------------- */
-int exa_recipe_load(const void *bytes, size_t len);            /* -> recipe id > 0, 0 on a malformed recipe  */
+int exa_recipe_load(const void *bytes, size_t len);            /* -> recipe id > 0, 0 on a malformed (or refused) recipe  */
+/* May model files bring device code of their own (registered functions this process has not registered itself)?  Default: no
+ * (EXAHIP_TRUST_MODEL_CODE=1 in the environment: yes).  on = 1 / 0 sets it for the process, on < 0 only asks.  Returns the setting
+ * in force before the call. */
+int exa_recipe_trust_code(int on);
 int exa_recipe_free(int recipe);
 /* P_nargs: how many values instantiation consumes — 0 for a fixed model, else the number of schema fields. */
 int exa_recipe_nargs(int recipe);

@@ -81,6 +81,9 @@ def test_registration_semantics(libs):
     assert L.exa_register_univariate(b"bad_ph", b"$1 + $2", b"=1", b"=0", None) == -1 and b"placeholder" in L.exa_last_error()   # f has no $2
     assert L.exa_register_bivariate(b"bad_ph2", b"$1 * $2", b"$4", b"$1", b"=0", b"=1", b"=0", None) == -1
     assert L.exa_register_univariate(None, b"$1", b"=1", b"=0", None) == -1
+    # a bare '$' at the end of a rule and a two-digit placeholder are refused at registration, not by the compiler at model build
+    assert L.exa_register_univariate(b"bad_ph3", b"$1 + $", b"=1", b"=0", None) == -1 and b"placeholder" in L.exa_last_error()
+    assert L.exa_register_univariate(b"bad_ph4", b"$1", b"$10", b"=0", None) == -1 and b"placeholder" in L.exa_last_error()
     b = L.exa_register_bivariate(b"reg_bin", b"$1 * $2", b"$2", b"$1", b"=0", b"=1", b"=0", None)
     assert b >= 1000
     with pytest.raises(ValueError):
@@ -208,6 +211,14 @@ L = capi.lib()
 for k in range(7):
     assert L.exa_register_univariate(b"decoy%d" % k, b"cosh($1)", b"sinh($1)", b"$2", None) == 1000 + k
     assert L.exa_register_bivariate(b"decoyb%d" % k, b"$1 - $2", b"=1", b"=-1", b"=0", b"=0", b"=0", None) == 1000 + k
+# ... and it has not said that model files may bring device code: the file is refused, nothing of it is registered
+try:
+    Recipe.load({path!r})
+    raise SystemExit("a file carrying device code was accepted without opt-in")
+except capi.ExaHipError as e:
+    assert "carries device code" in str(e) and "mysin" in str(e), str(e)
+assert L.exa_user_function(0, 1007, 0, None, 0) == -1 and L.exa_user_function(1, 1007, 0, None, 0) == -1
+assert L.exa_recipe_trust_code(-1) == 0 and L.exa_recipe_trust_code(1) == 0 and L.exa_recipe_trust_code(-1) == 1
 rec = Recipe.load({path!r})
 m = rec.instantiate(device=False)
 src = m.kernel_source()
@@ -271,6 +282,65 @@ except capi.ExaHipError as e:
 """
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "REFUSED" in out.stdout, out.stderr[-2000:]
+
+
+def test_a_model_file_with_code_needs_an_opt_in_unless_the_process_registered_the_same_rules(libs, tmp_path):
+    """the trailing section is HIP device source.  Refused by default; accepted when every entry is, rule for rule, a
+    registration the process made itself (this process: _pair registered them), under exa_recipe_trust_code(1), or under
+    EXAHIP_TRUST_MODEL_CODE=1.  A file WITHOUT the section that names a registered id is refused (the id is the writer's)."""
+    import os, struct, subprocess, sys
+    from exahip import Recipe, capi
+    user, _ = _pair()
+    path = str(tmp_path / "user.exarcp")
+    Recipe(user).save(path)
+    L = capi.lib()
+    assert L.exa_recipe_trust_code(-1) == 0
+    Recipe.load(path)                     # same rules already registered here: nothing new would be compiled
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys
+sys.path[:0] = [{os.path.join(root, "examodels.jl_amd")!r}]
+from exahip import Recipe, capi
+try:
+    Recipe.load({path!r})
+    print("ACCEPTED")
+except capi.ExaHipError as e:
+    print("REFUSED" if "carries device code" in str(e) else "OTHER " + str(e))
+"""
+    for env, want in (({}, "REFUSED"), ({"EXAHIP_TRUST_MODEL_CODE": "1"}, "ACCEPTED"), ({"EXAHIP_TRUST_MODEL_CODE": "0"}, "REFUSED")):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env))
+        assert out.returncode == 0 and out.stdout.strip() == want, (env, out.stdout, out.stderr[-2000:])
+    # the section cut off (and nothing else changed): nodes with fn >= 1000 and no definition
+    good = Recipe(user).bytes
+    k = good.rindex(struct.pack("<i", 5) + struct.pack("<ii", 0, 1000)) if struct.pack("<i", 5) + struct.pack("<ii", 0, 1000) in good else None
+    if k is not None:
+        with pytest.raises(capi.ExaHipError, match="does not define"):
+            Recipe(good[:k])
+
+
+def test_generated_text_does_not_depend_on_the_order_of_registration(libs):
+    """ids are per process; the module's text (its cache key) must not carry them, nor their order."""
+    import hashlib, os, subprocess, sys
+    from exahip import ExaModel
+    user, _ = _pair()
+    here = hashlib.sha256(ExaModel(user, device=False).kernel_source().encode()).hexdigest()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys, hashlib
+sys.path[:0] = [{os.path.join(root, "examodels.jl_amd")!r}, {os.path.join(root, "tests")!r}]
+from exahip import ExaModel, graph as G
+# the same five functions, registered in the REVERSE order (other ids)
+G.register_bivariate("mymul", "$1 * $2", "$2", "$1", "=0", "=1", "=0")
+G.register_bivariate("myhyp", "hypot($1, $2)", "$1 / $3", "$2 / $3", "($3 * $3 - $1 * $1) / ($3 * $3 * $3)", "-($1 * $2) / ($3 * $3 * $3)", "($3 * $3 - $2 * $2) / ($3 * $3 * $3)")
+G.register_univariate("mycube", "exa_user_cube($1)", "3.0 * $1 * $1", "6.0 * $1", helpers="static __device__ __forceinline__ double exa_user_cube(double t) {{ return t * t * t; }}")
+G.register_univariate("myexp", "exp($1)", "$2", "$3")
+import test_registered_functions as T
+user, _ = T._pair()
+print("KSRC", hashlib.sha256(ExaModel(user, device=False).kernel_source().encode()).hexdigest())
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert [l for l in out.stdout.splitlines() if l.startswith("KSRC")][0].split()[1] == here
 
 
 def test_user_function_section_is_validated(libs):
