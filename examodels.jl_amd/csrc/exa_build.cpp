@@ -17,6 +17,8 @@
 #include <dlfcn.h>
 #include <fcntl.h>
 #include <pwd.h>
+#include <spawn.h>
+#include <sys/wait.h>
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <unistd.h>
@@ -33,6 +35,8 @@
 #include <sstream>
 
 #include "exa_build.hpp"
+
+extern char **environ;
 
 namespace exa {
 namespace {
@@ -197,8 +201,21 @@ bool looks_like_code_object(const void *blob, size_t len) {
 bool looks_like_bundle(const void *blob, size_t len) { return len > 24 && memcmp(blob, "__CLANG_OFFLOAD_BUNDLE__", 24) == 0; }
 
 const char *kArch = "gfx950";
+// THE GUARD AGAINST THE ONE WRONG-RESULT CLASS hipcc has shown here (tests/sweeps/canary/REPORT.md, profiles/NOTES.md round 5): the
+// greedy SGPR allocator leaves live-range-split COPIES at the top of a control-flow join block, in front of the `s_or_b64 exec`
+// that re-enables the lanes; SIInstrInfo::isBasicBlockPrologue does not count them as prologue, so everything the VGPR allocator
+// later inserts "at the top of the block" (split copies, VGPR->AGPR copies, scratch spills, rematerialised constants) lands in front
+// of the exec restore and runs under the narrowed mask: the other lanes keep whatever the register held.  Register counts do not
+// show it (2 of the 6 affected kernels of round 4's cache had no AGPRs, no scratch, no spilled VGPRs).  The basic SGPR allocator
+// does not split live ranges — it spills, and SGPR spills ARE prologue — which removes the cause for every kernel of every module,
+// at no measurable cost (the kernels here are bound by VGPRs, not SGPRs; heavy kernels even spill fewer SGPRs:
+// profiles/r5_sgpr_regalloc_ab.txt).  $EXAHIP_SGPR_REGALLOC = greedy restores the compiler's default (the canary's fault), fast /
+// basic select explicitly.  tools/isa_prologue_check.py looks for the fault pattern in compiled code objects.
 std::vector<std::string> base_flags() {
     std::vector<std::string> f = {std::string("--offload-arch=") + kArch, "-O3", "-std=c++17", "-munsafe-fp-atomics", "-w"};
+    const char *ra = getenv("EXAHIP_SGPR_REGALLOC");
+    const std::string alloc = ra && *ra ? ra : "basic";
+    if (alloc != "greedy") { f.push_back("-mllvm"); f.push_back("-sgpr-regalloc=" + alloc); }
     const char *extra = getenv("EXAHIP_HIPCC_FLAGS");
     if (extra && *extra) {
         std::istringstream ss(extra);
@@ -313,7 +330,60 @@ Tool pick_tool(std::string &identity) {
     return Tool::Hipcc;
 }
 
+// hiprtc in a process of its own (csrc/exa_rtc_helper.cpp: LLVM latches -sgpr-regalloc at the first compilation of a process, so
+// inside a host that has compiled through this comgr before, the guard flag of base_flags() would be without effect).  The helper
+// sits next to libexahip.so; without it (a partial install), or under EXAHIP_RTC_INPROCESS=1, the compilation runs in this process
+// — correct whenever this library's compilations are the process's first through that comgr, which is the normal case.
+// Returns false when the helper is not there; throws on a compile error, like the in-process path.
+bool compile_hiprtc_helper(const std::string &source, const std::vector<std::string> &flags, std::vector<char> &image) {
+    const char *inproc = getenv("EXAHIP_RTC_INPROCESS");
+    if (inproc && *inproc && std::string(inproc) != "0") return false;
+    const std::string helper = lib_dir() + "/exa_rtc";
+    if (access(helper.c_str(), X_OK) != 0) return false;
+    Rtc &r = rtc();
+    // a private directory of this user (0700, mkdtemp): source in, code object and log out
+    const char *td = getenv("TMPDIR");
+    std::string tmpl = std::string(td && *td == '/' ? td : "/tmp") + "/exa_rtc.XXXXXX";
+    std::vector<char> dirbuf(tmpl.begin(), tmpl.end());
+    dirbuf.push_back('\0');
+    if (!mkdtemp(dirbuf.data())) return false;
+    const std::string dir = dirbuf.data(), src = dir + "/m.hip", obj = dir + "/m.hsaco", log = dir + "/m.log";
+    auto cleanup = [&] { unlink(src.c_str()); unlink(obj.c_str()); unlink(log.c_str()); rmdir(dir.c_str()); };
+    try {
+        { std::ofstream f(src, std::ios::binary); f.write(source.data(), (std::streamsize)source.size()); if (!f) throw std::runtime_error("cannot write " + src); }
+        std::vector<std::string> args = {helper, r.where, src, obj};
+        for (const auto &f : flags) args.push_back(f);
+        std::vector<char *> argv;
+        for (auto &a : args) argv.push_back(const_cast<char *>(a.c_str()));
+        argv.push_back(nullptr);
+        posix_spawn_file_actions_t fa;
+        posix_spawn_file_actions_init(&fa);
+        posix_spawn_file_actions_addopen(&fa, 2, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0600);
+        posix_spawn_file_actions_addopen(&fa, 1, "/dev/null", O_WRONLY, 0);
+        pid_t pid = 0;
+        const int rc = posix_spawn(&pid, helper.c_str(), &fa, nullptr, argv.data(), environ);
+        posix_spawn_file_actions_destroy(&fa);
+        if (rc != 0) { cleanup(); return false; }
+        int status = 0;
+        while (waitpid(pid, &status, 0) < 0 && errno == EINTR) {}
+        const int code = WIFEXITED(status) ? WEXITSTATUS(status) : 2;
+        if (code == 0 && read_regular_file(obj, image) && looks_like_code_object(image.data(), image.size())) { cleanup(); return true; }
+        std::vector<char> l;
+        std::string msg;
+        if (read_regular_file(log, l)) msg.assign(l.begin(), l.end());
+        if (msg.size() > 4000) msg.resize(4000);
+        cleanup();
+        if (code == 1) throw std::runtime_error("hiprtc failed (" + r.where + " in exa_rtc, " + join(flags) + "):\n" + msg);
+        if (WIFSIGNALED(status)) throw std::runtime_error("hiprtc failed: the compiler process died with signal " + std::to_string(WTERMSIG(status)) + "\n" + msg);
+        return false;       // the helper could not run (its libhiprtc did not load, ...): the in-process path will say why
+    } catch (...) { cleanup(); throw; }
+}
+
 std::vector<char> compile_hiprtc(const std::string &source, const std::vector<std::string> &flags) {
+    {
+        std::vector<char> image;
+        if (compile_hiprtc_helper(source, flags, image)) return image;
+    }
     Rtc &r = rtc();
     hiprtcProgram prog = nullptr;
     if (r.create(&prog, source.c_str(), "exa_module.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) throw std::runtime_error("hiprtcCreateProgram failed");

@@ -836,6 +836,43 @@ void ora_cons(void *hh, const double *x, double *g) {
     }
 }
 
+/* cons_nln! once more in __float128, with the magnitude of what each row summed (exa_quad.h): the arbiter for rows that cancel.
+ * g_q[i] = the quad result rounded to double, mag[i] = the first-order running error bound of the row's double-precision evaluation in
+ * units of eps (the contributions' bounds + one rounding per addition into the row).
+ * Returns 1, or 0 when a pattern uses a function without a quad restatement (the outputs are then meaningless). */
+#include "exa_quad.h"
+int ora_cons_quad(void *hh, const double *x, double *g_q, double *mag) {
+    ora_model *m = &((ora_handle *)hh)->m;
+    int ok = 1;
+    q128 *acc = (q128 *)calloc((size_t)(m->ncon > 0 ? m->ncon : 1), sizeof(q128));
+    q128 *mg = (q128 *)calloc((size_t)(m->ncon > 0 ? m->ncon : 1), sizeof(q128));
+    for (int k = 0; k < m->npat; k++) {
+        pattern *p = &m->pat[k];
+        if (p->kind == EXA_PAT_OBJ) continue;
+        const int64_t lo = shard_lo(m, p), hi = shard_hi(m, p);
+        /* base rows: one row per data point, disjoint — over the model's threads; augmentation terms share rows: sequential */
+        const int nt = p->kind == EXA_PAT_CON ? m->nthreads : 1;
+        int okp = 1;
+        (void)nt;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nt) reduction(&& : okp) if (nt > 1)
+#endif
+        for (int64_t I = lo; I < hi; I++) {
+            int ok1 = 1;
+            const qval_t v = qev(p, p->root, I, x, m->theta, &ok1);
+            const int64_t r = row_of(p, I, m->theta);
+            const int first = acc[r] == 0 && mg[r] == 0;
+            acc[r] += v.f;
+            mg[r] += v.mag + (first ? 0.0Q : fabsq(acc[r]));      /* every further addition into the row rounds once more */
+            okp = okp && ok1;
+        }
+        ok = ok && okp;
+    }
+    for (int64_t i = 0; i < m->ncon; i++) { g_q[i] = (double)acc[i]; mag[i] = (double)mg[i]; }
+    free(acc); free(mg);
+    return ok;
+}
+
 /* generic driver over data points for the derivative callbacks */
 typedef void (*point_fn)(const pattern *p, adnode *t, const ctx *c, void *user);
 static void drive(ora_handle *h, int k, const double *x, point_fn fn, void *user, int parallel) {

@@ -16,8 +16,8 @@ _LIB = None
 
 def build(force=False):
     so = os.path.join(_HERE, "libexaoracle.so")
-    src = os.path.join(_HERE, "exa_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("exa_oracle.c", "exa_special.h", "exa_quad.h")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
 
@@ -43,6 +43,7 @@ def lib():
         L.ora_obj.restype = dbl
         L.ora_obj.argtypes = [vp, vp]
         L.ora_cons.argtypes = [vp, vp, vp]
+        L.ora_cons_quad.argtypes = [vp, vp, vp, vp]
         L.ora_grad.argtypes = [vp, vp, vp]
         L.ora_sgrad.argtypes = [vp, vp, vp]
         L.ora_jac.argtypes = [vp, vp, vp]
@@ -127,6 +128,15 @@ class OracleModel:
         c = np.empty(self.ncon)
         self._L.ora_cons(self._h, _p(x), _p(c))
         return c
+
+    def cons_quad(self, x):
+        """(c, e): cons_nln! evaluated in __float128 (oracle/exa_quad.h) and rounded to double, and per row the first-order running
+        error bound of a double-precision evaluation, in units of eps — the arbiter for rows that cancel.  None when a pattern
+        uses a function without a quad restatement."""
+        x = _f64(x)
+        c, mag = np.empty(self.ncon), np.empty(self.ncon)
+        ok = self._L.ora_cons_quad(self._h, _p(x), _p(c), _p(mag))
+        return (c, mag) if ok else None
 
     def grad(self, x):
         x = _f64(x)

@@ -62,3 +62,86 @@ def test_the_fallback_can_be_switched_off(fresh_cache, monkeypatch):
     m.compile()
     prod = [a for a in m.build_audit() if a["module"] == "products"]
     assert {a["flags"] for a in prod} == {"default"} and any(not a["fits"] for a in prod)
+
+
+# ---- the guard sits on the CAUSE (round 5): SGPR split copies in front of a join block's exec restore -------------------------------
+def _fault_sites(blob, tmp_path, name):
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("isa_prologue_check", os.path.join(root, "tools", "isa_prologue_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    path = str(tmp_path / (name + ".hsaco"))
+    with open(path, "wb") as fh:
+        fh.write(blob)
+    return {k: sites for k, (sites, _, _) in chk.check_file(path).items() if sites}
+
+
+_CANARY_BUILD = r"""
+import sys
+sys.path[:0] = [{pkg!r}, {tests!r}]
+import randexpr
+from exahip import ExaModel
+m = ExaModel(randexpr.build_range_model(1, npts=1000, unit=True, blocks=True), device=False)
+m.compile()
+for name, blob in m.code_objects():
+    open({out!r} + "/" + name + ".hsaco", "wb").write(blob)
+print("HOW", m.build_info()[0])
+"""
+
+
+def test_the_compilers_default_sgpr_allocator_shows_the_fault_pattern_and_the_shipped_flags_do_not(tmp_path):
+    """tests/sweeps/canary/REPORT.md: under the compiler's default (greedy) SGPR allocator the canary's exa_hprodw has VGPR->AGPR
+    copies in front of a join block's `s_or_b64 exec` (the kernel that returned 983 wrong entries on the GPU); with the library's
+    base flags (-sgpr-regalloc=basic) no kernel of the module has a vector instruction there.  Static: llvm-objdump, no device.
+    One process per build, as in real use (plans and notes of a model are remembered per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = {}
+    for alloc in ("greedy", "basic"):
+        out = tmp_path / alloc
+        out.mkdir()
+        # the canary's first plan (12 pattern evaluations in one kernel), the base flags alone (no second compilation)
+        env = dict(os.environ, EXAHIP_CACHE_DIR=str(tmp_path / ("cache_" + alloc)), EXAHIP_WINDOW_REPLAN="0", EXAHIP_SAFE_FLAGS="none")
+        env.pop("EXAHIP_SGPR_REGALLOC", None)
+        if alloc == "greedy":
+            env["EXAHIP_SGPR_REGALLOC"] = "greedy"
+        code = _CANARY_BUILD.format(pkg=os.path.join(root, "examodels.jl_amd"), tests=os.path.join(root, "tests"), out=str(out))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        found[alloc] = {}
+        for f in sorted(os.listdir(out)):
+            with open(out / f, "rb") as fh:
+                found[alloc].update(_fault_sites(fh.read(), tmp_path, alloc + "_" + f[:-6]))
+    assert "exa_hprodw" in found["greedy"], "this compiler no longer shows the fault on the canary: the guard has become unnecessary for it, not wrong"
+    assert found["basic"] == {}
+
+
+def test_the_kernel_compiler_runs_in_a_process_of_its_own(fresh_cache, monkeypatch):
+    """csrc/exa_rtc_helper.cpp: LLVM latches -sgpr-regalloc at a process's first compilation, so the guard flag only means what it
+    says in a fresh process.  The helper sits next to the library; two compilations of ONE host process under different allocators
+    give different code (in-process, EXAHIP_RTC_INPROCESS=1, the second would silently repeat the first's allocator)."""
+    import os
+    from exahip import capi
+    assert os.access(os.path.join(os.path.dirname(capi.__file__), "exa_rtc"), os.X_OK)
+    blobs = []
+    for alloc in ("greedy", "basic"):
+        monkeypatch.setenv("EXAHIP_SGPR_REGALLOC", alloc)
+        m = ExaModel(models.rocket_model(40), device=False)
+        m.compile()
+        assert m.build_info()[0] == "hiprtc"
+        blobs.append(m.code_objects()[0][1])
+    assert blobs[0] != blobs[1]
+
+
+@pytest.mark.parametrize("make", [lambda: models.luksan_vlcek_model(200), lambda: models.rocket_model(1_000_000),
+                                  lambda: models.ac_power_model(models.synthetic_power_data(78_484, 126_015, 6_800, seed=0))], ids=["lv", "rocket1e6", "acopf78k"])
+def test_no_kernel_of_the_benchmark_modules_has_the_fault_pattern(make, tmp_path):
+    """Every kernel the bench runs (BASELINE configs 2-5), as shipped in kernel_cache/: no EXEC-dependent instruction in front of an exec restore."""
+    m = ExaModel(make(), device=False)
+    m.compile()
+    for name, blob in m.code_objects():
+        assert _fault_sites(blob, tmp_path, name) == {}, name

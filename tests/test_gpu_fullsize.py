@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import coo_slot, has_gpu, parity
+from conftest import coo_slot, has_gpu, parity, parity_cons
 from zoo import point
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
@@ -22,7 +22,7 @@ def maxrel(a, ref):
     return float(np.max(np.abs(a - ref) / scale))
 
 
-def full_compare(core, seed, check_products=False, label="model", strict=None):
+def full_compare(core, seed, check_products=False, label="model", strict=RTOL):
     import torch
     from exahip import ExaModel
     import oracle
@@ -40,7 +40,7 @@ def full_compare(core, seed, check_products=False, label="model", strict=None):
     # floored and strict (component-wise) relative error, conftest.parity: `strict` = the bound asserted on the latter
     parity(label, "hess", h.cpu().numpy(), o.hess_coord(x, y, sigma), RTOL, strict, where=lambda k: coo_slot(m, True, k))
     parity(label, "jac", j.cpu().numpy(), o.jac_coord(x), RTOL, strict, where=lambda k: coo_slot(m, False, k))
-    parity(label, "cons", c.cpu().numpy(), o.cons(x), RTOL, strict)
+    parity_cons(label, c.cpu().numpy(), o, x, RTOL)
     parity(label, "grad", g.cpu().numpy(), o.grad(x), RTOL, strict)
     fo = o.obj(x)
     assert abs(f - fo) <= RTOL * max(1.0, abs(fo))

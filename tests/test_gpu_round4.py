@@ -176,7 +176,7 @@ def test_a_78k_bus_case_file_through_the_real_case_path(libs, tmp_path):
     import subprocess
     import sys
     import torch
-    from conftest import parity
+    from conftest import parity, parity_cons
     from exahip import matpower
     path = str(tmp_path / "case78484_synthetic.m")
     info = matpower.write_synthetic_case(path, 78_484, 126_015, 6_800, seed=0)
@@ -190,10 +190,11 @@ def test_a_78k_bus_case_file_through_the_real_case_path(libs, tmp_path):
     x = m.meta.x0 + 0.05 * r.uniform(-1, 1, m.meta.nvar)
     y = r.standard_normal(m.meta.ncon)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-    parity("case78484 (generated)", "hess", m.hess_coord(xd, yd, 0.7).cpu().numpy(), o.hess_coord(x, y, 0.7))
-    parity("case78484 (generated)", "jac", m.jac_coord(xd).cpu().numpy(), o.jac_coord(x))
-    parity("case78484 (generated)", "cons", m.cons(xd).cpu().numpy(), o.cons(x))
-    parity("case78484 (generated)", "grad", m.grad(xd).cpu().numpy(), o.grad(x))
+    # component-wise 1e-10 on everything; the power-balance rows that cancel (5e-7 among terms of 1e4) through the __float128 arbiter
+    parity("case78484 (generated)", "hess", m.hess_coord(xd, yd, 0.7).cpu().numpy(), o.hess_coord(x, y, 0.7), 1e-10, 1e-10)
+    parity("case78484 (generated)", "jac", m.jac_coord(xd).cpu().numpy(), o.jac_coord(x), 1e-10, 1e-10)
+    parity_cons("case78484 (generated)", m.cons(xd).cpu().numpy(), o, x, 1e-10)
+    parity("case78484 (generated)", "grad", m.grad(xd).cpu().numpy(), o.grad(x), 1e-10, 1e-10)
     del m, o
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "4", "--case", path, "--steps", "20", "--warmup", "5", "--preheat-ms", "0",

@@ -219,7 +219,8 @@ int main(int argc, char** argv) {
             timeit(nm, [&] { k_wg_affine<512><<<grid, 256>>>(out, total, c); });
         }
         timeit("v10 3 x 4KB units, +512B misaligned", [&] { k_wg_affine<512><<<grid, 256>>>(out + 64, total - 64, 0); });
-        timeit("v10 6 x 4KB... (1024-double units)", [&] { k_wg_affine<1024><<<grid, 256>>>(out, total, 0); });
+        // (round 4 also listed k_wg_affine<1024> here: 256 * S / 1024 = 1.5 units per workgroup truncates to 1, the kernel wrote 2/3 of the
+        // bytes it was credited with — "9 283 GB/s" in profiles/r4_store_bench_7GB.txt is 6 189 GB/s of real stores.  Row removed.)
         {
             const unsigned gu = (unsigned)(((total + 511) / 512 + 4) / 5 + 8);
             timeit("v11 unit-affine flush (loads+LDS)", [&] { k_unit<false><<<gu, 448>>>(out, x, n); });
