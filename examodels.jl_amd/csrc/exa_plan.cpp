@@ -348,16 +348,21 @@ std::vector<T> copy_or(const T *src, int64_t n, T fill) {
 // the pattern names at the point — for a branch table: by from-bus, which is how a MATPOWER / PGLIB case file lists its branches.
 // The gathers of the data-indexed kernels are line-granular (profiles/r3_acopf_topology.json: the bus-ordered ACOPF runs 35-40 %
 // faster than the same network with its branches in random order).  Needs the host columns (a plan-only handle).
-std::vector<int64_t> locality_order(const Model &m, int pk) {
+std::vector<int64_t> locality_keys(const Model &m, int pk) {
     const Pattern &p = m.pats[pk];
     std::vector<int> roots;
     for (const exa_node_t &nd : p.nodes)
         if (nd.op == EXA_OP_VAR && std::find(roots.begin(), roots.end(), nd.a) == roots.end()) roots.push_back(nd.a);
-    std::vector<int64_t> key((size_t)p.n, 0), perm((size_t)p.n);
+    std::vector<int64_t> key((size_t)p.n, INT64_MAX);
+    for (int64_t I = 0; I < p.n; I++)
+        for (int r : roots) key[(size_t)I] = std::min(key[(size_t)I], eval_int(p, r, I));
+    return key;
+}
+std::vector<int64_t> locality_order(const Model &m, int pk) {
+    const Pattern &p = m.pats[pk];
+    std::vector<int64_t> key = locality_keys(m, pk), perm((size_t)p.n);
     for (int64_t I = 0; I < p.n; I++) {
-        int64_t k = INT64_MAX;
-        for (int r : roots) k = std::min(k, eval_int(p, r, I));
-        key[(size_t)I] = roots.empty() ? I : k;
+        if (key[(size_t)I] == INT64_MAX) key[(size_t)I] = I;      // (a pattern that reaches no variable keeps its order)
         perm[(size_t)I] = I;
     }
     std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });

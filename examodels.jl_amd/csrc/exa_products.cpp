@@ -421,6 +421,15 @@ int exa_tune(int id, int what, const double *x, const double *y) {
                 c = need(2, m.ncon); jv = need(3, h.lnnzj); hv = need(4, h.lnnzh);
                 (void)tune_order(h, CB_FUSED, [&] { do_fused(h, x, y, sigma, obj, c, jv, hv); });
             }
+            if (h.gridg > 0) {
+                // exa_eval_all with the gathered gradient's tiles inside the sweep's launch: its own block order, measured with the real call
+                c = need(2, m.ncon); jv = need(3, h.lnnzj); hv = need(4, h.lnnzh); g = need(5, m.nvar);
+                const std::vector<float> tv = ab_min(h, 2, 7, 6, [&](int k) { h.orderg = k; do_eval_all(h, x, y, sigma, obj, g, c, jv, hv); });
+                h.orderg = tv[0] < 0.99f * tv[1] ? 0 : 1;       // (the interleaved order is the default: the sequential one must win by more than the noise)
+                HIPCHK(hipStreamSynchronize(h.stream));
+                tune_store(source_key(h.gen.source), tune_signature(h, "orderg"), h.orderg);
+                if (verbose()) fprintf(stderr, "[exahip] tune exa_eval_all block order (ms per 6 launches): sequential %.4f interleaved %.4f -> %d\n", tv[0], tv[1], h.orderg);
+            }
         }
         if (what & 2) {
             g = need(5, m.nvar);

@@ -93,6 +93,10 @@ struct Handle {
     int64_t gridobj[2] = {0, 0};
     std::vector<std::pair<int64_t, int64_t>> con_hess_ranges;
     int order[CB_COUNT] = {0};              // which map is active
+    // exa_eval_all with the gathered gradient's tiles in the sweep's launch (dmapg): its own block order.  -1 = never measured: the
+    // interleaved one (a gradient tile then runs right after the tiles that pulled its stretch of x into L2 — LV 1e7: 0.201 ms
+    // against 0.218 sequential, profiles/NOTES.md round 3); exa_tune measures both with the real call and persists the winner
+    int orderg = -1;
     int norders[CB_COUNT] = {1};            // how many maps exist: exa_tune measures all of them
     int hess_variant = 0;                   // hess_coord! kernel: 0 exa_hess (one tile per workgroup), 1 chained, grouped, pipelined: exa_hesscl
                                             // (x staged through LDS) where this shard's stretches fit, else exa_hessc; 2 exa_hessc always
@@ -101,6 +105,12 @@ struct Handle {
     int64_t fused_nobj = 0;                 // objective partial sums written by exa_fused
     std::vector<DevBuf> dcols;              // flattened over patterns
     std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
+    // locality-ordered copies of table-driven patterns (ParamLayout::Pat::perm): [pattern][col] -> index into dcols of the permuted
+    // copy (-1: none); origslot[table pattern] -> dcols index of "original row of permuted row I" (-1: no permutation built: the
+    // table is short, or already in that order); locality: installed in P (exa_set_locality / EXAHIP_LOCALITY=0 switch it off)
+    std::vector<std::vector<int>> colslotq;
+    std::vector<int> origslot;
+    bool locality = true;
     DevBuf sx, sy, sv, sout, srows, scols;  // scratch of the *_host variants
     CompressedCOO cj, ch;                   // duplicate-summed COO maps (exa_compress)
     DevBuf cbuf;                            // uncompressed values of the last compressed evaluation

@@ -74,6 +74,14 @@ void fill_params(Handle &h) {
             if (p.cols[c].type == EXA_COL_RANGE) h.P[pp.col[c]] = p.cols[c].start;
             else h.P[pp.col[c]] = h.on_device ? (int64_t)(uintptr_t)h.dcols[h.colslot[k][c]].p : 0;
         }
+        if (pp.perm) {
+            // the order-free kernels' view of the table: the locality-ordered copy where one was built and is switched on, else the
+            // caller's order through the same words (origq = 0: "row I is row I")
+            const bool on = h.on_device && h.locality && !h.origslot.empty() && h.origslot[(size_t)pp.table] >= 0;
+            if (pp.table == (int)k) h.P[pp.origq] = on ? (int64_t)(uintptr_t)h.dcols[(size_t)h.origslot[k]].p : 0;
+            for (size_t c = 0; c < p.cols.size(); c++)
+                h.P[pp.colq[c]] = on ? (int64_t)(uintptr_t)h.dcols[(size_t)h.colslotq[k][c]].p : h.P[pp.col[c]];
+        }
     }
     if (h.on_device) h.dsink.ensure(8 * 64);
     h.lnnzj = local ? l1 : m.nnzj;
@@ -158,6 +166,10 @@ void fill_params(Handle &h) {
                 std::vector<int64_t> nbg = nb;
                 nbg.push_back((ve - vb + per - 1) / per);
                 h.gridg = total + nbg.back();
+                {
+                    int pv = -1;
+                    h.orderg = tune_lookup(source_key(h.gen.source), tune_signature(h, "orderg"), &pv) && (pv == 0 || pv == 1) ? pv : -1;
+                }
                 for (int k = 0; k < 2; k++) {
                     std::vector<int64_t> mp = build_units(nbg, k ? 128 : 0);
                     h.dmapg[k].ensure(sizeof(int64_t) * std::max<size_t>(mp.size(), 1));
@@ -339,7 +351,9 @@ CodeObject module_for(Handle &h, bool memory_only_ok) {
     bool regen = false;
     {
         std::vector<KernelInfo> ks;
-        if (!h.nostage && h.gen.layout.staged && code_object_kernels(co.image, ks)) {
+        // (EXAHIP_KEEP_STAGE=1 — test infrastructure for the A/B of profiles/r5_rocket_staging_ab.txt: keep an over-sized exa_hesscl)
+        const char *keep = getenv("EXAHIP_KEEP_STAGE");
+        if (!(keep && *keep == '1') && !h.nostage && h.gen.layout.staged && code_object_kernels(co.image, ks)) {
             bool cl_big = false, rest_big = false;
             for (const KernelInfo &k : ks) { if (k.name == "exa_hesscl") cl_big = !k.fits(); else if (k.name != "exa_grad" && k.name != "exa_jtprod" && k.name != "exa_hprod") rest_big = rest_big || !k.fits(); }
             if (cl_big && !rest_big) { h.nostage = true; regen = true; }
@@ -395,14 +409,50 @@ void to_device(Handle &h) {
     if (m.aug_linear || m.nconaug == 0) h.f_jprod1 = fn("exa_jprod1");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
     h.colslot.resize(m.pats.size());
+    h.colslotq.resize(m.pats.size());
+    h.origslot.assign(m.pats.size(), -1);
+    {
+        const char *le = getenv("EXAHIP_LOCALITY");
+        if (le && *le == '0') h.locality = false;
+    }
+    // Locality-ordered copies (ParamLayout::Pat::perm) — the reference sorts its scatter lists at build too (KA ext :44-53, 79-101).
+    // One permutation per table: rows in ascending order of the smallest variable any member pattern reaches through a data column
+    // at that row (stable: ties keep the caller's order) — for a branch table, by bus.  Built from the host columns, before they are
+    // released; tables of fewer than 4 096 rows and tables already in that order keep the caller's (no copy, origslot = -1).
+    std::vector<std::vector<int64_t>> perms(m.pats.size());
+    for (size_t r = 0; r < m.pats.size(); r++) {
+        const ParamLayout &L = h.gen.layout;
+        if (!L.pat[r].perm || L.pat[r].table != (int)r || m.pats[r].n < 4096) continue;
+        const int64_t n = m.pats[r].n;
+        std::vector<int64_t> key((size_t)n, INT64_MAX), perm((size_t)n);
+        for (size_t k = r; k < m.pats.size(); k++) {
+            if (L.pat[k].table != (int)r) continue;
+            const std::vector<int64_t> kk = locality_keys(m, (int)k);
+            for (int64_t I = 0; I < n; I++) key[(size_t)I] = std::min(key[(size_t)I], kk[(size_t)I]);
+        }
+        bool sorted = true;
+        for (int64_t I = 0; I < n; I++) { perm[(size_t)I] = I; sorted = sorted && (I == 0 || key[(size_t)I - 1] <= key[(size_t)I]); }
+        if (sorted) continue;
+        std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });
+        DevBuf ob;
+        ob.ensure(8 * (size_t)n);
+        HIPCHK(hipMemcpy(ob.p, perm.data(), 8 * (size_t)n, hipMemcpyHostToDevice));
+        h.origslot[r] = (int)h.dcols.size();
+        h.dcols.push_back(ob);
+        perms[r] = std::move(perm);
+    }
     for (size_t k = 0; k < m.pats.size(); k++) {
         Pattern &p = m.pats[k];
         h.colslot[k].assign(p.cols.size(), -1);
+        h.colslotq[k].assign(p.cols.size(), -1);
+        const int tab = h.gen.layout.pat[k].perm ? h.gen.layout.pat[k].table : -1;
+        const std::vector<int64_t> *perm = tab >= 0 && h.origslot[(size_t)tab] >= 0 ? &perms[(size_t)tab] : nullptr;
         for (size_t c = 0; c < p.cols.size(); c++) {
             Column &col = p.cols[c];
             if (col.type == EXA_COL_RANGE) continue;
             if (col.alias_pat >= 0) {      // a copy of a column that is already resident (exa_plan.cpp)
                 h.colslot[k][c] = h.colslot[col.alias_pat][col.alias_col];
+                h.colslotq[k][c] = h.colslotq[col.alias_pat][col.alias_col];
                 std::vector<int64_t>().swap(col.idata);
                 std::vector<double>().swap(col.fdata);
                 continue;
@@ -413,6 +463,16 @@ void to_device(Handle &h) {
             if (p.n) HIPCHK(hipMemcpy(b.p, src, 8 * (size_t)p.n, hipMemcpyHostToDevice));
             h.colslot[k][c] = (int)h.dcols.size();
             h.dcols.push_back(b);
+            if (perm) {
+                std::vector<int64_t> tmp((size_t)p.n);        // 8-byte words either way: permuted as raw bits
+                const int64_t *raw = (const int64_t *)src;
+                for (int64_t I = 0; I < p.n; I++) tmp[(size_t)I] = raw[(size_t)(*perm)[(size_t)I]];
+                DevBuf q;
+                q.ensure(8 * (size_t)p.n);
+                HIPCHK(hipMemcpy(q.p, tmp.data(), 8 * (size_t)p.n, hipMemcpyHostToDevice));
+                h.colslotq[k][c] = (int)h.dcols.size();
+                h.dcols.push_back(q);
+            }
             // the host copy is no longer needed once resident in HBM
             std::vector<int64_t>().swap(col.idata);
             std::vector<double>().swap(col.fdata);
@@ -670,7 +730,7 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
         const bool owner = h.gen.layout.active[CB_GRAD].empty();
         own_lo = h.world > 1 ? own_var_lo(h, h.rank) : 0; own_hi = h.world > 1 ? own_var_lo(h, h.rank + 1) : h.m->nvar;
         vb = owner ? own_lo : 0; ve = owner ? own_hi : h.m->nvar;
-        bmap = h.dmapg[h.order[CB_FUSED] ? 1 : 0].p;
+        bmap = h.dmapg[(h.orderg >= 0 ? h.orderg : 1) ? 1 : 0].p;
         n = h.gridg;
     }
     // objective partial sums: up to kObjFoldMax of them are folded by the objective workgroup that arrives last (as in do_obj)
@@ -786,7 +846,8 @@ int create(const exa_model_desc_t *desc, int *id_out, bool device) {
             h->first_key = source_key(h->gen.source);
             h->first_note = note0;
             h->loopfree_scatter = note0.find("loopfree") != std::string::npos;
-            h->nostage = note0.find("nostage") != std::string::npos;
+            const char *keep = getenv("EXAHIP_KEEP_STAGE");           // (test infrastructure: see module_for)
+            h->nostage = note0.find("nostage") != std::string::npos && !(keep && *keep == '1');
             h->gen = generate_module(*h->m, h->loopfree_scatter, h->nostage);
         }
         plan_products(*h);
@@ -1078,6 +1139,24 @@ int exa_locality_order(int id, int pattern, int64_t *perm_out) {
         std::memcpy(perm_out, perm.data(), 8 * perm.size());
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 2; }
+}
+
+/* The library's OWN use of that order (round 5): kernels whose result does not depend on the order in which the data points are
+ * evaluated — grad!, J'v and Hv by atomics into a zeroed vector — run on a locality-ordered COPY of every table-driven pattern's
+ * columns, built once at model build (one permutation per table; tables under 4 096 rows or already in order: none).  COO, rows and
+ * structures keep the caller's order.  on = 1 / 0 switches the copies in / out (EXAHIP_LOCALITY=0 in the environment: out from the
+ * start), on < 0 only asks.  Returns the number of tables with an installed permutation (0: none built, or switched off), -1 on a
+ * bad id. */
+int exa_set_locality(int id, int on) {
+    Handle *h = get(id);
+    if (!h) return -1;
+    int built = 0;
+    for (int s : h->origslot) built += s >= 0;
+    if (on >= 0 && h->on_device && (on != 0) != h->locality) {
+        const int st = guard(id, true, [&](Handle &hh) { hh.locality = on != 0; fill_params(hh); });
+        if (st != 0) return -1;
+    }
+    return h->locality ? built : 0;
 }
 
 // pattern-table view of a planned model that still holds its host columns

@@ -292,6 +292,11 @@ class ExaModel:
         capi.check(self._L.exa_locality_order(self.id, k, out.ctypes.data), "exa_locality_order")
         return out[:self.pattern_info(k)["n"]]
 
+    def set_locality(self, on=-1):
+        """exa_set_locality: the locality-ordered table copies of the order-free kernels (grad!, J'v, Hv by atomics) in / out; -1 asks.
+        Returns the number of tables with an installed permutation."""
+        return self._L.exa_set_locality(self.id, int(on))
+
     def kernel_source(self):
         return self._L.exa_kernel_source(self.id).decode()
 

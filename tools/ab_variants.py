@@ -20,7 +20,7 @@ if args and args[0] == "--cb":
 N = int(float(os.environ.get("SWEEP_N", "1e7")))
 which = os.environ.get("SWEEP_MODEL", "lv")
 reps = int(os.environ.get("SWEEP_REPS", "200" if N <= 2e7 else "40"))
-core = {"lv": lambda: models.luksan_vlcek_model(N), "rocket": lambda: models.rocket_model(1_000_000), "chain": lambda: models.cops_chain_model(N),
+core = {"lv": lambda: models.luksan_vlcek_model(N), "rocket": lambda: models.rocket_model(N if os.environ.get("SWEEP_N") else 1_000_000), "chain": lambda: models.cops_chain_model(N),
         "acopf": lambda: models.ac_power_model(models.synthetic_power_data(78_484, 126_015, 6_800, seed=0))}[which]()
 dev = torch.device("cuda:0")
 runs = {}
