@@ -53,7 +53,10 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
             if (table[k] == k) pp.origq = w++;
             for (size_t c = 0; c < m.pats[k].cols.size(); c++) {
                 const Column &col = m.pats[k].cols[c];
-                pp.colq.push_back(col.alias_pat >= 0 ? L.pat[col.alias_pat].colq[col.alias_col] : w++);
+                // (an aliased column shares the word of its first copy only when that copy is permuted by the SAME table's permutation:
+                // columns are aliased by content, so a pattern may alias columns of patterns over other tables)
+                const bool share = col.alias_pat >= 0 && L.pat[col.alias_pat].perm && L.pat[col.alias_pat].table == pp.table;
+                pp.colq.push_back(share ? L.pat[col.alias_pat].colq[col.alias_col] : w++);
             }
         }
     }

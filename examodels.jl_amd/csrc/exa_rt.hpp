@@ -110,7 +110,7 @@ struct Handle {
     // table is short, or already in that order); locality: installed in P (exa_set_locality / EXAHIP_LOCALITY=0 switch it off)
     std::vector<std::vector<int>> colslotq;
     std::vector<int> origslot;
-    bool locality = true;
+    bool locality = false;
     DevBuf sx, sy, sv, sout, srows, scols;  // scratch of the *_host variants
     CompressedCOO cj, ch;                   // duplicate-summed COO maps (exa_compress)
     DevBuf cbuf;                            // uncompressed values of the last compressed evaluation

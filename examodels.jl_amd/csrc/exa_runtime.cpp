@@ -80,7 +80,10 @@ void fill_params(Handle &h) {
             const bool on = h.on_device && h.locality && !h.origslot.empty() && h.origslot[(size_t)pp.table] >= 0;
             if (pp.table == (int)k) h.P[pp.origq] = on ? (int64_t)(uintptr_t)h.dcols[(size_t)h.origslot[k]].p : 0;
             for (size_t c = 0; c < p.cols.size(); c++)
+            {
+                if (on && h.colslotq[k][c] < 0) throw std::logic_error("locality copy: a column of a permuted table has no permuted copy");
                 h.P[pp.colq[c]] = on ? (int64_t)(uintptr_t)h.dcols[(size_t)h.colslotq[k][c]].p : h.P[pp.col[c]];
+            }
         }
     }
     if (h.on_device) h.dsink.ensure(8 * 64);
@@ -412,8 +415,11 @@ void to_device(Handle &h) {
     h.colslotq.resize(m.pats.size());
     h.origslot.assign(m.pats.size(), -1);
     {
+        // measured (profiles/r5_locality_ab.txt): on the random ACOPF graph the copies LOSE (J'v 0.040 -> 0.054 ms, Hv 0.038 -> 0.053) — sorting
+        // the branch rows by bus makes the gathers of ONE end local and turns the seven coalesced v[row] / y[row] reads of a fused group
+        // into gathers.  Off unless asked for (EXAHIP_LOCALITY=1, exa_set_locality): kept for tables whose patterns read nothing by row.
         const char *le = getenv("EXAHIP_LOCALITY");
-        if (le && *le == '0') h.locality = false;
+        h.locality = le && *le == '1';
     }
     // Locality-ordered copies (ParamLayout::Pat::perm) — the reference sorts its scatter lists at build too (KA ext :44-53, 79-101).
     // One permutation per table: rows in ascending order of the smallest variable any member pattern reaches through a data column
@@ -450,9 +456,22 @@ void to_device(Handle &h) {
         for (size_t c = 0; c < p.cols.size(); c++) {
             Column &col = p.cols[c];
             if (col.type == EXA_COL_RANGE) continue;
+            auto permuted_copy = [&](const void *src) {      // 8-byte words either way: permuted as raw bits
+                std::vector<int64_t> tmp((size_t)p.n);
+                const int64_t *raw = (const int64_t *)src;
+                for (int64_t I = 0; I < p.n; I++) tmp[(size_t)I] = raw[(size_t)(*perm)[(size_t)I]];
+                DevBuf q;
+                q.ensure(8 * (size_t)p.n);
+                HIPCHK(hipMemcpy(q.p, tmp.data(), 8 * (size_t)p.n, hipMemcpyHostToDevice));
+                h.colslotq[k][c] = (int)h.dcols.size();
+                h.dcols.push_back(q);
+            };
             if (col.alias_pat >= 0) {      // a copy of a column that is already resident (exa_plan.cpp)
                 h.colslot[k][c] = h.colslot[col.alias_pat][col.alias_col];
-                h.colslotq[k][c] = h.colslotq[col.alias_pat][col.alias_col];
+                // its permuted copy too, when the first copy is permuted by the same table's permutation (else this pattern gets its own)
+                const auto &ap = h.gen.layout.pat[(size_t)col.alias_pat];
+                if (perm && ap.perm && ap.table == tab) h.colslotq[k][c] = h.colslotq[col.alias_pat][col.alias_col];
+                else if (perm) permuted_copy(col.type == EXA_COL_I64 ? (const void *)col.idata.data() : (const void *)col.fdata.data());
                 std::vector<int64_t>().swap(col.idata);
                 std::vector<double>().swap(col.fdata);
                 continue;
@@ -463,16 +482,7 @@ void to_device(Handle &h) {
             if (p.n) HIPCHK(hipMemcpy(b.p, src, 8 * (size_t)p.n, hipMemcpyHostToDevice));
             h.colslot[k][c] = (int)h.dcols.size();
             h.dcols.push_back(b);
-            if (perm) {
-                std::vector<int64_t> tmp((size_t)p.n);        // 8-byte words either way: permuted as raw bits
-                const int64_t *raw = (const int64_t *)src;
-                for (int64_t I = 0; I < p.n; I++) tmp[(size_t)I] = raw[(size_t)(*perm)[(size_t)I]];
-                DevBuf q;
-                q.ensure(8 * (size_t)p.n);
-                HIPCHK(hipMemcpy(q.p, tmp.data(), 8 * (size_t)p.n, hipMemcpyHostToDevice));
-                h.colslotq[k][c] = (int)h.dcols.size();
-                h.dcols.push_back(q);
-            }
+            if (perm) permuted_copy(src);
             // the host copy is no longer needed once resident in HBM
             std::vector<int64_t>().swap(col.idata);
             std::vector<double>().swap(col.fdata);
@@ -1144,8 +1154,8 @@ int exa_locality_order(int id, int pattern, int64_t *perm_out) {
 /* The library's OWN use of that order (round 5): kernels whose result does not depend on the order in which the data points are
  * evaluated — grad!, J'v and Hv by atomics into a zeroed vector — run on a locality-ordered COPY of every table-driven pattern's
  * columns, built once at model build (one permutation per table; tables under 4 096 rows or already in order: none).  COO, rows and
- * structures keep the caller's order.  on = 1 / 0 switches the copies in / out (EXAHIP_LOCALITY=0 in the environment: out from the
- * start), on < 0 only asks.  Returns the number of tables with an installed permutation (0: none built, or switched off), -1 on a
+ * structures keep the caller's order.  on = 1 / 0 switches the copies in / out (default OUT — they lose where the patterns also read by
+ * row, profiles/r5_locality_ab.txt; EXAHIP_LOCALITY=1 in the environment: in from the start), on < 0 only asks.  Returns the number of tables with an installed permutation (0: none built, or switched off), -1 on a
  * bad id. */
 int exa_set_locality(int id, int on) {
     Handle *h = get(id);

@@ -145,3 +145,35 @@ def test_no_kernel_of_the_benchmark_modules_has_the_fault_pattern(make, tmp_path
     m.compile()
     for name, blob in m.code_objects():
         assert _fault_sites(blob, tmp_path, name) == {}, name
+
+
+def _scan_one(path):
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("isa_prologue_check", os.path.join(root, "tools", "isa_prologue_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    return path, {k: len(sites) for k, (sites, _, _) in chk.check_file(path).items() if sites}
+
+
+def test_no_kernel_of_any_zoo_module_has_the_fault_pattern(tmp_path):
+    """VERDICT r4 item 1c, on the cause instead of on a register count: every kernel of every module (model + product windows) of every zoo
+    model, as the library builds them, disassembled and searched for vector instructions in front of a join block's exec restore."""
+    import multiprocessing
+    import os
+    from zoo import ZOO
+    paths = []
+    for name, mk in ZOO.items():
+        m = ExaModel(mk(), device=False)
+        m.compile()
+        for k, (obj, blob) in enumerate(m.code_objects()):
+            p = str(tmp_path / f"{name}_{k}.hsaco")
+            with open(p, "wb") as fh:
+                fh.write(blob)
+            paths.append(p)
+    with multiprocessing.get_context("spawn").Pool(min(8, os.cpu_count() or 1)) as pool:
+        res = pool.map(_scan_one, paths)
+    bad = {os.path.basename(p): r for p, r in res if r}
+    assert not bad, bad
+    assert len(paths) >= len(ZOO)

@@ -1,14 +1,14 @@
 #!/usr/bin/env python
 """Rewrites the number rows of DESIGN.md §5 (the contract line table and the per-callback table) from the files under profiles/
-that they cite — profiles/r4_bench_default.json and profiles/r4_callbacks_config{2,3,4}.json — so that a refresh of the evidence
-(tools/refresh_profiles_r4.sh) and the document cannot drift apart.  usage: python tools/design_tables.py  (from the repo root)"""
+that they cite — profiles/r5_bench_default.json and profiles/r5_callbacks_config{2,3,4}.json — so that a refresh of the evidence
+(tools/refresh_profiles_r5.sh) and the document cannot drift apart.  usage: python tools/design_tables.py  (from the repo root)"""
 import json
 import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-b = json.loads(open(os.path.join(P, "r4_bench_default.json")).read().strip().splitlines()[-1])
-cb = {c: json.load(open(os.path.join(P, f"r4_callbacks_config{c}.json")))["callbacks"] for c in (2, 3, 4)}
+b = json.loads(open(os.path.join(P, "r5_bench_default.json")).read().strip().splitlines()[-1])
+cb = {c: json.load(open(os.path.join(P, f"r5_callbacks_config{c}.json")))["callbacks"] for c in (2, 3, 4)}
 path = os.path.join(ROOT, "DESIGN.md")
 lines = open(path).read().split("\n")
 
@@ -56,4 +56,4 @@ sub("| all five (`exa_eval_all`) |", f"| all five (`exa_eval_all`) | `exa_fused`
 sub("| compressed Hessian |", f"| compressed Hessian | `exa_chessw` (+`s`,`x`) / `exa_chessm` | instruction issue | {c('chess', 2)} | {fr('chess')} | {c('chess', 3)} | {c('chess', 4)} |")
 sub("| compressed Jacobian |", f"| compressed Jacobian | `exa_cjacw` / `exa_cjacp` | instruction issue | {c('cjac', 2)} | {fr('cjac')} | {c('cjac', 3)} | {c('cjac', 4)} |")
 open(path, "w").write("\n".join(lines))
-print("DESIGN.md §5 rows rewritten from profiles/r4_bench_default.json and profiles/r4_callbacks_config{2,3,4}.json")
+print("DESIGN.md §5 rows rewritten from profiles/r5_bench_default.json and profiles/r5_callbacks_config{2,3,4}.json")

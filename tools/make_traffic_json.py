@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/r4_traffic_config<k>.json from the PMC passes of tools/refresh_profiles_r4.sh: HBM bytes per launch of the
+"""profiles/r5_traffic_config<k>.json from the PMC passes of tools/refresh_profiles_r5.sh: HBM bytes per launch of the
 Hessian kernel = WRITE_SIZE + corrected FETCH_SIZE (separate rocprofv3 --pmc passes, per-dispatch averages), stamped with
 the NAME OF THE MODULE it was measured on and the workload size — bench.py attaches the number only when both match.
 usage: make_traffic_json.py CONFIG bench.json fetch_summary.txt write_summary.txt > profiles/r2_traffic_configK.json"""
@@ -26,7 +26,7 @@ CORR = 1.9391      # profiles/r1_pmc_calibration_store_bench.txt: a kernel readi
 out = {
     "workload": line["config"]["workload"], "baseline_config": config, "points": line["config"].get("points"),
     "module": line["build"]["module_name"], "kernel": kernel,
-    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/refresh_profiles_r4.sh), per-dispatch averages",
+    "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tools/refresh_profiles_r5.sh), per-dispatch averages",
     "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb, "dispatches": [nf, nw],
     "fetch_correction": CORR,
     "fetch_correction_source": "profiles/r1_pmc_calibration_store_bench.txt (the guide's gfx950 'FETCH_SIZE reports 1/2', calibrated on this access pattern); WRITE_SIZE needs none",

@@ -1,12 +1,12 @@
 #!/usr/bin/env python
 """Joins one tools/run_callbacks.py JSON with the rocprofv3 databases of the SAME command (a --kernel-trace --stats run and
-separate --pmc passes, tools/refresh_profiles_r4.sh) into one table per config: for every generated kernel its average
+separate --pmc passes, tools/refresh_profiles_r5.sh) into one table per config: for every generated kernel its average
 duration, the algorithmic bytes of the callback it serves, achieved GB/s against the 8 TB/s HBM peak, HBM traffic from
 the counters (WRITE_SIZE + 1.94 x FETCH_SIZE: the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md, calibrated
 in profiles/r1_pmc_calibration_store_bench.txt), VALU wavefront-instructions, the wait fractions and the busy cycles.
 Every fraction quoted in DESIGN.md §5 is recomputable from this file.
 
-usage: roofline_table.py callbacks.json STATS_DIR [PMC_DIR...] > profiles/r4_kernels_config<k>.md"""
+usage: roofline_table.py callbacks.json STATS_DIR [PMC_DIR...] > profiles/r5_kernels_config<k>.md"""
 import glob
 import json
 import os
