@@ -20,7 +20,7 @@ for variant in "default|" "safe|-mllvm -grow-region-complexity-budget=0" "sgpr-f
         printf "%-10s %-6s " "$name" "$p"
         "$tmp/canary_host" "$dir/hprodw_canary.dump" "$tmp/$name.hsaco" $p
         rc=$?
-        if [ "$name" = safe ] && [ $rc -ne 0 ]; then status=1; fi
+        if { [ "$name" = safe ] || [ "$name" = sgpr-basic ]; } && [ $rc -ne 0 ]; then status=1; fi
     done
 done
 rm -rf "$tmp"

@@ -87,3 +87,37 @@ def test_oracle_matches_symbolic_derivatives(libs, name):
     r, c = o.hess_structure()
     H = dense_lower(r, c, o.hess_coord(X0, np.array([-1.75]), 0.0), NVAR)
     assert close(H, -1.75 * gold_H)
+
+
+def test_the_quad_arbiter_and_the_double_oracle_agree_within_the_running_error_bound(libs):
+    """oracle/exa_quad.h: cons_nln! evaluated in __float128 with the first-order running error bound of a double-precision evaluation
+    (Higham 3.3).  On every zoo model and on an ACOPF network whose power-balance rows cancel, the double oracle is within the bound of the
+    quad value, row by row — what lets the GPU tests use the pair (1e-10 of the quad value, or K x the bound) as north_star's bar
+    (tests/conftest.py parity_cons).  Also pins the arbiter: where nothing cancels, quad and double agree to a few ulp."""
+    import oracle
+    from exahip import ExaModel, models
+    from zoo import ZOO, point
+    eps = np.finfo(np.float64).eps
+    cases = [(name, mk(), None) for name, mk in ZOO.items()]
+    core = models.ac_power_model(models.synthetic_power_data(3000, 4500, 300, seed=2))
+    cases.append(("acopf3000", core, models.acopf_start(core)))
+    seen_quad = 0
+    for name, core, x0 in cases:
+        m = ExaModel(core, device=False)
+        if m.meta.ncon == 0:
+            continue
+        o = oracle.OracleModel(m.ir)
+        x = x0 if x0 is not None else point(m.meta.x0, m.meta.ncon)[0]
+        quad = o.cons_quad(x)
+        if quad is None:
+            assert name == "specialfn"           # the SpecialFunctions extension has no quad restatement
+            continue
+        seen_quad += 1
+        q, e = quad
+        c = o.cons(x)
+        d = np.abs(c - q)
+        assert np.all(d <= 2.0 * eps * e + 1e-300), (name, float(np.max(d / np.maximum(eps * e, 1e-300))))
+        # rows that do not cancel (the result is at least a thousandth of what was summed): a few ulp apart
+        big = np.abs(q) * 1e3 >= e
+        assert np.all(d[big] <= 1e-12 * np.abs(q[big])), name
+    assert seen_quad >= 14
