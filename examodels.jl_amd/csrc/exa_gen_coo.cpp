@@ -476,12 +476,22 @@ void gen_fused_group_fn(std::ostringstream &os, const Model &m, const ParamLayou
             sc.merge();
             for (; emitted < E.lines.size(); emitted++) os << "    " << E.lines[emitted] << "\n";
             os << "    if (gout) {\n        const bool act = I0 < hi;\n";
+            // one-launch exa_eval_all (ParamLayout::gbits): the model build has PROVEN on the data that no variable is named twice by
+            // these items — each is then the variable's whole gradient entry: a plain store, no zero-filled g, no atomics (the
+            // untouched variables get their 0.0 from the zero tiles of the same launch)
+            if (L.gbits >= 0) {
+                os << "        if (P[" << L.gbits << "]) {\n";
+                for (const Scatter::Item &it : sc.items)
+                    os << "            if (act) gout[" << E.s(E.sub(it.vidx, Emitter::liti(1))) << "] = " << E.sd(it.val) << ";\n";
+                os << "        } else {\n";
+            }
             for (const Scatter::Item &it : sc.items) {
                 const std::string idx = E.s(E.sub(it.vidx, Emitter::liti(1)));
                 if (it.vidx.is_lit()) os << "        exa_wave_atomic_add(&gout[" << idx << "], act ? " << E.sd(it.val) << " : 0.0);\n";
                 else if (!affine(*it.p, it.ir).ok) os << "        exa_scatter_add1(gout, " << idx << ", " << E.sd(it.val) << ", act);\n";
                 else os << "        if (act) exa_atomic_add(&gout[" << idx << "], " << E.sd(it.val) << ");\n";
             }
+            if (L.gbits >= 0) os << "        }\n";
             os << "    }\n";
         }
         if (isobj) ret = "(I0 < hi ? " + E.sd(value) + " : 0.0)";

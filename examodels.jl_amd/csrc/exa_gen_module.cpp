@@ -79,6 +79,8 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
         L.active[CB_FUSED].push_back(k);
     }
     for (int cb = 0; cb < CB_COUNT; cb++) { L.blk[cb] = w++; L.ppt[cb] = 1; L.chain[cb] = cb == CB_HESSC ? kChainTiles : 0; }
+    // one-launch exa_eval_all (ParamLayout::gbits): only models whose objective gradient is scattered inside the sweep and nowhere else
+    if (!L.active[CB_GRAD].empty() && L.pull.empty()) L.gbits = w++;
     g_handover.clear();
     // EXAHIP_GROUP=0: every pattern on its own everywhere (the ungrouped kernels the grouped ones must equal bit for bit)
     const bool grouping = env_int("EXAHIP_GROUP", 1) != 0;
@@ -477,6 +479,13 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
                 os << " const double s = exa_block_sum(v); exa_obj_arrive(part, P[" << L.pat[grps[k].front()].ob << "] + tile_, s, done, nobj, obj_out);";
             else os << " (void)v;";
             os << " }\n";
+        }
+        if (L.gbits >= 0) {
+            // the zero tiles of the one-launch exa_eval_all: 0.0 for every variable no objective point writes (bitmap built at model build)
+            os << "    " << (grps.empty() ? "" : "else ") << "if (ps_ == " << grps.size() << ") {\n"
+                  "        const unsigned long long* bits = (const unsigned long long*)P[" << L.gbits << "];\n"
+                  "#pragma unroll\n        for (int u = 0; u < 8; u++) {\n            const long v = tile_ * (EXA_BLOCK * 8) + u * EXA_BLOCK + threadIdx.x;\n"
+                  "            if (v < v_end && !((bits[v >> 6] >> (v & 63)) & 1ull)) __builtin_nontemporal_store(0.0, &gout[v]);\n        }\n    }\n";
         }
         if (!L.pull.empty()) {
             os << "    " << (grps.empty() ? "" : "else ") << "if (ps_ == " << grps.size() << ") {\n"

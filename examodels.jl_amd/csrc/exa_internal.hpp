@@ -92,6 +92,9 @@ std::unique_ptr<Model> plan_model(const exa_model_desc_t *desc);   // throws std
 std::vector<int64_t> locality_order(const Model &m, int pattern);   // exa_locality_order (exa_plan.cpp)
 // per data point: the smallest variable any x[...] of the pattern names there (INT64_MAX: none).  Needs the host columns.
 std::vector<int64_t> locality_keys(const Model &m, int pattern);
+// bits[v / 64] >> (v % 64) & 1 <- some first-order slot of some point of the objective patterns `pats` is the 0-based variable v; false = a variable is
+// named twice (by two points, or by two slots of one point whose index expressions differ): the scatter is not injective.  Needs the host columns.
+bool scatter_bitmap(const Model &m, const std::vector<int> &pats, std::vector<uint64_t> &bits);
 
 // ---------------------------------------------------------------------------------------------------
 // Code generator (exa_gen_*.cpp; internals in exa_gen.hpp)
@@ -158,6 +161,11 @@ struct ParamLayout {
     std::vector<std::vector<int>> groups[CB_COUNT];
     std::vector<int> gtiles[CB_COUNT];
     int nwords = 0;
+    // exa_eval_all in ONE launch for models whose in-sweep objective gradient (data-indexed scatter) hits every variable AT MOST ONCE
+    // (checked on the data at model build, unsharded models): word of the device address of the bitmap "variable is written by an
+    // objective point" — non-zero = the sweep's objective tiles STORE their first partials (no atomics, no zero-filled g) and one more
+    // unit of the block map writes 0.0 to every variable the bitmap does not name.  -1: the module has no such path.
+    int gbits = -1;
     std::vector<int> pull;               // objective patterns whose gradient is GATHERED per variable (exa_grad_pull)
     int pull_ppt = 1;                    // variables per thread of exa_grad_pull
 };

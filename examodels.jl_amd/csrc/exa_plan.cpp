@@ -358,6 +358,31 @@ std::vector<int64_t> locality_keys(const Model &m, int pk) {
         for (int r : roots) key[(size_t)I] = std::min(key[(size_t)I], eval_int(p, r, I));
     return key;
 }
+bool scatter_bitmap(const Model &m, const std::vector<int> &pats, std::vector<uint64_t> &bits) {
+    bits.assign((size_t)(m.nvar + 63) / 64, 0);
+    for (int pk : pats) {
+        const Pattern &p = m.pats[pk];
+        // the distinct index EXPRESSIONS of the first-order slots (slots with the same expression are merged in registers, Scatter::merge)
+        std::vector<int> roots;
+        for (int s = 0; s < p.o1step; s++) {
+            const int ir = p.ad[p.slotvar1[s]].ir;
+            bool seen = false;
+            for (int q : roots) seen = seen || p.ad[p.slotvar1[s]].key == p.ad[q].key;
+            (void)ir;
+            if (!seen) roots.push_back(p.slotvar1[s]);
+        }
+        for (int64_t I = 0; I < p.n; I++)
+            for (int leaf : roots) {
+                const int64_t v = eval_int(p, p.ad[leaf].ir, I) - 1;
+                if (v < 0 || v >= m.nvar) return false;
+                uint64_t &w = bits[(size_t)(v >> 6)];
+                const uint64_t bit = 1ull << (v & 63);
+                if (w & bit) return false;
+                w |= bit;
+            }
+    }
+    return true;
+}
 std::vector<int64_t> locality_order(const Model &m, int pk) {
     const Pattern &p = m.pats[pk];
     std::vector<int64_t> key = locality_keys(m, pk), perm((size_t)p.n);

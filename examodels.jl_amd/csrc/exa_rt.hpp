@@ -87,6 +87,10 @@ struct Handle {
     DevBuf dmap[CB_COUNT][2];               // per-callback block maps: [0] units one after the other, [1] interleaved in runs of 128
     DevBuf dmapg[2];                        // exa_eval_all: the fused sweep's units + the gathered-gradient tiles (same two orders)
     int64_t gridg = 0;
+    // one-launch exa_eval_all of models whose in-sweep objective gradient is injective (ParamLayout::gbits): the bitmap of written
+    // variables (empty: not injective / not applicable), the block maps with the zero tiles as one more unit, their grid
+    DevBuf dgbits, dmapz[2];
+    int64_t gridz = 0;
     // objective-only forms of hess_coord! / hprod! (y == NULL): a second parameter table whose CB_HESS / CB_HPROD block maps
     // hold the objective groups alone, and the COO ranges of the constraint patterns (they receive exact zeros)
     DevBuf dPobj, dmapobj[2];
@@ -193,7 +197,7 @@ struct Handle {
             daugcoef.release(); daugcsr.release(); daugsrc.release(); dsink.release(); dP.release(); dtheta.release(); dpart.release(); ddone.release(); dobj.release();
             daugbuf.release(); daugrows.release(); daugptr.release(); daugperm.release(); dauglong.release(); daugpartial.release();
             for (auto &b : dmap) { b[0].release(); b[1].release(); }
-            dmapg[0].release(); dmapg[1].release(); dPobj.release(); dmapobj[0].release(); dmapobj[1].release();
+            dmapg[0].release(); dmapg[1].release(); dgbits.release(); dmapz[0].release(); dmapz[1].release(); dPobj.release(); dmapobj[0].release(); dmapobj[1].release();
             cj.release(); ch.release(); cbuf.release();
             for (Window *w : {&wj, &wh, &wp[0], &wp[1]}) { w->Q.release(); w->R.release(); w->X.release(); w->T.release(); w->E.release(); w->xbuf.release(); w->S.release(); w->F.release(); w->part.release(); }
             sj.pos.release(); sh.pos.release(); chm.release(); dM.release();
@@ -250,7 +254,7 @@ void do_cons(Handle &h, const double *x, double *c);
 void do_jac(Handle &h, const double *x, double *v);
 void do_hess(Handle &h, const double *x, const double *y, double sigma, double *v);
 void do_fused(Handle &h, const double *x, const double *y, double sigma, double *obj_dev, double *c, double *jv, double *hv, double *gout = nullptr,
-              bool with_pull = false);
+              bool with_pull = false, bool with_zero = false);
 void do_eval_all(Handle &h, const double *x, const double *y, double sigma, double *obj_dev, double *g, double *c, double *jv, double *hv);
 void do_jprod(Handle &h, const double *x, const double *v, double *Jv);
 void do_jtprod(Handle &h, const double *x, const double *v, double *Jtv);

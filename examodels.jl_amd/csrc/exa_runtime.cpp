@@ -159,6 +159,22 @@ void fill_params(Handle &h) {
             return map;
         };
         auto build = [&](int64_t run_len) { return build_units(nb, run_len); };
+        if (cb == CB_FUSED && L.gbits >= 0) {
+            // one-launch exa_eval_all: unsharded models whose objective scatter was proven injective at the build (to_device)
+            h.gridz = 0;
+            h.P[L.gbits] = 0;
+            if (h.on_device && h.world == 1 && h.dgbits.p) {
+                h.P[L.gbits] = (int64_t)(uintptr_t)h.dgbits.p;
+                std::vector<int64_t> nbz = nb;
+                nbz.push_back((m.nvar + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8));
+                h.gridz = total + nbz.back();
+                for (int k = 0; k < 2; k++) {
+                    std::vector<int64_t> mp = build_units(nbz, k ? 128 : 0);
+                    h.dmapz[k].ensure(sizeof(int64_t) * std::max<size_t>(mp.size(), 1));
+                    if (!mp.empty()) HIPCHK(hipMemcpy(h.dmapz[k].p, mp.data(), sizeof(int64_t) * mp.size(), hipMemcpyHostToDevice));
+                }
+            }
+        }
         if (cb == CB_FUSED) {
             // exa_eval_all: the same units + the tiles of the gathered gradient as one more unit (see exa_fused)
             h.gridg = 0;
@@ -425,6 +441,14 @@ void to_device(Handle &h) {
     // One permutation per table: rows in ascending order of the smallest variable any member pattern reaches through a data column
     // at that row (stable: ties keep the caller's order) — for a branch table, by bus.  Built from the host columns, before they are
     // released; tables of fewer than 4 096 rows and tables already in that order keep the caller's (no copy, origslot = -1).
+    // one-launch exa_eval_all (ParamLayout::gbits): is the objective's in-sweep scatter injective on THIS data?
+    if (h.gen.layout.gbits >= 0 && m.nvar > 0) {
+        std::vector<uint64_t> bits;
+        if (scatter_bitmap(m, h.gen.layout.active[CB_GRAD], bits)) {
+            h.dgbits.ensure(8 * bits.size());
+            HIPCHK(hipMemcpy(h.dgbits.p, bits.data(), 8 * bits.size(), hipMemcpyHostToDevice));
+        }
+    }
     std::vector<std::vector<int64_t>> perms(m.pats.size());
     for (size_t r = 0; r < m.pats.size(); r++) {
         const ParamLayout &L = h.gen.layout;
@@ -720,7 +744,7 @@ void do_hess(Handle &h, const double *x, const double *y, double sigma, double *
 // gout: null, or the gradient vector the objective patterns that are NOT gathered per variable add their first partials
 // to (exa_eval_all; the caller has zero-filled it or run exa_grad_pull into it)
 void do_fused(Handle &h, const double *x, const double *y, double sigma, double *obj_dev, double *c, double *jv, double *hv, double *gout,
-              bool with_pull) {
+              bool with_pull, bool with_zero) {
     const void *P = h.dP.p, *th = h.dtheta.p;
     void *part = h.dpart.p, *buf = h.daugbuf.p;
     // linear augmentation terms are added inside the sweep through the row lists of exa_cons1 when those exist: the rows a
@@ -742,6 +766,11 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
         vb = owner ? own_lo : 0; ve = owner ? own_hi : h.m->nvar;
         bmap = h.dmapg[(h.orderg >= 0 ? h.orderg : 1) ? 1 : 0].p;
         n = h.gridg;
+    }
+    if (with_zero && h.gridz > 0) {      // the zero tiles of the injective in-sweep gradient ride as one more unit (no order between them and anything)
+        ve = h.m->nvar;
+        bmap = h.dmapz[h.order[CB_FUSED] ? 1 : 0].p;
+        n = h.gridz;
     }
     // objective partial sums: up to kObjFoldMax of them are folded by the objective workgroup that arrives last (as in do_obj)
     int64_t nobj = h.fused_nobj;
@@ -779,11 +808,13 @@ void do_eval_all(Handle &h, const double *x, const double *y, double sigma, doub
         void *a0[] = {&P, &x, &th, &g, &vb, &ve, &own_lo, &own_hi};
         const int64_t per = (int64_t)kBlock * L.pull_ppt;
         launch(h, h.f_gradpull, (ve - vb + per - 1) / per, kBlock, a0);
-    } else if (!pull) {
-        zero_fill(h, g, nvar);
     }
+    // scattered patterns only: the sweep adds their first partials to a zero-filled g by atomics — or, where the build proved the scatter
+    // injective (ParamLayout::gbits), STORES them, and the zero tiles of the same launch cover the variables no objective point names
+    const bool direct = !pull && scatter && L.gbits >= 0 && h.world == 1 && h.gridz > 0 && h.P[(size_t)L.gbits] != 0;
+    if (!pull && !direct) zero_fill(h, g, nvar);
     // (only gathered patterns: their tiles ride inside the sweep's launch)
-    do_fused(h, x, y, sigma, obj_dev, c, jv, hv, g, /*with_pull=*/pull && !scatter);
+    do_fused(h, x, y, sigma, obj_dev, c, jv, hv, g, /*with_pull=*/pull && !scatter, /*with_zero=*/direct);
     if (owner) allgatherv(h, g, var_pieces(h));
     else if (scatter || pull) allreduce(h, g, nvar);
 }
@@ -1234,6 +1265,22 @@ int exa_eval_fused(int id, const double *x, const double *y, double w, double *o
         if ((h.m->ncon && (!c || !y)) || (h.m->nnzj && !jvals) || (h.m->nnzh && !hvals)) throw BadInput("null output");
         do_fused(h, x, y, w, obj_dev, c, jvals, hvals);
     });
+}
+/* How exa_eval_all produces grad! on this model, as it stands (shard, modes): 1 = the gathered gradient's tiles ride inside the sweep's
+ * launch (range-affine objective: LV, the rocket); 2 = the sweep's objective tiles STORE their first partials and zero tiles of the same
+ * launch cover the other variables (data-indexed objective whose scatter the model build proved injective on the data: ACOPF's
+ * generator costs) — one launch in both cases; 0 = a zero-fill launch, then the sweep adds by atomics; 3 = the gathered part in a launch
+ * of its own, then the sweep adds the scattered part by atomics; 4 = grad! by the sorted gather, separately.  -1: bad id. */
+int exa_eval_all_mode(int id) {
+    Handle *h = get(id);
+    if (!h) return -1;
+    const ParamLayout &L = h->gen.layout;
+    const bool scatter = !L.active[CB_GRAD].empty(), pull = !L.pull.empty();
+    if (h->on_device && resolve_grad_mode(*h) == 1) return 4;
+    if (pull && scatter) return 3;
+    if (pull) return 1;
+    if (scatter && L.gbits >= 0 && h->world == 1 && h->gridz > 0 && h->P[(size_t)L.gbits] != 0) return 2;
+    return 0;
 }
 int exa_eval_all(int id, const double *x, const double *y, double w, double *obj_dev, double *g, double *c, double *jvals, double *hvals) {
     if (!x || !obj_dev || !g) return 1;

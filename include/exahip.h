@@ -364,6 +364,15 @@ int exa_eval_fused(int id, const double *x, const double *y, double obj_weight, 
  * in the 256 MB MALL when the sweep reads it.  g [nvar] is fully overwritten.  Results equal the separate callbacks
  * (bitwise, except the atomically added part of g).  With exa_set_grad_mode(1) the gradient comes from the sorted gather. */
 int exa_eval_all(int id, const double *x, const double *y, double obj_weight, double *obj_dev, double *g, double *c, double *jvals, double *hvals);
+/* How exa_eval_all produces grad! on this model as it stands (shard, modes) — in ONE launch where it can (round 5):
+ *   1  the gathered gradient's tiles ride inside the sweep's launch as one more unit of its block map, interleaved with the tiles
+ *      that pull their stretch of x into L2 (range-affine objective: LV, the rocket);
+ *   2  the sweep's objective tiles STORE their first partials — no atomics, no zero-filled g — and zero tiles of the same launch write
+ *      0.0 to every other variable: a data-indexed objective whose scatter the model build has PROVEN injective on the data (a bitmap of
+ *      the written variables; ACOPF's generator costs); unsharded models;
+ *   0  a zero-fill launch, then the sweep adds by FP64 atomics;   3  the gathered part in a launch of its own, then the sweep adds the
+ *      scattered part by atomics;   4  grad! by the sorted gather, separately (exa_set_grad_mode(1) / exa_tune).      -1: bad id. */
+int exa_eval_all_mode(int id);
 
 /* ---- compressed COO: duplicate (row,col) entries summed (CompressedNLPModel, src/utils.jl:425-579; KA ext :1290-1319) --- */
 /* One-off set-up on the device: sorts the (col,row) pairs of both structures (stable), builds ptr/perm.  Entries come

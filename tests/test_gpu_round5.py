@@ -140,3 +140,49 @@ def test_locality_copies_on_random_table_models_with_content_aliased_columns(lib
             assert relerr(got, ref) <= 1e-9          # (deep random trees: the sweeps' tolerance)
     for a, b in zip(out[1], out[0]):
         assert relerr(a, b) <= 1e-11
+
+
+# ---- exa_eval_all in one launch for an injective data-indexed objective (the ACOPF half) --------------------------------
+def test_eval_all_stores_an_injective_objective_gradient_inside_the_sweep(acopf):
+    """ACOPF's generator costs reach pg through the generator table: every variable at most once (proven on the data at model build) — the
+    sweep's objective tiles store their first partials and zero tiles of the same launch cover the rest: g fully overwritten (it starts as NaN),
+    bitwise equal to grad! (each entry is ONE term either way), no zero-fill launch.  Sharded: back to atomics on a zeroed vector."""
+    import torch
+    m, o, x0 = acopf
+    x, y, sigma = point(x0, m.meta.ncon, seed=12)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    assert m.eval_all_mode() == 2
+    g = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)
+    f, g, c, j, h = m.eval_all(xd, yd, sigma, g=g)
+    torch.cuda.synchronize()
+    assert relerr(g.cpu().numpy(), o.grad(x)) <= RTOL and torch.equal(g, m.grad(xd))
+    assert relerr(h.cpu().numpy(), o.hess_coord(x, y, sigma)) <= RTOL and relerr(c.cpu().numpy(), o.cons(x)) <= RTOL
+    acc = np.zeros(m.meta.nvar)
+    try:
+        for r in range(3):
+            m.set_shard(r, 3)
+            assert m.eval_all_mode() == 0
+            gr = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)
+            acc += m.eval_all(xd, yd, sigma, g=gr)[1].cpu().numpy()
+    finally:
+        m.set_shard(0, 1)
+    assert relerr(acc, o.grad(x)) <= RTOL
+
+
+def test_eval_all_keeps_the_atomics_where_the_objective_scatter_is_not_injective(libs):
+    """Random table models: several objective patterns name the same variables through data columns — the build finds the collision and
+    exa_eval_all keeps the zero-fill + atomics; LV: the gathered gradient's tiles (mode 1)."""
+    import torch
+    import randexpr
+    from exahip import ExaModel, models
+    import oracle
+    m = ExaModel(randexpr.build_model(5, npat=8, depth=3).to_ir())
+    assert m.eval_all_mode() in (0, 3)
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=5)
+    dev = torch.device("cuda:0")
+    g = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)
+    g = m.eval_all(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), sigma, g=g)[1]
+    assert relerr(g.cpu().numpy(), o.grad(x)) <= 1e-9
+    assert ExaModel(models.luksan_vlcek_model(5000)).eval_all_mode() == 1
