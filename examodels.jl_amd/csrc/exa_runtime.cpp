@@ -444,7 +444,10 @@ void to_device(Handle &h) {
     // one-launch exa_eval_all (ParamLayout::gbits): is the objective's in-sweep scatter injective on THIS data?
     if (h.gen.layout.gbits >= 0 && m.nvar > 0) {
         std::vector<uint64_t> bits;
-        if (scatter_bitmap(m, h.gen.layout.active[CB_GRAD], bits)) {
+        int64_t pts = 0;
+        for (int k : h.gen.layout.active[CB_GRAD]) pts += m.pats[(size_t)k].n;
+        // (a host pass over the objective's data points: not worth it beyond a few 1e7 of them — such a model keeps the atomics)
+        if (pts <= 50000000 && scatter_bitmap(m, h.gen.layout.active[CB_GRAD], bits)) {
             h.dgbits.ensure(8 * bits.size());
             HIPCHK(hipMemcpy(h.dgbits.p, bits.data(), 8 * bits.size(), hipMemcpyHostToDevice));
         }
