@@ -177,3 +177,16 @@ def test_no_kernel_of_any_zoo_module_has_the_fault_pattern(tmp_path):
     bad = {os.path.basename(p): r for p, r in res if r}
     assert not bad, bad
     assert len(paths) >= len(ZOO)
+
+
+def test_the_in_process_compiler_is_still_there_as_a_fallback(fresh_cache, monkeypatch):
+    """EXAHIP_RTC_INPROCESS=1 (or a partial install without exa_rtc): hiprtc inside the host process, the same flags, the same code object."""
+    m = ExaModel(models.luksan_vlcek_model(50), device=False)
+    m.compile()
+    blob = m.code_objects()[0][1]
+    for f in fresh_cache.iterdir():
+        f.unlink()
+    monkeypatch.setenv("EXAHIP_RTC_INPROCESS", "1")
+    m2 = ExaModel(models.luksan_vlcek_model(50), device=False)
+    m2.compile()
+    assert m2.build_info()[0] == "hiprtc" and m2.code_objects()[0][1] == blob
