@@ -162,7 +162,7 @@ def pytest_collection_modifyitems(config, items):
     # tests that drive the GPU from OTHER processes (launchers, a C client, packed libraries, the standalone canary) have nothing to prebuild
     skip = pytest.mark.skip(reason="kernel prebuild: runs in another process")
     for it in items:
-        if any(t in it.nodeid for t in ("test_gpu_canary", "test_bench_launch_path", "test_two_ranks_share", "test_c_abi_client", "test_pack.py", "test_keep_source_and_verbose")):
+        if any(t in it.nodeid for t in ("test_gpu_canary", "test_bench_launch_path", "test_two_ranks_share", "test_c_abi_client", "test_pack.py", "test_keep_source_and_verbose", "test_a_packed_library_with_registered")):
             it.add_marker(skip)
 
 
