@@ -257,9 +257,13 @@ def traffic_for(m, config, per_gpu_points):
     with open(path) as fh:
         t = json.load(fh)
     kernel = HESS_KERNELS[m._L.exa_hess_variant(m.id)]
-    if t.get("module") != m._L.exa_module_name(m.id).decode() or t.get("points") != per_gpu_points or t.get("kernel") != kernel:
+    if t.get("module") != m._L.exa_module_name(m.id).decode() or t.get("points") != per_gpu_points:
         return None
-    return t.get("hbm_bytes_per_launch")
+    # (the passes hold the counters of every hess_coord! kernel exa_tune launched: the number of THE kernel this run executes)
+    by = t.get("hbm_bytes_per_launch_by_kernel") or {}
+    if kernel in by:
+        return by[kernel]
+    return t.get("hbm_bytes_per_launch") if t.get("kernel") == kernel else None
 
 
 def gather_ints(value, world, dev, backend):

@@ -20,6 +20,14 @@ def counter(path, name):
     raise SystemExit(f"{name} of {kernel} not found in {path}")
 
 
+def counter_of(path, name, kern):
+    for ln in open(path):
+        m = re.match(r"\s*(\S+)\s+" + name + r"\s+n=\s*(\d+)\s+avg=\s*([\d.eE+-]+)", ln)
+        if m and m.group(1) == kern:
+            return float(m.group(3))
+    return None
+
+
 f_kb, nf = counter(fetch, "FETCH_SIZE")
 w_kb, nw = counter(write, "WRITE_SIZE")
 CORR = 1.9391      # profiles/r1_pmc_calibration_store_bench.txt: a kernel reading a known 156250 KB in this 8-B/lane pattern reports 80578.89 KB
@@ -33,4 +41,13 @@ out = {
     "hbm_bytes_per_launch": int(round(1024 * (w_kb + CORR * f_kb))),
     "algorithmic_bytes_per_launch": line["roofline"]["algorithmic_bytes_per_launch"],
 }
+# exa_tune launches every hess_coord! kernel of the module in the same process: their counters are in the same passes.  Recorded per
+# kernel, so that a later process whose exa_tune picks the sibling (the chained pair is within 1 % of each other) still finds ITS number.
+CORR_ = CORR
+per = {}
+for kern in ("exa_hess", "exa_hessc", "exa_hesscl"):
+    fk, wk = counter_of(fetch, "FETCH_SIZE", kern), counter_of(write, "WRITE_SIZE", kern)
+    if fk is not None and wk is not None:
+        per[kern] = int(round(1024 * (wk + CORR_ * fk)))
+out["hbm_bytes_per_launch_by_kernel"] = per
 print(json.dumps(out, indent=1))
