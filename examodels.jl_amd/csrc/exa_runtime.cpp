@@ -79,8 +79,7 @@ void fill_params(Handle &h) {
             // caller's order through the same words (origq = 0: "row I is row I")
             const bool on = h.on_device && h.locality && !h.origslot.empty() && h.origslot[(size_t)pp.table] >= 0;
             if (pp.table == (int)k) h.P[pp.origq] = on ? (int64_t)(uintptr_t)h.dcols[(size_t)h.origslot[k]].p : 0;
-            for (size_t c = 0; c < p.cols.size(); c++)
-            {
+            for (size_t c = 0; c < p.cols.size(); c++) {
                 if (on && h.colslotq[k][c] < 0) throw std::logic_error("locality copy: a column of a permuted table has no permuted copy");
                 h.P[pp.colq[c]] = on ? (int64_t)(uintptr_t)h.dcols[(size_t)h.colslotq[k][c]].p : h.P[pp.col[c]];
             }
@@ -437,11 +436,7 @@ void to_device(Handle &h) {
         const char *le = getenv("EXAHIP_LOCALITY");
         h.locality = le && *le == '1';
     }
-    // Locality-ordered copies (ParamLayout::Pat::perm) — the reference sorts its scatter lists at build too (KA ext :44-53, 79-101).
-    // One permutation per table: rows in ascending order of the smallest variable any member pattern reaches through a data column
-    // at that row (stable: ties keep the caller's order) — for a branch table, by bus.  Built from the host columns, before they are
-    // released; tables of fewer than 4 096 rows and tables already in that order keep the caller's (no copy, origslot = -1).
-    // one-launch exa_eval_all (ParamLayout::gbits): is the objective's in-sweep scatter injective on THIS data?
+    // one-launch exa_eval_all (ParamLayout::gbits): is the objective's in-sweep scatter injective on THIS data?  (needs the host columns)
     if (h.gen.layout.gbits >= 0 && m.nvar > 0) {
         std::vector<uint64_t> bits;
         int64_t pts = 0;
@@ -452,6 +447,10 @@ void to_device(Handle &h) {
             HIPCHK(hipMemcpy(h.dgbits.p, bits.data(), 8 * bits.size(), hipMemcpyHostToDevice));
         }
     }
+    // Locality-ordered copies (ParamLayout::Pat::perm) — the reference sorts its scatter lists at build too (KA ext :44-53, 79-101).
+    // One permutation per table: rows in ascending order of the smallest variable any member pattern reaches through a data column
+    // at that row (stable: ties keep the caller's order) — for a branch table, by bus.  Built from the host columns, before they are
+    // released; tables of fewer than 4 096 rows and tables already in that order keep the caller's (no copy, origslot = -1).
     std::vector<std::vector<int64_t>> perms(m.pats.size());
     for (size_t r = 0; r < m.pats.size(); r++) {
         const ParamLayout &L = h.gen.layout;
@@ -1189,8 +1188,8 @@ int exa_locality_order(int id, int pattern, int64_t *perm_out) {
  * evaluated — grad!, J'v and Hv by atomics into a zeroed vector — run on a locality-ordered COPY of every table-driven pattern's
  * columns, built once at model build (one permutation per table; tables under 4 096 rows or already in order: none).  COO, rows and
  * structures keep the caller's order.  on = 1 / 0 switches the copies in / out (default OUT — they lose where the patterns also read by
- * row, profiles/r5_locality_ab.txt; EXAHIP_LOCALITY=1 in the environment: in from the start), on < 0 only asks.  Returns the number of tables with an installed permutation (0: none built, or switched off), -1 on a
- * bad id. */
+ * row, profiles/r5_locality_ab.txt; EXAHIP_LOCALITY=1 in the environment: in from the start), on < 0 only asks.  Returns the number of
+ * tables with an installed permutation (0: none built, or switched off), -1 on a bad id. */
 int exa_set_locality(int id, int on) {
     Handle *h = get(id);
     if (!h) return -1;
