@@ -190,3 +190,22 @@ def test_the_in_process_compiler_is_still_there_as_a_fallback(fresh_cache, monke
     m2 = ExaModel(models.luksan_vlcek_model(50), device=False)
     m2.compile()
     assert m2.build_info()[0] == "hiprtc" and m2.code_objects()[0][1] == blob
+
+
+def test_llc_alone_reproduces_the_fault_site_from_the_bitcode(tmp_path):
+    """tests/sweeps/canary/hprodw_canary.bc: the one kernel as optimized LLVM bitcode.  `llc` (no hipcc, no GPU) puts the VGPR->AGPR copies in
+    front of the join block's exec restore under the default SGPR allocator and nowhere near it under -sgpr-regalloc=basic: the report's
+    reproducer, and the guard's effect, on the compiler alone."""
+    import os
+    import subprocess
+    llc = "/opt/rocm/lib/llvm/bin/llc"
+    if not os.path.exists(llc):
+        pytest.skip("no llc in this image")
+    bc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sweeps", "canary", "hprodw_canary.bc")
+    found = {}
+    for name, extra in (("greedy", []), ("basic", ["-sgpr-regalloc=basic"])):
+        obj = str(tmp_path / (name + ".o"))
+        subprocess.run([llc, "-mtriple=amdgcn-amd-amdhsa", "-mcpu=gfx950", "-O3", "-filetype=obj", *extra, bc, "-o", obj], check=True, timeout=600)
+        with open(obj, "rb") as fh:
+            found[name] = _fault_sites(fh.read(), tmp_path, "llc_" + name)
+    assert "exa_hprodw" in found["greedy"] and found["basic"] == {}, found
