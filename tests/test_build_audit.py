@@ -209,3 +209,20 @@ def test_llc_alone_reproduces_the_fault_site_from_the_bitcode(tmp_path):
         with open(obj, "rb") as fh:
             found[name] = _fault_sites(fh.read(), tmp_path, "llc_" + name)
     assert "exa_hprodw" in found["greedy"] and found["basic"] == {}, found
+
+
+def test_the_mir_level_detector_agrees_on_the_canary():
+    """tools/mir_prologue_check.py: the same fault looked for in the compiler's own MIR after the VGPR allocator (no blind spot).  On the canary's source:
+    the one block under the compiler's default SGPR allocator (bb.926: two VGPR->AV copies in front of S_OR_B64 $exec), none under basic."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("mir_prologue_check", os.path.join(root, "tools", "mir_prologue_check.py"))
+    mir = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mir)
+    src = os.path.join(root, "tests", "sweeps", "canary", "hprodw_canary.hip")
+    n, found = mir.check_source(src, [])
+    assert n >= 9 and list(found) == ["exa_hprodw"] and len(found["exa_hprodw"]) == 1
+    assert any("av_64" in b and "COPY" in b for b in found["exa_hprodw"][0][1])
+    n, found = mir.check_source(src, ["-mllvm", "-sgpr-regalloc=basic"])
+    assert n >= 9 and found == {}
