@@ -328,6 +328,12 @@ end
 # the library's own device-resident parameter vector (npar doubles; get_value's view, nlp.jl:1270-1277): wrap it with
 # unsafe_wrap(ROCArray, convert(ROCPtr{Float64}, theta_ptr(m)), npar) to write parameters in place
 theta_ptr(m) = ccall((:exa_theta_ptr, LIB), Ptr{Cdouble}, (Cint,), m.ext.id)
+# how exa_eval_all produces grad! on this model (exa_eval_all_mode): 1 / 2 = inside the sweep's one launch, 0 / 3 = a launch in front, 4 = sorted gather
+eval_all_mode(m) = ccall((:exa_eval_all_mode, LIB), Cint, (Cint,), m.ext.id)
+# locality-ordered table copies for the order-free kernels (exa_set_locality; opt-in: measured slower where the patterns also read by row); -1 only asks
+locality!(m, on::Integer = 1) = ccall((:exa_set_locality, LIB), Cint, (Cint, Cint), m.ext.id, on)
+# may model files bring device code of their own (exa_recipe_trust_code)?  Returns the setting in force before the call.
+trust_model_code!(on::Bool) = ccall((:exa_recipe_trust_code, LIB), Cint, (Cint,), on) != 0
 # what the compiled kernels of the model need and which flags their modules were built with (exa_build_audit): one line per kernel
 function build_audit(m)
     n = ccall((:exa_build_audit, LIB), Cint, (Cint, Ptr{UInt8}, Cint), m.ext.id, C_NULL, 0)
