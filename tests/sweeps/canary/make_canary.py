@@ -1,5 +1,7 @@
 #!/usr/bin/env python
 """Produces the standalone reproducer of an over-sized window kernel's wrong sums, and checks the library's answer to it.
+(Round 5: the fault is root-caused — REPORT.md in this directory — and the library's base flags now remove its cause; this script still
+records the launch from the build with the round-4 fallback flags and compares the compiler's default against it.)
 TEST INFRASTRUCTURE (tests/sweeps/): imports the oracle as the checker.  Runs on a GPU box:
 
     python tests/sweeps/canary/make_canary.py [OUTDIR]          (default: this directory)
