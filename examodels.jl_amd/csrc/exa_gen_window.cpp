@@ -317,11 +317,20 @@ static void gen_window_x(std::ostringstream &os, const std::vector<int> &S, cons
           "        for (int e = T[2 + 3 * q]; e < T[3 + 3 * q]; e++) s += xbuf[E[e]];\n        cout[c] = s;\n    }\n"
           // fold of the shared-entry partial sums: F = [ngroups, then per group: first partial, count, entry];
           // groups in order (several may share an entry), fixed summation order
-          "    __shared__ double red[8];\n"
+          // (thread 0 carries the entry it is adding to in a register across consecutive groups of the same entry — the rocket's step length
+          // collects a group per pattern — and writes it once: c, c + s0, (c + s0) + s1, ... as before, without a global read-modify-write per group)
+          "    __shared__ double red[8];\n    long cur_ = -1;\n    double acc_ = 0.0;\n"
           "    for (long g = 0; g < F[0]; g++) {\n        __syncthreads();\n        const long off = F[1 + 3 * g], n = F[2 + 3 * g];\n        double a = 0.0;\n"
-          "        for (long i = t; i < n; i += 512) a += part[off + i];\n        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);\n"
+          // (eight loads in flight per thread, added in the same ascending order as a plain loop: with one load per iteration every
+          // addition waited for its own load — the rocket's J'v tail took 13 us for a few thousand partials)
+          "        for (long i0 = t; i0 < n; i0 += 512 * 8) {\n            double b_[8];\n#pragma unroll\n"
+          "            for (int k = 0; k < 8; k++) { const long i = i0 + (long)k * 512; b_[k] = i < n ? part[off + i] : 0.0; }\n#pragma unroll\n"
+          "            for (int k = 0; k < 8; k++) if (i0 + (long)k * 512 < n) a += b_[k];\n        }\n"
+          "        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);\n"
           "        if ((t & 63) == 0) red[t >> 6] = a;\n        __syncthreads();\n"
-          "        if (t == 0) { double s = 0.0; for (int w = 0; w < 8; w++) s += red[w]; cout[F[3 + 3 * g]] += s; }\n    }\n}\n";
+          "        if (t == 0) {\n            double s = 0.0;\n            for (int w = 0; w < 8; w++) s += red[w];\n            const long e_ = F[3 + 3 * g];\n"
+          "            if (e_ != cur_) { if (cur_ >= 0) cout[cur_] = acc_; cur_ = e_; acc_ = cout[e_]; }\n            acc_ += s;\n        }\n    }\n"
+          "    if (t == 0 && cur_ >= 0) cout[cur_] = acc_;\n}\n";
 }
 
 // entries EVERY point adds to (b = 0: the rocket's step length): per-workgroup sums over the regular points (S_ = [per
