@@ -81,6 +81,9 @@ struct Handle {
     DevBuf daugcoef;
     DevBuf daugcsr, daugsrc;                // exa_cons1: CSR over constraint rows of the augmentation terms (pattern << 40 | point)
     bool cons1 = false;
+    // cons_nln! of a model WITHOUT augmentation terms through exa_cons1 as well: its dispatch units are fused groups (equally long
+    // patterns evaluated by one thread: the rocket's three dynamics rows read h, v, m, tau once instead of once per pattern)
+    bool cons_fused = false;
     DevBuf dsink;                           // 64 doubles nobody reads (ParamLayout::sink)
     DevBuf dP, dtheta, dpart, ddone, dobj, daugbuf, daugrows, daugptr, daugperm, dauglong, daugpartial;
     int64_t aug_nlong = 0, aug_chunks = 0;   // rows collecting > 512 augmentation terms: cooperative summation

@@ -556,6 +556,13 @@ void to_device(Handle &h) {
             h.cons1 = true;
         }
     }
+    if (m.nconaug == 0) {
+        // (default: where a fused group of exa_cons1 really fuses something; EXAHIP_CONS_FUSED=0 / 1 overrides)
+        bool fuses = false;
+        for (const auto &g : h.gen.layout.groups[CB_CONS1]) fuses = fuses || g.size() > 1;
+        const char *cf = getenv("EXAHIP_CONS_FUSED");
+        h.cons_fused = cf && *cf ? *cf == '1' : fuses;
+    }
     HIPCHK(hipEventCreate(&h.ev0));
     HIPCHK(hipEventCreate(&h.ev1));
     fill_params(h);
@@ -699,7 +706,7 @@ void do_cons(Handle &h, const double *x, double *c) {
         if (h.m->nconaug) HIPCHK(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)h.m->nconaug, h.stream));
     }
     const void *P = h.dP.p, *th = h.dtheta.p;
-    if (h.cons1) {
+    if (h.cons1 || (h.cons_fused && h.m->nconaug == 0)) {
         // ONE launch: every base row's thread evaluates the row's augmentation terms itself (exa_cons1)
         const void *ptr = h.daugcsr.p, *src = h.daugsrc.p, *coef = h.daugcoef.p;
         void *a1[] = {&P, &x, &th, &c, &ptr, &src, &coef};

@@ -186,3 +186,30 @@ def test_eval_all_keeps_the_atomics_where_the_objective_scatter_is_not_injective
     g = m.eval_all(torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev), sigma, g=g)[1]
     assert relerr(g.cpu().numpy(), o.grad(x)) <= 1e-9
     assert ExaModel(models.luksan_vlcek_model(5000)).eval_all_mode() == 1
+
+
+def test_cons_of_a_model_without_augmentation_by_fused_groups(libs, monkeypatch):
+    """cons_nln! of the rocket (no augmentation terms) runs exa_cons1 — its three equally long dynamics patterns evaluated by one thread — by
+    default; EXAHIP_CONS_FUSED=0 gives the per-pattern exa_cons.  Same rows, same bits, both equal to the oracle; sharded rows still complete."""
+    import torch
+    from exahip import ExaModel, models
+    import oracle
+    core = models.rocket_model(3000)
+    m = ExaModel(core)
+    o = oracle.OracleModel(m.ir)
+    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=13)
+    c1 = m.cons(x)
+    monkeypatch.setenv("EXAHIP_CONS_FUSED", "0")
+    m0 = ExaModel(models.rocket_model(3000))
+    c0 = m0.cons(x)
+    assert np.array_equal(c0, c1) and relerr(c1, o.cons(x)) <= RTOL
+    dev = torch.device("cuda:0")
+    xd = torch.from_numpy(x).to(dev)
+    buf = torch.full((m.meta.ncon,), float("nan"), dtype=torch.float64, device=dev)
+    try:
+        for r in range(3):
+            m.set_shard(r, 3)
+            m.cons(xd, out=buf)
+    finally:
+        m.set_shard(0, 1)
+    assert np.array_equal(buf.cpu().numpy(), c1)
