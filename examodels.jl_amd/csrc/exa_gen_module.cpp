@@ -271,6 +271,12 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
     };
     scatter_lds(CB_GRAD);
     gen_dispatch(os, L, CB_GRAD, "grad", "P, x, th, out", ", lds");
+    if (L.gbits >= 0)
+        // the zero tiles of the one-launch grad! (one more unit of the block map; the buffer holds nvar in front of the bitmap)
+        os << "    else if (ps_ == " << L.active[CB_GRAD].size() << ") {\n        const long* gb_ = (const long*)P[" << L.gbits << "];\n"
+              "        const unsigned long long* bits = (const unsigned long long*)(gb_ + 1);\n        const long tile_ = e_ & ((1L << 40) - 1);\n#pragma unroll\n"
+              "        for (int u = 0; u < 8; u++) {\n            const long v = tile_ * (EXA_BLOCK * 8) + u * EXA_BLOCK + threadIdx.x;\n"
+              "            if (v < gb_[0] && !((bits[v >> 6] >> (v & 63)) & 1ull)) __builtin_nontemporal_store(0.0, &out[v]);\n        }\n    }\n";
     os << "}\n";
     // grad!, gather part: one thread per variable of [v_begin, v_end); also provides the zero of untouched variables (no
     // memset).  The value is COMPLETE — every data point of every gathered pattern that touches the variable, whatever the
@@ -483,7 +489,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
         if (L.gbits >= 0) {
             // the zero tiles of the one-launch exa_eval_all: 0.0 for every variable no objective point writes (bitmap built at model build)
             os << "    " << (grps.empty() ? "" : "else ") << "if (ps_ == " << grps.size() << ") {\n"
-                  "        const unsigned long long* bits = (const unsigned long long*)P[" << L.gbits << "];\n"
+                  "        const unsigned long long* bits = (const unsigned long long*)((const long*)P[" << L.gbits << "] + 1);\n"
                   "#pragma unroll\n        for (int u = 0; u < 8; u++) {\n            const long v = tile_ * (EXA_BLOCK * 8) + u * EXA_BLOCK + threadIdx.x;\n"
                   "            if (v < v_end && !((bits[v >> 6] >> (v & 63)) & 1ull)) __builtin_nontemporal_store(0.0, &gout[v]);\n        }\n    }\n";
         }

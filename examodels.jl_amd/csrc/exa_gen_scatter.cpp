@@ -160,10 +160,23 @@ void gen_first_fn(std::ostringstream &os, const Model &m, int pi, const ParamLay
     os << "static __device__ __forceinline__ void " << fn_name(pi, grad ? "grad" : "jac")
        << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* __restrict__ out, long tid"
        << ", double* lds" << (grad ? ", double* lit" : "") << ") {\n";
-    if (grad) emit_scatter_prologue(os, b, L, pi, full_wave);
+    // one-launch grad! (ParamLayout::gbits, as in the fused sweep): where the model build has proven that no variable is named twice by the
+    // objective's items, each item IS its variable's gradient entry — a plain store (the zero tiles of the same launch cover the rest)
+    std::vector<std::string> direct;
+    if (grad && L.gbits >= 0)
+        for (const Scatter::Item &it : sc.items) direct.push_back("if (act) out[" + b.e.s(b.e.sub(it.vidx, Emitter::liti(1))) + "] = " + b.e.sd(it.val) + ";");
+    if (grad) emit_scatter_prologue(os, b, L, pi, full_wave || !direct.empty());
     else emit_coo_prologue(os, b, L, pi, tile);
     emit_lines(os, b.e);
-    if (grad) { for (auto &s : stores) os << "    " << s << "\n"; }
+    if (grad) {
+        if (!direct.empty()) {
+            os << "    if (P[" << L.gbits << "]) {\n";
+            for (auto &s : direct) os << "        " << s << "\n";
+            os << "    } else {\n";
+        }
+        for (auto &s : stores) os << "    " << s << "\n";
+        if (!direct.empty()) os << "    }\n";
+    }
     else emit_coo_stores(os, b, L.pat[pi].o1, p.o1step, vals, tile);
     os << "}\n";
 }

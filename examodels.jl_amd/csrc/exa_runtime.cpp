@@ -130,6 +130,11 @@ void fill_params(Handle &h) {
             }
             total += nb[j];
         }
+        if (cb == CB_GRAD && L.gbits >= 0 && h.on_device && h.world == 1 && h.dgbits.p) {
+            // one-launch grad!: the zero tiles as one more unit (the objective tiles store, see gen_first_fn)
+            nb.push_back((m.nvar + (int64_t)kBlock * 8 - 1) / ((int64_t)kBlock * 8));
+            total += nb.back();
+        }
         h.grid[cb] = total;
         if (cb == CB_FUSED) {
             // objective partial sums of the fused sweep: one per workgroup of an OBJECTIVE pattern, at a compact index
@@ -443,6 +448,7 @@ void to_device(Handle &h) {
         for (int k : h.gen.layout.active[CB_GRAD]) pts += m.pats[(size_t)k].n;
         // (a host pass over the objective's data points: not worth it beyond a few 1e7 of them — such a model keeps the atomics)
         if (pts <= 50000000 && scatter_bitmap(m, h.gen.layout.active[CB_GRAD], bits)) {
+            bits.insert(bits.begin(), (uint64_t)m.nvar);        // [nvar, bitmap...]: the zero tiles of exa_grad read their bound from the buffer
             h.dgbits.ensure(8 * bits.size());
             HIPCHK(hipMemcpy(h.dgbits.p, bits.data(), 8 * bits.size(), hipMemcpyHostToDevice));
         }
@@ -625,7 +631,10 @@ void do_grad(Handle &h, const double *x, double *g) {
     const int64_t nvar = h.m->nvar;
     const bool scatter = !h.gen.layout.active[CB_GRAD].empty(), pull = !h.gen.layout.pull.empty();     // (the MODEL's patterns, not this shard's)
     const bool owner = pull && !scatter;
-    {
+    const int gb = h.gen.layout.gbits;
+    // (an objective whose scatter the build proved injective: its tiles store, the zero tiles ride in the same launch — no zero-fill launch)
+    const bool direct = scatter && !pull && gb >= 0 && h.world == 1 && h.P[(size_t)gb] != 0;
+    if (!direct) {
         // gathered patterns: plain coalesced store of every g[v] (zero where nothing contributes).  Without gathered patterns
         // the same kernel is the zero-fill under the atomics: a plain launch is cheaper than hipMemsetAsync (ACOPF grad!
         // 0.018 -> 0.009 ms, profiles/NOTES.md)

@@ -157,6 +157,12 @@ def test_eval_all_stores_an_injective_objective_gradient_inside_the_sweep(acopf)
     f, g, c, j, h = m.eval_all(xd, yd, sigma, g=g)
     torch.cuda.synchronize()
     assert relerr(g.cpu().numpy(), o.grad(x)) <= RTOL and torch.equal(g, m.grad(xd))
+    # grad! itself takes the same one-launch form: into a NaN-filled vector (every entry written: stores + zero tiles), twice
+    for _ in range(2):
+        g2 = torch.full((m.meta.nvar,), float("nan"), dtype=torch.float64, device=dev)
+        m.grad(xd, out=g2)
+        torch.cuda.synchronize()
+        assert torch.equal(g2, g)
     assert relerr(h.cpu().numpy(), o.hess_coord(x, y, sigma)) <= RTOL and relerr(c.cpu().numpy(), o.cons(x)) <= RTOL
     acc = np.zeros(m.meta.nvar)
     try:
