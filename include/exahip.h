@@ -373,6 +373,8 @@ int exa_eval_all(int id, const double *x, const double *y, double obj_weight, do
  *   0  a zero-fill launch, then the sweep adds by FP64 atomics;   3  the gathered part in a launch of its own, then the sweep adds the
  *      scattered part by atomics;   4  grad! by the sorted gather, separately (exa_set_grad_mode(1) / exa_tune).      -1: bad id. */
 int exa_eval_all_mode(int id);
+/* (exa_grad on its own takes the form of mode 2 wherever exa_eval_all does: one launch — stores + zero tiles — instead of a zero-fill
+ * launch followed by atomics.) */
 
 /* ---- compressed COO: duplicate (row,col) entries summed (CompressedNLPModel, src/utils.jl:425-579; KA ext :1290-1319) --- */
 /* One-off set-up on the device: sorts the (col,row) pairs of both structures (stable), builds ptr/perm.  Entries come

@@ -34,7 +34,8 @@ d = b["config5_n1"]; ms, v, f, t, k = g(d)
 tnote = ""
 if t is None:       # the PMC passes ran a process whose exa_tune picked the sibling chained kernel (they are within 1 % of each other): say so
     tj = json.load(open(os.path.join(P, "r5_traffic_config5.json")))
-    t, tnote = tj["hbm_bytes_per_launch"], f" (measured on `{tj['kernel']}`)"
+    by = tj.get("hbm_bytes_per_launch_by_kernel") or {}
+    t, tnote = (by[k], "") if k in by else (tj["hbm_bytes_per_launch"], f" (measured on `{tj['kernel']}`)")
 sub("| 5 at N = 1", f"| 5 at N = 1 (`scale_base`) | LV N = 1e8 | `{k}` | {ms:.3f} | {v:.3g} | 8.80 GB | {t / 1e9:.2f} GB{tnote} | {f:.3f} (0.66–0.73 across boxes of the pool) | — | — |")
 
 
