@@ -127,3 +127,70 @@ def test_fast_trig_2_sine_alone_in_value_contexts(libs, monkeypatch):
     xx, yy, s = point(lv.meta.x0, lv.meta.ncon, seed=3)
     np.testing.assert_allclose(lv.cons(xx), o.cons(xx), rtol=1e-12, atol=1e-13)
     np.testing.assert_allclose(lv.hess_coord(xx, yy, s), o.hess_coord(xx, yy, s), rtol=1e-10, atol=1e-12)
+
+
+def test_fast_exp_is_within_an_ulp_and_the_knob_brings_ocml_back(libs, monkeypatch):
+    """The prelude's exa_exp (two-FMA reduction by ln 2, degree-9 near-minimax polynomial, v_ldexp_f64; 24 vector instructions where
+    ocml's takes 40): <= 1.5 ulp against 40-digit mpmath over small, wide and boundary arguments, exact special values (0 -> 1,
+    overflow -> Inf, underflow -> 0, NaN -> NaN, +-Inf); EXAHIP_FAST_EXP=0 generates ocml's exp instead — both inside the bar on the
+    models that use exp."""
+    import mpmath
+    from exahip import ExaCore, ExaModel, rng
+    from exahip.graph import exp
+    import oracle
+    mpmath.mp.dps = 40
+    r = np.random.default_rng(0)
+    xs = np.concatenate([
+        r.uniform(-1, 1, 1500), r.uniform(-40, 40, 1500), r.uniform(-700, 709.7, 1500),
+        (np.arange(-500, 501) + 0.5) * np.log(2) * (1 + r.uniform(-1e-13, 1e-13, 1001)),       # next to the rounding boundaries of k
+        np.array([0.0, -0.0, 1e-300, -1e-300, 709.782712893384]),
+    ])
+    n = len(xs)
+    c = ExaCore()
+    x = c.add_var(n)
+    c.add_con(lambda i: exp(x[i]), rng(1, n))
+    m = ExaModel(c)
+    assert "exa_exp(" in m.kernel_source().split("exa_powi")[-1]
+    val, jac = m.cons(xs), m.jac_coord(xs)
+    for got in (val, jac):
+        worst = 0.0
+        for g, xv in zip(got, xs):
+            t = mpmath.exp(mpmath.mpf(float(xv)))
+            worst = max(worst, float(abs(mpmath.mpf(float(g)) - t) / mpmath.mpf(2) ** (mpmath.floor(mpmath.log(t, 2)) - 52)))
+        assert worst <= 1.5, worst
+    sp = np.zeros(n)
+    sp[:9] = [0.0, 709.79, 1e300, np.inf, -745.2, -1e300, -np.inf, np.nan, -745.0]
+    got = m.cons(sp)
+    assert got[0] == 1.0 and np.all(np.isinf(got[1:4])) and np.all(got[4:7] == 0.0) and np.isnan(got[7]) and got[8] == 5e-324
+    # the knob: ocml's exp in the generated text, the oracle's values either way
+    for name in ("rocket50", "lv1000"):
+        m1 = ExaModel(ZOO[name]())
+        monkeypatch.setenv("EXAHIP_FAST_EXP", "0")
+        m0 = ExaModel(ZOO[name]())
+        monkeypatch.delenv("EXAHIP_FAST_EXP")
+        assert "exa_exp(" in m1.kernel_source().split("exa_powi")[-1] and "exa_exp(" not in m0.kernel_source().split("exa_powi")[-1]
+        o = oracle.OracleModel(m1.ir)
+        xx, yy, s = point(m1.meta.x0, m1.meta.ncon, seed=12)
+        for mm in (m1, m0):
+            np.testing.assert_allclose(mm.hess_coord(xx, yy, s), o.hess_coord(xx, yy, s), rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(mm.jac_coord(xx), o.jac_coord(xx), rtol=1e-10, atol=1e-12)
+            np.testing.assert_allclose(mm.cons(xx), o.cons(xx), rtol=1e-10, atol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["acopf30", "rocket50", "lv1000"])
+def test_ktab_knob_coefficients_from_constant_memory_give_the_same_bits(libs, name, monkeypatch):
+    """EXAHIP_KTAB=1: the Horner coefficients of exa_sincos / exa_exp come from a table in constant memory (one s_load_dwordx16 per
+    polynomial) instead of literals (two s_mov_b32 each): the same values in the same instructions — every output bit for bit."""
+    from exahip import ExaModel
+    m0 = ExaModel(ZOO[name]())
+    monkeypatch.setenv("EXAHIP_KTAB", "1")
+    m1 = ExaModel(ZOO[name]())
+    assert m1.kernel_source().startswith("#define EXA_KTAB 1") and m0._L.exa_module_name(m0.id) != m1._L.exa_module_name(m1.id)
+    x, y, s = point(m0.meta.x0, m0.meta.ncon, seed=13)
+    v = np.random.default_rng(5).standard_normal(m0.meta.nvar)
+    w = np.random.default_rng(6).standard_normal(max(1, m0.meta.ncon))[:m0.meta.ncon]
+    a, b = _everything(m0, x, y, s, v, w), _everything(m1, x, y, s, v, w)
+    for k in ("obj", "cons", "jac", "hess", "jprod", "all_c", "all_j", "all_h"):
+        assert np.array_equal(a[k], b[k]), k
+    for k in ("grad", "jtprod", "hprod"):          # atomics where the scatter is data-indexed: the order of the additions is free
+        np.testing.assert_allclose(a[k], b[k], rtol=1e-12, atol=1e-13, err_msg=k)
