@@ -29,7 +29,7 @@ def _fused_fns():
     """The one-statement form (exa_register_univariate_fused): value and both derivatives from one evaluation."""
     from exahip import graph as G
     fsin = G.register_univariate("fsin", fused="exa_sincos($1, &$2, &$3); $4 = -$2;", py=np.sin)
-    fexp = G.register_univariate("fexp", fused="$2 = exp($1); $3 = $2; $4 = $2")          # no trailing semicolon: the generator adds it
+    fexp = G.register_univariate("fexp", fused="$2 = exa_exp($1); $3 = $2; $4 = $2")          # no trailing semicolon: the generator adds it
     return fsin, fexp
 
 
