@@ -541,6 +541,8 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
                      "resident_bytes_test": {"algorithmic_bytes": alg_bytes, "mall_bytes": MALL_BYTES, "cache_resident": alg_bytes < MALL_BYTES},
                      "launch_floor_ms": m.time_callback("launch", 200, xs),
                      "kernel": HESS_KERNELS[L.exa_hess_variant(m.id)], "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                     # occupancy the chained kernels are launched at (exa_tune: unused dynamic LDS that leaves 3 or 2 workgroups per CU; 0 = no throttle)
+                     "throttle_lds_bytes": int(L.exa_hess_throttle(m.id)),
                      "block_order": {0: "sequential", 1: "interleaved-128"}.get(L.exa_block_order(m.id, 4), "n/a"),
                      # one hess_coord! = ONE launch whatever the number of patterns (ACOPF: 15 patterns, one launch)
                      "launches_per_eval": 1, "patterns": int(m.npatterns)},

@@ -195,6 +195,17 @@ int product_mode_query(Handle &h, bool hess) {
     return (h.on_device ? window_possible(h, hess) : w.planned) ? 2 : 0;
 }
 
+// Dynamic LDS that leaves `wgs` workgroups of the chained hess_coord! kernel per CU (160 KB of LDS; static + dynamic <= 64 KB, the launch limit without
+// a function attribute); 0 when the kernel's own LDS already allows no more than that, or the kernel is not there.
+unsigned hess_throttle_bytes(Handle &h, int variant, int wgs) {
+    hipFunction_t f = variant == 1 && h.f_hesscl && h.stage_ok ? h.f_hesscl : h.f_hessc;
+    if (!f || wgs < 1) return 0;
+    int stat = 0;
+    if (hipFuncGetAttribute(&stat, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, f) != hipSuccess) return 0;
+    const int total = 160 * 1024 / (wgs + 1) + 1024;          // just too much for wgs + 1 workgroups
+    if (stat >= total || total > 64 * 1024) return 0;
+    return (unsigned)(total - stat);
+}
 }  // namespace rt
 }  // namespace exa
 
@@ -349,6 +360,12 @@ int exa_hess_variant(int id) {
     if (!h) return -1;
     return h->hess_variant == 1 && !(h->f_hesscl && h->stage_ok) ? 2 : h->hess_variant;
 }
+int exa_hess_throttle(int id) {
+    Handle *h = get(id);
+    if (!h) return -1;
+    if (h->hess_variant >= 1 && h->hess_dyn_auto && h->f_hessc) { h->hess_dyn_auto = false; h->hess_dyn_lds = hess_throttle_bytes(*h, h->hess_variant, 3); }
+    return h->hess_variant >= 1 ? (int)h->hess_dyn_lds : 0;
+}
 
 // ---- explicit tuning (the only place that measures; callbacks never do) ------------------------------------------------
 int exa_tune(int id, int what, const double *x, const double *y) {
@@ -397,25 +414,45 @@ int exa_tune(int id, int what, const double *x, const double *y) {
                     order_cl = h.order[CB_HESSC];
                     cand.push_back(1);
                 }
-                const std::vector<float> tv = ab_min(h, (int)cand.size(), 7, 6, [&](int k) {
-                    h.hess_variant = cand[(size_t)k];
-                    if (cand[(size_t)k] != 0 && h.order[CB_HESSC] != (cand[(size_t)k] == 1 ? order_cl : order_c)) install_order(h, CB_HESSC, cand[(size_t)k] == 1 ? order_cl : order_c);
+                // ... and the chained kernels at three occupancies: as many workgroups per CU as their registers allow, three, two — an LDS
+                // throttle (dynamic LDS nobody uses, exa_rt.hpp hess_dyn_lds).  Fewer, longer streams per CU win where the output outgrows
+                // the Infinity Cache (LV 1e8 exa_hesscl: 1.70 -> 1.62 ms at three workgroups) and on some boxes below it (profiles/r5_hess_occupancy.txt)
+                struct Cand { int variant; unsigned dyn; };
+                std::vector<Cand> cs;
+                const bool fixed_dyn = getenv("EXAHIP_HESS_DYN_LDS") != nullptr;
+                for (int v : cand) {
+                    cs.push_back({v, v == 0 || !fixed_dyn ? 0u : h.hess_dyn_lds});
+                    if (v == 0 || fixed_dyn) continue;
+                    for (int wgs : {3, 2}) { const unsigned d = hess_throttle_bytes(h, v, wgs); if (d) cs.push_back({v, d}); }
+                }
+                const std::vector<float> tv = ab_min(h, (int)cs.size(), 7, 6, [&](int k) {
+                    const int v = cs[(size_t)k].variant;
+                    h.hess_variant = v;
+                    h.hess_dyn_lds = cs[(size_t)k].dyn;
+                    if (v != 0 && h.order[CB_HESSC] != (v == 1 ? order_cl : order_c)) install_order(h, CB_HESSC, v == 1 ? order_cl : order_c);
                     do_hess(h, x, y, sigma, hv);
                 });
                 // the plain kernel stays unless another one wins by more than the noise of the measurement (1 %)
                 size_t best = 0;
-                for (size_t k = 1; k < cand.size(); k++)
+                for (size_t k = 1; k < cs.size(); k++)
                     if (tv[k] < 0.99f * tv[0] && (best == 0 || tv[k] < tv[best])) best = k;
-                h.hess_variant = cand[best];
+                // (a throttled candidate must beat its own unthrottled form by the same margin)
+                if (cs[best].dyn && !fixed_dyn)
+                    for (size_t k = 0; k < cs.size(); k++)
+                        if (cs[k].variant == cs[best].variant && cs[k].dyn == 0 && !(tv[best] < 0.99f * tv[k])) { best = k; break; }
+                h.hess_variant = cs[best].variant;
+                h.hess_dyn_lds = cs[best].dyn;
+                h.hess_dyn_auto = false;
                 install_order(h, CB_HESSC, h.hess_variant == 1 ? order_cl : order_c);
                 HIPCHK(hipStreamSynchronize(h.stream));
                 if (h.norders[CB_HESSC] > 1) tune_store(source_key(h.gen.source), tune_signature(h, "order" + std::to_string((int)CB_HESSC)), h.order[CB_HESSC]);
                 if (verbose()) {
                     fprintf(stderr, "[exahip] tune hess_coord kernels (ms per 6 launches):");
-                    for (size_t k = 0; k < cand.size(); k++) fprintf(stderr, " variant %d: %.4f", cand[k], tv[k]);
-                    fprintf(stderr, " -> variant %d\n", h.hess_variant);
+                    for (size_t k = 0; k < cs.size(); k++) fprintf(stderr, " variant %d%s%s: %.4f", cs[k].variant, cs[k].dyn ? " +LDS " : "", cs[k].dyn ? std::to_string(cs[k].dyn).c_str() : "", tv[k]);
+                    fprintf(stderr, " -> variant %d, %u bytes of throttle\n", h.hess_variant, h.hess_dyn_lds);
                 }
                 tune_store(source_key(h.gen.source), tune_signature(h, "hessvariant"), h.hess_variant);
+                if (!fixed_dyn) tune_store(source_key(h.gen.source), tune_signature(h, "hessdynlds"), (int)h.hess_dyn_lds);
             } else if (h.norders[CB_HESS] > 1) { hv = need(4, h.lnnzh); tune_order(h, CB_HESS, [&] { do_hess(h, x, y, sigma, hv); }); }
             if (h.norders[CB_FUSED] > 1) {
                 c = need(2, m.ncon); jv = need(3, h.lnnzj); hv = need(4, h.lnnzh);

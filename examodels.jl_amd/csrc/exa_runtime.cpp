@@ -230,6 +230,10 @@ void fill_params(Handle &h) {
     // for its pipelining with twice the registers: it wins where the call streams gigabytes through HBM (LV N = 3e7:
     // 0.472 against 0.529 ms, N = 1e8: 1.52 against 1.76) and loses where x, y and much of the output sit in the 256 MB
     // MALL or the arithmetic dominates (LV N = 1e7: 0.156 against 0.135 ms; rocket 0.108 / 0.086; ACOPF 0.034 / 0.018)
+    // occupancy throttle of the hess_coord! launches: dynamic LDS nobody uses (static + dynamic <= 64 KB: no function attribute needed)
+    // (chained kernels only; exa_tune decides between none / three / two workgroups per CU — the environment variable fixes it)
+    const char *dl = getenv("EXAHIP_HESS_DYN_LDS");
+    if (dl) h.hess_dyn_lds = (unsigned)std::min(49152, std::max(0, atoi(dl)));
     h.hess_variant = 0;
     if (L.chain[CB_HESSC] > 0) {
         const char *ce = getenv("EXAHIP_HESS_VARIANT");
@@ -237,6 +241,11 @@ void fill_params(Handle &h) {
         if (ce) h.hess_variant = std::min(2, std::max(0, atoi(ce)));
         else if (tune_lookup(source_key(h.gen.source), tune_signature(h, "hessvariant"), &pv)) h.hess_variant = std::min(2, std::max(0, pv));
         else h.hess_variant = h.hess_stream_bytes >= 1.5e9;
+        if (!dl) {
+            int pd = 0;
+            if (tune_lookup(source_key(h.gen.source), tune_signature(h, "hessdynlds"), &pd)) h.hess_dyn_lds = (unsigned)std::min(49152, std::max(0, pd));
+            else h.hess_dyn_auto = !ce && h.hess_stream_bytes >= 1.5e9;        // (measured at LV 1e8: 1.70 -> 1.62 ms, profiles/r5_hess_occupancy.txt)
+        }
     }
     // exa_hesscl stages, per wavefront, tile and stretch, ONE run of 64 + kStageHalo variables for the member clusters of the stretch: their
     // first variables (of THIS shard's first points) must lie within the halo of each other (ParamLayout::Stage)
@@ -574,10 +583,10 @@ void to_device(Handle &h) {
     fill_params(h);
 }
 
-void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **args) {
+void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **args, unsigned dyn_lds) {
     if (grid <= 0) return;
     if (grid > 0x7fffffffLL) throw std::runtime_error("grid too large");
-    HIPCHK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, block, 1, 1, 0, h.stream, args, nullptr));
+    HIPCHK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, block, 1, 1, dyn_lds, h.stream, args, nullptr));
 }
 
 // zero-fill of n doubles on the model's stream (exa_zero)
@@ -750,9 +759,10 @@ void do_hess(Handle &h, const double *x, const double *y, double sigma, double *
         return;
     }
     if (h.hess_variant >= 1 && h.f_hessc) {
+        if (h.hess_dyn_auto) { h.hess_dyn_auto = false; h.hess_dyn_lds = hess_throttle_bytes(h, h.hess_variant, 3); }
         void *sink = h.dsink.p;
         void *a[] = {&P, &x, &y, &th, &v, &sigma, &sink};
-        launch(h, h.hess_variant == 1 && h.f_hesscl && h.stage_ok ? h.f_hesscl : h.f_hessc, h.grid[CB_HESSC], kBlock, a);
+        launch(h, h.hess_variant == 1 && h.f_hesscl && h.stage_ok ? h.f_hesscl : h.f_hessc, h.grid[CB_HESSC], kBlock, a, h.hess_dyn_lds);
         return;
     }
     void *a[] = {&P, &x, &y, &th, &v, &sigma};

@@ -26,7 +26,7 @@ SYMBOLS = [
     "exa_chess_structure64", "exa_cjac_csc", "exa_chess_csc", "exa_cjac", "exa_chess",
     "exa_build_info", "exa_build_audit", "exa_debug_dump_window_launch", "exa_tune", "exa_comm_unique_id", "exa_comm_init", "exa_comm_attach", "exa_comm_hook", "exa_comm_free",
     "exa_comm_info", "exa_set_reduce", "exa_allreduce", "exa_set_coo_local", "exa_local_nnzj64", "exa_local_nnzh64",
-    "exa_coo_slices", "exa_shard_var_range", "exa_hess_variant", "exa_product_info", "exa_allgather_coo", "exa_shard_layout", "exa_collective_plan",
+    "exa_coo_slices", "exa_shard_var_range", "exa_hess_variant", "exa_hess_throttle", "exa_product_info", "exa_allgather_coo", "exa_shard_layout", "exa_collective_plan",
 ]
 # ... and include/exahip_recipe.h
 RECIPE_SYMBOLS = [
@@ -157,6 +157,7 @@ def lib():
     L.exa_coo_slices.argtypes = [i32, i32, vp]
     L.exa_shard_var_range.argtypes = [i32, vp, vp]
     L.exa_hess_variant.argtypes = [i32]
+    L.exa_hess_throttle.argtypes = [i32]
     L.exa_product_info.argtypes = [i32, i32, ctypes.c_char_p, i32]
     L.exa_allgather_coo.argtypes = [i32, i32, vp, vp]
     L.exa_shard_layout.argtypes = [i32, i32]

@@ -423,6 +423,11 @@ int exa_block_order(int id, int which);
  * and used when this shard's groups start within that halo of each other (else 1 runs exa_hessc and this returns 2).
  * Which one runs: the decision exa_tune measured and persisted, else by size (>= 1.5 GB streamed per call -> 1). */
 int exa_hess_variant(int id);
+/* Dynamic LDS (bytes) the chained hess_coord! kernels (variants 1, 2) are launched with: an occupancy throttle — memory nobody uses that
+ * leaves three or two workgroups per CU instead of as many as the registers allow.  Fewer, longer streams per CU win where the output
+ * outgrows the Infinity Cache (LV 1e8: 1.70 -> 1.62 ms) and on some boxes below it; exa_tune measures none / three / two next to the
+ * kernels themselves and persists the winner, EXAHIP_HESS_DYN_LDS=bytes fixes it.  0 = no throttle (the default without a tuning decision). */
+int exa_hess_throttle(int id);
 /* Explicit, BLOCKING tuning — the only entry point that measures.  what: bit 0 = block order of cons / jac / hess / fused
  * (models streaming >= 128 MB from several patterns), bit 1 = exa_jtprod / exa_hprod implementation, bit 2 = exa_grad
  * implementation (exa_set_grad_mode; only models whose objective scatters through a data index).  Both candidates of

@@ -194,3 +194,54 @@ def test_ktab_knob_coefficients_from_constant_memory_give_the_same_bits(libs, na
         assert np.array_equal(a[k], b[k]), k
     for k in ("grad", "jtprod", "hprod"):          # atomics where the scatter is data-indexed: the order of the additions is free
         np.testing.assert_allclose(a[k], b[k], rtol=1e-12, atol=1e-13, err_msg=k)
+
+
+def test_tile_ld_budget_knob_changes_the_staging_tile_not_the_values(libs, monkeypatch):
+    """EXAHIP_TILE_LD_BUDGET=bytes: the leading dimension of the slot-major COO staging tile is searched only among those whose tile fits the
+    budget per workgroup (the rocket's 47-slot pattern: LD 47 -> 17, 70 KB -> 25 KB).  A layout of the staging buffer: every value is
+    the same bit pattern, through another tile."""
+    from exahip import ExaModel
+    m0 = ExaModel(ZOO["rocket50"]())
+    monkeypatch.setenv("EXAHIP_TILE_LD_BUDGET", "40960")
+    m1 = ExaModel(ZOO["rocket50"]())
+    assert m0._L.exa_module_name(m0.id) != m1._L.exa_module_name(m1.id)
+    lds = lambda m: max(a["lds"] for a in m.build_audit() if a["kernel"] == "exa_hess")       # noqa: E731
+    assert lds(m1) < lds(m0) and lds(m1) <= 40960
+    x, y, s = point(m0.meta.x0, m0.meta.ncon, seed=14)
+    v = np.random.default_rng(5).standard_normal(m0.meta.nvar)
+    w = np.random.default_rng(6).standard_normal(max(1, m0.meta.ncon))[:m0.meta.ncon]
+    a, b = _everything(m0, x, y, s, v, w), _everything(m1, x, y, s, v, w)
+    for k in ("obj", "cons", "jac", "hess", "all_c", "all_j", "all_h"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_hess_throttle_is_the_same_kernel_at_another_occupancy(libs, tmp_path, monkeypatch):
+    """EXAHIP_HESS_DYN_LDS=bytes: the chained hess_coord! kernels launched with dynamic LDS nobody uses (three or two workgroups per CU instead
+    of as many as the registers allow) — the same kernel, the same bits.  Without the variable exa_tune measures none / three / two next to
+    the kernels themselves; its decision is one of the candidates, is persisted with the kernel choice, and a later model starts with it."""
+    import torch
+    from exahip import ExaModel, models
+    monkeypatch.setenv("EXAHIP_CACHE_DIR", str(tmp_path))
+    N = 2_000_000
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("EXAHIP_HESS_VARIANT", "1")
+    m0 = ExaModel(models.luksan_vlcek_model(N))
+    assert m0._L.exa_hess_variant(m0.id) == 1 and m0._L.exa_hess_throttle(m0.id) == 0
+    xd = torch.from_numpy(m0.meta.x0 + 0.05).to(dev)
+    yd = torch.ones(m0.meta.ncon, dtype=torch.float64, device=dev)
+    ref = m0.hess_coord(xd, yd, 0.5).clone()
+    for dyn in (26000, 40000):
+        monkeypatch.setenv("EXAHIP_HESS_DYN_LDS", str(dyn))
+        m = ExaModel(models.luksan_vlcek_model(N))
+        assert m._L.exa_hess_throttle(m.id) == dyn
+        assert torch.equal(m.hess_coord(xd, yd, 0.5), ref)
+    monkeypatch.delenv("EXAHIP_HESS_DYN_LDS")
+    monkeypatch.delenv("EXAHIP_HESS_VARIANT")
+    mt = ExaModel(models.luksan_vlcek_model(N))
+    mt.tune(1, xd, yd)
+    v, d = mt._L.exa_hess_variant(mt.id), mt._L.exa_hess_throttle(mt.id)
+    assert v in (0, 1, 2) and (d == 0 if v == 0 else 0 <= d <= 49152)
+    assert torch.equal(mt.hess_coord(xd, yd, 0.5), ref) or v == 0        # (the plain kernel contracts its multiply-adds in another body)
+    np.testing.assert_allclose(mt.hess_coord(xd, yd, 0.5).cpu().numpy(), ref.cpu().numpy(), rtol=1e-12, atol=1e-300)
+    m2 = ExaModel(models.luksan_vlcek_model(N))
+    assert (m2._L.exa_hess_variant(m2.id), m2._L.exa_hess_throttle(m2.id)) == (v, d)
