@@ -330,6 +330,8 @@ end
 theta_ptr(m) = ccall((:exa_theta_ptr, LIB), Ptr{Cdouble}, (Cint,), m.ext.id)
 # how exa_eval_all produces grad! on this model (exa_eval_all_mode): 1 / 2 = inside the sweep's one launch, 0 / 3 = a launch in front, 4 = sorted gather
 eval_all_mode(m) = ccall((:exa_eval_all_mode, LIB), Cint, (Cint,), m.ext.id)
+# which hess_coord! kernel tune! chose (0 exa_hess, 1 exa_hesscl, 2 exa_hessc) and the unused dynamic LDS its launches carry (an occupancy throttle)
+hess_kernel(m) = (ccall((:exa_hess_variant, LIB), Cint, (Cint,), m.ext.id), ccall((:exa_hess_throttle, LIB), Cint, (Cint,), m.ext.id))
 # locality-ordered table copies for the order-free kernels (exa_set_locality; opt-in: measured slower where the patterns also read by row); -1 only asks
 locality!(m, on::Integer = 1) = ccall((:exa_set_locality, LIB), Cint, (Cint, Cint), m.ext.id, on)
 # may model files bring device code of their own (exa_recipe_trust_code)?  Returns the setting in force before the call.
