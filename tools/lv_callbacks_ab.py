@@ -2,6 +2,8 @@
 """Every callback of LV at N points for ONE package directory (argv[1]: this tree's examodels.jl_amd or a copy of an older one), min over
 5 x 100 calls by hipEvents — run once per package in a fresh process, alternating, by the caller: the same-box A/B of two trees.
 usage: lv_callbacks_ab.py PKGDIR N [lv|rocket|acopf]   (N: points of LV / nh of the rocket; the ACOPF network is the 78 484-bus synthetic one)"""
+# An older tree to compare with:  mkdir tools/_old && git archive <commit> examodels.jl_amd include | tar -x -C tools/_old && make -C tools/_old/examodels.jl_amd/csrc
+# (round 5 used ccdf976 as tools/_old_r5 and 396dbc3 as tools/_old_r5b; both removed after the measurements)
 import os
 import sys
 

@@ -2,6 +2,8 @@
 """hess_coord! of LV at N points with each of the three kernels (EXAHIP_HESS_VARIANT=0|1|2: exa_hess / exa_hessc / exa_hesscl), for ONE
 package directory (argv[1]: this tree's examodels.jl_amd or a copy of an older one) — run once per (package, variant) in a fresh
 process by the caller, so that two libraries never share a process.  usage: lv_hess_ab.py PKGDIR N VARIANT [--compile-only]"""
+# An older tree to compare with:  mkdir tools/_old && git archive <commit> examodels.jl_amd include | tar -x -C tools/_old && make -C tools/_old/examodels.jl_amd/csrc
+# (round 5 used ccdf976 as tools/_old_r5 and 396dbc3 as tools/_old_r5b; both removed after the measurements)
 import os
 import sys
 
