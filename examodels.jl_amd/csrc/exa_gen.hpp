@@ -391,8 +391,9 @@ void gen_struct_fn(std::ostringstream &os, const Model &m, int pi, const ParamLa
 void gen_merged_hess_fn(std::ostringstream &os, const Model &m, const ParamLayout &L, int gi);
 void gen_merged_struct_fn(std::ostringstream &os, const Model &m, const ParamLayout &L, int gi);
 int merged_slot_count(const Model &m, const ParamLayout &L, const std::vector<int> &grp);
+// looped: the body as a LOOP over `ppt` consecutive block-map entries of `nent` (kernel arguments of exa_jacl / exa_consl), one tile each
 void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const std::string &call_prefix, const std::string &call_args,
-                  const std::string &tail_args = "");
+                  const std::string &tail_args = "", bool looped = false);
 void gen_dispatch_chained(std::ostringstream &os, const ParamLayout &L, int cb, const char *name, bool hess);
 void gen_dispatch_chained_staged(std::ostringstream &os, const Model &m, const ParamLayout &L);
 bool pattern_stage(const Model &m, int pi, const ParamLayout &L, ParamLayout::Stage *out);      // ParamLayout::stage of one pattern

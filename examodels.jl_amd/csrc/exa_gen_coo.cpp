@@ -536,13 +536,25 @@ void gen_struct_fn(std::ostringstream &os, const Model &m, int pi, const ParamLa
 
 // ---- fused kernels: blockIdx -> (pattern, tile) ------------------------------------------------------
 void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const std::string &call_prefix, const std::string &call_args,
-                  const std::string &tail_args) {
+                  const std::string &tail_args, bool looped) {
     const auto &act = L.active[cb];
     const int ppt = L.ppt[cb];
+    // Tile loop (exa_jacl, exa_consl; round 5): the workgroup walks `ppt` consecutive entries of the SAME block map, one tile each, in a loop
+    // that is not unrolled — the registers of one tile, a workgroup that lives ppt times as long.  Why: a wavefront slot of the one-tile kernels
+    // sits empty for ~1 500 - 2 000 cycles between two workgroups (average residency 6.1 of 8 wavefronts per SIMD in LV's exa_cons, profiles/
+    // r5_instruction_mix.txt), and the compiler hoists the literal coefficients of the math routines out of the loop (once per workgroup).
+    // (the entry of the NEXT tile is fetched — a scalar load through the constant address space: nothing on the device writes the map —
+    // before the current tile is evaluated: no dependent round trip at the head of an iteration)
+    const std::string bmap = "((const __attribute__((address_space(4))) long*)P[" + std::to_string(L.blk[cb]) + "])";
+    if (looped) os << "    const long b0_ = (long)blockIdx.x * ppt;\n    if (b0_ >= nent) return;\n    long en_ = " << bmap << "[b0_];\n"
+                      "#pragma unroll 1\n    for (int u_ = 0; u_ < ppt; u_++) {\n    const long b = b0_ + u_;\n    if (b >= nent) break;\n"
+                      "    const long e_ = en_;\n    en_ = " << bmap << "[b + 1 < nent ? b + 1 : b];\n";
+    else
     os << "    const long b = blockIdx.x;\n";
     // block map: which pattern and which tile this workgroup evaluates (interleaved by the runtime so that patterns
     // reading the same x ranges run on the same XCD at about the same time)
-    os << "    const long e_ = ((const long*)P[" << L.blk[cb] << "])[b];\n    const int ps_ = (int)(e_ >> 40);\n"
+    if (!looped) os << "    const long e_ = ((const long*)P[" << L.blk[cb] << "])[b];\n";
+    os << "    const int ps_ = (int)(e_ >> 40);\n"
           "    const long tid0 = (e_ & ((1L << 40) - 1)) * (EXA_BLOCK * " << ppt << ") + threadIdx.x;\n";
     const bool scatter = cb == CB_GRAD || cb == CB_JTPROD || cb == CB_HPROD;
     const bool grouped = cb == CB_JTPROD || cb == CB_HPROD || cb == CB_JAC || cb == CB_HESS;     // dispatch units are fused groups
@@ -566,6 +578,7 @@ void gen_dispatch(std::ostringstream &os, const ParamLayout &L, int cb, const st
         }
         os << "    }\n";
     }
+    if (looped) os << "    }\n";
 }
 
 // Chained dispatch (jac / hess), see ParamLayout::chain: entry = (group, first tile); T tiles, all patterns of the

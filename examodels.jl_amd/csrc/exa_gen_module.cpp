@@ -302,6 +302,22 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
         }
     }
     os << "}\n";
+    // exa_consl: exa_cons as a tile loop over `ppt` consecutive block-map entries (see gen_dispatch, looped)
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_consl(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ th, double* __restrict__ out, double* __restrict__ aug, long nent, int ppt) {\n";
+    if (L.ppt[CB_CONS] == 1) {
+        const auto &act = L.active[CB_CONS];
+        const std::string bmap = "((const __attribute__((address_space(4))) long*)P[" + std::to_string(L.blk[CB_CONS]) + "])";
+        os << "    const long b0_ = (long)blockIdx.x * ppt;\n    if (b0_ >= nent) return;\n    long en_ = " << bmap << "[b0_];\n"
+              "#pragma unroll 1\n    for (int u_ = 0; u_ < ppt; u_++) {\n    const long b = b0_ + u_;\n    if (b >= nent) break;\n"
+              "    const long e_ = en_;\n    en_ = " << bmap << "[b + 1 < nent ? b + 1 : b];\n    const int ps_ = (int)(e_ >> 40);\n"
+              "    const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
+        for (size_t k = 0; k < act.size(); k++)
+            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") { const double v_ = p" << act[k] << "_consv(P, x, th, tid0); p" << act[k]
+               << "_conss(P, out, aug, tid0, v_); }\n";
+        os << "    }\n";
+    }
+    os << "}\n";
     // cons_nln! in ONE launch (unsharded models whose rows collect at most EXA_AUG_LONG terms).  The reference runs the base
     // kernel, the augmentation kernels and compress_to_dense (KA ext :273-308, :691-697); exa_cons + exa_aug_gather are two
     // dependent launches.  Here the thread that owns base row r walks the row's augmentation terms — listed at build time
@@ -431,6 +447,12 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
           "const double* __restrict__ th, double* __restrict__ out) {\n";
     lds_decl(CB_JAC, false);
     gen_dispatch(os, L, CB_JAC, "jac", "P, x, th, out", ", lds");
+    os << "}\n";
+    // the same callback as a tile loop (gen_dispatch, looped): launched instead of exa_jac where the block map is long (exa_runtime.cpp do_jac)
+    os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jacl(const long* __restrict__ P, const double* __restrict__ x, "
+          "const double* __restrict__ th, double* __restrict__ out, long nent, int ppt) {\n";
+    lds_decl(CB_JAC, false);
+    gen_dispatch(os, L, CB_JAC, "jac", "P, x, th, out", ", lds", true);
     os << "}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hess(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma) {\n";

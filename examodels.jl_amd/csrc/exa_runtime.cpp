@@ -437,6 +437,8 @@ void to_device(Handle &h) {
     if (h.gen.layout.chain[CB_HESSC] > 0) h.f_hessc = fn("exa_hessc");
     if (h.gen.layout.chain[CB_HESSC] > 0 && h.gen.layout.staged) h.f_hesscl = fn("exa_hesscl");
     h.f_cons1 = fn("exa_cons1");
+    h.f_jacl = fn("exa_jacl"); h.f_consl = fn("exa_consl");
+    if (const char *tl = getenv("EXAHIP_TILE_LOOP")) h.tile_loop = std::min(64, std::max(0, atoi(tl)));
     h.f_gradv = fn("exa_gradv"); h.f_gstruct = fn("exa_gstruct");
     if (m.aug_linear || m.nconaug == 0) h.f_jprod1 = fn("exa_jprod1");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
@@ -589,6 +591,19 @@ void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **arg
     HIPCHK(hipModuleLaunchKernel(f, (unsigned)grid, 1, 1, block, 1, 1, dyn_lds, h.stream, args, nullptr));
 }
 
+// Tiles per workgroup of the looped first-order kernels (exa_consl / exa_jacl), 0 = the one-tile kernel.  A workgroup of the one-tile kernels lives
+// ~2 us and its wavefront slots then sit empty for most of another microsecond until the next workgroup arrives (LV 1e7 exa_cons: 6.1 of 8
+// wavefronts resident on average, profiles/r5_instruction_mix.txt); a loop over 4 (cons_nln!) / 8 (jac_coord!) block-map entries amortises that,
+// and the compiler keeps the literal coefficients of exp / sincos in SGPRs across tiles.  LV 1e8: cons_nln! 0.562 -> 0.513 ms, jac_coord! 0.815 ->
+// 0.709; LV 1e7: 0.0458 -> 0.0457, 0.0601 -> 0.0592; bitwise equal (profiles/r5_tile_loop_ab.txt).  Only where the block map is long enough to
+// keep every CU busy with the longer workgroups.
+int tile_loop_ppt(Handle &h, int cb) {
+    hipFunction_t f = cb == CB_JAC ? h.f_jacl : h.f_consl;
+    if (!f || h.gen.layout.ppt[cb] != 1 || h.tile_loop == 0 || h.tile_loop == 1) return 0;
+    if (h.tile_loop > 1) return h.tile_loop;
+    const int want = cb == CB_JAC ? 8 : 4;
+    return h.grid[cb] >= (int64_t)16384 * want / 4 ? want : 0;        // >= 8 workgroups per CU after the division
+}
 // zero-fill of n doubles on the model's stream (exa_zero)
 void zero_fill(Handle &h, void *p, int64_t n) {
     if (n <= 0) return;
@@ -733,14 +748,28 @@ void do_cons(Handle &h, const double *x, double *c) {
         return;
     }
     // base rows (plain stores into c) and augmentation terms (into the value buffer, coalesced)
-    void *a[] = {&P, &x, &th, &c, &buf};
-    launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a);
+    if (const int ppt = tile_loop_ppt(h, CB_CONS)) {
+        int64_t nent = h.grid[CB_CONS];
+        int pp = ppt;
+        void *al[] = {&P, &x, &th, &c, &buf, &nent, &pp};
+        launch(h, h.f_consl, (nent + ppt - 1) / ppt, kBlock, al);
+    } else {
+        void *a[] = {&P, &x, &th, &c, &buf};
+        launch(h, h.f_cons, h.grid[CB_CONS], kBlock, a);
+    }
     if (h.m->nconaug) aug_gather(h, buf, c);       // then one deterministic gather per target row
     if (owner) allgatherv(h, c, row_pieces(h));
     else allreduce(h, c, h.m->ncon);
 }
 void do_jac(Handle &h, const double *x, double *v) {
     const void *P = h.dP.p, *th = h.dtheta.p;
+    if (const int ppt = tile_loop_ppt(h, CB_JAC)) {
+        int64_t nent = h.grid[CB_JAC];
+        int pp = ppt;
+        void *al[] = {&P, &x, &th, &v, &nent, &pp};
+        launch(h, h.f_jacl, (nent + ppt - 1) / ppt, kBlock, al);
+        return;
+    }
     void *a[] = {&P, &x, &th, &v};
     launch(h, h.f_jac, h.grid[CB_JAC], kBlock, a);
 }

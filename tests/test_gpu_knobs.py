@@ -245,3 +245,39 @@ def test_hess_throttle_is_the_same_kernel_at_another_occupancy(libs, tmp_path, m
     np.testing.assert_allclose(mt.hess_coord(xd, yd, 0.5).cpu().numpy(), ref.cpu().numpy(), rtol=1e-12, atol=1e-300)
     m2 = ExaModel(models.luksan_vlcek_model(N))
     assert (m2._L.exa_hess_variant(m2.id), m2._L.exa_hess_throttle(m2.id)) == (v, d)
+
+
+@pytest.mark.parametrize("name", ["lv1000", "rocket50", "acopf30", "mixed"])
+def test_tile_loop_kernels_write_the_same_bits(libs, name, monkeypatch):
+    """exa_jacl / exa_consl: jac_coord! / cons_nln! as a loop over n consecutive block-map entries per workgroup (launched by default where the
+    block map is long: LV 1e7, covered at full size by test_gpu_fullsize.py; EXAHIP_TILE_LOOP=n forces it, 0 switches it off).  The same pattern
+    functions on the same tiles: every output bit for bit, into NaN-poisoned buffers, whole and as a 3-way sharded replay."""
+    import torch
+    from exahip import ExaModel
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("EXAHIP_TILE_LOOP", "0")
+    m0 = ExaModel(ZOO[name]())
+    x, y, s = point(m0.meta.x0, m0.meta.ncon, seed=15)
+    xd = torch.from_numpy(x).to(dev)
+    ref_c, ref_j = m0.cons(xd).clone(), m0.jac_coord(xd).clone()
+    for n in (3, 8):
+        monkeypatch.setenv("EXAHIP_TILE_LOOP", str(n))
+        m = ExaModel(ZOO[name]())
+        c = torch.full((max(1, m.meta.ncon) + 4,), float("nan"), dtype=torch.float64, device=dev)
+        j = torch.full((max(1, m.meta.nnzj) + 4,), float("nan"), dtype=torch.float64, device=dev)
+        m.cons(xd, out=c); m.jac_coord(xd, out=j)
+        torch.cuda.synchronize()
+        assert torch.equal(c[:m.meta.ncon], ref_c) and torch.equal(j[:m.meta.nnzj], ref_j)
+        assert bool(torch.isnan(c[m.meta.ncon:]).all()) and bool(torch.isnan(j[m.meta.nnzj:]).all())
+        whole = np.full(m.meta.nnzj, np.nan)
+        for rank in range(3):
+            m.set_shard(rank, 3)
+            m.set_coo_local(False)
+            j.fill_(float("nan"))
+            m.jac_coord(xd, out=j)
+            torch.cuda.synchronize()
+            part = j.cpu().numpy()[:m.meta.nnzj]
+            mine = ~np.isnan(part)
+            assert np.all(np.isnan(whole[mine]))
+            whole[mine] = part[mine]
+        assert np.array_equal(whole, ref_j.cpu().numpy())
