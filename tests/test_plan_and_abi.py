@@ -504,3 +504,16 @@ def test_pull_key_kernels_walk_the_block_map_like_the_scatter_kernels(libs, seed
         if f_keys > 1:
             assert f"u < {f_keys}" in body
     assert any(factor(main, k)[0] == 16 for k in ("exa_jtprod", "exa_hprod"))          # these seeds DO have a shared target
+
+
+def test_generated_module_has_the_tile_loop_kernels(libs):
+    """exa_jacl / exa_consl (cons_nln! / jac_coord! as a loop over `ppt` consecutive block-map entries, both launch arguments): part of every
+    module; the loop is not unrolled and the next entry is fetched through the constant address space (a scalar load) ahead of its tile."""
+    from exahip import ExaModel, models
+    for core in (models.luksan_vlcek_model(100), models.rocket_model(20)):
+        src = ExaModel(core, device=False).kernel_source()
+        for k in ("exa_jacl", "exa_consl"):
+            body = src.split("__launch_bounds__(EXA_BLOCK) " + k + "(")[1].split('extern "C"')[0]
+            assert "long nent, int ppt)" in body.split("{")[0]
+            assert "#pragma unroll 1\n    for (int u_ = 0; u_ < ppt; u_++)" in body and "if (b >= nent) break;" in body
+            assert "en_ = ((const __attribute__((address_space(4))) long*)P[" in body
