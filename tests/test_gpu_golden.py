@@ -17,7 +17,7 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 from conftest import has_gpu  # noqa: E402
 from exprs import EXPRS, NPAR, NVAR, SPECIAL_EXPRS  # noqa: E402
 from test_golden_oracle import CASES, T0, X0, NodeF, close, dense_lower  # noqa: E402
-from test_known_answers import CONS_CASES, LSTAR, XSTAR  # noqa: E402
+from test_known_answers import CONS_CASES, LSTAR, XSTAR, check_ipopt_logs, doc_parametric_lv10  # noqa: E402
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not has_gpu(), reason="needs an MI355X")]
 
@@ -112,6 +112,23 @@ def test_lv10_published_kkt_point_on_hip(libs):
     J = np.zeros((m.meta.ncon, m.meta.nvar))
     np.add.at(J, (jr - 1, jc - 1), m.jac_coord(XSTAR))
     assert np.max(np.abs(m.grad(XSTAR) + J.T @ LSTAR)) < 1e-6
+
+
+def test_reference_ipopt_logs_of_the_parametric_lv10_on_hip(libs):
+    """docs/src/parameters.md:95-295 on the HIP path: nnzj = 24 / nnzh = 75, obj(x0) for the three parameter sets (exa_set_value
+    between them, no rebuild), the six full-step Newton iterates of each log to the printed digits (each iterate is a function of
+    hess_coord!'s VALUES at the one before), the three optima."""
+    from exahip import ExaModel
+    core, th = doc_parametric_lv10()
+    m = ExaModel(core)
+    x0 = np.array(m.meta.x0)
+    assert m.obj(x0) == 2057.0
+    assert "%.2e" % np.max(np.abs(m.cons(x0))) == "2.48e+01"
+    check_ipopt_logs(m, x0, lambda v: m.set_value(th, v))
+    m.set_value(th, [200.0, 1.0])
+    assert abs(m.obj(x0) - 4089.8) < 1e-9
+    m.set_value(th, [200.0, 0.5])
+    assert abs(m.obj(x0) - 4081.05) < 1e-9
 
 
 def test_objective_callbacks_on_golden_rows(libs):

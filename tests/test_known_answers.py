@@ -264,3 +264,87 @@ def test_lv_compiled_baseline_equals_interpreter(libs):
     ref = o.hess_coord(x, y, 0.5)
     np.testing.assert_allclose(oracle.lv_hess_compiled(N, x, y, 0.5), ref, rtol=1e-14, atol=0)
     np.testing.assert_allclose(oracle.lv_hess_compiled(N, x, y, 0.5, threads=4), ref, rtol=1e-14, atol=0)
+
+
+# ---- the reference's own Ipopt logs of the parametric LV-10 model (docs/src/parameters.md) -----------------------------------
+# OBSERVED from a Julia run of the reference (the rendered output of docs/src/parameters.jl): counts, objective values at x0 for
+# three parameter sets, and three full-step Newton trajectories whose every iterate depends on the Hessian VALUES at the previous
+# one.  Columns as printed: objective, inf_pr, inf_du (scaled by Ipopt's objective scaling 100 / max|grad f(x0)|), ||d||.
+def doc_parametric_lv10(N=10):
+    """docs/src/parameters.md:24-82: θ = [100, 1]; objective FIRST (θ[1] (x[i-1]² - x[i])² + (x[i-1] - θ[2])², i = 2:N), then the
+    LV constraint over i = 1:N-2 — the insertion order decides the Hessian slot offsets."""
+    from exahip.graph import exp, sin
+    c = ExaCore()
+    th = c.add_par([100.0, 1.0])
+    x = c.add_var(N, start=np.array([models.luksan_vlcek_x0(i) for i in range(1, N + 1)]))
+    c.add_obj(lambda i: th[1] * (x[i - 1] ** 2 - x[i]) ** 2 + (x[i - 1] - th[2]) ** 2, rng(2, N))
+    c.add_con(lambda i: 3 * x[i + 1] ** 3 + 2 * x[i + 2] - 5 + sin(x[i + 1] - x[i + 2]) * sin(x[i + 1] + x[i + 2]) + 4 * x[i + 1]
+              - x[i] * exp(x[i] - x[i + 1]) - 3, rng(1, N - 2))
+    return c, th
+
+
+IPOPT_LOGS = {          # theta -> (rows of docs/src/parameters.md, unscaled final objective, final constraint violation, final scaled inf_du)
+    (100.0, 1.0): ("""
+   0  2.0570000e+03 2.48e+01 2.73e+01  -1.0 0.00e+00
+   1  1.0953147e+03 1.49e+01 8.27e+01  -1.0 2.20e+00
+   2  3.2865521e+02 4.28e+00 1.36e+02  -1.0 1.43e+00
+   3  1.3995370e+01 3.09e-01 2.18e+01  -1.0 5.63e-01
+   4  6.2325715e+00 1.73e-02 8.47e-01  -1.0 2.10e-01
+   5  6.2324586e+00 1.15e-05 8.16e-04  -1.7 3.35e-03
+   6  6.2324586e+00 8.35e-12 7.97e-10  -5.7 2.00e-06""", 6.232458632437464, 8.3542062156993779e-12, 7.9746301767912855e-10),     # :148-154, :177, :161, :160
+    (200.0, 1.0): ("""
+   0  4.0898000e+03 2.48e+01 2.70e+01  -1.0 0.00e+00
+   1  2.1810502e+03 1.49e+01 8.27e+01  -1.0 2.20e+00
+   2  6.5137192e+02 4.27e+00 1.36e+02  -1.0 1.43e+00
+   3  2.4064340e+01 3.08e-01 2.18e+01  -1.0 5.62e-01
+   4  8.6476680e+00 1.72e-02 8.45e-01  -1.0 2.10e-01
+   5  8.6474398e+00 1.15e-05 8.07e-04  -1.7 3.39e-03
+   6  8.6474398e+00 8.42e-12 7.91e-10  -5.7 2.03e-06""", 8.647439751691484, 8.4190432403374871e-12, 7.9051456515071309e-10),     # :207-213, :236, :220, :219
+    (200.0, 0.5): ("""
+   0  4.0810500e+03 2.48e+01 2.69e+01  -1.0 0.00e+00
+   1  2.1767809e+03 1.49e+01 8.26e+01  -1.0 2.20e+00
+   2  6.5050886e+02 4.27e+00 1.36e+02  -1.0 1.43e+00
+   3  2.4276149e+01 3.07e-01 2.18e+01  -1.0 5.61e-01
+   4  8.8465512e+00 1.72e-02 8.43e-01  -1.0 2.09e-01
+   5  8.8451636e+00 1.15e-05 8.04e-04  -1.7 3.40e-03
+   6  8.8451630e+00 8.47e-12 7.88e-10  -5.7 2.05e-06""", 8.845162987294774, 8.4678930534209940e-12, 7.8812124187921384e-10),     # :266-272, :295, :279, :278
+}
+
+
+def check_ipopt_logs(m, x0, set_theta):
+    """m: anything with the NLPModels callbacks (oracle or HIP model); set_theta(list) = the reference's set_parameter!"""
+    from kktsolve import newton_full_step
+    sizes = m if hasattr(m, "nnzj") else m.meta
+    assert (sizes.nvar, sizes.ncon, sizes.nnzj, sizes.nnzh) == (10, 8, 24, 75)      # :104-116, :133-139
+    for theta, (log, fstar, cviol, dinf) in IPOPT_LOGS.items():
+        set_theta(list(theta))
+        gmax = float(np.max(np.abs(m.grad(x0))))
+        if theta == (100.0, 1.0):
+            assert abs(gmax - 792.0) < 1e-9                    # :159-160: scaled / unscaled objective = 100 / 792
+            assert abs(100.0 / gmax - 7.8692659500473017e-01 / 6.2324586324374636e+00) < 1e-15
+        rows, x, y = newton_full_step(m, x0, sizes.ncon, 6)
+        printed = [ln.split() for ln in log.strip().splitlines()]
+        for k, (p, r) in enumerate(zip(printed, rows)):
+            obj, inf_pr, inf_du, dnorm = r[0], r[1], r[2] * 100.0 / gmax, r[3]
+            assert "%.7e" % obj == p[1], (theta, k, "objective", obj, p[1])
+            if k < 6:           # every printed digit
+                assert "%.2e" % inf_pr == p[2], (theta, k, "inf_pr", inf_pr, p[2])
+                assert "%.2e" % inf_du == p[3], (theta, k, "inf_du", inf_du, p[3])
+            else:               # the last iterate's residuals are 1e-4 above the rounding of the linear solves: the log's full-precision figures, 0.1 %
+                assert abs(inf_pr - cviol) <= 1e-3 * cviol and abs(inf_du - dinf) <= 1e-3 * dinf, (theta, inf_pr, cviol, inf_du, dinf)
+            assert "%.2e" % dnorm == p[5] or abs(dnorm - float(p[5])) <= 0.006 * float(p[5]), (theta, k, "||d||", dnorm, p[5])
+        assert abs(m.obj(x) - fstar) <= 1e-9 * fstar, (theta, m.obj(x), fstar)
+
+
+def test_reference_ipopt_logs_of_the_parametric_lv10(libs):
+    """docs/src/parameters.md:95-295 — the only numbers under /root/reference that depend on hess_coord! VALUES."""
+    core, th = doc_parametric_lv10()
+    o = oracle_model(core)
+    x0 = o.meta()[0]
+    assert o.obj(x0) == 2057.0                                  # :148
+    assert "%.2e" % np.max(np.abs(o.cons(x0))) == "2.48e+01"
+    check_ipopt_logs(o, x0, lambda v: o.set_value(th.offset, v))
+    o.set_value(th.offset, [200.0, 1.0])
+    assert abs(o.obj(x0) - 4089.8) < 1e-9                       # :207
+    o.set_value(th.offset, [200.0, 0.5])
+    assert abs(o.obj(x0) - 4081.05) < 1e-9                      # :266
