@@ -382,7 +382,7 @@ def main():
     warmup = args.warmup if args.warmup is not None else 100
 
     line = run_config(config, points, world, rank, dev, backend, steps, warmup, args, strong)
-    keep = ("value", "unit", "ms_per_step", "evals_per_s", "per_call_ms", "roofline", "cpu_baseline", "config", "steps", "warmup")
+    keep = ("value", "unit", "ms_per_step", "untuned_ms_per_step", "evals_per_s", "per_call_ms", "roofline", "cpu_baseline", "config", "steps", "warmup")
     if rank == 0 and world == 1 and config == 2 and not args.no_config5_n1:
         # the N=1 point of config 5's curve (LV N=1e8 on ONE GPU: x, y and the COO are far beyond the 256 MB MALL)
         try:
@@ -487,6 +487,14 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
     time_hess(1)
     first_call_ms = 1e3 * (time.perf_counter() - t_first)
     tune_ms = 0.0
+    # what a host that never calls exa_tune gets (the reference has no tuning call, KA ext :526-537): the plan-time defaults of
+    # exa_runtime.cpp fill_params — same preheat, same K launches, measured BEFORE exa_tune touches anything
+    t_pre = time.perf_counter()
+    while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+        time_hess(20 if nnzh < 3e8 else 4)
+    untuned = {"ms_per_step": time_hess(steps), "kernel": HESS_KERNELS[L.exa_hess_variant(m.id)],
+               "block_order": {0: "sequential", 1: "interleaved-128"}.get(L.exa_block_order(m.id, 4), "n/a"),
+               "throttle_lds_bytes": int(L.exa_hess_throttle(m.id))}
     if not args.no_tune:
         t_t = time.perf_counter()
         rc = L.exa_tune(m.id, 1, ctypes.c_void_p(xp), ctypes.c_void_p(yp))     # explicit, blocking, persisted
@@ -525,7 +533,7 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
     out = {
         "metric": "sparse Lagrangian Hessian throughput (hess_coord!), nonzeros/s; evals/s in evals_per_s",
         "value": value, "unit": "nnz/s", "n_gpus": world, "steps": steps, "warmup": warmup, "preheat_ms": args.preheat_ms,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": ("strong" if strong else "weak") if world > 1 else None, "vs_baseline": None,
+        "ms_per_step": ms_per_step, "untuned_ms_per_step": untuned["ms_per_step"], "higher_is_better": True, "scaling": ("strong" if strong else "weak") if world > 1 else None, "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": wl, "baseline_config": config, "points": points, "nvar": nvar, "ncon": ncon, "nnzh": nnzh, "obj_weight": sigma,
                    "parallelism": f"iterator-shard x{world}, local-slice COO, no data-path collective" if world > 1 else "1 GPU",
@@ -548,7 +556,7 @@ def run_config(config, points, world, rank, dev, backend, steps, warmup, args, s
                      "launches_per_eval": 1, "patterns": int(m.npatterns)},
         "build": {"module": how, "module_name": L.exa_module_name(m.id).decode(), "hess_kernel": HESS_KERNELS[L.exa_hess_variant(m.id)],
                   "compile_ms": compile_ms, "model_build_s": build_s, "first_hess_call_ms": first_call_ms,
-                  "tune_ms": tune_ms,
+                  "tune_ms": tune_ms, "untuned": untuned,
                   "note": "first_hess_call_ms = host time of the first exa_hess + its completion (asynchronous launch, no measuring inside)"},
     }
     # SURVEY §8d protocol: min and median over >= 30 individually event-bracketed calls (the reference harness reports

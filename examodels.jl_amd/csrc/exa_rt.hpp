@@ -104,6 +104,7 @@ struct Handle {
     // interleaved one (a gradient tile then runs right after the tiles that pulled its stretch of x into L2 — LV 1e7: 0.201 ms
     // against 0.218 sequential, profiles/NOTES.md round 3); exa_tune measures both with the real call and persists the winner
     int orderg = -1;
+    int orderg_default = 1;                 // what exa_eval_all runs while orderg is undecided: fill_params' plan-time rule
     int norders[CB_COUNT] = {1};            // how many maps exist: exa_tune measures all of them
     hipFunction_t f_jacl = nullptr, f_consl = nullptr;      // exa_jac / exa_cons as tile loops (exa_gen_coo.cpp gen_dispatch, looped)
     int tile_loop = -1;                     // tiles per workgroup of the looped kernels: -1 by the length of the block map, 0 / 1 off, n fixed (EXAHIP_TILE_LOOP)
