@@ -210,7 +210,11 @@ end
 # library's default null stream would not be ordered against the arrays' producers and consumers).
 usestream(m) = chk(ccall((:exa_set_stream, LIB), Cint, (Cint, Ptr{Cvoid}), m.ext.id, AMDGPU.stream().stream), "exa_set_stream")
 
-# Explicit, blocking tuning (block orders, hess_coord! kernel, product implementations); persisted by the library.
+# No tuning call is needed (the reference has none, ext/ExaModelsKernelAbstractions.jl:526-537): exa_new_from_table above decides the block
+# order and the hess_coord! kernel at plan time (interleaved where the heaviest patterns walk the same stretch of x and the call streams
+# < 1.5 GB; the chained kernel at three workgroups per CU beyond) and picks up any decision an earlier tune! persisted next to the cached
+# module for this module / device / sizes.  tune! is a refinement:
+# explicit, blocking tuning (block orders, hess_coord! kernel, product implementations); persisted by the library.
 tune!(m; what = 7) = (usestream(m); chk(ccall((:exa_tune, LIB), Cint, (Cint, Cint, Ptr{Cdouble}, Ptr{Cdouble}), m.ext.id, what, C_NULL, C_NULL), "exa_tune"))
 # grad!: 0 = gathered + FP64 atomics, 1 = gradient COO + sorted gather (the reference's scheme, deterministic), -1 = what tune! persisted
 deterministic!(m, on::Bool = true) = chk(ccall((:exa_set_deterministic, LIB), Cint, (Cint, Cint), m.ext.id, on), "exa_set_deterministic")
