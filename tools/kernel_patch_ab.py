@@ -1,0 +1,271 @@
+#!/usr/bin/env python
+"""A/B of HAND-PATCHED variants of a model's GENERATED module in the real library: the generated source of LV is taken from the
+library, a variant = a list of text substitutions on it, compiled here with hipcc --genco (the library's own flags), and handed to
+the library under the ORIGINAL module name through exa_cache_add — the model then runs the patched kernels with the library's own
+parameter table, block maps and launches.  Used to try a kernel idea on the real kernel before it is built into the generator
+(round 6: the store shapes of VERDICT r5 item 3).  Variants live in VARIANTS below; outputs are compared bitwise with the base's.
+
+  prepare (no GPU):   kernel_patch_ab.py prepare OUTDIR
+  measure (MI355X):   kernel_patch_ab.py run OUTDIR N HESS_VARIANT [name ...]      HESS_VARIANT: 0 exa_hess, 1 exa_hesscl, 2 exa_hessc"""
+import ctypes
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "examodels.jl_amd"))
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-w", "-mllvm", "-sgpr-regalloc=basic"]
+
+
+def sub(src, old, new, count=1):
+    assert src.count(old) >= 1, "patch site not found: " + old[:80]
+    return src.replace(old, new, count)
+
+
+# ---- variants -----------------------------------------------------------------------------------------------------------------------
+# XCD-affine chunk map for exa_hess (one 64-point chunk per WAVE instead of one 256-point tile per workgroup): the 4 KB unit most of a
+# chunk's bytes fall into decides the XCD (= blockIdx mod 8) that evaluates it.  S = 6: 32 chunks = 24 units per 8 workgroups;
+# S = 3: 64 chunks = 24 units per 16 workgroups.
+AFFINE_HELPERS = r'''
+static __device__ __forceinline__ long exa_affine_chunk6(long bq, long nblk, int w) {
+    const long g = bq >> 3; const int k = (int)(bq & 7);
+    if ((g + 1) * 8 > nblk) return bq * 4 + w;          // an incomplete last group keeps the identity map
+    long ch[4]; int n = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const unsigned v = (unsigned)(24 * g + k + 8 * i); const long j = v / 3u; const int r = (int)(v - 3u * (unsigned)j);
+        if (r == 0) ch[n++] = 4 * j; else if (r == 1) { ch[n++] = 4 * j + 1; ch[n++] = 4 * j + 2; } else ch[n++] = 4 * j + 3;
+    }
+    return ch[w];
+}
+static __device__ __forceinline__ long exa_affine_chunk3(long bq, long nblk, int w) {
+    const long g = bq >> 4; const int q = (int)(bq & 15), k = q & 7, half = q >> 3;
+    if ((g + 1) * 16 > nblk) return bq * 4 + w;
+    long ch[8]; int n = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const unsigned v = (unsigned)(24 * g + k + 8 * i); const long j = v / 3u; const int r = (int)(v - 3u * (unsigned)j);
+        if (r == 0) { ch[n++] = 8 * j; ch[n++] = 8 * j + 1; ch[n++] = 8 * j + 2; }
+        else if (r == 1) { ch[n++] = 8 * j + 3; ch[n++] = 8 * j + 4; }
+        else { ch[n++] = 8 * j + 5; ch[n++] = 8 * j + 6; ch[n++] = 8 * j + 7; }
+    }
+    return ch[half * 4 + w];
+}
+'''
+
+
+def v_affine_hess(src):
+    """exa_hess with the XCD-affine wave map (sequential block order assumed: pattern 0's tiles first)"""
+    src = sub(src, 'extern "C" __global__ void __launch_bounds__(EXA_BLOCK) exa_hess(', AFFINE_HELPERS + 'extern "C" __global__ void __launch_bounds__(EXA_BLOCK) exa_hess(')
+    old = '''    const long tid0 = (e_ & ((1L << 40) - 1)) * (EXA_BLOCK * 1) + threadIdx.x;
+    if (ps_ == 0) {
+        { const int u = 0; g0_hess(P, x, y, th, out, sigma, tid0 + u * EXA_BLOCK, lds); }
+    }
+    else if (ps_ == 1) {
+        { const int u = 0; g1_hess(P, x, y, th, out, sigma, tid0 + u * EXA_BLOCK, lds); }
+    }
+}'''
+    new = '''    const long tl_ = e_ & ((1L << 40) - 1);
+    const int w_ = threadIdx.x >> 6, ln_ = threadIdx.x & 63;
+    if (ps_ == 0) {
+        const long nb_ = (P[1] - P[0] + EXA_BLOCK - 1) / EXA_BLOCK;
+        g0_hess(P, x, y, th, out, sigma, exa_affine_chunk6(tl_, nb_, w_) * 64 + ln_, lds);
+    }
+    else if (ps_ == 1) {
+        const long nb_ = (P[11] - P[10] + EXA_BLOCK - 1) / EXA_BLOCK;
+        g1_hess(P, x, y, th, out, sigma, exa_affine_chunk3(tl_, nb_, w_) * 64 + ln_, lds);
+    }
+}'''
+    return sub(src, old, new)
+
+
+def v_stride8_hesscl(src):
+    """exa_hesscl / exa_hessc: the 4 tiles of a chain 8 tiles apart (every workgroup of one XCD then writes the same three residues of
+    4 KB units, like the plain kernel in the sequential order) instead of consecutive"""
+    for name in ("exa_hessc(", "exa_hesscl("):
+        at = src.index('extern "C" __global__ void __launch_bounds__(EXA_BLOCK) ' + name)
+        end = src.index('extern "C" __global__', at + 10)
+        body = src[at:end]
+        body = sub(body, "const long t0_ = (e_ & ((1L << 40) - 1)) * 4;",
+                   "const long q_ = (e_ & ((1L << 40) - 1)); const long t0_ = (q_ >> 3) * 32 + (q_ & 7);")
+        body = sub(body, "const long tend_ = t0_ + 4 < P[33] ? t0_ + 4 : P[33];", "const long tend_ = P[33];")
+        body = sub(body, "for (long t = t0_; t < tend_; t++) {", "for (long t = t0_; t < tend_ && t < t0_ + 32; t += 8) {")
+        body = body.replace("(t + 1 < tend_ ? t + 1 : t)", "(t + 8 < tend_ && t + 8 < t0_ + 32 ? t + 8 : t)")
+        src = src[:at] + body + src[end:]
+    return src
+
+
+# The v10 shape of tools/store_bench.hip in the REAL kernel (exa_hess, LV's constraint pattern, S = 6): a workgroup on XCD k = blockIdx mod 8
+# evaluates the points whose FIRST slot lies in the 4 KB units 24 g + k + {0, 8, 16} of the pattern's COO block — 86 + 85 + 85 = exactly 256
+# points, whatever g and k — stages them in the wavefronts' LDS tiles as today, and after ONE __syncthreads the workgroup streams each unit
+# out as 2 x (4 wavefronts x 512 B aligned to the unit) + the <= 4 doubles its last point reaches into the next unit.
+UNIT_AFFINE = r"""
+static __device__ __forceinline__ long exa_pfirst6(long u) { return (long)((256u * (unsigned)u + 2u) / 3u); }      // first point whose slot 0 lies in unit u: ceil(512 u / 6)
+"""
+
+
+def v_unit_affine_hess(src, spacing=8, run1k=False):
+    at = src.index("static __device__ __forceinline__ void g0_hess(")
+    end = src.index("\n}\n", at) + 3
+    body = src[at:end]
+    stage = body.replace("void g0_hess(", "void g0_hessS(")
+    stage = sub(stage, "    if (I0 - lane >= hi) return;\n", "")
+    stage = sub(stage, "    exa_flush_points<6, 64, 67>(out, obase, npts, tile, lane, 0);\n", "")
+    src = src[:end] + UNIT_AFFINE + stage + src[end:]
+    old = """    if (ps_ == 0) {
+        { const int u = 0; g0_hess(P, x, y, th, out, sigma, tid0 + u * EXA_BLOCK, lds); }
+    }"""
+    new = """    if (ps_ == 0) {
+        const long tl_ = e_ & ((1L << 40) - 1), g_ = tl_ >> 3;
+        const int k_ = (int)(tl_ & 7), t_ = threadIdx.x;
+        if (exa_pfirst6(24 * (g_ + 1)) <= P[1] - P[0]) {
+            const long u0 = SPACING == 8 ? 24 * g_ + k_ : 3 * tl_;
+            long ps[3], pe[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { ps[c] = exa_pfirst6(u0 + SPACING * c); pe[c] = exa_pfirst6(u0 + SPACING * c + 1); }
+            const int n0 = (int)(pe[0] - ps[0]), n1 = (int)(pe[1] - ps[1]);
+            const long pt = t_ < n0 ? ps[0] + t_ : (t_ < n0 + n1 ? ps[1] + (t_ - n0) : ps[2] + (t_ - n0 - n1));
+            g0_hessS(P, x, y, th, out, sigma, pt, lds);
+            __syncthreads();
+            double* __restrict__ dst = out + P[4] + 6L * P[0];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int off = c == 0 ? 0 : (c == 1 ? n0 : n0 + n1);
+                const long ub = 512L * (u0 + SPACING * c), first = 6L * ps[c], last = 6L * pe[c];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const long j = RUN1K ? (i < 2 ? ub + (t_ >> 6) * 128 + (t_ & 63) + 64 * i : ub + 512 + t_) : ub + t_ + 256 * i;
+                    if (j >= first && j < last) {
+                        const unsigned e = (unsigned)(j - first), q = e / 6u; const int s2 = (int)(e - 6u * q), tau = off + (int)q;
+                        __builtin_nontemporal_store(lds_all[(tau >> 6) * 402 + s2 * 67 + (tau & 63)], dst + j);
+                    }
+                }
+            }
+        } else {
+            const long tid0 = tl_ * EXA_BLOCK + threadIdx.x;
+            g0_hess(P, x, y, th, out, sigma, tid0, lds);
+        }
+    }"""
+    return sub(src, old, new.replace("SPACING", str(spacing)).replace("RUN1K", "1" if run1k else "0"))
+
+
+# Cache policy of the COO stores: the flushes through raw buffer stores (wave-uniform base = the run's first double, 32-bit byte offsets, lanes
+# without a slot get an offset beyond num_records: the hardware drops the store — no sink line, no branch) with the gfx942/gfx950 policy bits
+# aux = sc0 (1) | nt (2) | sc1 (16).  Base = global_store ... nt.
+CP_HELPER = r"""
+typedef unsigned int exa_u2 __attribute__((ext_vector_type(2)));
+template <int AUX>
+static __device__ __forceinline__ void exa_st(double v, double* base, int byteoff, int nbytes) {
+    const unsigned long a = (unsigned long)base;
+    const unsigned long au = ((unsigned long)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+    __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)au, 0, nbytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(exa_u2, v), r, byteoff, 0, AUX);
+}
+"""
+
+
+def v_cache_policy(src, aux):
+    src = sub(src, "template <int S, int PP, int LD>\nstatic __device__ __forceinline__ void exa_flush_points(", CP_HELPER + "template <int S, int PP, int LD>\nstatic __device__ __forceinline__ void exa_flush_points(")
+    # exa_flush_points: both paths
+    src = sub(src, "            if ((k + 1) * 64 <= CNT || j < CNT) __builtin_nontemporal_store(tile[s2 * LD + l2], dst + j);",
+              "            exa_st<AUX_>(tile[s2 * LD + ((k + 1) * 64 <= CNT || j < CNT ? l2 : 0)], dst, j * 8, CNT * 8);")
+    src = sub(src, "            if (j < CNT && g * PP + l2 < npts) __builtin_nontemporal_store(tile[s2 * LD + l2], dst + j);",
+              "            exa_st<AUX_>(tile[s2 * LD + (j < CNT ? l2 : 0)], dst, j < CNT && g * PP + l2 < npts ? j * 8 : 0x7ffffff0, CNT * 8);")
+    # exa_flush_points_nb
+    src = sub(src, "        double* __restrict__ p = ok ? dst + j : sink + lane;\n        __builtin_nontemporal_store(tile[s2 * LD + l2], p);",
+              "        exa_st<AUX_>(tile[s2 * LD + l2], dst, ok ? j * 8 : 0x7ffffff0, CNT * 8);")
+    return src.replace("AUX_", str(aux))
+
+
+VARIANTS = {
+    "base": lambda s: s,
+    "cp_plain": lambda s: v_cache_policy(s, 0),
+    "cp_sc0": lambda s: v_cache_policy(s, 1),
+    "cp_nt": lambda s: v_cache_policy(s, 2),
+    "cp_sc0_nt": lambda s: v_cache_policy(s, 3),
+    "cp_sc1": lambda s: v_cache_policy(s, 16),
+    "cp_sc0_sc1": lambda s: v_cache_policy(s, 17),
+    "cp_nt_sc1": lambda s: v_cache_policy(s, 18),
+    "cp_sc0_nt_sc1": lambda s: v_cache_policy(s, 19),
+    "affine_hess": v_affine_hess,
+    "stride8_chain": v_stride8_hesscl,
+    "unit_affine_hess": v_unit_affine_hess,                                            # (a+b), 512-B interleave of the wavefronts
+    "unit_affine_1k": lambda s: v_unit_affine_hess(s, 8, True),                        # (a+b), each wavefront an aligned 1 KB run per unit
+    "wg_flush_512": lambda s: v_unit_affine_hess(s, 1, False),                         # (a) alone: consecutive units, workgroup-level flush
+    "wg_flush_1k": lambda s: v_unit_affine_hess(s, 1, True),                           # (a) alone, 1 KB runs per wavefront
+}
+
+
+def lv_source():
+    from exahip import ExaModel, models
+    m = ExaModel(models.luksan_vlcek_model(1000), device=False)
+    return m.kernel_source(), m._L.exa_module_name(m.id).decode()
+
+
+def prepare(out):
+    os.makedirs(out, exist_ok=True)
+    src, key = lv_source()
+    open(os.path.join(out, "KEY"), "w").write(key)
+    procs = []
+    for name, fn in VARIANTS.items():
+        hip = os.path.join(out, name + ".hip")
+        open(hip, "w").write(fn(src))
+        procs.append((name, subprocess.Popen(["/opt/rocm/bin/hipcc", "--genco", *FLAGS, "-o", os.path.join(out, name + ".hsaco"), hip])))
+    for name, p in procs:
+        assert p.wait() == 0, name
+    print("prepared", list(VARIANTS), "for module", key)
+
+
+def run(out, N, hv, names):
+    import numpy as np
+    import torch
+    os.environ["EXAHIP_HESS_VARIANT"] = str(hv)
+    from exahip import ExaModel, capi, models
+    key = open(os.path.join(out, "KEY")).read().strip()
+    L = capi.lib()
+    names = names or sorted(f[:-6] for f in os.listdir(out) if f.endswith(".hsaco"))
+    if "base" in names:
+        names = ["base"] + [n for n in names if n != "base"]
+    r = np.random.default_rng(0)
+    ms = {}
+    ref = None
+    models_ = {}
+    core = models.luksan_vlcek_model(N)
+    for n in names:
+        blob = open(os.path.join(out, n + ".hsaco"), "rb").read()
+        assert L.exa_cache_add(key.encode(), blob, len(blob)) == 0, "exa_cache_add"
+        m = ExaModel(core)
+        assert m._L.exa_module_name(m.id).decode() == key and m.build_info()[0] == "preloaded", (m.build_info(), key)
+        models_[n] = m
+    m0 = models_[names[0]]
+    x = torch.from_numpy(m0.meta.x0 + 0.1 * r.uniform(-1, 1, N)).cuda()
+    y = torch.from_numpy(r.standard_normal(m0.meta.ncon)).cuda()
+    h = torch.empty(m0.meta.nnzh, dtype=torch.float64, device="cuda")
+    reps = 100 if N <= 2e7 else 20
+    for n in names:
+        h.fill_(float("nan"))
+        models_[n].hess_coord(x, y, 0.5, out=h)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = h.clone() if N <= 3e7 else (h[:1000000].clone(), h[-1000000:].clone(), float(h.sum()))
+            same = True
+        else:
+            same = torch.equal(h, ref) if N <= 3e7 else (torch.equal(h[:1000000], ref[0]) and torch.equal(h[-1000000:], ref[1]) and float(h.sum()) == ref[2])
+        ms[n] = [same]
+    for rnd in range(7):                     # interleaved rounds, minimum per variant
+        for n in names:
+            t = models_[n].time_callback("hess", reps, x, y, 0.5, out=h)
+            if rnd:
+                ms[n].append(t)
+    nbytes = 8 * (m0.meta.nnzh + m0.meta.nvar + m0.meta.ncon)
+    kern = {0: "exa_hess", 1: "exa_hesscl", 2: "exa_hessc"}[hv]
+    for n in names:
+        ts = sorted(ms[n][1:])
+        print(f"N={N:.0e} {kern:10s} {n:18s} min {ts[0]:.4f} median {ts[len(ts) // 2]:.4f} ms  {nbytes / ts[0] / 1e6 / 8000:.3f} of 8 TB/s  bitwise == base: {ms[n][0]}", flush=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "prepare":
+        prepare(sys.argv[2])
+    else:
+        run(sys.argv[2], int(float(sys.argv[3])), int(sys.argv[4]), sys.argv[5:])
