@@ -336,8 +336,6 @@ Tool pick_tool(std::string &identity) {
 // — correct whenever this library's compilations are the process's first through that comgr, which is the normal case.
 // Returns false when the helper is not there; throws on a compile error, like the in-process path.
 bool compile_hiprtc_helper(const std::string &source, const std::vector<std::string> &flags, std::vector<char> &image) {
-    const char *inproc = getenv("EXAHIP_RTC_INPROCESS");
-    if (inproc && *inproc && std::string(inproc) != "0") return false;
     const std::string helper = lib_dir() + "/exa_rtc";
     if (access(helper.c_str(), X_OK) != 0) return false;
     Rtc &r = rtc();
@@ -379,11 +377,30 @@ bool compile_hiprtc_helper(const std::string &source, const std::vector<std::str
     } catch (...) { cleanup(); throw; }
 }
 
+// Explicit opt-in to hiprtc INSIDE the host process (EXAHIP_RTC_INPROCESS=1).  Never a silent fallback (round 6): a host that compiled
+// anything through this comgr before us — a Julia process with AMDGPU.jl does — has latched the greedy SGPR allocator, and -sgpr-regalloc
+// in base_flags() is then silently ignored.
+bool rtc_inprocess_requested() {
+    const char *inproc = getenv("EXAHIP_RTC_INPROCESS");
+    return inproc && *inproc && std::string(inproc) != "0";
+}
+
 std::vector<char> compile_hiprtc(const std::string &source, const std::vector<std::string> &flags) {
-    {
+    if (!rtc_inprocess_requested()) {
         std::vector<char> image;
         if (compile_hiprtc_helper(source, flags, image)) return image;
+        // no helper (partial install), or it could not run: REFUSE — the guard flag means nothing in a process whose LLVM may have latched
+        // another allocator, and a wrong-result code object would then be trusted by every later process through the disk cache
+        throw std::runtime_error("the kernel compiler process " + lib_dir() + "/exa_rtc is missing or could not run: refusing to compile inside the host process "
+                                 "(LLVM latches -sgpr-regalloc at a process's first compilation; a host that compiled through this comgr before would disarm "
+                                 "the guard against the known miscompilation, tests/sweeps/canary/REPORT.md).  Install exa_rtc next to libexahip.so, set "
+                                 "EXAHIP_COMPILER=hipcc, or opt in with EXAHIP_RTC_INPROCESS=1 (compiled with the conservative allocator flags as well, cached under another name)");
     }
+    static std::once_flag warned;
+    std::call_once(warned, [] {
+        fprintf(stderr, "[exahip] WARNING: EXAHIP_RTC_INPROCESS=1: kernels are compiled by hiprtc inside this process; -sgpr-regalloc=basic only takes effect if no "
+                        "compilation ran in this process before.  Modules are built with the conservative allocator flags in addition and cached under a name of their own.\n");
+    });
     Rtc &r = rtc();
     hiprtcProgram prog = nullptr;
     if (r.create(&prog, source.c_str(), "exa_module.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) throw std::runtime_error("hiprtcCreateProgram failed");
@@ -483,7 +500,11 @@ CodeObject get_code_object(const std::string &source, bool memory_only_ok, bool 
     std::string identity;
     const Tool tool = pick_tool(identity);
     std::vector<std::string> flags = base_flags();
-    if (safe) for (const std::string &f : safe_flag_list()) flags.push_back(f);
+    // in-process hiprtc (explicit opt-in): the allocator flag may be latched away, so the region-splitting budget — an ordinary option, read at
+    // every compilation, which removes the fault site on its own (profiles/r5_guard_sweeps.txt) — always rides along, and the cache name says so
+    const bool inproc = tool == Tool::Hiprtc && rtc_inprocess_requested();
+    if (safe || inproc) for (const std::string &f : safe_flag_list()) flags.push_back(f);
+    if (inproc) identity += "|inprocess";
     const std::string file = co.key + "-" + sha256_hex(join(flags) + "|" + identity + "|" + kArch).substr(0, 12) + ".hsaco";
     for (const std::string &d : read_dirs()) {
         const std::string p = d + "/" + file;
@@ -494,7 +515,7 @@ CodeObject get_code_object(const std::string &source, bool memory_only_ok, bool 
         }
     }
     const std::string wdir = writable_cache_dir();
-    if (tool == Tool::Hiprtc) { co.image = compile_hiprtc(source, flags); co.how = "hiprtc"; }
+    if (tool == Tool::Hiprtc) { co.image = compile_hiprtc(source, flags); co.how = inproc ? "hiprtc-inprocess" : "hiprtc"; }
     else { co.image = compile_hipcc(source, wdir, flags); co.how = "hipcc"; }
     co.build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (!wdir.empty()) {

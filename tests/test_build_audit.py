@@ -179,17 +179,52 @@ def test_no_kernel_of_any_zoo_module_has_the_fault_pattern(tmp_path):
     assert len(paths) >= len(ZOO)
 
 
-def test_the_in_process_compiler_is_still_there_as_a_fallback(fresh_cache, monkeypatch):
-    """EXAHIP_RTC_INPROCESS=1 (or a partial install without exa_rtc): hiprtc inside the host process, the same flags, the same code object."""
+def test_in_process_compilation_is_an_explicit_opt_in_with_the_conservative_flags(fresh_cache, monkeypatch):
+    """EXAHIP_RTC_INPROCESS=1: hiprtc inside the host process — where -sgpr-regalloc may have been latched away by an earlier compilation
+    of the host (VERDICT r5 "what's weak" 2): the module is built with the conservative allocator flags IN ADDITION (an ordinary
+    option, read at every compilation) and cached under a name of its own, never under the helper's."""
     m = ExaModel(models.luksan_vlcek_model(50), device=False)
     m.compile()
-    blob = m.code_objects()[0][1]
-    for f in fresh_cache.iterdir():
-        f.unlink()
+    assert m.build_info()[0] == "hiprtc"
+    helper_files = {f.name for f in fresh_cache.iterdir() if f.name.endswith(".hsaco")}
     monkeypatch.setenv("EXAHIP_RTC_INPROCESS", "1")
     m2 = ExaModel(models.luksan_vlcek_model(50), device=False)
     m2.compile()
-    assert m2.build_info()[0] == "hiprtc" and m2.code_objects()[0][1] == blob
+    assert m2.build_info()[0] == "hiprtc-inprocess"            # not served from the helper's cache entry: another file name
+    inproc_files = {f.name for f in fresh_cache.iterdir() if f.name.endswith(".hsaco")} - helper_files
+    # (the model's module and its product windows, each a second time: same source keys, another flags / compiler hash in the name)
+    assert len(inproc_files) == len(helper_files) and {f.split('-')[0] for f in inproc_files} == {f.split('-')[0] for f in helper_files}
+    assert len({f.split('-')[1] for f in inproc_files}) == 1 and not ({f.split('-')[1] for f in inproc_files} & {f.split('-')[1] for f in helper_files})
+    assert all(a["fits"] for a in m2.build_audit())
+
+
+def test_a_missing_compiler_process_is_refused_not_replaced_silently(tmp_path):
+    """A partial install (libexahip.so without exa_rtc next to it): exa_compile fails with status 2 and says why — it does NOT compile in
+    the host process on its own."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    from exahip import capi
+    pkg = os.path.dirname(capi.__file__)
+    shutil.copy(os.path.join(pkg, "libexahip.so"), tmp_path / "libexahip.so")
+    code = f"""
+import ctypes, os, sys
+sys.path.insert(0, {os.path.dirname(pkg)!r})
+from exahip import capi
+capi.LIB_PATH = {str(tmp_path / 'libexahip.so')!r}
+from exahip import ExaModel, models
+m = ExaModel(models.luksan_vlcek_model(50), device=False)
+try:
+    m.compile()
+    print("COMPILED", m.build_info()[0])
+except capi.ExaHipError as e:
+    print("REFUSED", str(e)[:400])
+"""
+    env = dict(os.environ, EXAHIP_CACHE_DIR=str(tmp_path / "cache"), EXAHIP_COMPILER="hiprtc")
+    env.pop("EXAHIP_RTC_INPROCESS", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600).stdout
+    assert "REFUSED" in out and "status 2" in out and "refusing to compile inside the host process" in out, out
 
 
 def test_llc_alone_reproduces_the_fault_site_from_the_bitcode(tmp_path):
