@@ -190,10 +190,6 @@ struct Body {
     // whether some x load is NOT of that form (staged chained kernels, ParamLayout::stage)
     std::map<std::string, std::pair<int, int64_t>> xoff;
     bool xother = false;
-    // read the LOCALITY-ORDERED copy of the pattern's table (ParamLayout::Pat::perm; order-free kernels only): columns through
-    // colq, the row of a base constraint through the original-row column
-    bool perm = false;
-
     Body(const Model &mm, int pidx, const ParamLayout &ll, Emitter *shared = nullptr)
         : m(mm), p(mm.pats[pidx]), pi(pidx), L(ll), e(shared ? *shared : own_) { fv.resize(p.ad.size()); }
 
@@ -201,7 +197,7 @@ struct Body {
 
     Val column(int c) {
         const Column &col = p.cols[c];
-        const int w = perm ? L.pat[pi].colq[c] : L.pat[pi].col[c];
+        const int w = L.pat[pi].col[c];
         if (col.type == EXA_COL_RANGE) {
             if (col.step == 1) return e.raw(P(w) + " + I", true);
             return e.raw(P(w) + " + " + std::to_string(col.step) + "L * I", true);
@@ -303,10 +299,6 @@ struct Body {
         if (p.kind == EXA_PAT_CONAUG) {
             Val t = cval(p.target);
             return P(w) + " + " + e.s(e.sub(t, Emitter::liti(1)));
-        }
-        if (perm) {     // row I of the permuted table is row J of the caller's (J = I when no permutation is installed)
-            const std::string oq = P(L.pat[L.pat[pi].table].origq);
-            return P(w) + " + " + e.s(e.raw("(" + oq + " ? ((const long*)" + oq + ")[I] : I)", true));
         }
         return P(w) + " + I";
     }

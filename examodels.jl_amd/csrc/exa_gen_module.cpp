@@ -25,41 +25,6 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
             pp.col.push_back(col.alias_pat >= 0 ? L.pat[col.alias_pat].col[col.alias_col] : w++);      // one word per DISTINCT column
         }
     }
-    // Locality-ordered table copies (ParamLayout::Pat::perm): patterns over one table (linked by aliased columns) form a component;
-    // it gets a permutation when no member reads a RANGE column (then `I` occurs only as a row of the table) and some member
-    // reaches x through a data column.  A static property of the patterns: the module's text does not depend on the data.
-    if (env_int("EXAHIP_LOCALITY_COPY", 1) != 0) {
-        std::vector<int> table(np);
-        for (int k = 0; k < np; k++) {
-            table[k] = k;
-            for (const Column &col : m.pats[k].cols)
-                if (col.alias_pat >= 0) { table[k] = table[col.alias_pat]; break; }
-        }
-        std::vector<char> ok(np, 1), indexed(np, 0);
-        for (int k = 0; k < np; k++) {
-            const Pattern &p = m.pats[k];
-            bool range = p.n == 0, data_idx = false;
-            for (const Column &col : p.cols) range = range || col.type == EXA_COL_RANGE;
-            for (const exa_node_t &nd : p.nodes)
-                if (nd.op == EXA_OP_VAR && !affine(p, nd.a).ok) data_idx = true;
-            if (range || p.n != m.pats[table[k]].n) ok[table[k]] = 0;
-            if (data_idx) indexed[table[k]] = 1;
-        }
-        for (int k = 0; k < np; k++) {
-            auto &pp = L.pat[k];
-            pp.table = table[k];
-            pp.perm = ok[table[k]] && indexed[table[k]];
-            if (!pp.perm) continue;
-            if (table[k] == k) pp.origq = w++;
-            for (size_t c = 0; c < m.pats[k].cols.size(); c++) {
-                const Column &col = m.pats[k].cols[c];
-                // (an aliased column shares the word of its first copy only when that copy is permuted by the SAME table's permutation:
-                // columns are aliased by content, so a pattern may alias columns of patterns over other tables)
-                const bool share = col.alias_pat >= 0 && L.pat[col.alias_pat].perm && L.pat[col.alias_pat].table == pp.table;
-                pp.colq.push_back(share ? L.pat[col.alias_pat].colq[col.alias_col] : w++);
-            }
-        }
-    }
     for (int k = 0; k < np; k++) {
         const Pattern &p = m.pats[k];
         if (p.n == 0) continue;
@@ -159,7 +124,10 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
             L.gstretch[g] = ns;
             L.max_stretch = std::max(L.max_stretch, ns);
         }
-        L.staged = L.max_stretch >= 1 && L.max_stretch <= 8;
+        // ONE stretch only: staging is a single-array-stencil feature.  Several stretches (one per variable array: cops_chain's u, x1, x2, x3, the
+        // rocket's h, v, m, tau) were built in round 4 and lost every A/B — cops_chain 0.089 staged / 0.073 chained, rocket nh = 2e7 2.40 / 2.11
+        // (profiles/r4_staging_ab.txt, r5_rocket_staging_ab.txt): the extra LDS round trips cost more than the overlapping loads they replace.
+        L.staged = L.max_stretch == 1;
     }
     if (!L.staged) { L.stage.assign(np, ParamLayout::Stage()); L.gstretch.assign(L.groups[CB_HESSC].size(), 0); L.max_stretch = 0; }
     // streaming value kernels keep more loads in flight per wavefront with several points per thread (measured)

@@ -140,7 +140,6 @@ void emit_scatter_prologue(std::ostringstream &os, const Body &b, const ParamLay
 
 void gen_first_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L, bool grad) {
     Body b(m, pi, L);
-    b.perm = grad && L.pat[pi].perm;         // grad! adds into a zeroed vector: any order of the data points (jac_coord! never)
     const Pattern &p = b.p;
     b.forward(p.ad_root, 1, false);
     GenAlg a(b, p.comp1, p.o1step);
@@ -338,12 +337,8 @@ void gen_scatter_group_fn(std::ostringstream &os, const Model &m, const ParamLay
     Scatter sc(E, L);
     sc.loopfree = g_loopfree[cb];
     std::vector<std::unique_ptr<Body>> bodies;
-    // the locality-ordered copy of the group's table, when all of its patterns walk the same one (they add into a zeroed vector)
-    bool perm = true;
-    for (int pk : grp) perm = perm && L.pat[pk].perm && L.pat[pk].table == L.pat[grp.front()].table;
     for (int pk : grp) {
         bodies.emplace_back(new Body(m, pk, L, &E));
-        bodies.back()->perm = perm;
         if (hp) hprod_items(*bodies.back(), sc); else jtprod_items(*bodies.back(), sc);
     }
     std::vector<std::string> stores;

@@ -114,15 +114,6 @@ struct ParamLayout {
         int qlo = -1, qhi = -1;
         int ob = -1;            // OBJ patterns: first slot of this pattern's workgroups among the fused sweep's objective partials
         std::vector<int> col;   // per column: device pointer (I64/F64) or range start (RANGE)
-        // LOCALITY-ORDERED COPY of the pattern's table for the kernels whose output does not depend on the order in which the data
-        // points are evaluated (grad!, J'v, Hv by atomics).  perm: this pattern has one (a table-driven pattern that reaches x through a
-        // data column: ACOPF's branch rows); table: the pattern whose permutation it uses (patterns over ONE table — aliased columns,
-        // exa_plan.cpp — share it, so a fused group still walks one row per thread); colq: the permuted columns' words; origq: word of
-        // the column "original row of permuted row I" (0 at run time = no permutation installed: the kernels then read `col` order
-        // through the same text).  COO kernels never use these: row order is slot order.
-        bool perm = false;
-        int table = -1, origq = -1;
-        std::vector<int> colq;
     };
     std::vector<Pat> pat;
     std::vector<int> active[CB_COUNT];   // patterns handled by each callback, in dispatch order

@@ -117,12 +117,6 @@ struct Handle {
     int64_t fused_nobj = 0;                 // objective partial sums written by exa_fused
     std::vector<DevBuf> dcols;              // flattened over patterns
     std::vector<std::vector<int>> colslot;  // [pattern][col] -> index into dcols (or -1 for RANGE)
-    // locality-ordered copies of table-driven patterns (ParamLayout::Pat::perm): [pattern][col] -> index into dcols of the permuted
-    // copy (-1: none); origslot[table pattern] -> dcols index of "original row of permuted row I" (-1: no permutation built: the
-    // table is short, or already in that order); locality: installed in P (exa_set_locality / EXAHIP_LOCALITY=0 switch it off)
-    std::vector<std::vector<int>> colslotq;
-    std::vector<int> origslot;
-    bool locality = false;
     DevBuf sx, sy, sv, sout, srows, scols;  // scratch of the *_host variants
     CompressedCOO cj, ch;                   // duplicate-summed COO maps (exa_compress)
     DevBuf cbuf;                            // uncompressed values of the last compressed evaluation

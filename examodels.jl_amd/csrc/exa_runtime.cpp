@@ -74,16 +74,6 @@ void fill_params(Handle &h) {
             if (p.cols[c].type == EXA_COL_RANGE) h.P[pp.col[c]] = p.cols[c].start;
             else h.P[pp.col[c]] = h.on_device ? (int64_t)(uintptr_t)h.dcols[h.colslot[k][c]].p : 0;
         }
-        if (pp.perm) {
-            // the order-free kernels' view of the table: the locality-ordered copy where one was built and is switched on, else the
-            // caller's order through the same words (origq = 0: "row I is row I")
-            const bool on = h.on_device && h.locality && !h.origslot.empty() && h.origslot[(size_t)pp.table] >= 0;
-            if (pp.table == (int)k) h.P[pp.origq] = on ? (int64_t)(uintptr_t)h.dcols[(size_t)h.origslot[k]].p : 0;
-            for (size_t c = 0; c < p.cols.size(); c++) {
-                if (on && h.colslotq[k][c] < 0) throw std::logic_error("locality copy: a column of a permuted table has no permuted copy");
-                h.P[pp.colq[c]] = on ? (int64_t)(uintptr_t)h.dcols[(size_t)h.colslotq[k][c]].p : h.P[pp.col[c]];
-            }
-        }
     }
     if (h.on_device) h.dsink.ensure(8 * 64);
     h.lnnzj = local ? l1 : m.nnzj;
@@ -409,14 +399,12 @@ CodeObject module_for(Handle &h, bool memory_only_ok) {
     CodeObject co = get_code_object(h.gen.source, memory_only_ok, prefer_safe(h.gen.source));
     double spent = 0.0;
     // ... and exa_hesscl (the LDS-staged chained kernel: a few registers more than exa_hessc per staged stretch) is dropped when it ALONE is
-    // what outgrew the architectural registers (the rocket: 278 against 254): the model then runs exa_hessc where it would have run
+    // what outgrew the architectural registers (round 5's four-stretch kernel of the rocket: 278 against 254): the model then runs exa_hessc where it would have run
     // exa_hesscl, instead of having its whole module rebuilt with the conservative flags for a kernel it can do without
     bool regen = false;
     {
         std::vector<KernelInfo> ks;
-        // (EXAHIP_KEEP_STAGE=1 — test infrastructure for the A/B of profiles/r5_rocket_staging_ab.txt: keep an over-sized exa_hesscl)
-        const char *keep = getenv("EXAHIP_KEEP_STAGE");
-        if (!(keep && *keep == '1') && !h.nostage && h.gen.layout.staged && code_object_kernels(co.image, ks)) {
+        if (!h.nostage && h.gen.layout.staged && code_object_kernels(co.image, ks)) {
             bool cl_big = false, rest_big = false;
             for (const KernelInfo &k : ks) { if (k.name == "exa_hesscl") cl_big = !k.fits(); else if (k.name != "exa_grad" && k.name != "exa_jtprod" && k.name != "exa_hprod") rest_big = rest_big || !k.fits(); }
             if (cl_big && !rest_big) { h.nostage = true; regen = true; }
@@ -474,15 +462,6 @@ void to_device(Handle &h) {
     if (m.aug_linear || m.nconaug == 0) h.f_jprod1 = fn("exa_jprod1");
     h.f_js32 = fn("exa_jstruct32"); h.f_js64 = fn("exa_jstruct64"); h.f_hs32 = fn("exa_hstruct32"); h.f_hs64 = fn("exa_hstruct64");
     h.colslot.resize(m.pats.size());
-    h.colslotq.resize(m.pats.size());
-    h.origslot.assign(m.pats.size(), -1);
-    {
-        // measured (profiles/r5_locality_ab.txt): on the random ACOPF graph the copies LOSE (J'v 0.040 -> 0.054 ms, Hv 0.038 -> 0.053) — sorting
-        // the branch rows by bus makes the gathers of ONE end local and turns the seven coalesced v[row] / y[row] reads of a fused group
-        // into gathers.  Off unless asked for (EXAHIP_LOCALITY=1, exa_set_locality): kept for tables whose patterns read nothing by row.
-        const char *le = getenv("EXAHIP_LOCALITY");
-        h.locality = le && *le == '1';
-    }
     // one-launch exa_eval_all (ParamLayout::gbits): is the objective's in-sweep scatter injective on THIS data?  (needs the host columns)
     if (h.gen.layout.gbits >= 0 && m.nvar > 0) {
         std::vector<uint64_t> bits;
@@ -495,57 +474,14 @@ void to_device(Handle &h) {
             HIPCHK(hipMemcpy(h.dgbits.p, bits.data(), 8 * bits.size(), hipMemcpyHostToDevice));
         }
     }
-    // Locality-ordered copies (ParamLayout::Pat::perm) — the reference sorts its scatter lists at build too (KA ext :44-53, 79-101).
-    // One permutation per table: rows in ascending order of the smallest variable any member pattern reaches through a data column
-    // at that row (stable: ties keep the caller's order) — for a branch table, by bus.  Built from the host columns, before they are
-    // released; tables of fewer than 4 096 rows and tables already in that order keep the caller's (no copy, origslot = -1).
-    std::vector<std::vector<int64_t>> perms(m.pats.size());
-    for (size_t r = 0; r < m.pats.size(); r++) {
-        const ParamLayout &L = h.gen.layout;
-        if (!L.pat[r].perm || L.pat[r].table != (int)r || m.pats[r].n < 4096) continue;
-        const int64_t n = m.pats[r].n;
-        std::vector<int64_t> key((size_t)n, INT64_MAX), perm((size_t)n);
-        for (size_t k = r; k < m.pats.size(); k++) {
-            if (L.pat[k].table != (int)r) continue;
-            const std::vector<int64_t> kk = locality_keys(m, (int)k);
-            for (int64_t I = 0; I < n; I++) key[(size_t)I] = std::min(key[(size_t)I], kk[(size_t)I]);
-        }
-        bool sorted = true;
-        for (int64_t I = 0; I < n; I++) { perm[(size_t)I] = I; sorted = sorted && (I == 0 || key[(size_t)I - 1] <= key[(size_t)I]); }
-        if (sorted) continue;
-        std::stable_sort(perm.begin(), perm.end(), [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });
-        DevBuf ob;
-        ob.ensure(8 * (size_t)n);
-        HIPCHK(hipMemcpy(ob.p, perm.data(), 8 * (size_t)n, hipMemcpyHostToDevice));
-        h.origslot[r] = (int)h.dcols.size();
-        h.dcols.push_back(ob);
-        perms[r] = std::move(perm);
-    }
     for (size_t k = 0; k < m.pats.size(); k++) {
         Pattern &p = m.pats[k];
         h.colslot[k].assign(p.cols.size(), -1);
-        h.colslotq[k].assign(p.cols.size(), -1);
-        const int tab = h.gen.layout.pat[k].perm ? h.gen.layout.pat[k].table : -1;
-        const std::vector<int64_t> *perm = tab >= 0 && h.origslot[(size_t)tab] >= 0 ? &perms[(size_t)tab] : nullptr;
         for (size_t c = 0; c < p.cols.size(); c++) {
             Column &col = p.cols[c];
             if (col.type == EXA_COL_RANGE) continue;
-            auto permuted_copy = [&](const void *src) {      // 8-byte words either way: permuted as raw bits
-                std::vector<int64_t> tmp((size_t)p.n);
-                const int64_t *raw = (const int64_t *)src;
-                for (int64_t I = 0; I < p.n; I++) tmp[(size_t)I] = raw[(size_t)(*perm)[(size_t)I]];
-                DevBuf q;
-                q.ensure(8 * (size_t)p.n);
-                HIPCHK(hipMemcpy(q.p, tmp.data(), 8 * (size_t)p.n, hipMemcpyHostToDevice));
-                h.colslotq[k][c] = (int)h.dcols.size();
-                h.dcols.push_back(q);
-            };
             if (col.alias_pat >= 0) {      // a copy of a column that is already resident (exa_plan.cpp)
                 h.colslot[k][c] = h.colslot[col.alias_pat][col.alias_col];
-                // its permuted copy too, when the first copy is permuted by the same table's permutation (else this pattern gets its own)
-                const auto &ap = h.gen.layout.pat[(size_t)col.alias_pat];
-                if (perm && ap.perm && ap.table == tab) h.colslotq[k][c] = h.colslotq[col.alias_pat][col.alias_col];
-                else if (perm) permuted_copy(col.type == EXA_COL_I64 ? (const void *)col.idata.data() : (const void *)col.fdata.data());
                 std::vector<int64_t>().swap(col.idata);
                 std::vector<double>().swap(col.fdata);
                 continue;
@@ -556,7 +492,6 @@ void to_device(Handle &h) {
             if (p.n) HIPCHK(hipMemcpy(b.p, src, 8 * (size_t)p.n, hipMemcpyHostToDevice));
             h.colslot[k][c] = (int)h.dcols.size();
             h.dcols.push_back(b);
-            if (perm) permuted_copy(src);
             // the host copy is no longer needed once resident in HBM
             std::vector<int64_t>().swap(col.idata);
             std::vector<double>().swap(col.fdata);
@@ -1268,24 +1203,6 @@ int exa_locality_order(int id, int pattern, int64_t *perm_out) {
         std::memcpy(perm_out, perm.data(), 8 * perm.size());
         return 0;
     } catch (const std::exception &e) { g_err = e.what(); return 2; }
-}
-
-/* The library's OWN use of that order (round 5): kernels whose result does not depend on the order in which the data points are
- * evaluated — grad!, J'v and Hv by atomics into a zeroed vector — run on a locality-ordered COPY of every table-driven pattern's
- * columns, built once at model build (one permutation per table; tables under 4 096 rows or already in order: none).  COO, rows and
- * structures keep the caller's order.  on = 1 / 0 switches the copies in / out (default OUT — they lose where the patterns also read by
- * row, profiles/r5_locality_ab.txt; EXAHIP_LOCALITY=1 in the environment: in from the start), on < 0 only asks.  Returns the number of
- * tables with an installed permutation (0: none built, or switched off), -1 on a bad id. */
-int exa_set_locality(int id, int on) {
-    Handle *h = get(id);
-    if (!h) return -1;
-    int built = 0;
-    for (int s : h->origslot) built += s >= 0;
-    if (on >= 0 && h->on_device && (on != 0) != h->locality) {
-        const int st = guard(id, true, [&](Handle &hh) { hh.locality = on != 0; fill_params(hh); });
-        if (st != 0) return -1;
-    }
-    return h->locality ? built : 0;
 }
 
 // pattern-table view of a planned model that still holds its host columns

@@ -296,11 +296,6 @@ class ExaModel:
         """exa_eval_all_mode: how exa_eval_all produces grad! (1 / 2: inside the sweep's one launch; 0 / 3: a launch in front; 4: sorted)."""
         return self._L.exa_eval_all_mode(self.id)
 
-    def set_locality(self, on=-1):
-        """exa_set_locality: the locality-ordered table copies of the order-free kernels (grad!, J'v, Hv by atomics) in / out; -1 asks.
-        Returns the number of tables with an installed permutation."""
-        return self._L.exa_set_locality(self.id, int(on))
-
     def kernel_source(self):
         return self._L.exa_kernel_source(self.id).decode()
 

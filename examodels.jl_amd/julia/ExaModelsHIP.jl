@@ -336,8 +336,6 @@ theta_ptr(m) = ccall((:exa_theta_ptr, LIB), Ptr{Cdouble}, (Cint,), m.ext.id)
 eval_all_mode(m) = ccall((:exa_eval_all_mode, LIB), Cint, (Cint,), m.ext.id)
 # which hess_coord! kernel tune! chose (0 exa_hess, 1 exa_hesscl, 2 exa_hessc) and the unused dynamic LDS its launches carry (an occupancy throttle)
 hess_kernel(m) = (ccall((:exa_hess_variant, LIB), Cint, (Cint,), m.ext.id), ccall((:exa_hess_throttle, LIB), Cint, (Cint,), m.ext.id))
-# locality-ordered table copies for the order-free kernels (exa_set_locality; opt-in: measured slower where the patterns also read by row); -1 only asks
-locality!(m, on::Integer = 1) = ccall((:exa_set_locality, LIB), Cint, (Cint, Cint), m.ext.id, on)
 # may model files bring device code of their own (exa_recipe_trust_code)?  Returns the setting in force before the call.
 trust_model_code!(on::Bool) = ccall((:exa_recipe_trust_code, LIB), Cint, (Cint,), on) != 0
 # what the compiled kernels of the model need and which flags their modules were built with (exa_build_audit): one line per kernel

@@ -137,19 +137,10 @@ int     exa_meta(int id, double *x0, double *lvar, double *uvar, double *lcon, d
  * nlp.jl:1991-1992): the caller applies the permutation to the table (and to y / bounds of the rows it generates) BEFORE
  * building the model.  Needs the host columns: an exa_plan_only handle. */
 int     exa_locality_order(int id, int pattern, int64_t *perm_out);
-/* What the library does with that order ITSELF: kernels whose result does not depend on the order in which the data points are
- * evaluated — grad!, J'v and Hv by atomics into a zeroed vector — run on a locality-ordered COPY of every table-driven pattern's
- * columns (patterns over one table share one permutation: rows by the smallest variable reached through a data column), built once at
- * model build, as the reference sorts its scatter lists at build (KA ext :44-53, 79-101); tables under 4 096 rows, or already in
- * that order, get none.  jac_coord!, hess_coord!, cons_nln!, the structures and everything else that has a slot / row order keep the
- * caller's.  on = 1 / 0 switches the copies in / out, on < 0 only asks.  DEFAULT OUT (EXAHIP_LOCALITY=1: in): measured on the 78 484-bus
- * ACOPF with random branch ends, the copies LOSE — J'v 0.040 -> 0.054 ms, Hv 0.038 -> 0.053 (profiles/r5_locality_ab.txt): sorting the branch
- * rows by bus makes the gathers and atomics of ONE end local, and turns the seven coalesced v[row] / y[row] reads of the fused branch
- * group into gathers.  (The "bus-ordered listing is 37 % faster" of rounds 3-4 compared two different GRAPHS — the bus-ordered synthetic
- * network also draws both ends of a branch close together — not two orders of one graph.)  The mechanism stays for tables whose
- * patterns read nothing by row (objective patterns: grad!).  Returns the number of tables with an installed permutation (0: none
- * built, or switched off), -1 on a bad id. */
-int     exa_set_locality(int id, int on);
+/* (Round 5 also let the library run its order-free kernels — grad!, J'v, Hv by atomics — on a locality-ordered COPY of every table
+ * (exa_set_locality).  Measured on the 78 484-bus ACOPF with random branch ends the copies LOST (J'v 0.040 -> 0.054 ms, profiles/r5_locality_ab.txt:
+ * sorting the branch rows by bus turns the coalesced v[row] / y[row] reads of the fused branch group into gathers); round 6 removed them —
+ * they doubled the table memory of every model and put a row indirection on the hot path of kernels that never used it.) */
 /* Generated HIP source of the model's module (NUL-terminated, owned by the library). */
 const char *exa_kernel_source(int id);
 /* ... of module k: 0 the model's module (= exa_kernel_source), 1 the product windows' ("" when the model has none). */

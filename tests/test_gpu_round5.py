@@ -1,7 +1,5 @@
-"""-m gpu, round 5: the library's own use of locality for ORDER-FREE outputs (exa_set_locality: grad!, J'v, Hv by atomics run on a
-locality-ordered copy of every table-driven pattern's columns; VERDICT r4 item 4 — the reference sorts its scatter lists at build,
-ext/ExaModelsKernelAbstractions.jl:44-53, 79-101), everything with a slot / row order untouched.  Built, correct — and measured SLOWER
-on the random ACOPF graph (profiles/r5_locality_ab.txt), so it is opt-in: these tests switch it on."""
+"""-m gpu, round 5: exa_eval_all in one launch for injective data-indexed objectives, cons_nln! by fused groups.  (The locality-ordered table
+copies this file used to test — built in round 5, measured slower on the random ACOPF graph, profiles/r5_locality_ab.txt — were removed in round 6.)"""
 import numpy as np
 import pytest
 
@@ -29,117 +27,14 @@ def acopf(libs):
     return m, oracle.OracleModel(m.ir, threads=8), models.acopf_start(core)
 
 
-def test_locality_copies_are_built_for_table_driven_patterns_only(acopf, libs):
-    from exahip import ExaModel, models
+def test_the_locality_copies_are_gone(acopf, libs):
+    """Round 5's locality-ordered table copies (exa_set_locality) lost their A/B (profiles/r5_locality_ab.txt) and were removed in round 6: no
+    permutation word, no row indirection in any kernel, no second copy of a table's columns."""
     m, _, _ = acopf
-    assert m.set_locality(-1) == 0                       # off by default: measured slower where the patterns also read by row (exahip.h)
-    assert m.set_locality(1) >= 1                        # the branch table (9 000 rows, random order) has a permutation to install
-    src = m.kernel_source()
-    assert "? ((const long*)P[" in src                   # the order-free kernels read the original row through the permutation column
-    lv = ExaModel(models.luksan_vlcek_model(10_000))
-    assert lv.set_locality(-1) == 0 and "? ((const long*)P[" not in lv.kernel_source()       # range-iterated patterns: nothing to permute
-
-
-def test_order_free_callbacks_on_the_locality_ordered_copies(acopf):
-    """grad!, J'v, Hv with the copies in: against the oracle (1e-10) and against the same kernels on the caller's order (1e-12: the
-    same terms, added in another order by atomics either way); with the copies out the results are the round-4 ones."""
-    m, o, x0 = acopf
-    x, y, sigma = point(x0, m.meta.ncon, seed=9)
-    v = np.random.default_rng(1).standard_normal(m.meta.nvar)
-    w = np.random.default_rng(2).standard_normal(m.meta.ncon)
-    m.set_product_mode(0, 0)                # atomics: the implementation that uses the copies
-    ref = {"grad": o.grad(x), "jtprod": o.jtprod(x, w), "hprod": o.hprod(x, y, v, sigma)}
-    got = {}
-    for on in (1, 0, 1):
-        assert (m.set_locality(on) >= 1) == bool(on)
-        got[on] = {"grad": m.grad(x), "jtprod": m.jtprod(x, w), "hprod": m.hprod(x, y, v, sigma)}
-        for k in ref:
-            assert relerr(got[on][k], ref[k]) <= RTOL, (on, k)
-    for k in ref:
-        assert relerr(got[1][k], got[0][k]) <= 1e-12, k
-    # what has a slot / row order does not move at all
-    m.set_locality(1)
-    a = (m.cons(x), m.jac_coord(x), m.hess_coord(x, y, sigma), m.jprod(x, v))
-    m.set_locality(0)
-    b = (m.cons(x), m.jac_coord(x), m.hess_coord(x, y, sigma), m.jprod(x, v))
-    m.set_locality(1)
-    for p, q in zip(a, b):
-        assert np.array_equal(p, q)
-
-
-def test_sharded_partial_sums_on_the_locality_ordered_copies(acopf):
-    """Three ranks replayed on one GPU: each adds the contributions of ITS stretch of the permuted table; the partial sums add up to
-    the whole (which rows a rank holds differs from the COO's shard of the caller's order — nothing depends on that)."""
-    import torch
-    m, o, x0 = acopf
-    x, y, sigma = point(x0, m.meta.ncon, seed=10)
-    v = np.random.default_rng(3).standard_normal(m.meta.nvar)
-    w = np.random.default_rng(4).standard_normal(m.meta.ncon)
-    dev = torch.device("cuda:0")
-    xd, yd, vd, wd = (torch.from_numpy(a).to(dev) for a in (x, y, v, w))
-    m.set_product_mode(0, 0)
-    m.set_locality(1)
-    G = 3
-    jtv, hv, g = np.zeros(m.meta.nvar), np.zeros(m.meta.nvar), np.zeros(m.meta.nvar)
-    try:
-        for r in range(G):
-            m.set_shard(r, G)
-            assert m.set_locality(-1) >= 1
-            jtv += m.jtprod(xd, wd).cpu().numpy()
-            hv += m.hprod(xd, yd, vd, sigma).cpu().numpy()
-            g += m.grad(xd).cpu().numpy()
-    finally:
-        m.set_shard(0, 1)
-    assert relerr(jtv, o.jtprod(x, w)) <= RTOL
-    assert relerr(hv, o.hprod(x, y, v, sigma)) <= RTOL
-    assert relerr(g, o.grad(x)) <= RTOL
-
-
-def test_locality_copies_under_register_poison(acopf, tmp_path):
-    from poison import make_poison
-    m, o, x0 = acopf
-    x, y, sigma = point(x0, m.meta.ncon, seed=11)
-    v = np.random.default_rng(5).standard_normal(m.meta.nvar)
-    w = np.random.default_rng(6).standard_normal(m.meta.ncon)
-    poison = make_poison(str(tmp_path))
-    m.set_product_mode(0, 0)
-    m.set_locality(1)
-    for _ in range(2):
-        poison()
-        assert relerr(m.jtprod(x, w), o.jtprod(x, w)) <= RTOL
-        poison()
-        assert relerr(m.hprod(x, y, v, sigma), o.hprod(x, y, v, sigma)) <= RTOL
-        poison()
-        assert relerr(m.grad(x), o.grad(x)) <= RTOL
-
-
-@pytest.mark.parametrize("seed", [0, 3])
-def test_locality_copies_on_random_table_models_with_content_aliased_columns(libs, seed):
-    """Twelve random patterns over ONE table of 5 000 rows (tests/randexpr.py): columns are aliased BY CONTENT, so a pattern may alias
-    columns of several other patterns — the case that crashed the first version (a permuted word taken from a pattern that had none).
-    Copies in: grad!, J'v, Hv against the oracle; copies out: the same numbers to 1e-12."""
-    import randexpr
-    from exahip import ExaModel
-    import oracle
-    saved = randexpr.NPTS
-    randexpr.NPTS = 5000
-    try:
-        m = ExaModel(randexpr.build_model(seed, npat=12, depth=3).to_ir())
-    finally:
-        randexpr.NPTS = saved
-    o = oracle.OracleModel(m.ir, threads=8)
-    x, y, sigma = point(m.meta.x0, m.meta.ncon, seed=seed)
-    v = np.random.default_rng(7).standard_normal(m.meta.nvar)
-    w = np.random.default_rng(8).standard_normal(m.meta.ncon)
-    m.set_product_mode(0, 0)
-    out = {}
-    for on in (1, 0):
-        m.set_locality(on)
-        out[on] = (m.grad(x), m.jtprod(x, w), m.hprod(x, y, v, sigma))
-        for got, ref in zip(out[on], (o.grad(x), o.jtprod(x, w), o.hprod(x, y, v, sigma))):
-            assert relerr(got, ref) <= 1e-9          # (deep random trees: the sweeps' tolerance)
-    for a, b in zip(out[1], out[0]):
-        assert relerr(a, b) <= 1e-11
+    assert "? ((const long*)P[" not in m.kernel_source() and not hasattr(m._L, "exa_set_locality_checked")
+    import ctypes
+    with pytest.raises(AttributeError):
+        ctypes.CDLL(m._L._name).exa_set_locality
 
 
 # ---- exa_eval_all in one launch for an injective data-indexed objective (VERDICT r4 item 3, the ACOPF half) --------------------------------
