@@ -74,13 +74,9 @@ int tile_ld(int S) {
     const int pp = tile_pp(S), cnt = S * pp;
     int best = pp + 1;
     long best_cost = -1;
-    // EXAHIP_TILE_LD_BUDGET=bytes bounds the search by the tile's footprint per workgroup.  Measured and NOT the default: the conflict-free
-    // LD = 47 of the rocket's 47-slot pattern (16 points per pass) is a 70 KB tile, two workgroups per CU where the registers allow three;
-    // LD = 17 (25 KB, 15 extra LDS cycles per pass) gives the third workgroup and LOSES: hess_coord! 0.0881 -> 0.0917 ms at nh = 1e6,
-    // 2.08 -> 2.14 at 2e7 (profiles/r5_rocket_tile_ld_ab.txt) — the transposed read's conflicts cost more than the occupancy buys.
-    const long budget = env_int("EXAHIP_TILE_LD_BUDGET", 0);
+    // (the search is NOT bounded by the tile's footprint: the conflict-free LD = 47 of the rocket's 47-slot pattern is a 70 KB tile, two workgroups
+    // per CU where the registers allow three; LD = 17 gives the third and LOSES — hess_coord! 0.0881 -> 0.0917 ms, profiles/r5_rocket_tile_ld_ab.txt)
     for (int ld = pp; ld <= pp + 32; ld++) {
-        if (budget > 0 && ld > pp + 1 && (long)(kBlock / 64) * S * ld * 8 > budget) break;
         long cost = 0;
         for (int k = 0; k * 64 < cnt; k++)
             for (int half = 0; half < 2; half++) {

@@ -177,44 +177,6 @@ def test_fast_exp_is_within_an_ulp_and_the_knob_brings_ocml_back(libs, monkeypat
             np.testing.assert_allclose(mm.cons(xx), o.cons(xx), rtol=1e-10, atol=1e-12)
 
 
-@pytest.mark.parametrize("name", ["acopf30", "rocket50", "lv1000"])
-def test_ktab_knob_coefficients_from_constant_memory_give_the_same_bits(libs, name, monkeypatch):
-    """EXAHIP_KTAB=1: the Horner coefficients of exa_sincos / exa_exp come from a table in constant memory (one s_load_dwordx16 per
-    polynomial) instead of literals (two s_mov_b32 each): the same values in the same instructions — every output bit for bit."""
-    from exahip import ExaModel
-    m0 = ExaModel(ZOO[name]())
-    monkeypatch.setenv("EXAHIP_KTAB", "1")
-    m1 = ExaModel(ZOO[name]())
-    assert m1.kernel_source().startswith("#define EXA_KTAB 1") and m0._L.exa_module_name(m0.id) != m1._L.exa_module_name(m1.id)
-    x, y, s = point(m0.meta.x0, m0.meta.ncon, seed=13)
-    v = np.random.default_rng(5).standard_normal(m0.meta.nvar)
-    w = np.random.default_rng(6).standard_normal(max(1, m0.meta.ncon))[:m0.meta.ncon]
-    a, b = _everything(m0, x, y, s, v, w), _everything(m1, x, y, s, v, w)
-    for k in ("obj", "cons", "jac", "hess", "jprod", "all_c", "all_j", "all_h"):
-        assert np.array_equal(a[k], b[k]), k
-    for k in ("grad", "jtprod", "hprod"):          # atomics where the scatter is data-indexed: the order of the additions is free
-        np.testing.assert_allclose(a[k], b[k], rtol=1e-12, atol=1e-13, err_msg=k)
-
-
-def test_tile_ld_budget_knob_changes_the_staging_tile_not_the_values(libs, monkeypatch):
-    """EXAHIP_TILE_LD_BUDGET=bytes: the leading dimension of the slot-major COO staging tile is searched only among those whose tile fits the
-    budget per workgroup (the rocket's 47-slot pattern: LD 47 -> 17, 70 KB -> 25 KB).  A layout of the staging buffer: every value is
-    the same bit pattern, through another tile."""
-    from exahip import ExaModel
-    m0 = ExaModel(ZOO["rocket50"]())
-    monkeypatch.setenv("EXAHIP_TILE_LD_BUDGET", "40960")
-    m1 = ExaModel(ZOO["rocket50"]())
-    assert m0._L.exa_module_name(m0.id) != m1._L.exa_module_name(m1.id)
-    lds = lambda m: max(a["lds"] for a in m.build_audit() if a["kernel"] == "exa_hess")       # noqa: E731
-    assert lds(m1) < lds(m0) and lds(m1) <= 40960
-    x, y, s = point(m0.meta.x0, m0.meta.ncon, seed=14)
-    v = np.random.default_rng(5).standard_normal(m0.meta.nvar)
-    w = np.random.default_rng(6).standard_normal(max(1, m0.meta.ncon))[:m0.meta.ncon]
-    a, b = _everything(m0, x, y, s, v, w), _everything(m1, x, y, s, v, w)
-    for k in ("obj", "cons", "jac", "hess", "all_c", "all_j", "all_h"):
-        assert np.array_equal(a[k], b[k]), k
-
-
 def test_hess_throttle_is_the_same_kernel_at_another_occupancy(libs, tmp_path, monkeypatch):
     """EXAHIP_HESS_DYN_LDS=bytes: the chained hess_coord! kernels launched with dynamic LDS nobody uses (three or two workgroups per CU instead
     of as many as the registers allow) — the same kernel, the same bits.  Without the variable exa_tune measures none / three / two next to
