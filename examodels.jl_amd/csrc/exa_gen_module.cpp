@@ -206,9 +206,8 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
                << "const double t_ = p" << act[k] << "_val(P, x, th, I < h_ ? I : h_); v += I <= h_ ? t_ : 0.0; }\n    }\n";
         }
     }
-    // done != null: the workgroup that finishes LAST folds the partial sums itself, in index order (deterministic), and re-arms
-    // the counter — one launch instead of two (exa_reduce_partials is the second, used when there are too many partials for
-    // one workgroup).  Release / acquire at device scope around the counter; the partials are read with device-scope loads.
+    // the workgroup that finishes LAST folds the partial sums itself, in index order (deterministic), and re-arms the counter(s):
+    // one launch at any size (exa_obj_arrive).  Release / acquire at device scope around the counters; device-scope loads of the partials.
     os << "    const double s = exa_block_sum(v);\n    exa_obj_arrive(part, b, s, done, gridDim.x, out);\n}\n";
     // gradient COO + its structure (sorted grad!, gen_gradv_fn): the dispatch of exa_obj
     for (int which = 0; which < 2; which++) {

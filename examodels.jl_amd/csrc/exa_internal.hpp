@@ -189,10 +189,6 @@ struct WindowPat {             // one (pattern, stride class) pass
     int space = 0;              // block-owned variant: which output space (column block) the pass writes to
 };
 constexpr int kStageHalo = 16;     // doubles of halo a wavefront stages beyond its 64 points (exa_hesscl)
-// exa_obj: up to this many workgroups, the one that arrives last folds the partial sums inside the launch (rocket 1e6: obj
-// 0.011 -> 0.005 ms, ACOPF 0.015 -> 0.005).  Arrivals are same-address atomics + a device-scope release, ~12-25 ns each,
-// serialised chip-wide: 4 883 workgroups (LV 1e7) took 0.124 ms against 0.021 with the second launch
-constexpr int64_t kObjFoldMax = 512;
 constexpr int kSharedTiles = 8;   // chunks of kBlock points per workgroup of the shared-entry kernel (exa_c*s)
 struct WindowShared {          // slots of a pattern that land on ONE entry for every data point (b = 0: a literal index):
     int k = 0;                  // summed per workgroup, folded in a fixed order by the tail kernel (exa_*x)

@@ -74,7 +74,7 @@ struct Handle {
     std::string devname;
     hipStream_t stream = nullptr;
     hipModule_t module = nullptr;
-    hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_red = nullptr, f_zero = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
+    hipFunction_t f_auglong = nullptr, f_augfold = nullptr, f_auggather = nullptr, f_gradpull = nullptr, f_fused = nullptr, f_jprod = nullptr, f_jtprod = nullptr, f_hprod = nullptr, f_obj = nullptr, f_zero = nullptr, f_grad = nullptr, f_cons = nullptr, f_jac = nullptr,
                   f_hess = nullptr, f_hessc = nullptr, f_hesscl = nullptr, f_cons1 = nullptr, f_jprod1 = nullptr, f_js32 = nullptr, f_js64 = nullptr, f_hs32 = nullptr, f_hs64 = nullptr;
     std::vector<int64_t> P;                 // host copy of the parameter table
     std::vector<int64_t> grid = std::vector<int64_t>(CB_COUNT, 0);

@@ -325,8 +325,10 @@ void fill_params(Handle &h) {
     if (h.on_device) {
         h.dP.ensure(sizeof(int64_t) * h.P.size());
         HIPCHK(hipMemcpy(h.dP.p, h.P.data(), sizeof(int64_t) * h.P.size(), hipMemcpyHostToDevice));
-        h.dpart.ensure(sizeof(double) * (size_t)(std::max(h.grid[CB_OBJ], h.grid[CB_FUSED]) + 1));
-        if (!h.ddone.p) { h.ddone.ensure(64); HIPCHK(hipMemset(h.ddone.p, 0, 64)); }      // exa_obj's arrival counter (re-armed by the kernel)
+        // objective partials (+ the shard sums of the two-level fold, exa_obj_arrive: n rounded up to whole shards + up to 1024 of them) and the arrival
+        // counters: [0] the single / top one, [1 + r] shard r's (up to 1024), 128 B apart, re-armed by the kernel
+        h.dpart.ensure(sizeof(double) * (size_t)(std::max(h.grid[CB_OBJ], h.grid[CB_FUSED]) + 2 * 1024 + 1));
+        if (!h.ddone.p) { h.ddone.ensure(1025 * 128); HIPCHK(hipMemset(h.ddone.p, 0, 1025 * 128)); }
     }
 }
 
@@ -448,7 +450,7 @@ void to_device(Handle &h) {
     h.on_device = true;   // from here on the destructor releases whatever was acquired
     HIPCHK(hipModuleLoadData(&h.module, image.data()));
     auto fn = [&](const char *name) { hipFunction_t f; HIPCHK(hipModuleGetFunction(&f, h.module, name)); return f; };
-    h.f_obj = fn("exa_obj"); h.f_red = fn("exa_reduce_partials"); h.f_zero = fn("exa_zero"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
+    h.f_obj = fn("exa_obj"); h.f_zero = fn("exa_zero"); h.f_grad = fn("exa_grad"); h.f_cons = fn("exa_cons");
     h.f_auggather = fn("exa_aug_gather"); h.f_gradpull = fn("exa_grad_pull");
     h.f_auglong = fn("exa_aug_long"); h.f_augfold = fn("exa_aug_fold");
     h.f_fused = fn("exa_fused");
@@ -600,15 +602,11 @@ void do_obj(Handle &h, const double *x, double *out_dev) {
     void *part = h.dpart.p;
     int64_t n = h.grid[CB_OBJ];
     if (n == 0) { HIPCHK(hipMemsetAsync(out_dev, 0, sizeof(double), h.stream)); allreduce(h, out_dev, 1); return; }
-    // up to kObjFoldMax workgroups: the one of exa_obj that finishes last folds the partial sums (one launch); more: a second
-    // launch of 1024 threads
-    void *done = n <= kObjFoldMax ? h.ddone.p : nullptr;
+    // ONE launch at any size: the workgroup of exa_obj that finishes last folds the partial sums (beyond 512 workgroups through 32
+    // sharded arrival counters and 32 shard sums, exa_obj_arrive)
+    void *done = h.ddone.p;
     void *a1[] = {&P, &x, &th, &part, &done, &out_dev};
     launch(h, h.f_obj, n, kBlock, a1);
-    if (!done) {
-        void *a2[] = {&part, &n, &out_dev};
-        launch(h, h.f_red, 1, 1024, a2);
-    }
     allreduce(h, out_dev, 1);
 }
 // grad!.  Gathered (range-affine) objective patterns are evaluated per VARIABLE, so a sharded model shards them by variable
@@ -795,13 +793,12 @@ void do_fused(Handle &h, const double *x, const double *y, double sigma, double 
         bmap = h.dmapz[h.order[CB_FUSED] ? 1 : 0].p;
         n = h.gridz;
     }
-    // objective partial sums: up to kObjFoldMax of them are folded by the objective workgroup that arrives last (as in do_obj)
+    // objective partial sums: folded by the objective workgroup that arrives last (as in do_obj)
     int64_t nobj = h.fused_nobj;
-    void *done = n > 0 && nobj > 0 && nobj <= kObjFoldMax ? h.ddone.p : nullptr;
+    void *done = h.ddone.p;
     void *a[] = {&P, &x, &y, &th, &part, &c, &buf, &jv, &hv, &sigma, &ap, &as, &ac, &gout, &bmap, &vb, &ve, &own_lo, &own_hi, &done, &nobj, &obj_dev};
     launch(h, h.f_fused, n, kBlock, a);
-    if (n > 0 && nobj > 0) { if (!done) { void *a2[] = {&part, &nobj, &obj_dev}; launch(h, h.f_red, 1, 1024, a2); } }
-    else HIPCHK(hipMemsetAsync(obj_dev, 0, sizeof(double), h.stream));
+    if (!(n > 0 && nobj > 0)) HIPCHK(hipMemsetAsync(obj_dev, 0, sizeof(double), h.stream));
     if (h.m->nconaug && !inline_aug) aug_gather(h, buf, c);
     allreduce(h, obj_dev, 1);
     if (h.m->ncon) { if (owner) allgatherv(h, c, row_pieces(h)); else allreduce(h, c, h.m->ncon); }

@@ -179,6 +179,8 @@ def v_cache_policy(src, aux):
 
 VARIANTS = {
     "base": lambda s: s,
+    "obj_noarrive": lambda s: sub(s, "    exa_obj_arrive(part, b, s, done, gridDim.x, out);\n}", "    if (threadIdx.x == 0) part[b] = s;\n}"),
+    "obj_nostore": lambda s: sub(s, "    const double s = exa_block_sum(v);\n    exa_obj_arrive(part, b, s, done, gridDim.x, out);\n}", "    if (v == 12345.678) part[b] = v;\n}"),
     "cp_plain": lambda s: v_cache_policy(s, 0),
     "cp_sc0": lambda s: v_cache_policy(s, 1),
     "cp_nt": lambda s: v_cache_policy(s, 2),
@@ -264,8 +266,37 @@ def run(out, N, hv, names):
         print(f"N={N:.0e} {kern:10s} {n:18s} min {ts[0]:.4f} median {ts[len(ts) // 2]:.4f} ms  {nbytes / ts[0] / 1e6 / 8000:.3f} of 8 TB/s  bitwise == base: {ms[n][0]}", flush=True)
 
 
+def run_cb(out, N, which, names):
+    """time another callback (obj / cons / jac / grad) of the variants; outputs are NOT compared"""
+    import numpy as np
+    import torch
+    from exahip import ExaModel, capi, models
+    key = open(os.path.join(out, "KEY")).read().strip()
+    L = capi.lib()
+    core = models.luksan_vlcek_model(N)
+    ms, mods = {}, {}
+    for n in names:
+        blob = open(os.path.join(out, n + ".hsaco"), "rb").read()
+        assert L.exa_cache_add(key.encode(), blob, len(blob)) == 0
+        mods[n] = ExaModel(core)
+        assert mods[n].build_info()[0] == "preloaded"
+    m0 = mods[names[0]]
+    r = np.random.default_rng(0)
+    x = torch.from_numpy(m0.meta.x0 + 0.1 * r.uniform(-1, 1, N)).cuda()
+    buf = torch.empty(max(m0.meta.nnzj, m0.meta.nvar), dtype=torch.float64, device="cuda")
+    for rnd in range(7):
+        for n in names:
+            t = mods[n].time_callback(which, 200, x, out=buf)
+            if rnd:
+                ms.setdefault(n, []).append(t)
+    for n in names:
+        print(f"N={N:.0e} {which:6s} {n:18s} min {min(ms[n]):.5f} median {sorted(ms[n])[3]:.5f} ms", flush=True)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "prepare":
+    if sys.argv[1] == "cb":
+        run_cb(sys.argv[2], int(float(sys.argv[3])), sys.argv[4], sys.argv[5:])
+    elif sys.argv[1] == "prepare":
         prepare(sys.argv[2])
     else:
         run(sys.argv[2], int(float(sys.argv[3])), int(sys.argv[4]), sys.argv[5:])
