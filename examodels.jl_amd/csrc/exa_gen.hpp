@@ -376,6 +376,9 @@ inline std::string fn_name(int pi, const char *cb) { return "p" + std::to_string
 // pattern / group device functions
 void gen_value_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L);
 void gen_cons_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L);
+void gen_cons_two_stage(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L);      // pK_consL / pK_consE (exa_consl)
+void gen_jac_group_two_stage(std::ostringstream &os, const Model &m, const ParamLayout &L, int gi); // gK_jacL / gK_jacE (exa_jacl)
+void gen_dispatch_looped(std::ostringstream &os, const ParamLayout &L, int cb);                     // the pipelined tile loop of exa_consl / exa_jacl
 void gen_hess_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L);
 void gen_coo_group_fn(std::ostringstream &os, const Model &m, const ParamLayout &L, int cb, int gi, bool permuted = false);
 void gen_fused_group_fn(std::ostringstream &os, const Model &m, const ParamLayout &L, int gi);

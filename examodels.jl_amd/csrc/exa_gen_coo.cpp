@@ -27,12 +27,18 @@ static bool is_memory_read(const std::string &expr) {
 }
 // staged != null: x loads listed there (name -> LDS index expression: stretch base + the cluster's lane offset + literal distance) are
 // NOT loaded: the evaluation stage reads them from the wavefront's staged stretches, xs[...]
-static Split split_body_staged(const Emitter &e, const std::map<std::string, std::string> *staged);
+// line_marks / eval_marks: for every line index in line_marks (ascending), the number of evaluation-stage lines emitted before that line
+// (a fused group's function stores a pattern's slots right behind the lines that complete them)
+static Split split_body_staged(const Emitter &e, const std::map<std::string, std::string> *staged, const std::vector<size_t> *line_marks = nullptr,
+                               std::vector<size_t> *eval_marks = nullptr);
 Split split_body(const Emitter &e) { return split_body_staged(e, nullptr); }
-static Split split_body_staged(const Emitter &e, const std::map<std::string, std::string> *staged) {
+static Split split_body_staged(const Emitter &e, const std::map<std::string, std::string> *staged, const std::vector<size_t> *line_marks,
+                               std::vector<size_t> *eval_marks) {
     Split sp;
-    size_t d = 0;
-    for (size_t li = 0; li < e.lines.size(); li++) {
+    size_t d = 0, mk = 0;
+    for (size_t li = 0; li <= e.lines.size(); li++) {
+        while (line_marks && mk < line_marks->size() && (*line_marks)[mk] == li) { eval_marks->push_back(sp.eval.size()); mk++; }
+        if (li == e.lines.size()) break;
         const std::string &line = e.lines[li];
         if (d < e.defs.size() && e.defs[d].line == (int)li) {
             const Emitter::Def &df = e.defs[d++];
@@ -266,6 +272,24 @@ void gen_cons_fn(std::ostringstream &os, const Model &m, int pi, const ParamLayo
     os << "}\n";
 }
 
+// cons_nln! value in two stages for the pipelined tile loop (exa_consl): pK_consL issues the loads of point tid (clamped into the shard) and
+// hands them over, pK_consE evaluates from the hand-over registers.  The value is the same expression as pK_val: bitwise equal.
+void gen_cons_two_stage(std::ostringstream &os, const Model &m, int pi, const ParamLayout &L) {
+    Body b(m, pi, L);
+    Val v = b.e.tod(b.cval(b.p.root));
+    const Split sp = split_body(b.e);
+    g_handover[{CB_CONS, pi}] = {sp.nin, sp.nik};
+    const std::string head = "    const long I_ = " + b.P(L.pat[pi].lo) + " + tid, hi_ = " + b.P(L.pat[pi].hi) + ";\n    const long I = I_ < hi_ ? I_ : (hi_ > 0 ? hi_ - 1 : 0);\n";
+    os << "static __device__ __forceinline__ void " << fn_name(pi, "consL")
+       << "(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, long tid, double* in, long* ik) {\n" << head;
+    for (const auto &l : sp.load) os << "    " << l << "\n";
+    os << "    (void)I;\n}\n";
+    os << "static __device__ __forceinline__ double " << fn_name(pi, "consE")
+       << "(const long* __restrict__ P, const double* in, const long* ik, long tid) {\n" << head;
+    for (const auto &l : sp.eval) os << "    " << l << "\n";
+    os << "    (void)I;\n    return " << b.e.s(v) << ";\n}\n";
+}
+
 // COO-writing pattern function in two stages (see split_body): pK_<cb>L loads, pK_<cb>E evaluates and stores.
 static void emit_two_stage(std::ostringstream &os, Body &b, const ParamLayout &L, int pi, int cb, const char *name, bool hess, bool tile,
                     int word_o, int S, const std::vector<std::string> &vals) {
@@ -398,6 +422,96 @@ void gen_coo_group_fn(std::ostringstream &os, const Model &m, const ParamLayout 
         else emit_coo_stores(os, b, word, S, vals, use_tile(S), "out", "_" + std::to_string(pk));
     }
     os << "}\n";
+}
+
+// jac_coord! group function in two stages for the pipelined tile loop (exa_jacl): gK_jacL = the loads of the whole fused group at point tid,
+// gK_jacE = the arithmetic and the COO stores of every pattern of the group, each pattern's stores right behind the lines that complete its
+// slots (as in gK_jac).  Lanes and whole wavefronts beyond the shard evaluate its last point and store nothing (the flush's range check).
+void gen_jac_group_two_stage(std::ostringstream &os, const Model &m, const ParamLayout &L, int gi) {
+    const int cb = CB_JAC;
+    const auto &grp = L.groups[cb][gi];
+    Emitter E;
+    std::vector<size_t> line_marks, eval_marks;
+    struct St { int pk, S, word; std::vector<std::string> vals; };
+    std::vector<St> sts;
+    for (int pk : grp) {
+        Body b(m, pk, L, &E);
+        const Pattern &p = b.p;
+        b.forward(p.ad_root, 1, false);
+        GenAlg a(b, p.comp1, p.o1step);
+        grpass(p, p.ad_root, a, Emitter::litf(1.0));
+        St st{pk, p.o1step, L.pat[pk].o1, {}};
+        for (int s2 = 0; s2 < st.S; s2++) st.vals.push_back(E.sd(a.acc[s2]));
+        sts.push_back(st);
+        line_marks.push_back(E.lines.size());
+    }
+    const Split sp = split_body_staged(E, nullptr, &line_marks, &eval_marks);
+    g_handover[{cb, gi}] = {sp.nin, sp.nik};
+    Body b0(m, grp.front(), L);
+    const std::string head = "    const long I0 = " + b0.P(L.pat[grp.front()].lo) + " + tid;\n    const long hi = " + b0.P(L.pat[grp.front()].hi) +
+                             ";\n    const long I = I0 < hi ? I0 : (hi > 0 ? hi - 1 : 0);\n";
+    os << "static __device__ __forceinline__ void g" << gi << "_jacL(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, long tid, "
+          "double* in, long* ik) {\n" << head;
+    for (const auto &l : sp.load) os << "    " << l << "\n";
+    os << "    (void)I;\n}\n";
+    os << "static __device__ __forceinline__ void g" << gi << "_jacE(const long* __restrict__ P, const double* in, const long* ik, double* __restrict__ out, long tid, double* lds) {\n"
+       << head << "    const int lane = threadIdx.x & 63;\n    (void)lane;\n";
+    size_t at = 0;
+    for (size_t j = 0; j < sts.size(); j++) {
+        for (; at < eval_marks[j]; at++) os << "    " << sp.eval[at] << "\n";
+        Body b(m, sts[j].pk, L);
+        emit_coo_stores(os, b, sts[j].word, sts[j].S, sts[j].vals, use_tile(sts[j].S), "out", "_" + std::to_string(sts[j].pk));
+    }
+    for (; at < sp.eval.size(); at++) os << "    " << sp.eval[at] << "\n";
+    os << "}\n";
+}
+
+// Tile loop of exa_consl / exa_jacl, SOFTWARE-PIPELINED (round 6): the workgroup walks `ppt` consecutive entries of the block map; the loads of
+// the NEXT entry's tile are issued before the current tile is evaluated and stored (what exa_hessc does for hess_coord!), so a wavefront's loads
+// have a whole evaluation to land in instead of stalling its first arithmetic.  Entries may belong to different dispatch units (patterns /
+// fused groups): one hand-over array sized for the largest, a uniform branch per stage.  The last tile of a workgroup loads itself again (no
+// extra HBM traffic, a fixed number of memory instructions per iteration).  Measured by hand on LV before it was built (tools/kernel_patch_ab.py
+// cons_pipe): cons_nln! 1e7 0.0451 -> 0.0421 ms, 3e7 0.126 -> 0.121, 1e8 0.514 -> 0.448; bitwise equal.
+void gen_dispatch_looped(std::ostringstream &os, const ParamLayout &L, int cb) {
+    const bool jac = cb == CB_JAC;
+    const size_t nunits = jac ? L.groups[cb].size() : L.active[cb].size();
+    auto key = [&](size_t k) { return jac ? (int)k : L.active[cb][k]; };
+    int nin = 0, nik = 0;       // (no placeholder registers: an unused long pair claimed by the asm statements below cost LV's exa_consl its 7th wavefront per SIMD)
+    for (size_t k = 0; k < nunits; k++) { const auto ho = g_handover[{cb, key(k)}]; nin = std::max(nin, ho.first); nik = std::max(nik, ho.second); }
+    const std::string bmap = "((const __attribute__((address_space(4))) long*)P[" + std::to_string(L.blk[cb]) + "])";
+    const std::string fnL = jac ? "_jacL" : "_consL", pre = jac ? "g" : "p";
+    auto loads = [&](const std::string &e, const std::string &sfx, const char *ind) {
+        os << ind << "{ const int ps_ = (int)(" << e << " >> 40); const long t_ = (" << e << " & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
+        // (ONE dispatch unit: no branch — the parameter-table reads of the stage functions are then unconditional and the compiler hoists them
+        // out of the loop; under a uniform branch it reloads P[lo], P[hi], P[col] in every iteration, a dependent scalar round trip in front
+        // of the loads: LV cons_nln! 0.0462 -> 0.0434 ms from that alone)
+        for (size_t k = 0; k < nunits; k++)
+            os << ind << "  " << (nunits == 1 ? "" : (k ? "else " : "") + ("if (ps_ == " + std::to_string(k) + ") ")) << pre << key(k) << fnL << "(P, x, th, t_, " << (nin ? "in" + sfx : std::string("nullptr")) << ", " << (nik ? "ik" + sfx : std::string("nullptr")) << ");\n";
+        if (nunits == 1) os << ind << "  (void)ps_;\n";
+        os << ind << "}\n";
+    };
+    os << "    const long b0_ = (long)blockIdx.x * ppt;\n    if (b0_ >= nent) return;\n    long en_ = " << bmap << "[b0_];\n"
+       << "    double in_[" << std::max(1, nin) << "], inn_[" << std::max(1, nin) << "]; long ik_[" << std::max(1, nik) << "], ikn_[" << std::max(1, nik) << "];\n";
+    // (several units: a tile of a unit with fewer hand-over values leaves the rest of the arrays as they were — defined once, here)
+    if (nunits > 1) os << "#pragma unroll\n    for (int q = 0; q < " << std::max(1, nin) << "; q++) { in_[q] = 0.0; inn_[q] = 0.0; }\n"
+                       << "#pragma unroll\n    for (int q = 0; q < " << std::max(1, nik) << "; q++) { ik_[q] = 0; ikn_[q] = 0; }\n";
+    loads("en_", "_", "    ");
+    os << "#pragma unroll\n    for (int q = 0; q < " << nin << "; q++) asm volatile(\"\" : \"+v\"(in_[q]));\n"
+       << "#pragma unroll\n    for (int q = 0; q < " << nik << "; q++) asm volatile(\"\" : \"+v\"(ik_[q]));\n"
+       << "#pragma unroll 1\n    for (int u_ = 0; u_ < ppt; u_++) {\n        const long b = b0_ + u_;\n        if (b >= nent) break;\n"
+       << "        const long e_ = en_;\n        en_ = u_ + 1 < ppt && b + 1 < nent ? " << bmap << "[b + 1] : e_;\n";
+    loads("en_", "n_", "        ");
+    os << "        const int ps_ = (int)(e_ >> 40);\n        const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
+    if (nunits == 1) os << "        (void)ps_;\n";
+    for (size_t k = 0; k < nunits; k++) {
+        os << "        " << (nunits == 1 ? "" : (k ? "else " : "") + ("if (ps_ == " + std::to_string(k) + ") "));
+        if (jac) os << "g" << key(k) << "_jacE(P, " << (nin ? "in_" : "nullptr") << ", " << (nik ? "ik_" : "nullptr") << ", out, tid0, lds);\n";
+        else os << "{ const double v_ = p" << key(k) << "_consE(P, " << (nin ? "in_" : "nullptr") << ", " << (nik ? "ik_" : "nullptr") << ", tid0); p" << key(k) << "_conss(P, out, aug, tid0, v_); }\n";
+    }
+    // (the hand-over registers are claimed at the BOTTOM of the iteration: the wait for the next tile's loads then lands behind this tile's
+    // arithmetic and stores — see gen_dispatch_chained)
+    os << "#pragma unroll\n        for (int q = 0; q < " << nin << "; q++) { asm volatile(\"\" : \"+v\"(inn_[q])); in_[q] = inn_[q]; }\n"
+       << "#pragma unroll\n        for (int q = 0; q < " << nik << "; q++) { asm volatile(\"\" : \"+v\"(ikn_[q])); ik_[q] = ikn_[q]; }\n    }\n";
 }
 
 // ---- fused sweep: value + Jacobian slots + Hessian slots from ONE second-order forward sweep --------

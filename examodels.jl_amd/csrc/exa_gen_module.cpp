@@ -173,6 +173,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
         }
         else {
             gen_cons_fn(os, m, k, L);
+            if (L.ppt[CB_CONS] == 1) gen_cons_two_stage(os, m, k, L);
             gen_jprod_fn(os, m, k, L);
             if (p.o1step > 0) gen_struct_fn(os, m, k, L, false);
         }
@@ -182,6 +183,8 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
         for (size_t g = 0; g < L.groups[cb].size(); g++) gen_scatter_group_fn(os, m, L, cb, (int)g);
     for (int cb : {CB_JAC, CB_HESS})
         for (size_t g = 0; g < L.groups[cb].size(); g++) gen_coo_group_fn(os, m, L, cb, (int)g);
+    if (L.ppt[CB_JAC] == 1)
+        for (size_t g = 0; g < L.groups[CB_JAC].size(); g++) gen_jac_group_two_stage(os, m, L, (int)g);
     for (size_t g = 0; g < L.groups[CB_FUSED].size(); g++) gen_fused_group_fn(os, m, L, (int)g);
     // scatter kernels whose patterns have targets shared by ALL data points process 16 tiles per workgroup: the shared
     // target then receives one atomic per wavefront per 16 tiles (same-address atomics serialise chip-wide at ~10 ns:
@@ -272,18 +275,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
     // exa_consl: exa_cons as a tile loop over `ppt` consecutive block-map entries (see gen_dispatch, looped)
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_consl(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out, double* __restrict__ aug, long nent, int ppt) {\n";
-    if (L.ppt[CB_CONS] == 1) {
-        const auto &act = L.active[CB_CONS];
-        const std::string bmap = "((const __attribute__((address_space(4))) long*)P[" + std::to_string(L.blk[CB_CONS]) + "])";
-        os << "    const long b0_ = (long)blockIdx.x * ppt;\n    if (b0_ >= nent) return;\n    long en_ = " << bmap << "[b0_];\n"
-              "#pragma unroll 1\n    for (int u_ = 0; u_ < ppt; u_++) {\n    const long b = b0_ + u_;\n    if (b >= nent) break;\n"
-              "    const long e_ = en_;\n    en_ = " << bmap << "[b + 1 < nent ? b + 1 : b];\n    const int ps_ = (int)(e_ >> 40);\n"
-              "    const long tid0 = (e_ & ((1L << 40) - 1)) * EXA_BLOCK + threadIdx.x;\n";
-        for (size_t k = 0; k < act.size(); k++)
-            os << "    " << (k ? "else " : "") << "if (ps_ == " << k << ") { const double v_ = p" << act[k] << "_consv(P, x, th, tid0); p" << act[k]
-               << "_conss(P, out, aug, tid0, v_); }\n";
-        os << "    }\n";
-    }
+    if (L.ppt[CB_CONS] == 1) gen_dispatch_looped(os, L, CB_CONS);
     os << "}\n";
     // cons_nln! in ONE launch (unsharded models whose rows collect at most EXA_AUG_LONG terms).  The reference runs the base
     // kernel, the augmentation kernels and compress_to_dense (KA ext :273-308, :691-697); exa_cons + exa_aug_gather are two
@@ -419,7 +411,7 @@ Generated generate_module(const Model &m, bool loopfree_scatter, bool nostage) {
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_jacl(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ th, double* __restrict__ out, long nent, int ppt) {\n";
     lds_decl(CB_JAC, false);
-    gen_dispatch(os, L, CB_JAC, "jac", "P, x, th, out", ", lds", true);
+    if (L.ppt[CB_JAC] == 1) gen_dispatch_looped(os, L, CB_JAC);
     os << "}\n";
     os << "extern \"C\" __global__ void __launch_bounds__(EXA_BLOCK) exa_hess(const long* __restrict__ P, const double* __restrict__ x, "
           "const double* __restrict__ y, const double* __restrict__ th, double* __restrict__ out, double sigma) {\n";

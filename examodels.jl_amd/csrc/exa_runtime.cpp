@@ -561,16 +561,19 @@ void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **arg
 
 // Tiles per workgroup of the looped first-order kernels (exa_consl / exa_jacl), 0 = the one-tile kernel.  A workgroup of the one-tile kernels lives
 // ~2 us and its wavefront slots then sit empty for most of another microsecond until the next workgroup arrives (LV 1e7 exa_cons: 6.1 of 8
-// wavefronts resident on average, profiles/r5_instruction_mix.txt); a loop over 4 (cons_nln!) / 8 (jac_coord!) block-map entries amortises that,
-// and the compiler keeps the literal coefficients of exp / sincos in SGPRs across tiles.  LV 1e8: cons_nln! 0.562 -> 0.513 ms, jac_coord! 0.815 ->
-// 0.709; LV 1e7: 0.0458 -> 0.0457, 0.0601 -> 0.0592; bitwise equal (profiles/r5_tile_loop_ab.txt).  Only where the block map is long enough to
-// keep every CU busy with the longer workgroups.
+// wavefronts resident on average, profiles/r5_instruction_mix.txt); a loop over 4 / 8 block-map entries amortises that, the compiler keeps the
+// literal coefficients of exp / sincos in SGPRs across tiles, and — round 6 — the loop is software-pipelined (the next tile's loads issued before
+// this tile is evaluated, gen_dispatch_looped).  One model per setting alternating in one process (tools/tile_loop_ab.py, profiles/r6_tile_loop_ab.txt):
+// LV 1e8 cons_nln! 0.575 -> 0.468 ms, jac_coord! 0.790 -> 0.578 (round 5's loop without the pipelining: 0.513 / 0.709); 3e7 0.133 -> 0.131 and
+// 0.180 -> 0.162; 1e7 0.0488 -> 0.0496 (nothing) and 0.0615 -> 0.0569; bitwise equal.  Only where the block map is long enough to keep every CU busy
+// with the longer workgroups.
 int tile_loop_ppt(Handle &h, int cb) {
     hipFunction_t f = cb == CB_JAC ? h.f_jacl : h.f_consl;
     if (!f || h.gen.layout.ppt[cb] != 1 || h.tile_loop == 0 || h.tile_loop == 1) return 0;
     if (h.tile_loop > 1) return h.tile_loop;
-    const int want = cb == CB_JAC ? 8 : 4;
-    return h.grid[cb] >= (int64_t)16384 * want / 4 ? want : 0;        // >= 8 workgroups per CU after the division
+    if (h.grid[cb] < 16384) return 0;                                   // (3e6 points: the loop loses)
+    if (cb == CB_JAC) return h.grid[cb] >= 32768 ? 8 : 0;
+    return h.grid[cb] >= 65536 ? 8 : 4;
 }
 // zero-fill of n doubles on the model's stream (exa_zero)
 void zero_fill(Handle &h, void *p, int64_t n) {
