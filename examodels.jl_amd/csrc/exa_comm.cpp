@@ -118,7 +118,7 @@ std::vector<CollOp> plan_allgather(const std::vector<Piece> &pieces, int world) 
     for (int s : sets) {
         std::vector<Piece> ps;
         for (const Piece &q : pieces) if (q.set == s && q.count > 0) ps.push_back(q);
-        bool regular = world > 1 && (int)ps.size() == world;
+        bool regular = (int)ps.size() == world;
         for (int r = 0; regular && r < world; r++) {
             regular = ps[r].root == r && (r == 0 || ps[r].off == ps[r - 1].off + ps[r - 1].count);
             if (regular && r + 1 < world) regular = ps[r].count == ps[0].count;

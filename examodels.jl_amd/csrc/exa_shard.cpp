@@ -45,7 +45,9 @@ std::vector<Piece> window_pieces(const Handle &h, const Handle::Window &w) {
 // where they are regular (plan_allgather, exa_comm.cpp), grouped broadcasts otherwise; a host reducer (exa_comm_hook) only
 // knows how to sum, so the other ranks' pieces are zeroed and the covering range summed.
 void allgatherv(Handle &h, double *buf, const std::vector<Piece> &pieces, bool force) {
-    if ((!h.reduce && !force) || h.world == 1 || pieces.empty()) return;
+    // (world 1: nothing to do — except for a FORCED gather, exa_allgather_coo, over a real communicator: the one-piece plan is issued, so that
+    // the call exercises ncclAllGather in place on a single-GPU machine)
+    if ((!h.reduce && !force) || (h.world == 1 && !(force && h.nccl)) || pieces.empty()) return;
     if (h.nccl) {
         rccl_run_plan_f64(h.nccl, buf, plan_allgather(pieces, h.world), h.rank, h.stream);
     } else if (h.hook) {
@@ -288,11 +290,7 @@ int exa_shard_layout(int id, int which) {
  * Returns the number of operations of the plan (call again with a larger buffer when > cap), 0 for world 1 / nothing to do, -1 bad
  * argument.  which as exa_shard_layout: 0 obj, 1 grad, 2 cons, 3 jac COO, 4 hess COO (exa_allgather_coo), 5 jprod, 6 jtprod,
  * 7 hprod, 8 the cons vector of the fused sweeps.  Host logic only: works for plan-only handles (tests/test_shard_layout.py). */
-int exa_collective_plan(int id, int which, int64_t *out, int cap) {
-    Handle *hh = get(id);
-    if (!hh || which < 0 || which > 8 || (cap > 0 && !out)) return -1;
-    Handle &h = *hh;
-    if (h.world == 1) return 0;
+static std::vector<CollOp> collective_ops(int id, Handle &h, int which) {
     const int layout = exa_shard_layout(id, which);
     std::vector<CollOp> ops;
     const Model &m = *h.m;
@@ -304,8 +302,29 @@ int exa_collective_plan(int id, int which, int64_t *out, int cap) {
     case 3: case 4: ops = plan_allgather(coo_pieces(h, which == 4), h.world); break;
     case 6: case 7: if (layout == 1) ops = plan_allgather(window_pieces(h, h.wp[which - 6]), h.world); else reduce_all(m.nvar); break;
     }
+    return ops;
+}
+int exa_collective_plan(int id, int which, int64_t *out, int cap) {
+    Handle *hh = get(id);
+    if (!hh || which < 0 || which > 8 || (cap > 0 && !out)) return -1;
+    Handle &h = *hh;
+    if (h.world == 1) return 0;
+    const std::vector<CollOp> ops = collective_ops(id, h, which);
     for (size_t k = 0; k < ops.size() && (int)k < cap; k++) { out[4 * k] = ops[k].kind; out[4 * k + 1] = ops[k].off; out[4 * k + 2] = ops[k].count; out[4 * k + 3] = ops[k].root; }
     return (int)ops.size();
+}
+/* Deferred completion: issues, on the model's stream through the attached RCCL communicator, exactly the operations of
+ * exa_collective_plan(which) on buf — what the callback does itself at its end unless exa_set_reduce(id, 0) switched that off (a host that
+ * wants the collective of one callback to overlap the kernels of the next).  buf: the callback's output vector (global length).
+ * With a WORLD-1 communicator the plan of one piece per vector is issued all the same — a real in-place ncclAllGather / ncclAllReduce of
+ * the vector onto itself: how a single-GPU machine exercises the transport and the plan (tests/test_gpu_comm.py).  Returns 0, 1 (bad
+ * argument, no RCCL communicator), 2. */
+int exa_comm_complete(int id, int which, double *buf) {
+    if (!buf || which < 0 || which > 8) return 1;
+    return guard(id, true, [&](Handle &h) {
+        if (!h.nccl) throw BadInput("exa_comm_complete needs an RCCL communicator (exa_comm_init)");
+        rccl_run_plan_f64(h.nccl, buf, collective_ops(id, h, which), h.rank, h.stream);
+    });
 }
 /* Makes a sharded Jacobian (hess = 0) / Hessian (hess = 1) COO vector whole on every rank: all-gather-v of the ranks' slot
  * ranges (a piece travels once; nothing is zero-filled or summed — an all-reduce of zero-padded vectors would move world x

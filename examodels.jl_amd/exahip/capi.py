@@ -17,7 +17,7 @@ _LIB = None
 SYMBOLS = [
     "exa_abi_version", "exa_last_error", "exa_new_from_table", "exa_plan_only", "exa_compile", "exa_code_object_path",
     "exa_free", "exa_module_name", "exa_cache_add", "exa_cache_note", "exa_module_alias", "exa_module_alias_note", "exa_code_object_count", "exa_code_object", "exa_nvar", "exa_ncon", "exa_nnzj", "exa_nnzh", "exa_nvar64", "exa_ncon64", "exa_nnzj64", "exa_nnzh64",
-    "exa_nnzg64", "exa_npatterns", "exa_pattern_info", "exa_pattern_comp", "exa_meta", "exa_locality_order", "exa_eval_all_mode", "exa_kernel_source", "exa_module_source",
+    "exa_nnzg64", "exa_npatterns", "exa_pattern_info", "exa_pattern_comp", "exa_meta", "exa_locality_order", "exa_comm_complete", "exa_eval_all_mode", "exa_kernel_source", "exa_module_source",
     "exa_register_univariate", "exa_register_univariate_fused", "exa_register_bivariate", "exa_user_function", "exa_set_stream", "exa_set_shard", "exa_set_value", "exa_set_value_dev", "exa_theta_ptr", "exa_obj", "exa_obj_async", "exa_grad", "exa_cons", "exa_jac",
     "exa_hess", "exa_jprod", "exa_jtprod", "exa_hprod", "exa_jprod_host", "exa_jtprod_host", "exa_hprod_host", "exa_jac_structure", "exa_hess_structure", "exa_jac_structure64", "exa_hess_structure64",
     "exa_obj_host", "exa_grad_host", "exa_cons_host", "exa_jac_host", "exa_hess_host", "exa_jac_structure_host",
@@ -132,6 +132,7 @@ def lib():
     L.exa_locality_order.argtypes = [i32, i32, vp]
     L.exa_eval_all_mode.argtypes = [i32]
     L.exa_collective_plan.argtypes = [i32, i32, vp, i32]
+    L.exa_comm_complete.argtypes = [i32, i32, vp]
     L.exa_set_value_dev.argtypes = [i32, ctypes.c_int64, vp, ctypes.c_int64]
     L.exa_register_univariate.argtypes = [ctypes.c_char_p] * 5
     L.exa_register_bivariate.argtypes = [ctypes.c_char_p] * 8

@@ -393,6 +393,13 @@ class ExaModel:
         capi.check(self._L.exa_allreduce(self.id, t.data_ptr(), t.numel()), "exa_allreduce")
         return t
 
+    def comm_complete(self, which, buf):
+        """exa_comm_complete: the collective operations of exa_collective_plan(which) on buf, through the attached RCCL communicator (deferred
+        completion after set_reduce(False); with a world-1 communicator a real in-place ncclAllGather / ncclAllReduce of buf onto itself)."""
+        self._use_torch_stream(buf)
+        capi.check(self._L.exa_comm_complete(self.id, int(which), buf.data_ptr()), "exa_comm_complete")
+        return buf
+
     def allgather_coo(self, local, hess=True, out=None):
         """exa_allgather_coo: the sharded Jacobian / Hessian COO vector whole on every rank (all-gather-v of the slot ranges).
         `local`: this rank's exa_jac / exa_hess output (packed local slice, or global-length with its slots in place)."""

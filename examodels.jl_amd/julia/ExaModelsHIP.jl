@@ -232,6 +232,8 @@ end
 comm_init!(m, rank::Integer, world::Integer, uid::Vector{UInt8}) =
     chk(ccall((:exa_comm_init, LIB), Cint, (Cint, Cint, Cint, Ptr{UInt8}), m.ext.id, rank, world, uid), "exa_comm_init")
 comm_free!(m) = chk(ccall((:exa_comm_free, LIB), Cint, (Cint,), m.ext.id), "exa_comm_free")
+# deferred completion (after `exa_set_reduce(id, 0)`): the collective plan of callback `which` issued on `buf` through the attached communicator
+comm_complete!(m, which::Integer, buf) = (usestream(m); chk(ccall((:exa_comm_complete, LIB), Cint, (Cint, Cint, Ptr{Cdouble}), m.ext.id, which, pointer(buf)), "exa_comm_complete"))
 coo_local!(m, on::Bool = true) = chk(ccall((:exa_set_coo_local, LIB), Cint, (Cint, Cint), m.ext.id, on), "exa_set_coo_local")
 local_nnzj(m) = ccall((:exa_local_nnzj64, LIB), Int64, (Cint,), m.ext.id)
 local_nnzh(m) = ccall((:exa_local_nnzh64, LIB), Int64, (Cint,), m.ext.id)

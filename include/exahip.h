@@ -220,6 +220,12 @@ int exa_shard_layout(int id, int which);
  * the library issues through RCCL inside one ncclGroupStart / End, and what a host layer with its own transport (MPI.jl) should
  * issue.  Returns the number of operations (0 for world 1), -1 for a bad argument.  No device needed. */
 int exa_collective_plan(int id, int which, int64_t *out, int cap);
+/* Deferred completion: issues, on the model's stream through the attached RCCL communicator, exactly the operations of
+ * exa_collective_plan(which) on buf (the callback's output vector, global length) — what the callback does itself at its end unless
+ * exa_set_reduce(id, 0) switched that off: a host overlaps the collective of one callback with the kernels of the next.  With a WORLD-1
+ * communicator the one-piece plan is issued all the same (a real in-place ncclAllGather / ncclAllReduce of the vector onto itself): how a
+ * single-GPU machine exercises transport and plan.  0 ok, 1 bad argument / no RCCL communicator, 2 internal. */
+int exa_comm_complete(int id, int which, double *buf);
 /* A sharded Jacobian (hess = 0) / Hessian (hess = 1) COO vector made whole on every rank: all-gather-v of the ranks' slot
  * ranges (a piece travels once; an all-reduce of zero-padded vectors would move world x the data).  `local` = what this
  * rank's exa_jac / exa_hess wrote: the packed local slice (exa_set_coo_local) or the global-length vector with the rank's

@@ -59,6 +59,46 @@ def test_rccl_allreduce_runs_behind_the_abi_world1(libs, name):
     assert m.comm_info() == (0, 1, "none")
 
 
+@pytest.mark.parametrize("name", ["lv1000", "rocket50", "acopf30"])
+def test_rccl_allgather_branch_runs_on_one_device(libs, name):
+    """everything the first multi-GPU run will execute for the first time, on ONE device.  A real RCCL communicator of
+    world 1; exa_allgather_coo (forced gather) and exa_comm_complete issue the ONE-PIECE plans of the COO vectors, grad!, cons_nln! and the
+    products through rccl_run_plan_f64 — in-place ncclAllGather where the vector is sharded by owner, ncclAllReduce where it is left as partial
+    sums — inside ncclGroupStart / End on the model's stream.  Gathering / summing over one rank is the identity: not a bit may move."""
+    import torch
+    from exahip import ExaModel
+    m = ExaModel(ZOO[name]())
+    x, y, s = point(m.meta.x0, m.meta.ncon, seed=22)
+    dev = torch.device("cuda:0")
+    xd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(y).to(dev)
+    m.comm_init(0, 1, m.comm_unique_id())
+    assert m.comm_info() == (0, 1, "rccl")
+    m.set_reduce(False)                              # the callbacks leave their vectors alone: completion is issued below, explicitly
+    vecs = {1: m.grad(xd).clone(), 2: m.cons(xd).clone(), 3: m.jac_coord(xd).clone(), 4: m.hess_coord(xd, yd, s).clone(),
+            6: m.jtprod(xd, yd).clone(), 7: m.hprod(xd, yd, xd, s).clone()}
+    torch.cuda.synchronize()
+    kinds = set()
+    for which, v in vecs.items():
+        if v.numel() == 0:
+            continue
+        layout = m._L.exa_shard_layout(m.id, which)
+        kinds.add(0 if which in (3, 4) or layout == 1 else 2)
+        before = v.clone()
+        m.comm_complete(which, v)
+        torch.cuda.synchronize()
+        assert torch.equal(v, before), which
+    assert 0 in kinds                                # at least the COO vectors went through ncclAllGather
+    for hess, v in ((False, vecs[3]), (True, vecs[4])):
+        if v.numel():
+            out = m.allgather_coo(v.clone(), hess=hess)
+            torch.cuda.synchronize()
+            assert torch.equal(out, v)
+    m.comm_free()
+    from exahip import capi
+    with pytest.raises(capi.ExaHipError, match="needs an RCCL communicator"):
+        m.comm_complete(1, vecs[1])
+
+
 def test_host_reducer_hook_is_called_for_every_reducing_callback(libs):
     """exa_comm_hook: the library hands (device buffer, count, stream) of exactly the vectors that need the sum."""
     import torch

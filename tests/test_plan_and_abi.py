@@ -424,13 +424,15 @@ def test_staged_hessian_kernel_is_generated_where_the_stencil_allows(libs, tmp_p
 
 
 def test_generated_module_has_the_zero_fill_and_the_folding_objective(libs):
-    """exa_zero (the zero-fill under the atomics: a launch of the module instead of hipMemsetAsync) and the arrival counter of
-    exa_obj (the last workgroup folds the partial sums, up to kObjFoldMax workgroups) are part of every module."""
+    """exa_zero (the zero-fill under the atomics: a launch of the module instead of hipMemsetAsync) and the arrival counters of
+    exa_obj (the last workgroup folds the partial sums — ONE launch at any size since round 6: sharded counters beyond 512 workgroups,
+    arrivals as sc1 store + vmcnt(0) + relaxed add instead of a device-scope release) are part of every module."""
     from exahip import ExaModel, models
     src = ExaModel(models.luksan_vlcek_model(100), device=False).kernel_source()
     assert "void __launch_bounds__(EXA_BLOCK) exa_zero(double* __restrict__ out, long n)" in src
     assert "exa_obj(const long* __restrict__ P, const double* __restrict__ x, const double* __restrict__ th, double* part, unsigned* done, double* __restrict__ out)" in src
-    assert "__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)" in src
+    assert "exa_publish(); last_ = __hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)" in src
+    assert "exa_reduce_partials" not in src and "__ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT" not in src
     # Horner steps of exa_sincos take their coefficients from SGPRs
     assert 'asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k))' in src
 
