@@ -195,16 +195,31 @@ int product_mode_query(Handle &h, bool hess) {
     return (h.on_device ? window_possible(h, hess) : w.planned) ? 2 : 0;
 }
 
-// Dynamic LDS that leaves `wgs` workgroups of the chained hess_coord! kernel per CU (160 KB of LDS; static + dynamic <= 64 KB, the launch limit without
-// a function attribute); 0 when the kernel's own LDS already allows no more than that, or the kernel is not there.
-unsigned hess_throttle_bytes(Handle &h, int variant, int wgs) {
+// Dynamic LDS that leaves `wgs` workgroups of the chained hess_coord! kernel per CU (the CU's LDS asked from the device: 160 KB on MI355X;
+// static + dynamic <= 64 KB, the launch limit without a function attribute); 0 when the kernel's own LDS already allows no more than
+// that, or the kernel is not there.
+static int hess_static_lds(Handle &h, int variant) {
     hipFunction_t f = variant == 1 && h.f_hesscl && h.stage_ok ? h.f_hesscl : h.f_hessc;
-    if (!f || wgs < 1) return 0;
-    int stat = 0;
-    if (hipFuncGetAttribute(&stat, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, f) != hipSuccess) return 0;
-    const int total = 160 * 1024 / (wgs + 1) + 1024;          // just too much for wgs + 1 workgroups
+    int stat = -1;
+    if (!f || hipFuncGetAttribute(&stat, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, f) != hipSuccess) return -1;
+    return stat;
+}
+unsigned hess_throttle_bytes(Handle &h, int variant, int wgs) {
+    const int stat = hess_static_lds(h, variant);
+    if (stat < 0 || wgs < 1) return 0;
+    int dev = 0, cu_lds = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu_lds, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || cu_lds <= 0)
+        cu_lds = 160 * 1024;
+    const int total = cu_lds / (wgs + 1) + 1024;          // just too much for wgs + 1 workgroups
     if (stat >= total || total > 64 * 1024) return 0;
     return (unsigned)(total - stat);
+}
+// A throttle that came from outside (EXAHIP_HESS_DYN_LDS, a persisted tuning decision of another library version): usable only when
+// static + dynamic fit the 64 KB a launch may ask for without a function attribute — else 0 (no throttle) instead of a failing launch.
+unsigned hess_throttle_clamp(Handle &h, int variant, unsigned want) {
+    const int stat = hess_static_lds(h, variant);
+    if (stat < 0 || want == 0) return 0;
+    return (long)stat + (long)want <= 64 * 1024 ? want : 0;
 }
 }  // namespace rt
 }  // namespace exa

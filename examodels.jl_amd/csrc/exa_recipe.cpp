@@ -125,7 +125,12 @@ const char *tname(int t) { return t == T_I64 ? "i64" : "f64"; }
 
 // may model files bring device code of their own? -1 = not said (the environment decides), 0 / 1 = exa_recipe_trust_code
 std::atomic<int> g_trust_code{-1};
+// ... and for ONE load on ONE thread (exa_recipe_load_trusted: the loader of a packed library, whose embedded recipe is native code
+// already).  Not the process-wide switch: a concurrent exa_recipe_load of an untrusted file on another thread stays refused, and the
+// process's own setting (unset / 0 / 1) is never touched.
+thread_local int t_trusted_load = 0;
 bool trust_model_code() {
+    if (t_trusted_load > 0) return true;
     const int v = g_trust_code.load();
     if (v >= 0) return v > 0;
     const char *e = getenv("EXAHIP_TRUST_MODEL_CODE");
@@ -576,6 +581,10 @@ int exa_recipe_trust_code(int on) {
     const int before = trust_model_code() ? 1 : 0;
     if (on >= 0) g_trust_code.store(on ? 1 : 0);
     return before;
+}
+int exa_recipe_load_trusted(const void *bytes, size_t len) {
+    struct Scope { Scope() { t_trusted_load++; } ~Scope() { t_trusted_load--; } } scope;
+    return exa_recipe_load(bytes, len);
 }
 int exa_recipe_load(const void *bytes, size_t len) {
     if (!bytes) return 0;

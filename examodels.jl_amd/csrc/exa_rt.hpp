@@ -109,6 +109,7 @@ struct Handle {
     hipFunction_t f_jacl = nullptr, f_consl = nullptr;      // exa_jac / exa_cons as tile loops (exa_gen_coo.cpp gen_dispatch, looped)
     int tile_loop = -1;                     // tiles per workgroup of the looped kernels: -1 by the length of the block map, 0 / 1 off, n fixed (EXAHIP_TILE_LOOP)
     bool hess_dyn_auto = false;             // no decision yet for a model that streams past the Infinity Cache: three workgroups per CU, resolved at the first chained launch
+    unsigned hess_dyn_ok = 0, hess_dyn_ok_for = ~0u; int hess_dyn_ok_variant = -1;      // hess_dyn_lds as checked against the kernel's static LDS (do_hess)
     unsigned hess_dyn_lds = 0;              // dynamic LDS added to the hess_coord! launches: an occupancy throttle (EXAHIP_HESS_DYN_LDS; exa_tune)
     int hess_variant = 0;                   // hess_coord! kernel: 0 exa_hess (one tile per workgroup), 1 chained, grouped, pipelined: exa_hesscl
                                             // (x staged through LDS) where this shard's stretches fit, else exa_hessc; 2 exa_hessc always
@@ -235,6 +236,7 @@ CodeObject module_for(Handle &h, bool memory_only_ok);
 void to_device(Handle &h);
 void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **args, unsigned dyn_lds = 0);
 unsigned hess_throttle_bytes(Handle &h, int variant, int wgs);
+unsigned hess_throttle_clamp(Handle &h, int variant, unsigned want);      // 0 unless static + want <= 64 KB for the kernel the variant runs
 int tile_loop_ppt(Handle &h, int cb);
 void zero_fill(Handle &h, void *p, int64_t n);
 void aug_gather(Handle &h, void *buf, double *c);

@@ -758,7 +758,13 @@ void do_hess(Handle &h, const double *x, const double *y, double sigma, double *
         if (h.hess_dyn_auto) { h.hess_dyn_auto = false; h.hess_dyn_lds = hess_throttle_bytes(h, h.hess_variant, 3); }
         void *sink = h.dsink.p;
         void *a[] = {&P, &x, &y, &th, &v, &sigma, &sink};
-        launch(h, h.hess_variant == 1 && h.f_hesscl && h.stage_ok ? h.f_hesscl : h.f_hessc, h.grid[CB_HESSC], kBlock, a, h.hess_dyn_lds);
+        // (a throttle from the environment or from a persisted decision is checked once against THIS kernel's static LDS: static + dynamic
+        // beyond 64 KB would fail the launch — then no throttle)
+        if (h.hess_dyn_ok_for != h.hess_dyn_lds || h.hess_dyn_ok_variant != h.hess_variant) {
+            h.hess_dyn_ok = hess_throttle_clamp(h, h.hess_variant, h.hess_dyn_lds);
+            h.hess_dyn_ok_for = h.hess_dyn_lds; h.hess_dyn_ok_variant = h.hess_variant;
+        }
+        launch(h, h.hess_variant == 1 && h.f_hesscl && h.stage_ok ? h.f_hesscl : h.f_hessc, h.grid[CB_HESSC], kBlock, a, h.hess_dyn_ok);
         return;
     }
     void *a[] = {&P, &x, &y, &th, &v, &sigma};

@@ -30,7 +30,7 @@ SYMBOLS = [
 ]
 # ... and include/exahip_recipe.h
 RECIPE_SYMBOLS = [
-    "exa_recipe_load", "exa_recipe_trust_code", "exa_recipe_free", "exa_recipe_nargs", "exa_recipe_argtype", "exa_recipe_schema", "exa_recipe_new",
+    "exa_recipe_load", "exa_recipe_load_trusted", "exa_recipe_trust_code", "exa_recipe_free", "exa_recipe_nargs", "exa_recipe_argtype", "exa_recipe_schema", "exa_recipe_new",
     "exa_recipe_plan", "exa_data_begin", "exa_data_free", "exa_set_scalar_i64", "exa_set_scalar_f64", "exa_set_array_i64",
     "exa_set_array_f64", "exa_set_col_i64", "exa_set_col_f64", "exa_data_ready", "exa_new_from_data", "exa_plan_from_data",
     "exa_nblocks", "exa_block_name", "exa_block", "exa_get_value_block", "exa_set_value_block", "exa_get_value", "exa_describe",
@@ -164,6 +164,7 @@ def lib():
     # include/exahip_recipe.h
     cp, sz = ctypes.c_char_p, ctypes.c_size_t
     L.exa_recipe_load.argtypes = [vp, sz]
+    L.exa_recipe_load_trusted.argtypes = [vp, sz]
     L.exa_recipe_trust_code.argtypes = [i32]
     for f in ("exa_recipe_free", "exa_recipe_nargs", "exa_data_begin", "exa_data_free", "exa_data_ready", "exa_new_from_data",
               "exa_plan_from_data", "exa_nblocks"):

@@ -60,7 +60,7 @@
  *                   it in the host's context.  A file with this section is CODE, not data.  exa_recipe_load therefore refuses a file
  *                   whose entries are not, rule for rule, registrations the process has already made itself, unless the host opted
  *                   in: exa_recipe_trust_code(1), or EXAHIP_TRUST_MODEL_CODE=1 in the environment.  (A packed library, exahip.pack, is
- *                   native code already: its loader opts in for its own embedded recipe only.)
+ *                   native code already: its loader reads its own embedded recipe through exa_recipe_load_trusted.)
  * A fully concrete model is the special case nfields = 0, nsyms = 0 (everything literal / inline): the same
  * bytes are the library's model file format (exa_recipe_load + exa_recipe_new).
  */
@@ -80,6 +80,10 @@ int exa_recipe_load(const void *bytes, size_t len);            /* -> recipe id >
  * (EXAHIP_TRUST_MODEL_CODE=1 in the environment: yes).  on = 1 / 0 sets it for the process, on < 0 only asks.  Returns the setting
  * in force before the call. */
 int exa_recipe_trust_code(int on);
+/* exa_recipe_load for bytes the CALLER vouches for (they are part of its own native code: the embedded recipe of a packed library,
+ * exahip.pack): device code in the file is accepted for this one call on this one thread; the process-wide setting above — unset, 0 or
+ * 1 — is neither consulted nor changed, and a concurrent exa_recipe_load of a foreign file on another thread stays refused. */
+int exa_recipe_load_trusted(const void *bytes, size_t len);
 int exa_recipe_free(int recipe);
 /* P_nargs: how many values instantiation consumes — 0 for a fixed model, else the number of schema fields. */
 int exa_recipe_nargs(int recipe);

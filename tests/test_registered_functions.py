@@ -237,6 +237,37 @@ print("INFO", [m.pattern_info(k) for k in range(4)])
 """
 
 
+def test_trusted_load_is_per_call_and_leaves_the_process_setting_alone(libs, tmp_path):
+    """exa_recipe_load_trusted: what a packed library's loader uses for its own embedded recipe — device code in the bytes is
+    accepted for that ONE call; the process-wide setting stays what it was (unset here: the environment still decides afterwards), and the
+    same bytes through plain exa_recipe_load are still refused."""
+    import os, subprocess, sys
+    from exahip import Recipe
+    user, _ = _pair()
+    path = str(tmp_path / "user.exarcp")
+    Recipe(user).save(path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"""
+import sys
+sys.path[:0] = [{os.path.join(root, 'examodels.jl_amd')!r}]
+from exahip import capi
+L = capi.lib()
+raw = open({path!r}, 'rb').read()
+assert L.exa_recipe_trust_code(-1) == 0
+assert L.exa_recipe_load(raw, len(raw)) == 0 and b'carries device code' in L.exa_last_error()
+rid = L.exa_recipe_load_trusted(raw, len(raw))
+assert rid > 0, L.exa_last_error()
+assert L.exa_recipe_trust_code(-1) == 0                      # untouched: not latched to 0 or 1
+import os
+os.environ['EXAHIP_TRUST_MODEL_CODE'] = '1'                  # ... so the environment still decides afterwards
+assert L.exa_recipe_trust_code(-1) == 1
+print('OK')
+"""
+    env = {k: v for k, v in os.environ.items() if k != "EXAHIP_TRUST_MODEL_CODE"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0 and "OK" in out.stdout, out.stderr[-2000:]
+
+
 def test_a_model_file_carries_its_registered_functions(libs, tmp_path):
     """A recipe / model file that uses registered functions loads into a process that never registered them (or registered others
     first): the trailing section of the wire format (include/exahip_recipe.h) registers them at load and renumbers the nodes."""
