@@ -143,6 +143,8 @@ def test_fast_exp_is_within_an_ulp_and_the_knob_brings_ocml_back(libs, monkeypat
     xs = np.concatenate([
         r.uniform(-1, 1, 1500), r.uniform(-40, 40, 1500), r.uniform(-700, 709.7, 1500),
         (np.arange(-500, 501) + 0.5) * np.log(2) * (1 + r.uniform(-1e-13, 1e-13, 1001)),       # next to the rounding boundaries of k
+        #  the subnormal results, exp(x) < 2.2e-308, and the approach to the overflow threshold
+        r.uniform(-745.13, -708.39, 2000), r.uniform(709.0, 709.782712893384, 2000),
         np.array([0.0, -0.0, 1e-300, -1e-300, 709.782712893384]),
     ])
     n = len(xs)
@@ -156,7 +158,8 @@ def test_fast_exp_is_within_an_ulp_and_the_knob_brings_ocml_back(libs, monkeypat
         worst = 0.0
         for g, xv in zip(got, xs):
             t = mpmath.exp(mpmath.mpf(float(xv)))
-            worst = max(worst, float(abs(mpmath.mpf(float(g)) - t) / mpmath.mpf(2) ** (mpmath.floor(mpmath.log(t, 2)) - 52)))
+            ulp_exp = max(int(mpmath.floor(mpmath.log(t, 2))) - 52, -1074)          # (subnormal results: the spacing stays 2^-1074)
+            worst = max(worst, float(abs(mpmath.mpf(float(g)) - t) / mpmath.mpf(2) ** ulp_exp))
         assert worst <= 1.5, worst
     sp = np.zeros(n)
     sp[:9] = [0.0, 709.79, 1e300, np.inf, -745.2, -1e300, -np.inf, np.nan, -745.0]
