@@ -257,8 +257,45 @@ def v_p_as4(src, touch=False):
     return "\n".join(out)
 
 
+# Decomposition of the owner-computes window kernels, exa_hprodw of LV: what the launch costs without its arithmetic
+# (the access skeleton: loads of x, y, v, the LDS planes, the barrier, the gather, the store), and without planes / barrier / gather.
+def _hpv_skeleton(src):
+    """p0_hpv / p1_hpv replaced by bodies that load what the real ones load and combine it with a few FMAs"""
+    for fn, nout in (("p0_hpv", 3), ("p1_hpv", 2)):
+        at = src.index("static __device__ __forceinline__ void " + fn + "(")
+        brace = src.index("{\n", at)
+        end = src.index("\n}\n", at)
+        body = src[brace + 2:end]
+        loads = [ln for ln in body.split("\n") if re.search(r"= (x|y|v)\[", ln) or re.match(r"\s*const long k\d+ = ", ln)]
+        names = [re.match(r"\s*const double (t\d+) = ", ln).group(1) for ln in loads if re.match(r"\s*const double t\d+ = (x|y|v)\[", ln)]
+        comb = " + ".join(names) if names else "0.0"
+        new_body = "\n".join(loads) + "\n    const double s_ = " + comb + ";\n" + "".join(f"    o_[{k}] = s_ * {k + 1}.0 + sigma;\n" for k in range(nout))
+        src = src[:brace + 2] + new_body + src[end:]
+    return src
+
+
+def w_skeleton(src):
+    return _hpv_skeleton(src)
+
+
+def w_noplanes(src):
+    """the real arithmetic, but every thread stores its own first value: no LDS planes, no barrier, no gather"""
+    at = src.index("exa_hprodw(")
+    a = src.index("        win[0 + threadIdx.x] = v0[0];", at)
+    b = src.index("        if ((int)threadIdx.x < W && e_ < ncomp)", at)
+    return src[:a] + "        const long e_ = c0 + threadIdx.x;\n        double acc_ = v0[0] + v0[1] + v0[2] + v1[0] + v1[1];\n" + src[b:]
+
+
+def w_skeleton_noplanes(src):
+    return w_noplanes(_hpv_skeleton(src))
+
+
 VARIANTS = {
     "base": lambda s: s,
+    "w_base": lambda s: s,
+    "w_skeleton": w_skeleton,
+    "w_noplanes": w_noplanes,
+    "w_skeleton_noplanes": w_skeleton_noplanes,
     "p_as4": v_p_as4,
     "p_as4_touch": lambda s: v_p_as4(s, True),
     "loop_alwaysnext": v_loop_alwaysnext,
@@ -285,20 +322,24 @@ VARIANTS = {
 
 
 def lv_source():
+    """(source, module name) of the model's module and of its product-window module"""
     from exahip import ExaModel, models
     m = ExaModel(models.luksan_vlcek_model(1000), device=False)
-    return m.kernel_source(), m._L.exa_module_name(m.id).decode()
+    m.compile()
+    names = [n for n, _ in m.code_objects()]
+    return (m.kernel_source(), names[0]), (m.module_source(1), names[1])
 
 
 def prepare(out):
     os.makedirs(out, exist_ok=True)
-    src, key = lv_source()
+    (src, key), (wsrc, wkey) = lv_source()
     open(os.path.join(out, "KEY"), "w").write(key)
+    open(os.path.join(out, "WKEY"), "w").write(wkey)
     procs = []
     for name, fn in VARIANTS.items():
         hip = os.path.join(out, name + ".hip")
         try:
-            text = fn(src)
+            text = fn(wsrc if name.startswith("w_") else src)          # w_*: variants of the product-window module (exa_hprodw / exa_jtprodw)
         except AssertionError as e:         # a variant written against an older generator (its winner is built in by now): reported, skipped
             print("skipped", name, "-", e)
             continue
@@ -363,31 +404,47 @@ def run_cb(out, N, which, names):
     import torch
     from exahip import ExaModel, capi, models
     key = open(os.path.join(out, "KEY")).read().strip()
+    wkey = open(os.path.join(out, "WKEY")).read().strip()
     L = capi.lib()
     core = models.luksan_vlcek_model(N)
     ms, mods = {}, {}
+    base, wbase = (open(os.path.join(out, f + ".hsaco"), "rb").read() for f in ("base", "w_base"))
     for n in names:
         blob = open(os.path.join(out, n + ".hsaco"), "rb").read()
-        assert L.exa_cache_add(key.encode(), blob, len(blob)) == 0
+        for k, b in ((key, base if n.startswith("w_") else blob), (wkey, blob if n.startswith("w_") else wbase)):
+            assert L.exa_cache_add(k.encode(), b, len(b)) == 0
         mods[n] = ExaModel(core)
         assert mods[n].build_info()[0] == "preloaded"
     m0 = mods[names[0]]
     r = np.random.default_rng(0)
     x = torch.from_numpy(m0.meta.x0 + 0.1 * r.uniform(-1, 1, N)).cuda()
     buf = torch.empty(max(m0.meta.nnzj, m0.meta.nvar), dtype=torch.float64, device="cuda")
+    yv = torch.from_numpy(r.standard_normal(max(m0.meta.ncon, m0.meta.nvar))).cuda()
+    import time
+
+    def timed(m, which, reps):
+        if which in ("hprod", "jtprod"):           # (no exa_time_callback for the products: events around back-to-back calls from Python, >= 50 us each)
+            fn = (lambda: m.hprod(x, yv[:m0.meta.ncon], yv[:m0.meta.nvar], 0.5, out=buf[:m0.meta.nvar])) if which == "hprod" else (lambda: m.jtprod(x, yv[:m0.meta.ncon], out=buf[:m0.meta.nvar]))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fn(); torch.cuda.synchronize(); e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record(); torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        return m.time_callback(which, reps, x, out=buf)
     same = {}
     ref = None
     for n in names:
         buf.fill_(float("nan"))
-        mods[n].time_callback(which, 1, x, out=buf)
+        timed(mods[n], which, 1)
         torch.cuda.synchronize()
-        k = {"cons": m0.meta.ncon, "jac": m0.meta.nnzj, "grad": m0.meta.nvar}.get(which, 0)
+        k = {"cons": m0.meta.ncon, "jac": m0.meta.nnzj, "grad": m0.meta.nvar, "hprod": m0.meta.nvar, "jtprod": m0.meta.nvar}.get(which, 0)
         if ref is None:
             ref = buf[:k].clone()
         same[n] = bool(torch.equal(buf[:k], ref)) if k else None
     for rnd in range(7):
         for n in names:
-            t = mods[n].time_callback(which, 200, x, out=buf)
+            t = timed(mods[n], which, 200)
             if rnd:
                 ms.setdefault(n, []).append(t)
     for n in names:

@@ -22,7 +22,7 @@ from exahip import CompressedExaModel, ExaModel  # noqa: E402
 
 # callback -> the generated kernels that carry its traffic (the first one is the dominant kernel)
 KERNELS = {
-    "obj": ["exa_obj", "exa_reduce_partials"], "grad": ["exa_grad_pull", "exa_grad", "exa_gradw"], "cons": ["exa_cons1", "exa_cons", "exa_consl", "exa_aug_gather"],
+    "obj": ["exa_obj"], "grad": ["exa_grad_pull", "exa_grad", "exa_gradw"], "cons": ["exa_cons1", "exa_cons", "exa_consl", "exa_aug_gather"],
     "jac": ["exa_jac", "exa_jacl"], "hess": ["exa_hess", "exa_hesscl", "exa_hessc"], "jprod": ["exa_jprod1", "exa_jprod"],
     "jtprod": ["exa_jtprodw", "exa_jtprods", "exa_jtprodx", "exa_jtprod"], "hprod": ["exa_hprodw", "exa_hprods", "exa_hprodx", "exa_hprod"],
     "fused": ["exa_fused"], "eval_all": ["exa_fused", "exa_grad_pull", "exa_grad"],
