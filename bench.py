@@ -24,6 +24,13 @@ peak) and "cpu_baseline" (the C restatement of the reference CPU algorithm, orac
 reference is timed instead when a `julia` with ExaModels is found on the box).
 """
 import argparse
+import os as _os
+# the all-cores CPU baseline (cpu_baseline): OpenMP threads bound to their cores before any OpenMP runtime is loaded, so that a page a thread
+# touched first stays local to it; stated in the line ("placement")
+_os.environ.setdefault("OMP_PROC_BIND", "close")
+_os.environ.setdefault("OMP_PLACES", "cores")
+CPU_PLACEMENT = ("output first-touched by the parallel run (static schedule), OMP_PROC_BIND=" + _os.environ["OMP_PROC_BIND"] +
+                 " OMP_PLACES=" + _os.environ["OMP_PLACES"] + "; inputs (160 MB of 880) on the main thread's node")
 import ctypes
 import json
 import os
@@ -159,8 +166,12 @@ def cpu_baseline(config, points, threads_all):
                "sample": f"LuksanVlcek N={N} hess_coord!, 3 evals, hand-specialised C port of the two patterns, 1 thread",
                "evals_per_s": 1.0 / t1}
         if th > 1:
-            tn = timeit(lambda: oracle.lv_hess_compiled(N, x, y, 0.5, out=out, threads=th), 3)
-            res["all_cores"] = {"value": nnzh / tn, "cores": th, "evals_per_s": 1.0 / tn,
+            # placement pinned (VERDICT r5 "what's weak" 10: 1.97e9 on one box, 8.5e9 on another): a FRESH output vector whose pages the
+            # parallel run itself touches first (timeit's warm-up call, the same static schedule as the timed calls — the 720 MB then sit on the
+            # NUMA nodes of the threads that write them instead of on the main thread's), threads bound to their cores (OMP_PROC_BIND, below)
+            out_par = np.empty(nnzh)
+            tn = timeit(lambda: oracle.lv_hess_compiled(N, x, y, 0.5, out=out_par, threads=th), 3)
+            res["all_cores"] = {"value": nnzh / tn, "cores": th, "evals_per_s": 1.0 / tn, "placement": CPU_PLACEMENT,
                                 "note": "OpenMP over data points (proxy for the KernelAbstractions CPU() backend)"}
         n2 = min(N, 1_000_000)
         o = oracle.OracleModel(models.luksan_vlcek_model(n2).to_ir(), threads=1)
@@ -185,8 +196,9 @@ def cpu_baseline(config, points, threads_all):
                      "recursions per pattern (oracle/compiled.py), 1 thread",
            "evals_per_s": 1.0 / t1}
     if th > 1:
-        tn = timeit(lambda: ch(x, y, 0.5, out=buf, threads=th), 5)
-        res["all_cores"] = {"value": o.nnzh / tn, "cores": th, "evals_per_s": 1.0 / tn,
+        buf_par = np.empty(o.nnzh)           # (first touched by the parallel run: see the LV leg)
+        tn = timeit(lambda: ch(x, y, 0.5, out=buf_par, threads=th), 5)
+        res["all_cores"] = {"value": o.nnzh / tn, "cores": th, "evals_per_s": 1.0 / tn, "placement": CPU_PLACEMENT,
                             "note": "the same, OpenMP over data points (proxy for the KernelAbstractions CPU() backend)"}
     ti = timeit(lambda: o.hess_coord(x, y, 0.5, out=buf), 1)
     res["interpreter"] = {"value": o.nnzh / ti, "cores": 1, "sample": "the same model, generic tree-walking test oracle"}
