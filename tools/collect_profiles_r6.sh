@@ -1,0 +1,11 @@
+# After `bash tools/refresh_profiles_r6.sh` ran on the GPU box (its outputs come back under gpurun_out/r6p/): copies the files
+# the documents cite into profiles/ and rewrites the number rows of DESIGN.md §5 from them.  Run from the repo root.
+set -e
+O=gpurun_out/r6p
+for c in 2 3 4; do cp $O/callbacks_config$c.json profiles/r6_callbacks_config$c.json; cp $O/r6_kernels_config$c.md profiles/; done
+if [ -f $O/r6_bench_default.json ]; then
+for c in 2 3 4 5; do cp $O/r6_stats_config$c.txt profiles/; cp $O/r6_traffic_config$c.json profiles/; done
+tail -1 $O/r6_bench_default.json > profiles/r6_bench_default.json
+tail -1 $O/r6_bench_no_tune.json > profiles/r6_bench_no_tune.json
+fi
+python tools/design_tables.py
