@@ -263,7 +263,7 @@ def traffic_for(m, config, per_gpu_points):
     """HBM bytes per launch from the PMC counters: measured in separate rocprofv3 passes (cannot run inside the timed
     process) and committed under profiles/ TOGETHER WITH the name of the module they were measured on — attached only
     when this run executes exactly that module on exactly that workload, null otherwise (never a stale number)."""
-    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic_config{config}.json") for r in (5, 4, 3, 2)) if os.path.exists(q)), None)
+    path = next((q for q in (os.path.join(ROOT, "profiles", f"r{r}_traffic_config{config}.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(q)), None)
     if path is None:
         return None
     with open(path) as fh:

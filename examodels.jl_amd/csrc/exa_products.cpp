@@ -506,18 +506,8 @@ int exa_tune(int id, int what, const double *x, const double *y) {
                     auto wnd = [&] { if (hess) run_product_window(h, true, x, y, x, sigma, g); else run_product_window(h, false, x, nullptr, y, 0.0, g); };
                     if (pick_faster(h, base, wnd) == 1) { best = 2; if (other == 1) drop_sorted(h, hess != 0); }
                 }
-                if (pull_possible(h, hess != 0)) {
-                    // the owner pull against the winner so far
-                    pull_setup(h, hess != 0);
-                    if (h.pl[hess].ready) {
-                        const int other = best;
-                        auto base = [&] { if (hess) { if (other == 1) do_hprod_sorted(h, x, y, x, sigma, g); else do_hprod(h, x, y, x, sigma, g); }
-                                          else { if (other == 1) do_jtprod_sorted(h, x, y, g); else do_jtprod(h, x, y, g); } };
-                        auto pull = [&] { if (hess) do_pull(h, true, x, y, x, sigma, g); else do_pull(h, false, x, nullptr, y, 0.0, g); };
-                        if (other != 2 && pick_faster(h, base, pull) == 1) { best = 3; if (other == 1) drop_sorted(h, hess != 0); }
-                        else { h.pl[hess].idx.release(); h.pl[hess].ready = false; }
-                    }
-                }
+                // (the owner pull — mode 3 — is NOT a candidate: it lost to the atomics on every data-indexed model measured, profiles/r4_pull_ab.txt;
+                // it stays the deterministic implementation, exa_set_deterministic / exa_set_product_mode(…, 3))
                 mode = best;
                 tune_store(source_key(h.gen.source), tune_signature(h, hess ? "hprod" : "jtprod"), best);
             }

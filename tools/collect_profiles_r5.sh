@@ -7,4 +7,4 @@ if [ -f $O/r5_bench_default.json ]; then
 for c in 2 3 4 5; do cp $O/r5_stats_config$c.txt profiles/; cp $O/r5_traffic_config$c.json profiles/; done
 tail -1 $O/r5_bench_default.json > profiles/r5_bench_default.json
 fi
-python tools/design_tables.py
+python tools/measurements_md.py

@@ -8,4 +8,4 @@ for c in 2 3 4 5; do cp $O/r6_stats_config$c.txt profiles/; cp $O/r6_traffic_con
 tail -1 $O/r6_bench_default.json > profiles/r6_bench_default.json
 tail -1 $O/r6_bench_no_tune.json > profiles/r6_bench_no_tune.json
 fi
-python tools/design_tables.py
+python tools/measurements_md.py
