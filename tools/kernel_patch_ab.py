@@ -310,8 +310,21 @@ def v_hesscl_bufload(src):
     return pat.sub("g0_[0] = exa_ld_run(x + a_, xlast0_ - a_ + 1, lane); g1_[0] = exa_ld_run(x + a_, xlast0_ - a_ + 1, lane < halo0_ ? 64 + lane : lane);", src)
 
 
+# exa_hesscl: the streamed inputs (the staged x run, y) by non-temporal loads
+def v_hesscl_ntload(src):
+    at = src.index('extern "C" __global__ void __launch_bounds__(EXA_BLOCK) exa_hesscl(')
+    end = src.index('extern "C" __global__', at + 10)
+    body = src[at:end].replace("g0_[0] = x[a0_]; g1_[0] = x[lane < halo0_ ? a1_ : a0_];", "g0_[0] = __builtin_nontemporal_load(&x[a0_]); g1_[0] = __builtin_nontemporal_load(&x[lane < halo0_ ? a1_ : a0_]);")
+    src = src[:at] + body + src[end:]
+    a2 = src.index("static __device__ __forceinline__ void p0_hessclL(")
+    e2 = src.index("\n}\n", a2)
+    fn = re.sub(r"= y\[([^\]]+)\];", r"= __builtin_nontemporal_load(&y[\1]);", src[a2:e2])
+    return src[:a2] + fn + src[e2:]
+
+
 VARIANTS = {
     "base": lambda s: s,
+    "hesscl_ntload": v_hesscl_ntload,
     "hesscl_bufload": v_hesscl_bufload,
     "w_base": lambda s: s,
     "w_skeleton": w_skeleton,
