@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 closing sweeps on the FINAL tree, library AS SHIPPED (guard flag + round-4 fence + re-planning), FRESH seeds, register poison on,
+# Round-6 closing sweeps on the FINAL tree, library AS SHIPPED (guard flag + round-4 fence + re-planning), FRESH seeds, register poison on,
 # one process per chunk / seed.   tools/final_sweeps_r5.sh prebuild  (build machine)   |   tools/final_sweeps_r5.sh [OUTDIR]  (GPU box)
 R0=${R0:-100}; NR=${NR:-30}; D0=${D0:-8000}; ND=${ND:-24}; E0=${E0:-9000}
 if [ "$1" = prebuild ]; then
@@ -7,7 +7,7 @@ if [ "$1" = prebuild ]; then
   (for s in $(seq $D0 $((D0 + ND - 1))); do echo "$s 12 6"; done; for s in $(seq $E0 $((E0 + ND - 1))); do echo "$s 8 4"; done) | PREBUILD=1 xargs -P 5 -L 1 python tests/sweeps/random_model_check.py > /dev/null 2>&1
   wait; exit 0
 fi
-O=${1:-gpurun_out/r5e}; mkdir -p $O
+O=${1:-gpurun_out/r6e}; mkdir -p $O
 for fl in blocks unit mixed; do
   for s in $(seq $R0 10 $((R0 + NR - 1))); do
     timeout 900 python tests/sweeps/range_model_check.py $s 10 $fl --poison 2>&1 | grep -E "^seed|Error|error" >> $O/final_range_$fl.log || echo "chunk $s $fl: timeout / crash" >> $O/final_range_$fl.log
