@@ -306,8 +306,8 @@ int exa_hprod (int id, const double *x, const double *y, const double *v, double
  * the window out with plain coalesced stores — no zero-fill, no atomics, bit-reproducible; a sharded model owns a range of
  * windows per rank (complete values, all-gather-v instead of all-reduce).  mode 3: OWNER PULL — models whose targets come from
  * data columns (ACOPF: bus variables reached through the branch table; no windows there): a list target variable -> the (fused
- * group, data point, item) contributions that land on it is built once (exa_set_product_mode(…, 3), exa_tune or a persisted
- * decision at model build: never inside a callback), and a thread per variable re-evaluates its items — one specialised function
+ * group, data point, item) contributions that land on it is built once (exa_set_product_mode(…, 3) / exa_set_deterministic or a persisted
+ * decision at model build: never inside a callback; exa_tune no longer tries it — it lost to the atomics on every model measured), and a thread per variable re-evaluates its items — one specialised function
  * per item — and stores the sum: no zero-fill, no atomics, a fixed order of additions (bit-reproducible), every entry written
  * exactly once; unsharded models whose variables collect at most 512 contributions each (status 1 otherwise).  -1 (default)
  * undecided: the decision exa_tune measured and persisted for this module / device / sizes ("chosen by measured contention") if
@@ -409,8 +409,11 @@ int exa_compress_info(int id, int hess, char *buf, int cap, int *len_out);
 int exa_time_callback(int id, int which, int reps, const double *x, const double *y, double obj_weight,
                       double *out, float *ms_out);
 int exa_sync(int id);
-/* Order of the (pattern, tile) workgroups of a multi-pattern callback: 0 patterns one after the other (default),
- * 1 interleaved in runs of 128 workgroups, -2 bad argument.  which: 2 cons, 3 jac, 4 hess, 5 fused. */
+/* Order of the (pattern, tile) workgroups of a multi-pattern callback: 0 patterns one after the other, 1 interleaved in runs of 128
+ * workgroups, -2 bad argument.  which: 2 cons, 3 jac, 4 hess, 5 fused.  Decided AT PLAN TIME, no tuning call needed (the reference has none,
+ * ext/ExaModelsKernelAbstractions.jl:526-537): 1 where the two heaviest dispatch units of the callback walk the same stretch of x (their index
+ * expressions are affine in a range column and their variable ranges overlap by half) and the call streams < 1.5 GB — the stretch one unit
+ * just read is then still in the Infinity Cache when the other arrives —, else 0; a decision exa_tune persisted wins over this default. */
 int exa_block_order(int id, int which);
 /* hess_coord! has three generated kernels: 0 = exa_hess, one (pattern, 256-point tile) per workgroup; 2 = exa_hessc, a
  * workgroup walks 4 consecutive tiles of a GROUP of co-indexed patterns with the next inputs loaded before the current
@@ -418,14 +421,18 @@ int exa_block_order(int id, int which);
  * 1 = exa_hesscl, exa_hessc with each wavefront's stretch of x (64 points + halo) loaded once and staged through LDS —
  * generated when every pattern of every group reads x at (one unit-step range) + literal offsets no more than 16 apart,
  * and used when this shard's groups start within that halo of each other (else 1 runs exa_hessc and this returns 2).
- * Which one runs: the decision exa_tune measured and persisted, else by size (>= 1.5 GB streamed per call -> 1). */
+ * Which one runs: by size at plan time (>= 1.5 GB streamed per call -> 1, else 0) — what exa_tune picks on the benchmark shapes —, unless exa_tune
+ * measured and persisted another choice for this module / device / sizes. */
 int exa_hess_variant(int id);
 /* Dynamic LDS (bytes) the chained hess_coord! kernels (variants 1, 2) are launched with: an occupancy throttle — memory nobody uses that
  * leaves three or two workgroups per CU instead of as many as the registers allow.  Fewer, longer streams per CU win where the output
  * outgrows the Infinity Cache (LV 1e8: 1.70 -> 1.62 ms) and on some boxes below it; exa_tune measures none / three / two next to the
- * kernels themselves and persists the winner, EXAHIP_HESS_DYN_LDS=bytes fixes it.  0 = no throttle (the default without a tuning decision). */
+ * kernels themselves and persists the winner, EXAHIP_HESS_DYN_LDS=bytes fixes it.  Without a decision: three workgroups per CU for a model that
+ * streams >= 1.5 GB per call, else 0 = no throttle.  A value from the environment or from a persisted decision is used only when the kernel's
+ * static LDS + it fit the 64 KB a launch may ask for (else 0). */
 int exa_hess_throttle(int id);
-/* Explicit, BLOCKING tuning — the only entry point that measures.  what: bit 0 = block order of cons / jac / hess / fused
+/* Explicit, BLOCKING tuning — the only entry point that measures, and OPTIONAL: every decision has a plan-time default (above) that equals what
+ * this call picks on the benchmark shapes (bench.py prints both).  what: bit 0 = block order of cons / jac / hess / fused
  * (models streaming >= 128 MB from several patterns), bit 1 = exa_jtprod / exa_hprod implementation, bit 2 = exa_grad
  * implementation (exa_set_grad_mode; only models whose objective scatters through a data index).  Both candidates of
  * each decision are timed on the model's stream at (x, y) (DEVICE pointers; NULL = x0 / ones; outputs go to scratch),
