@@ -383,7 +383,7 @@ typedef struct {
     double *theta;
     double *x0, *lvar, *uvar, *lcon, *ucon;
     int nthreads;
-    int rank, world;   /* iterator shard of every pattern: [n*rank/world, n*(rank+1)/world) (tests of the N>1 host logic) */
+    int rank, world;   /* iterator shard of every pattern: [part_lo(n, rank), part_lo(n, rank + 1)) (tests of the N>1 host logic) */
 } ora_model;
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -785,8 +785,14 @@ int64_t ora_nnzj(void *h) { return ((ora_handle *)h)->m.nnzj; }
 int64_t ora_nnzh(void *h) { return ((ora_handle *)h)->m.nnzh; }
 int64_t ora_nnzg(void *h) { return ((ora_handle *)h)->m.nnzg; }
 int ora_npatterns(void *h) { return ((ora_handle *)h)->m.npat; }
-static inline int64_t shard_lo(const ora_model *m, const pattern *p) { return (int64_t)((__int128)p->n * m->rank / m->world); }
-static inline int64_t shard_hi(const ora_model *m, const pattern *p) { return (int64_t)((__int128)p->n * (m->rank + 1) / m->world); }
+/* the library's partition (examodels.jl_amd/csrc/exa_internal.hpp part_lo): floor(n / G) items per rank, the last rank the remainder on top — equal
+ * pieces: one in-place all-gather completes an owner-sharded vector —; fewer than 16 items per rank: floor(n r / G) */
+static inline int64_t ora_part_lo(int64_t n, int r, int G) {
+    if (r >= G) return n;
+    return n >= 16LL * G ? (n / G) * (int64_t)r : (int64_t)((__int128)n * r / G);
+}
+static inline int64_t shard_lo(const ora_model *m, const pattern *p) { return ora_part_lo(p->n, m->rank, m->world); }
+static inline int64_t shard_hi(const ora_model *m, const pattern *p) { return ora_part_lo(p->n, m->rank + 1, m->world); }
 void ora_set_shard(void *h, int rank, int world) { ((ora_handle *)h)->m.rank = rank; ((ora_handle *)h)->m.world = world; }
 void ora_set_threads(void *h, int n) { ((ora_handle *)h)->m.nthreads = n < 1 ? 1 : n; }
 void ora_set_theta(void *h, int64_t off, const double *v, int64_t len) { memcpy(((ora_handle *)h)->m.theta + off, v, sizeof(double) * len); }
