@@ -337,7 +337,7 @@ def main():
     ap.add_argument("--no-config5-n1", action="store_true", help="skip the LV N=1e8 single-GPU point attached to the default line")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the config3 / config4 objects attached to the default line")
     ap.add_argument("--no-scale-base", action="store_true", help="N > 1: skip the one-GPU run of the same workload on rank 0 (scale_base)")
-    ap.add_argument("--no-tune", action="store_true", help="skip exa_tune (block order stays sequential unless persisted)")
+    ap.add_argument("--no-tune", action="store_true", help="skip exa_tune: the plan-time defaults of the library (what a host that never tunes runs)")
     ap.add_argument("--all-callbacks", action="store_true", help="also time obj/cons/grad/jac (secondary)")
     ap.add_argument("--no-collectives", action="store_true", help="N > 1: skip the secondary grad! + RCCL all-reduce timing")
     ap.add_argument("--collective-timeout", type=float, default=120.0, help="N > 1: seconds the secondary collective timing may take before the line is printed without it")
