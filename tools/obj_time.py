@@ -1,3 +1,6 @@
+#!/usr/bin/env python
+"""obj of LV at three sizes (one / two-level arrival fold): value against numpy, run-to-run equality of five calls, ms per call by exa_time_callback.
+usage (GPU box, repo root): python tools/obj_time.py"""
 import sys
 sys.path[:0]=["examodels.jl_amd"]
 import numpy as np, torch
