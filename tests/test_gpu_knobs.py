@@ -212,7 +212,7 @@ def test_hess_throttle_is_the_same_kernel_at_another_occupancy(libs, tmp_path, m
     assert (m2._L.exa_hess_variant(m2.id), m2._L.exa_hess_throttle(m2.id)) == (v, d)
 
 
-@pytest.mark.parametrize("name", ["lv1000", "rocket50", "acopf30", "mixed"])
+@pytest.mark.parametrize("name", sorted(ZOO))       # (round 6: the loops are software-pipelined two-stage code of their own — every zoo model)
 def test_tile_loop_kernels_write_the_same_bits(libs, name, monkeypatch):
     """exa_jacl / exa_consl: jac_coord! / cons_nln! as a loop over n consecutive block-map entries per workgroup (launched by default where the
     block map is long: LV 1e7, covered at full size by test_gpu_fullsize.py; EXAHIP_TILE_LOOP=n forces it, 0 switches it off).  The same pattern
