@@ -27,10 +27,12 @@ import argparse
 import os as _os
 # the all-cores CPU baseline (cpu_baseline): OpenMP threads bound to their cores before any OpenMP runtime is loaded, so that a page a thread
 # touched first stays local to it; stated in the line ("placement")
-_os.environ.setdefault("OMP_PROC_BIND", "close")
-_os.environ.setdefault("OMP_PLACES", "cores")
-CPU_PLACEMENT = ("output first-touched by the parallel run (static schedule), OMP_PROC_BIND=" + _os.environ["OMP_PROC_BIND"] +
-                 " OMP_PLACES=" + _os.environ["OMP_PLACES"] + "; inputs (160 MB of 880) on the main thread's node")
+# (one-process runs only: the ranks of a multi-GPU job must not all be bound to the same cores; cpu_baseline runs at N = 1 anyway)
+if int(_os.environ.get("WORLD_SIZE", "1")) == 1:
+    _os.environ.setdefault("OMP_PROC_BIND", "close")
+    _os.environ.setdefault("OMP_PLACES", "cores")
+CPU_PLACEMENT = ("output first-touched by the parallel run (static schedule), OMP_PROC_BIND=" + _os.environ.get("OMP_PROC_BIND", "unset") +
+                 " OMP_PLACES=" + _os.environ.get("OMP_PLACES", "unset") + "; inputs (160 MB of 880) on the main thread's node")
 import ctypes
 import json
 import os
