@@ -565,15 +565,16 @@ void launch(Handle &h, hipFunction_t f, int64_t grid, unsigned block, void **arg
 // literal coefficients of exp / sincos in SGPRs across tiles, and — round 6 — the loop is software-pipelined (the next tile's loads issued before
 // this tile is evaluated, gen_dispatch_looped).  One model per setting alternating in one process (tools/tile_loop_ab.py, profiles/r6_tile_loop_ab.txt):
 // LV 1e8 cons_nln! 0.575 -> 0.468 ms, jac_coord! 0.790 -> 0.578 (round 5's loop without the pipelining: 0.513 / 0.709); 3e7 0.133 -> 0.131 and
-// 0.180 -> 0.162; 1e7 0.0488 -> 0.0496 (nothing) and 0.0615 -> 0.0569; bitwise equal.  Only where the block map is long enough to keep every CU busy
+// 0.180 -> 0.162; 1e7 0.0488 -> 0.0496 (cons_nln!: the one-tile kernel stays there) and 0.0615 -> 0.0569; bitwise equal.  Only where the block map is long enough to keep every CU busy
 // with the longer workgroups.
 int tile_loop_ppt(Handle &h, int cb) {
     hipFunction_t f = cb == CB_JAC ? h.f_jacl : h.f_consl;
     if (!f || h.gen.layout.ppt[cb] != 1 || h.tile_loop == 0 || h.tile_loop == 1) return 0;
     if (h.tile_loop > 1) return h.tile_loop;
-    if (h.grid[cb] < 16384) return 0;                                   // (3e6 points: the loop loses)
+    // (cons_nln! at LV 1e7 — 39 063 entries —: one tile 0.0474-0.0488 ms, the loop 0.0494-0.0502: it pays from ~1e5 entries on; jac_coord!,
+    // whose tiles also flush COO slots, from 32 768)
     if (cb == CB_JAC) return h.grid[cb] >= 32768 ? 8 : 0;
-    return h.grid[cb] >= 65536 ? 8 : 4;
+    return h.grid[cb] >= 65536 ? 8 : 0;
 }
 // zero-fill of n doubles on the model's stream (exa_zero)
 void zero_fill(Handle &h, void *p, int64_t n) {
