@@ -2,7 +2,7 @@
 """EXAHIP_TILE_LOOP A/B on LV: cons_nln! / jac_coord! by the one-tile kernels (0) against the pipelined tile-loop kernels exa_consl / exa_jacl with n tiles
 per workgroup (unset = the library's rule).  One module, the launch differs.  One model per setting, the settings ALTERNATE in 7 rounds of 200 launches
 (exa_time_callback: back to back from C — a Python call per launch is host-bound below ~0.05 ms), minimum per setting; outputs compared bit for bit with
-the first setting's.  usage: tile_loop_ab.py [N]"""
+the first setting's.  usage: tile_loop_ab.py [N] [n1,n2,...]"""
 import os
 import sys
 
@@ -14,7 +14,7 @@ import torch  # noqa: E402
 from exahip import ExaModel, models  # noqa: E402
 
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10_000_000
-settings = ("0", None, "2", "4", "8", "16")
+settings = ("0", None) + tuple(sys.argv[2].split(",") if len(sys.argv) > 2 else ("2", "4", "8", "16"))
 ms = {}
 core = models.luksan_vlcek_model(N)
 for tl in settings:
