@@ -447,16 +447,18 @@ int exa_tune(int id, int what, const double *x, const double *y) {
                     if (v != 0 && h.order[CB_HESSC] != (v == 1 ? order_cl : order_c)) install_order(h, CB_HESSC, v == 1 ? order_cl : order_c);
                     do_hess(h, x, y, sigma, hv);
                 });
-                // the plain kernel stays unless another one wins by 3 %: rounds of six launches between other candidates flatter the chained kernels by a few
-                // per cent against what they do back to back (one box, minutes apart: tuned to exa_hesscl 0.1404 ms in the timed region, to exa_hess 0.1307;
-                // gpurun_out/r5am) — where they really win it is by 6 % and more (LV 1e7 on the fast boxes, LV 1e8 everywhere)
-                size_t best = 0;
-                for (size_t k = 1; k < cs.size(); k++)
-                    if (tv[k] < 0.97f * tv[0] && (best == 0 || tv[k] < tv[best])) best = k;
-                // (a throttled candidate must beat its own unthrottled form by the same margin)
-                if (cs[best].dyn && !fixed_dyn)
-                    for (size_t k = 0; k < cs.size(); k++)
-                        if (cs[k].variant == cs[best].variant && cs[k].dyn == 0 && !(tv[best] < 0.99f * tv[k])) { best = k; break; }
+                // The PLAN-TIME DEFAULT stays unless another candidate wins by 3 % (round 6; round 5: "the plain kernel stays unless ..."): rounds of six
+                // launches between other candidates rank candidates that are within a few per cent of each other by noise — one box tuned LV 1e7 to
+                // exa_hesscl at 0.1404 ms in the timed region against exa_hess's 0.1307 (gpurun_out/r5am); another dropped LV 1e8's throttle for a 0.3 % lead
+                // in the rounds and then ran 1.636 ms where the default ran 1.499 in the same process (profiles/r6_bench_default.json, first version).
+                // Where a candidate really wins it is by 6 % and more.
+                const int def_variant = h.hess_stream_bytes >= 1.5e9 ? (h.f_hesscl && h.stage_ok ? 1 : 2) : 0;
+                const unsigned def_dyn = def_variant && !fixed_dyn ? hess_throttle_bytes(h, def_variant, 3) : (def_variant ? h.hess_dyn_lds : 0u);
+                size_t def = 0;
+                for (size_t k = 0; k < cs.size(); k++) if (cs[k].variant == def_variant && cs[k].dyn == def_dyn) def = k;
+                size_t best = def;
+                for (size_t k = 0; k < cs.size(); k++)
+                    if (k != def && tv[k] < 0.97f * tv[def] && tv[k] < tv[best]) best = k;
                 h.hess_variant = cs[best].variant;
                 h.hess_dyn_lds = cs[best].dyn;
                 h.hess_dyn_auto = false;

@@ -339,6 +339,7 @@ std::vector<float> ab_min(Handle &h, int ncand, int rounds, int launches, F &&ru
 template <class F>
 float tune_order(Handle &h, int cb, F &&run) {
     const int n = std::max(1, h.norders[cb]);
+    const int def = n > 1 && h.order[cb] == 1 ? 1 : 0;       // what the callback runs now (the plan-time default, or an earlier decision): kept unless the other order wins by 2 %
     float t[2] = {1e30f, 1e30f};
     // bring the clocks up first: the governor idles at ~570 MHz and needs tens of ms of load, and at low clocks the
     // orders rank differently than in steady state (measured: cold tuning picked the slower order 2 times out of 3)
@@ -359,7 +360,7 @@ float tune_order(Handle &h, int cb, F &&run) {
         const std::vector<float> tm = ab_min(h, std::min(n, 2), 4, 4, [&](int k) { install_order(h, cb, k); run(); });
         for (size_t k = 0; k < tm.size(); k++) t[k] = tm[k];
     }
-    const int best = n > 1 && t[1] < t[0] ? 1 : 0;
+    const int best = n > 1 && t[1 - def] < 0.98f * t[def] ? 1 - def : def;
     install_order(h, cb, best);
     HIPCHK(hipStreamSynchronize(h.stream));
     if (n > 1) tune_store(source_key(h.gen.source), tune_signature(h, "order" + std::to_string(cb)), best);
