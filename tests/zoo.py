@@ -87,7 +87,21 @@ def specialfn_model(n=40):
     return c
 
 
+def docparam_model(N=10):
+    """docs/src/parameters.md:24-82 — the reference's own documented parametric model (θ = [100, 1], objective added FIRST): the model whose
+    Ipopt logs pin counts and Hessian values (tests/test_known_answers.py)."""
+    from exahip.graph import exp, sin
+    c = ExaCore()
+    th = c.add_par([100.0, 1.0])
+    x = c.add_var(N, start=np.array([models.luksan_vlcek_x0(i) for i in range(1, N + 1)]))
+    c.add_obj(lambda i: th[1] * (x[i - 1] ** 2 - x[i]) ** 2 + (x[i - 1] - th[2]) ** 2, rng(2, N))
+    c.add_con(lambda i: 3 * x[i + 1] ** 3 + 2 * x[i + 2] - 5 + sin(x[i + 1] - x[i + 2]) * sin(x[i + 1] + x[i + 2]) + 4 * x[i + 1]
+              - x[i] * exp(x[i] - x[i + 1]) - 3, rng(1, N - 2))
+    return c
+
+
 ZOO = {
+    "lv10_docparam": docparam_model,
     "lv3": lambda: models.luksan_vlcek_model(3),
     "lv20": lambda: models.luksan_vlcek_model(20),
     "lv20_objfirst": lambda: models.luksan_vlcek_model(20, obj_first=True),

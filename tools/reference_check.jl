@@ -21,7 +21,7 @@
 # augmentation model of test/NLPTest/conaug_test.jl:200-213, the two COPS models of benchmark/runbenchmark.jl:239-282 (hanging
 # chain, electrons on a sphere) and this repository's two feature models (`mixed`: parameters with an offset index range,
 # table iterators with Int and Float columns, a 1-D augmentation, literal and data exponents; `stepped`: StepRange iterators,
-# exa_sum / exa_prod, Constant algebra, a parameterised power) — 16 of the 16 fixture models.
+# exa_sum / exa_prod, Constant algebra, a parameterised power) — 18 of the 18 fixture models (round 6: + the parametric LV-10 of docs/src/parameters.md).
 using ExaModels, NLPModels, Printf
 using SpecialFunctions   # loads ExaModelsSpecialFunctions (ext/): the `specialfn` model
 import JSON   # any JSON reader will do; JSON.jl is what ExaModels' own test environment has
@@ -54,6 +54,15 @@ function lv_model(N; obj_first = false)            # benchmark/runbenchmark.jl:1
         @add_con(c, s, 3x[i+1]^3 + 2 * x[i+2] - 5 + sin(x[i+1] - x[i+2])sin(x[i+1] + x[i+2]) + 4x[i+1] - x[i]exp(x[i] - x[i+1]) - 3 for i = 1:(N-2))
         @add_obj(c, 100 * (x[i-1]^2 - x[i])^2 + (x[i-1] - 1)^2 for i = 2:N)
     end
+    return ExaModel(c; prod = true)
+end
+
+function docparam_model(N = 10)                    # docs/src/parameters.md:24-82, as documented: theta = [100, 1], the objective FIRST
+    c = ExaCore(concrete = Val(true))
+    @add_par(c, θ, [100.0, 1.0])
+    @add_var(c, x, N; start = (lv_x0(i) for i = 1:N))
+    @add_obj(c, θ[1] * (x[i-1]^2 - x[i])^2 + (x[i-1] - θ[2])^2 for i = 2:N)
+    @add_con(c, s, 3x[i+1]^3 + 2 * x[i+2] - 5 + sin(x[i+1] - x[i+2])sin(x[i+1] + x[i+2]) + 4x[i+1] - x[i]exp(x[i] - x[i+1]) - 3 for i = 1:(N-2))
     return ExaModel(c; prod = true)
 end
 
@@ -234,7 +243,7 @@ function stepped_model()                           # tests/zoo.py stepped_model:
 end
 
 const MODELS = [
-    ("lv3", a -> lv_model(3)), ("lv20", a -> lv_model(20)), ("lv20_objfirst", a -> lv_model(20; obj_first = true)),
+    ("lv10_docparam", a -> docparam_model(10)), ("lv3", a -> lv_model(3)), ("lv20", a -> lv_model(20)), ("lv20_objfirst", a -> lv_model(20; obj_first = true)),
     ("lv1000", a -> lv_model(1000)), ("lv10000", a -> lv_model(10_000)),
     ("lv_split_20x1", a -> lv_split_model(20, 1)), ("lv_split_20x2", a -> lv_split_model(20, 2)), ("lv_struct_20x2", a -> lv_struct_model(20, 2)),
     ("trivialmax", a -> trivialmax_model(6)), ("conaug2d", a -> conaug2d_model()),
