@@ -89,11 +89,15 @@ if os.environ.get("CHECK_ALL"):
         vals = o.jac_coord(x) if kind == "jac" else o.hess_coord(x, y, 0.7)
         dense = np.zeros(nrow * m.meta.nvar)
         np.add.at(dense, (cc - 1) * nrow + (r - 1), np.where(np.isfinite(vals), vals, 0.0))
+        # (a matrix entry one of whose duplicates is NaN / Inf is NaN / Inf in the compressed COO — the sum of its duplicates — while `dense` above
+        # holds the sum of the finite ones: such entries are not comparable and are left out (seed 8816: 26 of them))
+        tainted = np.zeros(nrow * m.meta.nvar, dtype=bool)
+        tainted[((cc - 1) * nrow + (r - 1))[~np.isfinite(vals)]] = True
         cr, ccol = (cm.jac_structure() if kind == "jac" else cm.hess_structure())
         cv = (cm.jac_coord(xd) if kind == "jac" else cm.hess_coord(xd, yd, 0.7)).cpu().numpy()
         got = np.zeros_like(dense)
         got[((ccol - 1) * nrow + (cr - 1)).cpu().numpy()] = np.where(np.isfinite(cv), cv, 0.0)
-        errs += [rel(got, dense)]
+        errs += [rel(got[~tainted], dense[~tainted])]
 if os.environ.get("SHARDS"):
     # the same model cut into SHARDS shards (one after the other on this GPU; host-pointer entry points: entries a rank does
     # not own come back as zeros, so owner pieces add up like partial sums): obj / grad! / cons_nln! /
