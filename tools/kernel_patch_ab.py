@@ -322,8 +322,43 @@ def v_hesscl_ntload(src):
     return src[:a2] + fn + src[e2:]
 
 
+# The flush with 16-byte stores: a lane takes two consecutive doubles of the run (two transposed LDS reads), one buffer_store_dwordx4 — half the
+# store instructions, 1 KB per instruction
+def v_flush16(src):
+    a = src.index("template <int S, int PP, int LD>\nstatic __device__ __forceinline__ void exa_flush_points(")
+    b = src.index("// (the chained callbacks' name for the same flush;")
+    new = """typedef unsigned int exa_u4_t __attribute__((ext_vector_type(4)));
+template <int S, int PP, int LD>
+static __device__ __forceinline__ void exa_flush_points(double* __restrict__ out, long obase, long npts, const double* tile, int lane, int g) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    constexpr int CNT = S * PP;
+    long left = npts - (long)g * PP;
+    left = left < 0 ? 0 : (left > PP ? PP : left);
+    const __amdgpu_buffer_rsrc_t run = exa_run_rsrc(out + obase + (long)CNT * g, (int)left * S * 8);
+    static_assert(CNT % 2 == 0, "pairs");
+#pragma unroll
+    for (int k = 0; k * 128 < CNT; k++) {
+        int j = k * 128 + 2 * lane;
+        const int off = j * 8;
+        if ((k + 1) * 128 > CNT && j >= CNT) j = 0;
+        const int l0 = j / S, s0 = j - l0 * S, l1 = (j + 1) / S, s1 = (j + 1) - l1 * S;
+        const double a0 = tile[s0 * LD + l0], a1 = tile[s1 * LD + l1];
+        const exa_u2_t u0 = __builtin_bit_cast(exa_u2_t, a0), u1 = __builtin_bit_cast(exa_u2_t, a1);
+        exa_u4_t q; q.x = u0.x; q.y = u0.y; q.z = u1.x; q.w = u1.y;
+        __builtin_amdgcn_raw_buffer_store_b128(q, run, off, 0, 2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+"""
+    return src[:a] + new + src[b:]
+
+
 VARIANTS = {
     "base": lambda s: s,
+    "flush16": v_flush16,
     "hesscl_ntload": v_hesscl_ntload,
     "hesscl_bufload": v_hesscl_bufload,
     "w_base": lambda s: s,
